@@ -1,0 +1,530 @@
+// Dense arm: exact inner-product top-k over a row-major f32 corpus shard.
+//
+// Replaces faiss IndexFlat(IP).add/search at MEVI/faiss_search.py:13-21 and the
+// in-cluster matmul+sort at MEVI/main_models.py:3967-3968,4012.
+//
+// Structure (see DESIGN.md "Dense arm"):
+//   * ip_filter_kernel  -- f32 MFMA (v_mfma_f32_32x32x2_f32) tile GEMM
+//     docs[128] x queries[128] per workgroup, K streamed through LDS in 32-wide
+//     slabs (register-staged double buffer).  The score matrix is never
+//     written: the epilogue compares every accumulator with the query's running
+//     threshold tau[q] (its current k-th best score) and appends the few
+//     survivors to a per-query candidate list with one atomic each.
+//   * compact_kernel    -- one workgroup per query: bitonic-sorts current top-k
+//     + new candidates in LDS (64-bit score|id keys), keeps the best k, raises
+//     tau[q].
+//   The corpus is walked in geometrically growing chunks (each chunk doubles
+//   the number of rows seen) so the expected number of survivors per chunk is
+//   ~k per query; a query whose candidate list overflows (adversarial row
+//   order) is flagged and recomputed by the guaranteed path (chunk <= capacity).
+//   * finalize_kernel   -- keys -> (f32 score, i64 id) with faiss-style padding.
+//
+// Numerics: each score is the f32 fmaf chain over k = 0..dim-1 in order (the
+// LDS image de-interleaves even/odd k so that MFMA lane half 0 supplies even k
+// and half 1 odd k); oracle/mevi_oracle.c computes the same chain on the CPU,
+// so parity is bit-exact.
+
+#include "common.h"
+
+#include <float.h>
+#include <math.h>
+#include <vector>
+
+namespace mevi {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;          // docs per workgroup tile   (MFMA A rows)
+constexpr int BN = 128;          // queries per workgroup tile (MFMA B cols)
+constexpr int BK = 32;           // K slab
+constexpr int LDSROW = 36;       // floats per LDS row: 16 even-k | 16 odd-k | 4 pad
+constexpr int NTHREADS = 256;    // 4 waves, each owns a 64x64 sub-tile
+constexpr int MAX_SORT = 16384;  // largest LDS sort (128 KiB of keys)
+
+struct TopkGeom {
+  int k;    // results per query
+  int S;    // per-query slots in `buf` (power of two): [0,k) top list, [k,S) candidates
+  int cap;  // S - k
+};
+
+static inline int next_pow2(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+static inline TopkGeom make_geom(int k) {
+  TopkGeom g;
+  g.k = k;
+  int S = next_pow2(k) * 4;
+  if (S < 1024) S = 1024;
+  if (S > MAX_SORT) S = MAX_SORT;
+  g.S = S;
+  g.cap = S - k;
+  return g;
+}
+
+// ---------------------------------------------------------------------------
+// XCD-aware bijective block remap: blocks that share `bid % 8` share an XCD (L2),
+// so give each XCD a contiguous range of work items (doc tiles with all their
+// query tiles) -- the doc tile is then fetched from HBM once per XCD L2.
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void ip_filter_kernel(
+    const float *__restrict__ Q, int nq, const float *__restrict__ D,
+    long long doc_begin, long long doc_end, int dim,
+    const float *__restrict__ tau, unsigned long long *__restrict__ buf,
+    unsigned int *__restrict__ count, int S, int k, int cap,
+    unsigned int id_base, int n_qtiles, int n_dtiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDSROW];
+
+  const int nwg = n_qtiles * n_dtiles;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int dtile = wg / n_qtiles;
+  const int qtile = wg - dtile * n_qtiles;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave >> 1;  // doc half of the tile
+  const int wn = wave & 1;   // query half of the tile
+  const int lrow = lane & 31;
+  const int half = lane >> 5;
+
+  // ---- staging map: thread -> (row, 4 consecutive k) of the 128x32 slab ----
+  const int srow = t >> 3;        // 0..31 (+32*i)
+  const int skq = (t & 7) * 4;    // k offset inside the slab
+  const long long drow0 = doc_begin + (long long)dtile * BM;
+  const int qrow0 = qtile * BN;
+
+  const float *dptr[4];
+  const float *qptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long long dr = drow0 + srow + 32 * i;
+    if (dr > doc_end - 1) dr = doc_end - 1;  // clamp: result masked in the epilogue
+    dptr[i] = D + (size_t)dr * (size_t)dim + skq;
+    int qr = qrow0 + srow + 32 * i;
+    if (qr > nq - 1) qr = nq - 1;
+    qptr[i] = Q + (size_t)qr * (size_t)dim + skq;
+  }
+
+  float4 ra[4], rb[4];
+  const int nslab = (dim + BK - 1) / BK;
+
+  auto gload = [&](int s) {
+    const int kk = s * BK;
+    const bool in = (kk + skq) < dim;  // dim % 4 == 0 -> a float4 is all-in or all-out
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = in ? *reinterpret_cast<const float4 *>(dptr[i] + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = in ? *reinterpret_cast<const float4 *>(qptr[i] + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // LDS image per row: [k even (16 floats)] [k odd (16 floats)] [pad 4]
+  auto lstore = [&](int bufi) {
+    float *sA = lds + bufi * (BM + BN) * LDSROW;
+    float *sB = sA + BM * LDSROW;
+    const int e = skq >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 32 * i;
+      *reinterpret_cast<float2 *>(sA + r * LDSROW + e) = make_float2(ra[i].x, ra[i].z);
+      *reinterpret_cast<float2 *>(sA + r * LDSROW + 16 + e) = make_float2(ra[i].y, ra[i].w);
+      *reinterpret_cast<float2 *>(sB + r * LDSROW + e) = make_float2(rb[i].x, rb[i].z);
+      *reinterpret_cast<float2 *>(sB + r * LDSROW + 16 + e) = make_float2(rb[i].y, rb[i].w);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) gload(s + 1);
+
+    const float *sA = lds + (s & 1) * (BM + BN) * LDSROW;
+    const float *sB = sA + BM * LDSROW;
+    const float *pa = sA + (64 * wm + lrow) * LDSROW + 16 * half;
+    const float *pb = sB + (64 * wn + lrow) * LDSROW + 16 * half;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float4 a0 = *reinterpret_cast<const float4 *>(pa + 4 * jj);
+      float4 a1 = *reinterpret_cast<const float4 *>(pa + 32 * LDSROW + 4 * jj);
+      float4 b0 = *reinterpret_cast<const float4 *>(pb + 4 * jj);
+      float4 b1 = *reinterpret_cast<const float4 *>(pb + 32 * LDSROW + 4 * jj);
+      const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
+      const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
+      const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
+      }
+    }
+
+    if (s + 1 < nslab) lstore((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: threshold filter -----------------------------------------
+  // C/D map of 32x32 MFMA: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*half (doc)
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int qi = qrow0 + 64 * wn + 32 * ni + lrow;
+    const bool qok = qi < nq;
+    const float tq = qok ? tau[qi] : INFINITY;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[mi][ni][r];
+        if (v > tq) {
+          const long long dr = drow0 + 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (dr < doc_end) {
+            const unsigned int slot = atomicAdd(&count[qi], 1u);
+            if (slot < (unsigned int)cap) {
+              buf[(size_t)qi * S + k + slot] = make_key(v, id_base + (unsigned int)dr);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// In-LDS bitonic sort (descending) of P 64-bit keys by NT threads.
+template <int NT>
+__device__ inline void bitonic_sort_desc(unsigned long long *s, int P, int t) {
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < (P >> 1); i += NT) {
+        const int lo = 2 * i - (i & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = s[lo], b = s[hi];
+        if ((a < b) == desc) {
+          s[lo] = b;
+          s[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void init_state_kernel(unsigned long long *buf, unsigned int *count,
+                                                        float *tau, unsigned int *failed, long long nq,
+                                                        int S, int k) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = nq * (long long)k;
+  if (i < total) {
+    const long long q = i / k;
+    const int j = (int)(i - q * k);
+    buf[q * S + j] = 0ull;
+  }
+  if (i < nq) {
+    count[i] = 0u;
+    tau[i] = -INFINITY;
+    failed[i] = 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(unsigned long long *__restrict__ buf,
+                                                     unsigned int *__restrict__ count,
+                                                     float *__restrict__ tau,
+                                                     unsigned int *__restrict__ failed, int S, int k,
+                                                     int cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  const int q = blockIdx.x;
+  const int t = threadIdx.x;
+  const unsigned int c_raw = count[q];
+  if (c_raw == 0u) return;  // nothing new for this query (uniform per block)
+  const int c = c_raw > (unsigned int)cap ? cap : (int)c_raw;
+  const int n = k + c;
+  int P = 512;
+  while (P < n) P <<= 1;
+  unsigned long long *row = buf + (size_t)q * S;
+  for (int i = t; i < P; i += 256) skeys[i] = (i < n) ? row[i] : 0ull;
+  __syncthreads();
+  bitonic_sort_desc<256>(skeys, P, t);
+  for (int i = t; i < k; i += 256) row[i] = skeys[i];
+  if (t == 0) {
+    const unsigned long long kth = skeys[k - 1];
+    tau[q] = (kth != 0ull) ? key_score(kth) : -INFINITY;
+    count[q] = 0u;
+    if (c_raw > (unsigned int)cap) failed[q] = 1u;
+  }
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long *__restrict__ buf, int S,
+                                                      int k, long long nq, float *__restrict__ out_score,
+                                                      long long *__restrict__ out_id) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * (long long)k) return;
+  const long long q = i / k;
+  const int j = (int)(i - q * k);
+  const unsigned long long key = buf[q * S + j];
+  if (key == 0ull) {
+    out_score[i] = -FLT_MAX;
+    out_id[i] = -1;
+  } else {
+    out_score[i] = key_score(key);
+    out_id[i] = (long long)key_id(key);
+  }
+}
+
+// rows of src selected by idx -> dst (float4 granularity)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src,
+                                                         const int *__restrict__ idx, int nrows, int dim,
+                                                         float *__restrict__ dst) {
+  const int r = blockIdx.x;
+  if (r >= nrows) return;
+  const float4 *s = reinterpret_cast<const float4 *>(src + (size_t)idx[r] * dim);
+  float4 *d = reinterpret_cast<float4 *>(dst + (size_t)r * dim);
+  for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) d[i] = s[i];
+}
+
+// top-k rows of the fallback state -> rows idx[r] of the main state
+__global__ __launch_bounds__(256) void scatter_top_kernel(const unsigned long long *__restrict__ src,
+                                                         const int *__restrict__ idx, int nrows, int S,
+                                                         int k, unsigned long long *__restrict__ dst) {
+  const int r = blockIdx.x;
+  if (r >= nrows) return;
+  const unsigned long long *s = src + (size_t)r * S;
+  unsigned long long *d = dst + (size_t)idx[r] * S;
+  for (int i = threadIdx.x; i < k; i += blockDim.x) d[i] = s[i];
+}
+
+// shard lists -> keys, one workgroup per query, sort, keep k_out
+__global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ scores,
+                                                   const long long *__restrict__ ids, int nlists,
+                                                   long long nq, int k_in, int k_out,
+                                                   float *__restrict__ out_score,
+                                                   long long *__restrict__ out_id) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  const long long q = blockIdx.x;
+  const int t = threadIdx.x;
+  const int n = nlists * k_in;
+  int P = 512;
+  while (P < n) P <<= 1;
+  for (int i = t; i < P; i += 256) {
+    unsigned long long key = 0ull;
+    if (i < n) {
+      const int l = i / k_in, j = i - l * k_in;
+      const size_t off = ((size_t)l * nq + q) * k_in + j;
+      const long long id = ids[off];
+      if (id >= 0) key = make_key(scores[off], (unsigned int)id);
+    }
+    skeys[i] = key;
+  }
+  __syncthreads();
+  bitonic_sort_desc<256>(skeys, P, t);
+  for (int i = t; i < k_out; i += 256) {
+    const unsigned long long key = (i < P) ? skeys[i] : 0ull;
+    const size_t off = (size_t)q * k_out + i;
+    if (key == 0ull) {
+      out_score[off] = -FLT_MAX;
+      out_id[off] = -1;
+    } else {
+      out_score[off] = key_score(key);
+      out_id[off] = (long long)key_id(key);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct SearchState {
+  unsigned long long *buf;  // [nq, S]
+  unsigned int *count;      // [nq]
+  float *tau;               // [nq]
+  unsigned int *failed;     // [nq]
+};
+
+static size_t state_bytes(int64_t nq, const TopkGeom &g) {
+  return align_up((size_t)nq * g.S * 8, 256) + 3 * align_up((size_t)nq * 4, 256);
+}
+
+static SearchState carve_state(char *&p, int64_t nq, const TopkGeom &g) {
+  SearchState st;
+  st.buf = reinterpret_cast<unsigned long long *>(p);
+  p += align_up((size_t)nq * g.S * 8, 256);
+  st.count = reinterpret_cast<unsigned int *>(p);
+  p += align_up((size_t)nq * 4, 256);
+  st.tau = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * 4, 256);
+  st.failed = reinterpret_cast<unsigned int *>(p);
+  p += align_up((size_t)nq * 4, 256);
+  return st;
+}
+
+thread_local double g_growth = 0.0;
+thread_local mevi_ip_topk_stats g_stats = {0, 0, 0};
+
+// Walk docs [0, nd) in chunks; returns number of filter launches, <0 on error.
+static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, int dim,
+                        const TopkGeom &g, uint32_t id_base, const SearchState &st, bool guaranteed,
+                        hipStream_t stream) {
+  const long long total = nq * (long long)g.k;
+  const long long init_n = total > nq ? total : nq;
+  hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, stream,
+                     st.buf, st.count, st.tau, st.failed, (long long)nq, g.S, g.k);
+  if ((size_t)g.S * 8 > 65536) {  // dynamic LDS beyond 64 KiB must be opted into
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(compact_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, g.S * 8) != hipSuccess) {
+      set_error("ip_topk: cannot raise dynamic LDS to %d bytes", g.S * 8);
+      return -1;
+    }
+  }
+  const int n_qtiles = (int)((nq + BN - 1) / BN);
+  double growth = g_growth > 0.0 ? g_growth : (double)(g.cap / (3 * g.k));
+  if (growth < 1.0) growth = 1.0;
+  const int64_t cap_docs = (g.cap / BM) * BM;  // chunk that can never overflow, tile aligned
+  int64_t seen = 0, launches = 0;
+  while (seen < nd) {
+    int64_t chunk = cap_docs;
+    if (!guaranteed && seen >= g.k) {
+      int64_t grown = (int64_t)((double)seen * growth);
+      grown = grown / BM * BM;
+      if (grown > chunk) chunk = grown;
+    }
+    if (chunk > nd - seen) chunk = nd - seen;
+    const int64_t n_dtiles = (chunk + BM - 1) / BM;
+    const int64_t nwg = n_dtiles * n_qtiles;
+    if (nwg > 0x7fffffffLL) {
+      set_error("ip_topk: grid too large (%lld workgroups)", (long long)nwg);
+      return -1;
+    }
+    hipLaunchKernelGGL(ip_filter_kernel, dim3((unsigned)nwg), dim3(NTHREADS), 0, stream, Q, (int)nq, D,
+                       (long long)seen, (long long)(seen + chunk), dim, st.tau, st.buf, st.count, g.S, g.k,
+                       g.cap, id_base, n_qtiles, (int)n_dtiles);
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nq), dim3(256), (size_t)g.S * 8, stream, st.buf,
+                       st.count, st.tau, st.failed, g.S, g.k, g.cap);
+    seen += chunk;
+    ++launches;
+  }
+  if (hipGetLastError() != hipSuccess) {
+    set_error("ip_topk: kernel launch failed");
+    return -1;
+  }
+  return launches;
+}
+
+}  // namespace
+}  // namespace mevi
+
+using namespace mevi;
+
+extern "C" size_t mevi_ip_topk_workspace_bytes(int64_t nq, int64_t dim, int64_t k) {
+  if (nq <= 0 || k <= 0 || k > 4096 || dim <= 0) return 0;
+  const TopkGeom g = make_geom((int)k);
+  // main state + fallback state + gathered fallback queries + index list
+  return 2 * state_bytes(nq, g) + align_up((size_t)nq * dim * 4, 256) + align_up((size_t)nq * 4, 256) + 256;
+}
+
+extern "C" void mevi_ip_topk_set_growth(double growth) { g_growth = growth; }
+extern "C" void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out) {
+  if (out) *out = g_stats;
+}
+
+extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, int64_t nd, int64_t dim,
+                                int64_t k, int64_t id_offset, float *out_score, int64_t *out_id,
+                                void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  g_stats = {0, 0, 0};
+  MEVI_REQUIRE(nq >= 0 && nd >= 0 && dim > 0 && k > 0, MEVI_ERR_INVALID_ARG,
+               "ip_topk: bad shape nq=%lld nd=%lld dim=%lld k=%lld", (long long)nq, (long long)nd,
+               (long long)dim, (long long)k);
+  if (nq == 0) return MEVI_OK;
+  MEVI_REQUIRE(q && out_score && out_id && (docs || nd == 0), MEVI_ERR_INVALID_ARG, "ip_topk: null pointer");
+  MEVI_REQUIRE(dim % 4 == 0, MEVI_ERR_UNSUPPORTED, "ip_topk: dim=%lld must be a multiple of 4", (long long)dim);
+  MEVI_REQUIRE(k <= 4096, MEVI_ERR_UNSUPPORTED, "ip_topk: k=%lld > 4096 not supported", (long long)k);
+  MEVI_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)docs % 16) == 0, MEVI_ERR_INVALID_ARG,
+               "ip_topk: q/docs must be 16-byte aligned");
+  MEVI_REQUIRE(id_offset >= 0 && id_offset + nd < 0xFFFFFFFFLL, MEVI_ERR_UNSUPPORTED,
+               "ip_topk: id_offset + nd must be < 2^32-1");
+  MEVI_REQUIRE(nq < (1LL << 31) && dim < (1LL << 24), MEVI_ERR_UNSUPPORTED, "ip_topk: nq/dim too large");
+  const size_t need = mevi_ip_topk_workspace_bytes(nq, dim, k);
+  MEVI_REQUIRE(workspace && workspace_bytes >= need, MEVI_ERR_WORKSPACE,
+               "ip_topk: workspace %zu bytes < required %zu", workspace_bytes, need);
+  MEVI_REQUIRE(((uintptr_t)workspace % 256) == 0, MEVI_ERR_INVALID_ARG, "ip_topk: workspace must be 256-byte aligned");
+
+  const TopkGeom g = make_geom((int)k);
+  char *p = reinterpret_cast<char *>(workspace);
+  SearchState st = carve_state(p, nq, g);
+  SearchState fb = carve_state(p, nq, g);
+  float *qsub = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * dim * 4, 256);
+  int *fidx = reinterpret_cast<int *>(p);
+
+  int64_t launches = run_pass(q, nq, docs, nd, (int)dim, g, (uint32_t)id_offset, st, false, stream);
+  if (launches < 0) return MEVI_ERR_HIP;
+  g_stats.n_chunks = launches;
+
+  // One sync: did any query overflow its candidate list?
+  std::vector<unsigned int> failed((size_t)nq);
+  MEVI_HIP_CHECK(hipMemcpyAsync(failed.data(), st.failed, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+  MEVI_HIP_CHECK(hipStreamSynchronize(stream));
+  std::vector<int> idx;
+  for (int64_t i = 0; i < nq; ++i)
+    if (failed[(size_t)i]) idx.push_back((int)i);
+  if (!idx.empty()) {
+    const int64_t nf = (int64_t)idx.size();
+    g_stats.n_failed_queries = nf;
+    MEVI_HIP_CHECK(hipMemcpyAsync(fidx, idx.data(), (size_t)nf * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nf), dim3(256), 0, stream, q, fidx, (int)nf, (int)dim, qsub);
+    int64_t fl = run_pass(qsub, nf, docs, nd, (int)dim, g, (uint32_t)id_offset, fb, true, stream);
+    if (fl < 0) return MEVI_ERR_HIP;
+    g_stats.n_fallback_chunks = fl;
+    hipLaunchKernelGGL(scatter_top_kernel, dim3((unsigned)nf), dim3(256), 0, stream, fb.buf, fidx, (int)nf, g.S, g.k, st.buf);
+    // idx (host) must outlive the async H2D copy
+    MEVI_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  const long long total = nq * (long long)k;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, st.buf, g.S,
+                     g.k, (long long)nq, out_score, reinterpret_cast<long long *>(out_id));
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" size_t mevi_topk_merge_workspace_bytes(int64_t, int64_t, int64_t, int64_t) { return 0; }
+
+extern "C" int mevi_topk_merge_f32(const float *scores, const int64_t *ids, int64_t nlists, int64_t nq,
+                                   int64_t k_in, int64_t k_out, float *out_score, int64_t *out_id,
+                                   void *, size_t, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(nlists > 0 && nq >= 0 && k_in > 0 && k_out > 0, MEVI_ERR_INVALID_ARG, "topk_merge: bad shape");
+  if (nq == 0) return MEVI_OK;
+  MEVI_REQUIRE(scores && ids && out_score && out_id, MEVI_ERR_INVALID_ARG, "topk_merge: null pointer");
+  MEVI_REQUIRE(nlists * k_in <= MAX_SORT, MEVI_ERR_UNSUPPORTED,
+               "topk_merge: nlists*k_in=%lld > %d (merge hierarchically)", (long long)(nlists * k_in), MAX_SORT);
+  MEVI_REQUIRE(k_out <= MAX_SORT, MEVI_ERR_UNSUPPORTED, "topk_merge: k_out too large");
+  int P = 512;
+  while (P < nlists * k_in) P <<= 1;
+  if ((size_t)P * 8 > 65536) {
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
+  }
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), (size_t)P * 8, stream, scores,
+                     reinterpret_cast<const long long *>(ids), (int)nlists, (long long)nq, (int)k_in, (int)k_out,
+                     out_score, reinterpret_cast<long long *>(out_id));
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}

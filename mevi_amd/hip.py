@@ -1,0 +1,77 @@
+"""ctypes binding of libmevi_hip.so (C ABI: include/mevi_hip.h).
+
+The library is loaded lazily and loudly: a missing .so or a missing GPU raises --
+there is no eager/CPU fallback anywhere in mevi_amd.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_int, c_int64, c_size_t, c_void_p
+
+import torch  # noqa: F401  (loads the HIP runtime the extension binds to)
+
+from .build import LIB
+
+_lib = None
+
+
+class MeviHipError(RuntimeError):
+    pass
+
+
+class IpTopkStats(ctypes.Structure):
+    _fields_ = [("n_chunks", c_int64), ("n_failed_queries", c_int64), ("n_fallback_chunks", c_int64)]
+
+
+_SIGNATURES = {
+    "mevi_abi_version": (c_int, []),
+    "mevi_last_error": (ctypes.c_char_p, []),
+    "mevi_ip_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "mevi_ip_topk_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mevi_topk_merge_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "mevi_topk_merge_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mevi_ip_topk_set_growth": (None, [c_double]),
+    "mevi_ip_topk_get_stats": (None, [ctypes.POINTER(IpTopkStats)]),
+}
+
+
+def exported_symbols():
+    """Names every entry point include/mevi_hip.h declares."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise MeviHipError(
+                f"{LIB} not found: build it with `python -m mevi_amd.build` "
+                "(or __graft_entry__.build()); mevi_amd has no CPU fallback")
+        L = ctypes.CDLL(LIB)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().mevi_last_error().decode("utf-8", "replace")
+        raise MeviHipError(f"{what} failed with status {status}: {msg}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise MeviHipError("no MI355X visible (torch.cuda.is_available() is False); "
+                           "mevi_amd has no CPU fallback")
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr())

@@ -1,0 +1,149 @@
+"""GPU parity of the dense arm (mevi_ip_topk_f32 / mevi_topk_merge_f32 through the C ABI)
+against oracle/mevi_oracle.c.  Bar: BIT-EXACT scores and identical ids -- both sides
+compute the same sequential fmaf chain and order by (score desc, id asc)."""
+import numpy as np
+import pytest
+import torch
+
+from mevi_amd import dense, hip
+from oracle import dense as odense
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(q, d, k, cuda, id_offset=0):
+    s, i = dense.ip_topk(torch.from_numpy(q).to(cuda), torch.from_numpy(d).to(cuda), k, id_offset=id_offset)
+    torch.cuda.synchronize()
+    return s.cpu().numpy(), i.cpu().numpy()
+
+
+def _check(q, d, k, cuda, id_offset=0):
+    s, i = _run(q, d, k, cuda, id_offset)
+    es, ei = odense.ip_topk_exact(q, d, k, id_offset)
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
+    return s, i
+
+
+def _stats():
+    st = hip.IpTopkStats()
+    hip.lib().mevi_ip_topk_get_stats(st)
+    return st
+
+
+@pytest.mark.parametrize("nq,nd,dim,k", [
+    (200, 20000, 768, 100),    # C1-shaped slice
+    (1, 5000, 768, 10),        # single query
+    (130, 4099, 768, 1000),    # ragged tiles, k=1000 (the reference's topk)
+    (37, 1000, 100, 7),        # dim not a multiple of the 32-wide K slab
+    (5, 129, 4, 3),            # tiny dim
+    (64, 9000, 768, 4096),     # largest supported k
+])
+def test_ip_topk_bit_exact(cuda, nq, nd, dim, k):
+    rng = np.random.default_rng(nq * 7919 + nd)
+    q = rng.standard_normal((nq, dim), dtype=np.float32)
+    d = rng.standard_normal((nd, dim), dtype=np.float32)
+    _check(q, d, k, cuda)
+
+
+def test_k_larger_than_corpus_pads_like_faiss(cuda):
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((9, 64), dtype=np.float32)
+    d = rng.standard_normal((50, 64), dtype=np.float32)
+    s, i = _check(q, d, 80, cuda)
+    assert (i[:, 50:] == -1).all() and (s[:, 50:] == -np.finfo(np.float32).max).all()
+    assert (np.sort(i[:, :50], axis=1) == np.arange(50)).all()
+
+
+def test_empty_corpus_and_empty_queries(cuda):
+    q = np.zeros((3, 8), np.float32)
+    s, i = _run(q, np.zeros((0, 8), np.float32), 5, cuda)
+    assert (i == -1).all() and (s == -np.finfo(np.float32).max).all()
+    s, i = _run(np.zeros((0, 8), np.float32), np.ones((10, 8), np.float32), 5, cuda)
+    assert s.shape == (0, 5) and i.shape == (0, 5)
+
+
+def test_exact_ties_break_by_ascending_id(cuda):
+    # MSMARCO holds duplicate passages -> exact score ties (SURVEY "Tie semantics")
+    rng = np.random.default_rng(11)
+    base = rng.integers(-3, 4, size=(40, 32)).astype(np.float32)
+    d = np.concatenate([base] * 30, axis=0)           # every row appears 30 times
+    q = rng.integers(-3, 4, size=(17, 32)).astype(np.float32)
+    s, i = _check(q, d, 100, cuda)
+    for r in range(q.shape[0]):
+        for a in range(99):
+            if s[r, a] == s[r, a + 1]:
+                assert i[r, a] < i[r, a + 1]
+
+
+def test_id_offset_and_shard_merge_equals_unsharded(cuda):
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((70, 128), dtype=np.float32)
+    d = rng.standard_normal((10007, 128), dtype=np.float32)
+    k = 200
+    full_s, full_i = _check(q, d, k, cuda)
+    for world in (2, 3, 8):
+        ls, li = [], []
+        for r in range(world):
+            a, b = dense.shard_range(d.shape[0], r, world)
+            s, i = _run(q, d[a:b], k, cuda, id_offset=a)
+            ls.append(s)
+            li.append(i)
+        ms, mi = dense.topk_merge(torch.from_numpy(np.stack(ls)).to(cuda), torch.from_numpy(np.stack(li)).to(cuda), k)
+        np.testing.assert_array_equal(mi.cpu().numpy(), full_i)
+        np.testing.assert_array_equal(ms.cpu().numpy().view(np.uint32), full_s.view(np.uint32))
+        os_, oi_ = odense.topk_merge(np.stack(ls), np.stack(li), k)
+        np.testing.assert_array_equal(oi_, full_i)
+
+
+def test_adversarial_row_order_takes_guaranteed_path(cuda):
+    # rows sorted by ascending score for every query: each chunk floods the
+    # candidate list -> overflow -> flagged queries are recomputed exactly.
+    rng = np.random.default_rng(9)
+    dim, nd, k = 32, 60000, 50
+    direction = rng.standard_normal(dim).astype(np.float32)
+    scale = np.linspace(-1.0, 1.0, nd, dtype=np.float32)[:, None]
+    d = scale * direction[None, :] + 1e-3 * rng.standard_normal((nd, dim)).astype(np.float32)
+    q = np.stack([direction * (1 + 0.1 * j) for j in range(6)]).astype(np.float32)
+    q = np.concatenate([q, rng.standard_normal((10, dim)).astype(np.float32)])
+    _check(q, d, k, cuda)
+    st = _stats()
+    assert st.n_failed_queries >= 6 and st.n_fallback_chunks > 0
+
+
+def test_growth_override_changes_chunking_not_results(cuda):
+    rng = np.random.default_rng(21)
+    q = rng.standard_normal((33, 64), dtype=np.float32)
+    d = rng.standard_normal((50000, 64), dtype=np.float32)
+    L = hip.lib()
+    try:
+        L.mevi_ip_topk_set_growth(0.0)
+        a = _check(q, d, 20, cuda)
+        n0 = _stats().n_chunks
+        L.mevi_ip_topk_set_growth(1.0)
+        b = _check(q, d, 20, cuda)
+        n1 = _stats().n_chunks
+    finally:
+        L.mevi_ip_topk_set_growth(0.0)
+    assert n1 > n0
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_blas_restatement_agrees_to_rounding(cuda):
+    # the faiss-style BLAS evaluation differs from the fmaf chain only by f32 rounding
+    rng = np.random.default_rng(8)
+    q = rng.standard_normal((50, 768), dtype=np.float32)
+    d = rng.standard_normal((30000, 768), dtype=np.float32)
+    s, i = _run(q, d, 100, cuda)
+    bs, bi = odense.ip_topk_blas(q, d, 100)
+    assert np.abs(s - bs).max() <= 1e-3          # |score| ~ 100, f32 eps * sum|a*b|
+    assert (i == bi).mean() > 0.99               # only near-ties may swap
+
+
+def test_rejects_bad_arguments(cuda):
+    q = torch.zeros((4, 6), device=cuda)
+    d = torch.zeros((9, 6), device=cuda)
+    with pytest.raises(hip.MeviHipError):
+        dense.ip_topk(q, d, 3)                    # dim % 4 != 0
+    with pytest.raises(hip.MeviHipError):
+        dense.ip_topk(torch.zeros((4, 8), device=cuda), torch.zeros((9, 8), device=cuda), 5000)  # k > 4096

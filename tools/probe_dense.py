@@ -1,0 +1,29 @@
+"""Quick timing probe of the dense arm (not the bench): python tools/probe_dense.py [nd] [nq] [k]."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from mevi_amd import dense, hip  # noqa: E402
+
+nd = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 6980
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+dim = 768
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(1)
+q = torch.randn((nq, dim), device=dev, generator=g)
+d = torch.empty((nd, dim), device=dev)
+for a in range(0, nd, 1 << 20):
+    d[a:a + (1 << 20)] = 0.05 * torch.randn((min(1 << 20, nd - a), dim), device=dev, generator=g) + 0.02
+for it in range(3):
+    torch.cuda.synchronize()
+    t = time.time()
+    s, i = dense.ip_topk(q, d, k)
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    st = hip.IpTopkStats()
+    hip.lib().mevi_ip_topk_get_stats(st)
+    print(f"nd={nd} nq={nq} k={k}: {dt*1e3:.1f} ms  {2*nq*nd*dim/dt/1e12:.1f} TFLOP/s  "
+          f"chunks={st.n_chunks} failed={st.n_failed_queries}", flush=True)
