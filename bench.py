@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MEVI hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): the dense arm of MEVI, i.e. what
+`faiss_search.py --param Flat` computes for MSMARCO dev: 6980 x 768 f32 queries
+against the 8,841,823 x 768 f32 passage-embedding matrix (27.16 GB, resident in
+HBM), exact inner-product top-1000.  One "step" = one full search of all queries.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: the corpus is row-sharded (ceil(N_docs/N) rows per rank), queries are
+replicated, every rank searches its shard with global ids, one RCCL all-gather of
+the per-shard top-k + a device merge (mevi_amd.dense.sharded_ip_topk).  Total
+work is fixed => "scaling": "strong".  Rank 0 prints ONE JSON line.
+
+Synthetic data (there is no network for MSMARCO): corpus rows ~ 0.05*N(0,1) + 0.02
+generated on device from per-block seeds, queries = planted neighbours of rows in
+block 0 (so rank-1 correctness is checkable without the oracle).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mevi_amd import dense, hip  # noqa: E402
+
+N_DOCS = 8_841_823   # MEVI/marco_eval_nci_rq.sh:26 (--save_hard_neg = corpus size)
+N_QUERIES = 6980     # MSMARCO dev
+DIM = 768
+TOPK = 1000          # MEVI/faiss_search.py:88
+BLOCK = 65536        # rows per RNG block (seed = 10_000 + block index)
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def gen_block(b, device, n_docs):
+    rows = min(BLOCK, n_docs - b * BLOCK)
+    g = torch.Generator(device=device).manual_seed(10_000 + b)
+    return 0.05 * torch.randn((rows, DIM), device=device, generator=g) + 0.02
+
+
+def gen_shard(start, end, device, n_docs):
+    out = torch.empty((end - start, DIM), dtype=torch.float32, device=device)
+    b = start // BLOCK
+    while b * BLOCK < end:
+        blk = gen_block(b, device, n_docs)
+        lo = max(start, b * BLOCK)
+        hi = min(end, b * BLOCK + blk.shape[0])
+        out[lo - start:hi - start] = blk[lo - b * BLOCK:hi - b * BLOCK]
+        b += 1
+    return out
+
+
+def planted_ids(nq, n_docs):
+    return (np.arange(nq, dtype=np.int64) * 9) % min(BLOCK, n_docs)
+
+
+def gen_queries(nq, device, n_docs):
+    blk0 = gen_block(0, device, n_docs)
+    gid = torch.from_numpy(planted_ids(nq, n_docs)).to(device)
+    g = torch.Generator(device=device).manual_seed(1234)
+    return (blk0[gid] + 0.005 * torch.randn((nq, DIM), device=device, generator=g)).contiguous()
+
+
+def cpu_baseline(n_docs, nq_full, target_s=12.0):
+    """faiss-Flat-style CPU evaluation (numpy sgemm + partial sort = oracle.dense.ip_topk_blas)
+    on a bounded sample, scaled linearly in rows to the full corpus."""
+    from oracle import dense as odense
+
+    nd_s = min(n_docs, 500_000)
+    rng = np.random.default_rng(7)
+    d = (0.05 * rng.standard_normal((nd_s, DIM), dtype=np.float32) + 0.02).astype(np.float32)
+    q_all = (0.05 * rng.standard_normal((nq_full, DIM), dtype=np.float32) + 0.02).astype(np.float32)
+    t = time.time()
+    odense.ip_topk_blas(q_all[:128], d, TOPK)
+    cal = time.time() - t
+    nq_s = int(min(nq_full, max(128, 128 * target_s / max(cal, 1e-3))))
+    t = time.time()
+    odense.ip_topk_blas(q_all[:nq_s], d, TOPK)
+    dt = time.time() - t
+    qps_sample = nq_s / dt
+    qps_full = qps_sample * nd_s / n_docs
+    try:
+        import threadpoolctl
+        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count()
+    return {
+        "value": qps_full, "unit": "queries/s", "cores": int(cores), "kind": "port",
+        "sample": f"{nq_s} queries x {nd_s} docs x {DIM} f32, top-{TOPK}, numpy sgemm + argpartition "
+                  f"(faiss Flat-IP style) took {dt:.2f}s; scaled x{nd_s}/{n_docs} rows to the full corpus",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--docs", type=int, default=N_DOCS, help="corpus rows (default: MSMARCO 8,841,823)")
+    ap.add_argument("--queries", type=int, default=N_QUERIES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    hip.require_gpu()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n_docs, nq = args.docs, args.queries
+    start, end = dense.shard_range(n_docs, rank, world)
+    docs = gen_shard(start, end, device, n_docs)
+    query = gen_queries(nq, device, n_docs)
+    torch.cuda.synchronize()
+
+    L = hip.lib()
+
+    def step():
+        return dense.sharded_ip_topk(query, docs, TOPK, id_offset=start)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        s, i = step()
+    barrier()
+    L.mevi_ip_topk_set_profiling(1)
+    filt_ms = filt_flops = comp_ms = 0.0
+    launches = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s, i = step()
+        st = hip.IpTopkStats()
+        L.mevi_ip_topk_get_stats(st)
+        filt_ms += st.filter_ms
+        comp_ms += st.compact_ms
+        filt_flops += st.filter_flops
+        launches += st.n_chunks + st.n_fallback_chunks
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.mevi_ip_topk_set_profiling(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity (untimed): every query's planted neighbour must be its rank-1 hit
+    top1 = i[:, 0].cpu().numpy()
+    planted_ok = float((top1 == planted_ids(nq, n_docs)).mean())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        achieved = filt_flops / (filt_ms * 1e-3) / 1e12 if filt_ms > 0 else None
+        out = {
+            "metric": "queries/sec @ MRR@10-match, MSMARCO dev, 1/2/4/8 MI355X",
+            "value": nq * args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2 dense arm (faiss_search.py Flat): %d x %d f32 queries x %d x %d f32 docs, "
+                            "exact inner-product top-%d" % (nq, DIM, n_docs, DIM, TOPK),
+                "queries": nq, "docs": n_docs, "dim": DIM, "topk": TOPK,
+                "parallelism": "corpus row-sharded x%d, RCCL all-gather of per-shard top-k" % world
+                if world > 1 else "single GPU",
+                "planted_top1_ok": planted_ok,
+            },
+            "roofline": {
+                "kernel": "ip_filter_kernel",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS if achieved else None,
+                "traffic": None,
+                "launches": launches,
+                "avg_launch_ms": filt_ms / launches if launches else None,
+                "algorithmic_flops_per_launch": filt_flops / launches if launches else None,
+                "other_kernels_ms_per_step": {"compact_kernel": comp_ms / args.steps},
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n_docs, nq)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,8 +82,12 @@ typedef struct mevi_ip_topk_stats {
   int64_t n_chunks;          /* filter launches of the main pass */
   int64_t n_failed_queries;  /* queries re-run through the guaranteed path */
   int64_t n_fallback_chunks; /* filter launches of the guaranteed path */
+  double filter_ms;          /* sum of ip_filter_kernel durations (HIP events on the call's stream; profiling on) */
+  double compact_ms;         /* sum of compact_kernel durations (profiling on) */
+  double filter_flops;       /* algorithmic flops of those filter launches: 2 * nq * rows * dim */
 } mevi_ip_topk_stats;
 void mevi_ip_topk_set_growth(double growth);
+void mevi_ip_topk_set_profiling(int enable); /* record HIP events around every filter/compact launch */
 void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out);
 
 #ifdef __cplusplus

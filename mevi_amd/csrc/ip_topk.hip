@@ -115,9 +115,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void ip_filter_kernel(
   }
 
   float4 ra[4], rb[4];
-  const int nslab = (dim + BK - 1) / BK;
+  const int nfull = dim / BK;          // slabs loaded without a K guard
+  const int nslab = (dim + BK - 1) / BK;  // + one guarded tail slab when dim % 32 != 0
 
+  // Global -> register loads of slab s.  The full-slab form is unconditional so the
+  // loads stay in flight across the MFMA block (the wait lands in lstore()).
   auto gload = [&](int s) {
+    const int kk = s * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const float4 *>(dptr[i] + kk);
+      rb[i] = *reinterpret_cast<const float4 *>(qptr[i] + kk);
+    }
+  };
+  auto gload_tail = [&](int s) {
     const int kk = s * BK;
     const bool in = (kk + skq) < dim;  // dim % 4 == 0 -> a float4 is all-in or all-out
 #pragma unroll
@@ -149,14 +160,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ip_filter_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
-
-  for (int s = 0; s < nslab; ++s) {
-    if (s + 1 < nslab) gload(s + 1);
-
-    const float *sA = lds + (s & 1) * (BM + BN) * LDSROW;
+  auto compute = [&](int bufi) {
+    const float *sA = lds + bufi * (BM + BN) * LDSROW;
     const float *sB = sA + BM * LDSROW;
     const float *pa = sA + (64 * wm + lrow) * LDSROW + 16 * half;
     const float *pb = sB + (64 * wn + lrow) * LDSROW + 16 * half;
@@ -178,10 +183,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void ip_filter_kernel(
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
       }
     }
+  };
 
-    if (s + 1 < nslab) lstore((s + 1) & 1);
+  // Pin the staged registers at this program point: the even/odd shuffle (and the
+  // vmcnt wait it needs) must not be hoisted above the MFMA block.
+  auto pin = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
+      asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
+    }
+  };
+
+  if (nfull > 0) gload(0); else gload_tail(0);
+  lstore(0);
+  __syncthreads();
+
+  int s = 0;
+  for (; s + 1 < nfull; ++s) {  // steady state: the next slab is a full one
+    gload(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    pin();
+    lstore((s + 1) & 1);
     __syncthreads();
   }
+  if (nslab > nfull && nfull > 0) {  // guarded K tail (dim % 32 != 0)
+    gload_tail(s + 1);
+    compute(s & 1);
+    lstore((s + 1) & 1);
+    __syncthreads();
+    ++s;
+  }
+  compute(s & 1);
 
   // ---- epilogue: threshold filter -----------------------------------------
   // C/D map of 32x32 MFMA: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*half (doc)
@@ -376,7 +411,30 @@ static SearchState carve_state(char *&p, int64_t nq, const TopkGeom &g) {
 }
 
 thread_local double g_growth = 0.0;
-thread_local mevi_ip_topk_stats g_stats = {0, 0, 0};
+thread_local int g_profile = 0;
+thread_local mevi_ip_topk_stats g_stats = {0, 0, 0, 0.0, 0.0, 0.0};
+thread_local std::vector<hipEvent_t> g_events;  // triples: before filter, after filter, after compact
+
+static void profile_mark(hipStream_t stream) {
+  if (!g_profile) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, stream);
+  g_events.push_back(e);
+}
+
+// call after the stream has been synchronised
+static void profile_collect() {
+  for (size_t i = 0; i + 3 <= g_events.size(); i += 3) {
+    float f = 0.f, c = 0.f;
+    (void)hipEventElapsedTime(&f, g_events[i], g_events[i + 1]);
+    (void)hipEventElapsedTime(&c, g_events[i + 1], g_events[i + 2]);
+    g_stats.filter_ms += f;
+    g_stats.compact_ms += c;
+  }
+  for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
+  g_events.clear();
+}
 
 // Walk docs [0, nd) in chunks; returns number of filter launches, <0 on error.
 static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, int dim,
@@ -412,11 +470,15 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       set_error("ip_topk: grid too large (%lld workgroups)", (long long)nwg);
       return -1;
     }
+    profile_mark(stream);
     hipLaunchKernelGGL(ip_filter_kernel, dim3((unsigned)nwg), dim3(NTHREADS), 0, stream, Q, (int)nq, D,
                        (long long)seen, (long long)(seen + chunk), dim, st.tau, st.buf, st.count, g.S, g.k,
                        g.cap, id_base, n_qtiles, (int)n_dtiles);
+    profile_mark(stream);
     hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nq), dim3(256), (size_t)g.S * 8, stream, st.buf,
                        st.count, st.tau, st.failed, g.S, g.k, g.cap);
+    profile_mark(stream);
+    g_stats.filter_flops += 2.0 * (double)nq * (double)chunk * (double)dim;
     seen += chunk;
     ++launches;
   }
@@ -440,6 +502,7 @@ extern "C" size_t mevi_ip_topk_workspace_bytes(int64_t nq, int64_t dim, int64_t 
 }
 
 extern "C" void mevi_ip_topk_set_growth(double growth) { g_growth = growth; }
+extern "C" void mevi_ip_topk_set_profiling(int enable) { g_profile = enable; }
 extern "C" void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out) {
   if (out) *out = g_stats;
 }
@@ -448,7 +511,9 @@ extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, i
                                 int64_t k, int64_t id_offset, float *out_score, int64_t *out_id,
                                 void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  g_stats = {0, 0, 0};
+  g_stats = {0, 0, 0, 0.0, 0.0, 0.0};
+  for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
+  g_events.clear();
   MEVI_REQUIRE(nq >= 0 && nd >= 0 && dim > 0 && k > 0, MEVI_ERR_INVALID_ARG,
                "ip_topk: bad shape nq=%lld nd=%lld dim=%lld k=%lld", (long long)nq, (long long)nd,
                (long long)dim, (long long)k);
@@ -482,6 +547,7 @@ extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, i
   std::vector<unsigned int> failed((size_t)nq);
   MEVI_HIP_CHECK(hipMemcpyAsync(failed.data(), st.failed, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
   MEVI_HIP_CHECK(hipStreamSynchronize(stream));
+  profile_collect();
   std::vector<int> idx;
   for (int64_t i = 0; i < nq; ++i)
     if (failed[(size_t)i]) idx.push_back((int)i);
@@ -496,6 +562,7 @@ extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, i
     hipLaunchKernelGGL(scatter_top_kernel, dim3((unsigned)nf), dim3(256), 0, stream, fb.buf, fidx, (int)nf, g.S, g.k, st.buf);
     // idx (host) must outlive the async H2D copy
     MEVI_HIP_CHECK(hipStreamSynchronize(stream));
+    profile_collect();
   }
   const long long total = nq * (long long)k;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, st.buf, g.S,

@@ -19,7 +19,8 @@ class MeviHipError(RuntimeError):
 
 
 class IpTopkStats(ctypes.Structure):
-    _fields_ = [("n_chunks", c_int64), ("n_failed_queries", c_int64), ("n_fallback_chunks", c_int64)]
+    _fields_ = [("n_chunks", c_int64), ("n_failed_queries", c_int64), ("n_fallback_chunks", c_int64),
+                ("filter_ms", c_double), ("compact_ms", c_double), ("filter_flops", c_double)]
 
 
 _SIGNATURES = {
@@ -32,6 +33,7 @@ _SIGNATURES = {
     "mevi_topk_merge_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mevi_ip_topk_set_growth": (None, [c_double]),
+    "mevi_ip_topk_set_profiling": (None, [c_int]),
     "mevi_ip_topk_get_stats": (None, [ctypes.POINTER(IpTopkStats)]),
 }
 
