@@ -35,11 +35,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;          // docs per workgroup tile   (MFMA A rows)
-constexpr int BN = 128;          // queries per workgroup tile (MFMA B cols)
+constexpr int BM = 128;          // docs per wave-group tile (MFMA A rows)
 constexpr int BK = 32;           // K slab
-constexpr int LDSROW = 36;       // floats per LDS row: 16 even-k | 16 odd-k | 4 pad
-constexpr int NTHREADS = 256;    // 4 waves, each owns a 64x64 sub-tile
 constexpr int MAX_SORT = 16384;  // largest LDS sort (128 KiB of keys)
 
 struct TopkGeom {
@@ -75,154 +72,238 @@ __device__ inline int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void ip_filter_kernel(
-    const float *__restrict__ Q, int nq, const float *__restrict__ D,
-    long long doc_begin, long long doc_end, int dim,
-    const float *__restrict__ tau, unsigned long long *__restrict__ buf,
-    unsigned int *__restrict__ count, int S, int k, int cap,
-    unsigned int id_base, int n_qtiles, int n_dtiles) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDSROW];
+// ---------------------------------------------------------------------------
+// ip_filter_kernel: f32-MFMA tile GEMM with a threshold-filter epilogue.
+//
+// One 512-thread workgroup per CU, two 4-wave groups.  Group g owns the 128-doc
+// tile (2*dpair+g); both share one query tile of QT = 64*NI rows.  Inside a group
+// wave (wm, wn) owns 64 docs x 32*NI queries = 2 x NI MFMA accumulators (32x32).
+// The two waves that share a SIMD belong to different groups and alternate roles:
+//   MFMA role    -- 16 k-steps x (2*NI) v_mfma_f32_32x32x2_f32 on slab s.  A wave
+//                   issues in order and the matrix pipe holds ONE MFMA (64 cycles),
+//                   so every other instruction sits in the shadow of an MFMA: the
+//                   stream is pinned (sched_group_barrier) to {MFMA, ds_read} x(2+NI),
+//                   {MFMA, global_load}, MFMA... per pair of k-steps; fragment reads
+//                   run two pairs ahead, the global loads of the slab this group
+//                   stages next are spread one per pair.
+//   staging role -- convert the staged registers into the LDS image of the next
+//                   slab (raised priority: a handful of ds_write2_b32).
+// Hand-over is early: the MFMA role executes its barrier once its last LDS read
+// has been issued (after pair 5 of 8), so the other group warms up (first LDS
+// reads) underneath the remaining MFMAs and the pipe does not idle at the switch.
+//   G0: [compute(s) + loads(s+1)] [lstore(s+1)] barrier ...
+//   G1: [lstore(s+1)] barrier [compute(s) + loads(s+2)] ...
+// LDS image: row-major [row][k], natural k order, odd row stride (33 floats) so
+// that both the b32 fragment reads (32 rows, same k) and the staging stores are
+// bank-conflict free.  MFMA lane half h consumes k = 2j + h, which makes each score
+// the sequential fmaf chain over k (bit-exact contract with the oracle).
+// Diagnostic build only (VARIANT 3): s_memtime stamps per wave of one workgroup.
+__device__ unsigned long long g_stamps[8 * 8 * 8];
+#define PP_STAMP(slot)                                                                          \
+  do {                                                                                          \
+    if (VARIANT == 3 && blockIdx.x == 4096 && s < 8) {                                          \
+      unsigned long long _t;                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+      if (lane == 0) g_stamps[((t >> 6) * 8 + s) * 8 + (slot)] = _t;                            \
+    }                                                                                           \
+  } while (0)
 
-  const int nwg = n_qtiles * n_dtiles;
+constexpr int PP_THREADS = 512;
+constexpr int PP_LD = 33;  // floats per LDS row
+
+template <int NI, bool KTAIL, int VARIANT>
+__global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
+    const float *__restrict__ Q, int nq, const float *__restrict__ D, long long doc_begin,
+    long long doc_end, int dim, const float *__restrict__ tau, unsigned long long *__restrict__ buf,
+    unsigned int *__restrict__ count, int S, int k, int cap, unsigned int id_base, int n_qtiles,
+    int n_dpairs) {
+  constexpr int QT = 64 * NI;          // query rows per workgroup
+  constexpr int ROWS = 2 * BM + QT;    // LDS rows per buffer: A0[128] | A1[128] | B[QT]
+  constexpr int NLOAD = 4 + NI;        // float4 global loads per thread per slab
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 * ROWS * PP_LD floats
+
+  const int nwg = n_qtiles * n_dpairs;
   const int wg = xcd_remap(blockIdx.x, nwg);
-  const int dtile = wg / n_qtiles;
-  const int qtile = wg - dtile * n_qtiles;
+  const int dpair = wg / n_qtiles;
+  const int qtile = wg - dpair * n_qtiles;
 
   const int t = threadIdx.x;
+  const int grp = __builtin_amdgcn_readfirstlane(t >> 8);  // wave-uniform
+  const int tg = t & 255;
   const int lane = t & 63;
-  const int wave = t >> 6;
-  const int wm = wave >> 1;  // doc half of the tile
-  const int wn = wave & 1;   // query half of the tile
+  const int wave = tg >> 6;
+  const int wm = wave >> 1;
+  const int wn = wave & 1;
   const int lrow = lane & 31;
   const int half = lane >> 5;
 
-  // ---- staging map: thread -> (row, 4 consecutive k) of the 128x32 slab ----
-  const int srow = t >> 3;        // 0..31 (+32*i)
-  const int skq = (t & 7) * 4;    // k offset inside the slab
-  const long long drow0 = doc_begin + (long long)dtile * BM;
-  const int qrow0 = qtile * BN;
+  const int srow = tg >> 3;
+  const int skq = (tg & 7) * 4;
+  const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
+  const int qrow0 = qtile * QT;
 
+  // staging duty of this thread: 4 float4 of its group's doc tile, NI float4 of the
+  // shared query tile (rows (QT/2)*grp + ...)
   const float *dptr[4];
-  const float *qptr[4];
+  const float *qptr[NI];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     long long dr = drow0 + srow + 32 * i;
-    if (dr > doc_end - 1) dr = doc_end - 1;  // clamp: result masked in the epilogue
+    if (dr > doc_end - 1) dr = doc_end - 1;  // clamp: masked in the epilogue
     dptr[i] = D + (size_t)dr * (size_t)dim + skq;
-    int qr = qrow0 + srow + 32 * i;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int qr = qrow0 + (QT / 2) * grp + srow + 32 * i;
     if (qr > nq - 1) qr = nq - 1;
     qptr[i] = Q + (size_t)qr * (size_t)dim + skq;
   }
 
-  float4 ra[4], rb[4];
-  const int nfull = dim / BK;          // slabs loaded without a K guard
-  const int nslab = (dim + BK - 1) / BK;  // + one guarded tail slab when dim % 32 != 0
+  float4 ra[4], rb[NI];
+  const int nslab = (dim + BK - 1) / BK;
 
-  // Global -> register loads of slab s.  The full-slab form is unconditional so the
-  // loads stay in flight across the MFMA block (the wait lands in lstore()).
+  auto gload_one = [&](int s, int i) {
+    int kk = s * BK;
+    if (KTAIL && kk + skq + 4 > dim) kk = dim - 4 - skq;  // stay in bounds; zeroed in lstore
+    if (i < 4) ra[i] = *reinterpret_cast<const float4 *>(dptr[i] + kk);
+    else rb[i - 4] = *reinterpret_cast<const float4 *>(qptr[i - 4] + kk);
+  };
   auto gload = [&](int s) {
-    const int kk = s * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const float4 *>(dptr[i] + kk);
-      rb[i] = *reinterpret_cast<const float4 *>(qptr[i] + kk);
-    }
+    for (int i = 0; i < NLOAD; ++i) gload_one(s, i);
   };
-  auto gload_tail = [&](int s) {
-    const int kk = s * BK;
-    const bool in = (kk + skq) < dim;  // dim % 4 == 0 -> a float4 is all-in or all-out
+  auto lstore = [&](int s) {
+    float *base = lds + (s & 1) * ROWS * PP_LD;
+    float *sA = base + (grp * BM + srow) * PP_LD + skq;
+    float *sB = base + (2 * BM + (QT / 2) * grp + srow) * PP_LD + skq;
+    const bool zero = KTAIL && (s * BK + skq >= dim);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = in ? *reinterpret_cast<const float4 *>(dptr[i] + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[i] = in ? *reinterpret_cast<const float4 *>(qptr[i] + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = ra[i];
+      if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float *p = sA + 32 * i * PP_LD;
+      p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
     }
-  };
-  // LDS image per row: [k even (16 floats)] [k odd (16 floats)] [pad 4]
-  auto lstore = [&](int bufi) {
-    float *sA = lds + bufi * (BM + BN) * LDSROW;
-    float *sB = sA + BM * LDSROW;
-    const int e = skq >> 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = srow + 32 * i;
-      *reinterpret_cast<float2 *>(sA + r * LDSROW + e) = make_float2(ra[i].x, ra[i].z);
-      *reinterpret_cast<float2 *>(sA + r * LDSROW + 16 + e) = make_float2(ra[i].y, ra[i].w);
-      *reinterpret_cast<float2 *>(sB + r * LDSROW + e) = make_float2(rb[i].x, rb[i].z);
-      *reinterpret_cast<float2 *>(sB + r * LDSROW + 16 + e) = make_float2(rb[i].y, rb[i].w);
+    for (int i = 0; i < NI; ++i) {
+      float4 v = rb[i];
+      if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float *p = sB + 32 * i * PP_LD;
+      p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NI];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  auto compute = [&](int bufi) {
-    const float *sA = lds + bufi * (BM + BN) * LDSROW;
-    const float *sB = sA + BM * LDSROW;
-    const float *pa = sA + (64 * wm + lrow) * LDSROW + 16 * half;
-    const float *pb = sB + (64 * wn + lrow) * LDSROW + 16 * half;
+  auto compute = [&](int s, int gs, bool with_barrier) {
+    const float *base = lds + (s & 1) * ROWS * PP_LD;
+    const float *pa = base + (grp * BM + 64 * wm + lrow) * PP_LD + half;
+    const float *pb = base + (2 * BM + 32 * NI * wn + lrow) * PP_LD + half;
+    float av[2][16], bv[NI][16];
+    auto ld = [&](int pr) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      float4 a0 = *reinterpret_cast<const float4 *>(pa + 4 * jj);
-      float4 a1 = *reinterpret_cast<const float4 *>(pa + 32 * LDSROW + 4 * jj);
-      float4 b0 = *reinterpret_cast<const float4 *>(pb + 4 * jj);
-      float4 b1 = *reinterpret_cast<const float4 *>(pb + 32 * LDSROW + 4 * jj);
-      const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
-      const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
-      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
-      const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+      for (int j = 2 * pr; j < 2 * pr + 2; ++j) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
+        for (int mi = 0; mi < 2; ++mi) av[mi][j] = pa[32 * mi * PP_LD + 2 * j];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bv[ni][j] = pb[32 * ni * PP_LD + 2 * j];
+      }
+    };
+    ld(0);
+    ld(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      if (pr + 2 < 8) ld(pr + 2);
+      if (gs >= 0 && pr < NLOAD) gload_one(gs, pr);
+#pragma unroll
+      for (int j = 2 * pr; j < 2 * pr + 2; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+      // sched_group_barrier(mask, count, sync id): 0x008 MFMA, 0x100 DS read, 0x020 VMEM read
+      constexpr int NM = 4 * NI;  // MFMAs in this pair of k-steps
+      const bool rd = (pr + 2 < 8), gl = (gs >= 0 && pr < NLOAD);
+      if (rd) {
+#pragma unroll
+        for (int i = 0; i < 2 + NI; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      if (gl) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      if (rd && gl) __builtin_amdgcn_sched_group_barrier(0x008, NM - (2 + NI) - 1, 0);
+      else if (rd) __builtin_amdgcn_sched_group_barrier(0x008, NM - (2 + NI), 0);
+      else if (gl) __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
+      else __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      // Early hand-over: after pair 5 every LDS read of this slab has been issued (the
+      // barrier's lgkmcnt(0) retires them), so the other group may start its phase now.
+      if (pr == 5) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (with_barrier) __syncthreads();
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
-  // Pin the staged registers at this program point: the even/odd shuffle (and the
-  // vmcnt wait it needs) must not be hoisted above the MFMA block.
-  auto pin = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
-      asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
-    }
-  };
-
-  if (nfull > 0) gload(0); else gload_tail(0);
+  // ---- prologue: slab 0 staged by everyone; G1 already has slab 1 in flight
+  gload(0);
   lstore(0);
+  if (grp == 1 && nslab > 1) gload(1);
   __syncthreads();
 
-  int s = 0;
-  for (; s + 1 < nfull; ++s) {  // steady state: the next slab is a full one
-    gload(s + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(s & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    pin();
-    lstore((s + 1) & 1);
-    __syncthreads();
+  // Two role-specialised loops (wave-uniform branch; both execute 2*(nslab-1) barriers,
+  // one inside compute() and one after lstore()).
+  if (grp == 0) {
+    for (int s = 0; s + 1 < nslab; ++s) {
+      PP_STAMP(0);
+      compute(s, s + 1, true);
+      PP_STAMP(1);
+      __builtin_amdgcn_s_setprio(3);
+      lstore(s + 1);
+      __builtin_amdgcn_s_setprio(0);
+      PP_STAMP(2);
+      __syncthreads();
+      PP_STAMP(3);
+    }
+  } else {
+    for (int s = 0; s + 2 < nslab; ++s) {
+      PP_STAMP(0);
+      __builtin_amdgcn_s_setprio(3);
+      lstore(s + 1);
+      __builtin_amdgcn_s_setprio(0);
+      PP_STAMP(1);
+      __syncthreads();
+      PP_STAMP(2);
+      compute(s, s + 2, true);
+      PP_STAMP(3);
+    }
+    if (nslab >= 2) {
+      lstore(nslab - 1);
+      __syncthreads();
+      compute(nslab - 2, -1, true);
+    }
   }
-  if (nslab > nfull && nfull > 0) {  // guarded K tail (dim % 32 != 0)
-    gload_tail(s + 1);
-    compute(s & 1);
-    lstore((s + 1) & 1);
-    __syncthreads();
-    ++s;
-  }
-  compute(s & 1);
+  compute(nslab - 1, -1, false);  // last slab: nothing left to stage, both groups run together
 
-  // ---- epilogue: threshold filter -----------------------------------------
-  // C/D map of 32x32 MFMA: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*half (doc)
+  // ---- epilogue: threshold filter -------------------------------------------
+  // C/D map of the 32x32 MFMA: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*half (doc)
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int qi = qrow0 + 64 * wn + 32 * ni + lrow;
+  for (int ni = 0; ni < NI; ++ni) {
+    const int qi = qrow0 + 32 * NI * wn + 32 * ni + lrow;
     const bool qok = qi < nq;
     const float tq = qok ? tau[qi] : INFINITY;
 #pragma unroll
@@ -412,6 +493,7 @@ static SearchState carve_state(char *&p, int64_t nq, const TopkGeom &g) {
 
 thread_local double g_growth = 0.0;
 thread_local int g_profile = 0;
+thread_local int g_variant = 0;  // 3: diagnostic stamp build
 thread_local mevi_ip_topk_stats g_stats = {0, 0, 0, 0.0, 0.0, 0.0};
 thread_local std::vector<hipEvent_t> g_events;  // triples: before filter, after filter, after compact
 
@@ -451,29 +533,55 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       return -1;
     }
   }
-  const int n_qtiles = (int)((nq + BN - 1) / BN);
+  // Query-tile width: NI = 2 (128 query rows per workgroup).  NI = 4 (256 rows, 128
+  // MFMAs per phase) was measured at the same MFMA-pipe utilisation (85.6 % vs 85.4 %)
+  // and pads nq further, so only NI = 2 is instantiated.
+  const int ni = 2;
+  const int qt = 64 * ni;
+  const int n_qtiles = (int)((nq + qt - 1) / qt);
   double growth = g_growth > 0.0 ? g_growth : (double)(g.cap / (3 * g.k));
   if (growth < 1.0) growth = 1.0;
-  const int64_t cap_docs = (g.cap / BM) * BM;  // chunk that can never overflow, tile aligned
+  const int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
+  const size_t pp_lds = (size_t)2 * (2 * BM + qt) * PP_LD * sizeof(float);
+  const bool ktail = (dim % BK) != 0;
+  const void *fn = nullptr;
+#define MEVI_PICK(NI_, T_, V_) fn = reinterpret_cast<const void *>(ip_filter_kernel<NI_, T_, V_>)
+  if (g_variant == 3 && !ktail) MEVI_PICK(2, false, 3);
+  else if (ktail) MEVI_PICK(2, true, 0);
+  else MEVI_PICK(2, false, 0);
+#undef MEVI_PICK
+  // opt in to > 64 KiB dynamic LDS (per device; cheap, so done on every call)
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds) != hipSuccess) {
+    set_error("ip_topk: cannot raise dynamic LDS to %zu bytes", pp_lds);
+    return -1;
+  }
   int64_t seen = 0, launches = 0;
   while (seen < nd) {
     int64_t chunk = cap_docs;
     if (!guaranteed && seen >= g.k) {
       int64_t grown = (int64_t)((double)seen * growth);
-      grown = grown / BM * BM;
+      grown = grown / (2 * BM) * (2 * BM);
       if (grown > chunk) chunk = grown;
     }
     if (chunk > nd - seen) chunk = nd - seen;
-    const int64_t n_dtiles = (chunk + BM - 1) / BM;
+    const int64_t n_dtiles = (chunk + 2 * BM - 1) / (2 * BM);  // doc-tile pairs (ping-pong kernel)
     const int64_t nwg = n_dtiles * n_qtiles;
     if (nwg > 0x7fffffffLL) {
       set_error("ip_topk: grid too large (%lld workgroups)", (long long)nwg);
       return -1;
     }
     profile_mark(stream);
-    hipLaunchKernelGGL(ip_filter_kernel, dim3((unsigned)nwg), dim3(NTHREADS), 0, stream, Q, (int)nq, D,
-                       (long long)seen, (long long)(seen + chunk), dim, st.tau, st.buf, st.count, g.S, g.k,
-                       g.cap, id_base, n_qtiles, (int)n_dtiles);
+{
+      int nq_i = (int)nq, n_dp = (int)n_dtiles, n_qt = n_qtiles;
+      long long d0 = (long long)seen, d1 = (long long)(seen + chunk);
+      const float *tau_c = st.tau;
+      void *args[] = {(void *)&Q, &nq_i, (void *)&D, &d0, &d1, &dim, (void *)&tau_c, (void *)&st.buf,
+                      (void *)&st.count, (void *)&g.S, (void *)&g.k, (void *)&g.cap, &id_base, &n_qt, &n_dp};
+      if (hipLaunchKernel(fn, dim3((unsigned)nwg), dim3(PP_THREADS), args, pp_lds, stream) != hipSuccess) {
+        set_error("ip_topk: filter kernel launch failed");
+        return -1;
+      }
+    }
     profile_mark(stream);
     hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nq), dim3(256), (size_t)g.S * 8, stream, st.buf,
                        st.count, st.tau, st.failed, g.S, g.k, g.cap);
@@ -503,6 +611,10 @@ extern "C" size_t mevi_ip_topk_workspace_bytes(int64_t nq, int64_t dim, int64_t 
 
 extern "C" void mevi_ip_topk_set_growth(double growth) { g_growth = growth; }
 extern "C" void mevi_ip_topk_set_profiling(int enable) { g_profile = enable; }
+extern "C" void mevi_debug_set_variant(int v) { g_variant = v; }
+extern "C" int mevi_debug_read_stamps(unsigned long long *host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -4;
+}
 extern "C" void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out) {
   if (out) *out = g_stats;
 }

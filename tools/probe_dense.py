@@ -4,7 +4,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mevi_amd import dense, hip  # noqa: E402
 
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
@@ -17,7 +18,12 @@ q = torch.randn((nq, dim), device=dev, generator=g)
 d = torch.empty((nd, dim), device=dev)
 for a in range(0, nd, 1 << 20):
     d[a:a + (1 << 20)] = 0.05 * torch.randn((min(1 << 20, nd - a), dim), device=dev, generator=g) + 0.02
-for it in range(3):
+import ctypes
+variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]  # 12: NI=2, 14: NI=4
+hip.lib().mevi_ip_topk_set_profiling(1)
+for it in range(3 * len(variants)):
+    v = variants[it % len(variants)]
+    hip.lib().mevi_debug_set_variant(ctypes.c_int(v))
     torch.cuda.synchronize()
     t = time.time()
     s, i = dense.ip_topk(q, d, k)
@@ -25,5 +31,6 @@ for it in range(3):
     dt = time.time() - t
     st = hip.IpTopkStats()
     hip.lib().mevi_ip_topk_get_stats(st)
-    print(f"nd={nd} nq={nq} k={k}: {dt*1e3:.1f} ms  {2*nq*nd*dim/dt/1e12:.1f} TFLOP/s  "
-          f"chunks={st.n_chunks} failed={st.n_failed_queries}", flush=True)
+    print(f"v{v} nd={nd} nq={nq} k={k}: {dt*1e3:.1f} ms  {2*nq*nd*dim/dt/1e12:.1f} TFLOP/s  "
+          f"chunks={st.n_chunks} failed={st.n_failed_queries} filter={st.filter_ms:.1f}ms "
+          f"({st.filter_flops/st.filter_ms/1e9:.1f} TF) compact={st.compact_ms:.1f}ms", flush=True)
