@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Dense search CLI -- same argv, Python API and output file as the reference's
+MEVI/faiss_search.py:80-98, served by the MI355X inner-product top-k instead of faiss-cpu.
+
+`--param` is accepted as the reference forwards it to faiss.index_factory; every index string
+is answered with EXACT search (the "Flat" result), see SURVEY D2.
+With torch.distributed initialised (torchrun) the corpus file is row-sharded across ranks.
+"""
+import argparse
+import os
+
+import numpy as np
+
+from mevi_amd.dense import search, shard_range, sharded_ip_topk  # noqa: F401  (API parity: search)
+from mevi_amd.io import read, to_file  # noqa: F401
+
+
+def _distributed_search(query, doc_path, dim, topk):
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_rows = os.path.getsize(doc_path) // (4 * dim)
+    a, b = shard_range(n_rows, rank, world)
+    shard = np.fromfile(doc_path, dtype=np.float32, count=(b - a) * dim, offset=a * dim * 4).reshape(-1, dim)
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    s, i = sharded_ip_topk(torch.from_numpy(query).to(dev), torch.from_numpy(shard).to(dev), topk, id_offset=a)
+    return s.cpu().numpy(), i.cpu().numpy()
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--query_path", type=str, required=True)
+    parser.add_argument("--doc_path", type=str, required=True)
+    parser.add_argument("--output_path", type=str, required=True)
+    parser.add_argument("--raw_query_path", type=str, required=True)
+    parser.add_argument("--dim", type=int, default=768)
+    parser.add_argument("--topk", type=int, default=1000)
+    parser.add_argument("--param", type=str, default="IVF100,Flat")
+    args = parser.parse_args()
+    query = read(args.query_path, args.dim)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+        print(f"Param {args.param} trained: True.")
+        dists, indices = _distributed_search(query, args.doc_path, args.dim, args.topk)
+        if dist.get_rank() == 0:
+            print(indices.dtype, indices.shape, dists.dtype, dists.shape)
+            to_file(args.raw_query_path, args.output_path, dists, indices)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        doc = read(args.doc_path, args.dim)
+        dists, indices = search(query, doc, args.dim, args.topk, args.param)
+        print(indices.dtype, indices.shape, dists.dtype, dists.shape)
+        to_file(args.raw_query_path, args.output_path, dists, indices)

@@ -1,0 +1,135 @@
+"""On-disk formats of the MEVI hot path.
+
+* raw little-endian f32 matrices (`docemb.bin`, `query_emb.bin`): faiss_search.read
+  (MEVI/faiss_search.py:9-10)
+* dense ranked TSV `query\\t\\tid,id,...\\tscore,score,...`: faiss_search.to_file
+  (MEVI/faiss_search.py:71-77)
+* per-rank result logs merged by rank 0 (`*_coarse.tsv`, `*_fine.tsv`, `*_hn<N>.tsv`):
+  main_models.LogTxtFile (MEVI/main_models.py:244-273)
+* readers for the consumers (evaluate.py / ensemble_marco.py parse_file, :91-110)
+"""
+import ast
+import os
+import pickle
+
+import numpy as np
+
+
+def read(path, dim):
+    """Raw f32 file -> [rows, dim] (raises like numpy if the size does not divide)."""
+    return np.fromfile(path, dtype=np.float32).reshape(-1, dim)
+
+
+def _fmt_f32(values):
+    # the reference prints str(float(x)) of each f32 widened to double (ndarray.tolist())
+    return ",".join(map(repr, values.astype(np.float64).tolist()))
+
+
+def to_file(query_path, output_path, dists, indices):
+    """Dense ranked TSV, one line per line of `query_path` (query text = field 0)."""
+    dists = np.asarray(dists)
+    indices = np.asarray(indices)
+    with open(query_path, "r") as fr, open(output_path, "w") as fw:
+        for i, line in enumerate(fr):
+            query = line.split("\t")[0]
+            preds = ",".join(map(str, indices[i].tolist()))
+            fw.write(f"{query}\t\t{preds}\t{_fmt_f32(dists[i])}\n")
+
+
+class RankLog:
+    """Per-rank append log merged by rank 0 -- the role of main_models.LogTxtFile.
+
+    Every rank appends tab-joined tuples to `<tmpdir>/<basename>_<rank>`; `merge()`
+    (after a barrier supplied by the caller) concatenates the rank files in rank order
+    into the final path and removes them.  Tuple fields are rendered with str(), so
+    lists appear as Python reprs exactly like `print(*line, sep='\\t')` does.
+    """
+
+    def __init__(self, path, rank=0, nrank=1, barrier=None, tmpdir="/tmp", flush_every=50000):
+        self.path = path
+        self.rank, self.nrank = rank, nrank
+        self.barrier = barrier or (lambda: None)
+        self.prefix = os.path.join(tmpdir, os.path.basename(path))
+        self.tmp = f"{self.prefix}_{rank}"
+        if os.path.exists(self.tmp):
+            raise FileExistsError(f"stale rank log {self.tmp}: remove it (a previous run crashed)")
+        self.flush_every = flush_every
+        self.lines = []
+
+    def add(self, fields):
+        self.lines.append("\t".join(str(f) for f in fields))
+        if len(self.lines) >= self.flush_every:
+            self.flush()
+
+    def flush(self):
+        if self.lines:
+            with open(self.tmp, "a") as f:
+                f.write("\n".join(self.lines) + "\n")
+            self.lines = []
+
+    def merge(self):
+        self.flush()
+        if not os.path.exists(self.tmp):
+            open(self.tmp, "a").close()
+        self.barrier()
+        if self.rank == 0:
+            with open(self.path, "w") as out:
+                for r in range(self.nrank):
+                    part = f"{self.prefix}_{r}"
+                    with open(part, "r") as f:
+                        for chunk in iter(lambda: f.read(1 << 24), ""):
+                            out.write(chunk)
+            for r in range(self.nrank):
+                part = f"{self.prefix}_{r}"
+                if os.path.isfile(part):
+                    os.remove(part)
+        self.barrier()
+
+
+# ---- readers ---------------------------------------------------------------
+def parse_list(field):
+    """One TSV field -> Python list, as the reference's eval_list does (ensemble_marco.py:85-89):
+    a bare comma list gets brackets added.  Flat numeric lists take a fast path."""
+    if field[0] != "[":
+        try:
+            return [int(x) for x in field.split(",")]
+        except ValueError:
+            try:
+                return [float(x) for x in field.split(",")]
+            except ValueError:
+                field = f"[{field}]"
+    return ast.literal_eval(field)
+
+
+def parse_file(path, template):
+    """(pred, score, cluster) dicts keyed by query text; `template` maps role -> column."""
+    qi = template["query"]
+    cols = [template.get(k) for k in ("pred", "score", "cluster")]
+    out = ({}, {}, {})
+    with open(path, "r") as f:
+        for line in f:
+            items = line.rstrip("\n").split("\t")
+            q = items[qi]
+            for c, d in zip(cols, out):
+                if c is not None:
+                    d[q] = parse_list(items[c])
+    return out
+
+
+def load_parsed(path, template):
+    """parse_file with the reference's `.pkl` side cache (ensemble_marco.py:130-139),
+    except that a cache older than its TSV is ignored (the reference serves it stale)."""
+    if path.endswith(".pkl"):
+        with open(path, "rb") as f:
+            return pickle.load(f)
+    cache = path[: -(len(path.split(".")[-1]) + 1)] + ".pkl"
+    if os.path.exists(cache) and os.path.getmtime(cache) >= os.path.getmtime(path):
+        with open(cache, "rb") as f:
+            return pickle.load(f)
+    res = parse_file(path, template)
+    try:
+        with open(cache, "wb") as f:
+            pickle.dump(res, f)
+    except OSError:
+        pass
+    return res

@@ -1,0 +1,98 @@
+"""Host-side consumers and writers against goldens captured from the UNMODIFIED reference
+(tools/capture_goldens.py g6 g7): evaluate.py / ensemble_marco.py stdout + ofile bytes,
+faiss_search.to_file bytes, LogTxtFile lines."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+G6 = os.path.join(GOLD, "g6_consumers")
+
+
+@pytest.fixture()
+def g6_dir(tmp_path):
+    for f in os.listdir(G6):
+        if f.endswith((".tsv", ".pkl")):
+            shutil.copy(os.path.join(G6, f), tmp_path)
+    return str(tmp_path)
+
+
+@pytest.mark.parametrize("name", ["evaluate_default", "evaluate_recall5_20", "ensemble_default",
+                                  "ensemble_grid", "ensemble_nofine"])
+def test_cli_output_matches_reference(name, g6_dir):
+    exp = json.load(open(os.path.join(G6, "expected.json")))[name]
+    argv = [a.replace("{d}", g6_dir) for a in exp["argv"]]
+    cmd = [sys.executable, os.path.join(ROOT, argv[0])] + argv[1:]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=g6_dir,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == exp["stdout"]
+    if exp["ofile"] is not None:
+        out = [f for f in ("eval_out.txt", "ens_out.txt") if os.path.exists(os.path.join(g6_dir, f))]
+        assert open(os.path.join(g6_dir, out[0])).read() == exp["ofile"]
+
+
+def test_stale_parse_cache_is_not_served(g6_dir):
+    """The reference pickles the parsed TSV next to it and reuses it forever; we ignore a cache
+    older than its TSV (documented deviation, SURVEY 'Bug-compatible ensemble')."""
+    from mevi_amd import io as mio
+    from mevi_amd.metrics import RANKED_TEMPLATE
+
+    path = os.path.join(g6_dir, "dense.tsv")
+    a, _, _ = mio.load_parsed(path, RANKED_TEMPLATE)
+    assert os.path.exists(os.path.join(g6_dir, "dense.pkl"))
+    lines = open(path).read().splitlines()
+    q0 = lines[0].split("\t")[0]
+    lines[0] = f"{q0}\t\t7,8,9\t3.0,2.0,1.0"
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    os.utime(path, (os.path.getmtime(path) + 5, os.path.getmtime(path) + 5))
+    b, _, _ = mio.load_parsed(path, RANKED_TEMPLATE)
+    assert b[q0] == [7, 8, 9] and a[q0] != b[q0]
+
+
+def test_to_file_bytes(tmp_path):
+    from mevi_amd import io as mio
+
+    g = json.load(open(os.path.join(GOLD, "g7_writers.json")))["to_file"]
+    qf, of = tmp_path / "q.tsv", tmp_path / "o.tsv"
+    qf.write_text(g["raw_query"])
+    dists = np.frombuffer(bytes.fromhex(g["dists_hex"]), dtype=np.float32).reshape(g["shape"])
+    mio.to_file(str(qf), str(of), dists, np.array(g["indices"], dtype=np.int64))
+    assert of.read_text() == g["expected"]
+
+
+def test_rank_log_merge_bytes(tmp_path):
+    from mevi_amd import io as mio
+
+    g = json.load(open(os.path.join(GOLD, "g7_writers.json")))["logtxt"]
+    final = str(tmp_path / "res_coarse.tsv")
+    logs = [mio.RankLog(final, r, 2, tmpdir=str(tmp_path)) for r in range(2)]
+    for ln in g["rank0"]:
+        logs[0].add(ln)
+    for ln in g["rank1"]:
+        logs[1].add(ln)
+    logs[1].flush()
+    logs[0].merge()
+    assert open(final).read() == g["expected"]
+    assert not os.path.exists(logs[0].tmp) and not os.path.exists(logs[1].tmp)
+    with pytest.raises(FileExistsError):
+        open(logs[0].tmp, "w").close()
+        mio.RankLog(final, 0, 2, tmpdir=str(tmp_path))
+
+
+def test_read_raw_f32(tmp_path):
+    from mevi_amd import io as mio
+
+    a = np.arange(24, dtype=np.float32).reshape(3, 8)
+    p = tmp_path / "e.bin"
+    a.tofile(p)
+    assert np.array_equal(mio.read(str(p), 8), a)
+    with pytest.raises(ValueError):
+        mio.read(str(p), 7)

@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Capture golden vectors by importing the read-only reference (/root/reference).
+
+Runs ONLY in the build container.  Everything written to tests/golden/ is data
+(seeded inputs + the reference's outputs); no reference source travels.
+
+  python tools/capture_goldens.py [g4 g5 g6 g7 g1 g2 g3 ...]   (default: all)
+"""
+import io
+import json
+import os
+import pickle
+import shutil
+import subprocess
+import sys
+import tempfile
+from argparse import Namespace
+from contextlib import redirect_stdout
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+
+REF = ref_import.REF
+
+
+# --------------------------------------------------------------------------- G4
+def g4_rq():
+    """RQ encode / forward / beam search of MEVI/pq.py (ProductQuantization('rq', M, bits, 'l2'))."""
+    ref_import.setup()
+    import torch
+    from pq import ProductQuantization
+
+    for (M, bits, dim, n) in [(4, 5, 768, 192), (3, 8, 64, 300), (4, 5, 32, 257)]:
+        K = 2 ** bits
+        rng = np.random.default_rng(100 + M * 10 + bits)
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+        C = (rng.standard_normal((M, K, dim)) * (0.8 / np.arange(1, M + 1))[:, None, None]).astype(np.float32)
+        pq = ProductQuantization("rq", M, bits, "l2", dim, pq_init_method="none", pq_update_method="none")
+        with torch.no_grad():
+            pq.codebook.copy_(torch.from_numpy(C))
+        pq.eval()
+        with io.StringIO() as buf, redirect_stdout(buf):
+            cluster, mapping = pq.get_document_cluster(X, 0, 1, batch_size=128, return_mapping=True)
+        codes = np.array([mapping[i] for i in range(n)], dtype=np.int32)
+        proba, index, _ = pq.forward(torch.from_numpy(X.copy()), return_loss=False)
+        assert np.array_equal(index.numpy(), codes)
+        out = dict(X=X, C=C, codes=codes, forward_proba=proba.numpy().astype(np.float32))
+        for R in (5, 10):
+            if R > K:
+                continue
+            lab, sc = pq.beam_search(torch.from_numpy(X[:64].copy()), R, return_proba=True)
+            out[f"beam{R}_labels"] = lab.numpy().astype(np.int32)
+            out[f"beam{R}_scores"] = sc.numpy().astype(np.float32)
+        rec = torch.stack([pq.get_reconstruct_vector(torch.from_numpy(codes[r].astype(np.int64)))
+                           for r in range(32)])  # 1-D index per row (the only form infer() uses, main_models.py:3938)
+        out["reconstruct32"] = rec.detach().numpy().astype(np.float32)
+        # cluster dict in a flat form: sorted (code tuple -> doc ids)
+        keys = sorted(cluster)
+        out["cluster_keys"] = np.array(keys, dtype=np.int32)
+        out["cluster_sizes"] = np.array([len(cluster[k]) for k in keys], dtype=np.int32)
+        out["cluster_docs"] = np.array([d for k in keys for d in cluster[k]], dtype=np.int64)
+        np.savez_compressed(os.path.join(GOLD, f"g4_rq_{M}_{bits}_{dim}.npz"), **out)
+        print("g4", M, bits, dim, "clusters", len(keys))
+
+
+# --------------------------------------------------------------------------- G5
+def g5_tree_codec():
+    """Token codec + shared-layer prefix tree (main_models.TreeBuilder / encode_single_newid / decode_token)."""
+    ref_import.setup()
+    import torch
+    from main_models import TreeBuilder, decode_token, encode_single_newid
+    from main_utils import dec_2d
+
+    cases = []
+    for (M, K) in [(4, 32), (3, 256), (3, 16), (2, 4)]:
+        args = Namespace(kary=K, position=1, label_length_cutoff=M, max_output_length=M + 2,
+                         codebook=1, subvector_num=M, output_vocab_size=K)
+        rng = np.random.default_rng(M * 1000 + K)
+        codes = rng.integers(0, K, size=(12, M))
+        enc = [encode_single_newid(args, list(map(int, c))) for c in codes]
+        enc_str = encode_single_newid(args, "-".join(str(int(x)) for x in codes[0]))
+        # tree exactly as T5FineTuner.build_tree (main_models.py:1698-1706)
+        builder = TreeBuilder(share_sons=True)
+        newids = [encode_single_newid(args, [i for _ in range(M)]) for i in range(K)]
+        for i in range(M):
+            builder.add_layer([ids[i] for ids in newids])
+        builder.add_layer([1])
+        root = builder.build()
+        levels = []
+        node = root
+        while node.children:
+            levels.append(sorted(node.children.keys()))
+            node = next(iter(node.children.values()))
+        seqs = torch.tensor([[0] + e for e in enc], dtype=torch.long)
+        dec, eos = decode_token(args, seqs.clone())
+        d2 = dec_2d(dec, 3)
+        cases.append(dict(M=M, K=K, codes=codes.tolist(), encoded=enc, encoded_from_str=enc_str,
+                          tree_levels=levels, decoded=dec.tolist(), eos_is_none=eos is None,
+                          dec_2d_shape=list(d2.shape), dec_2d=d2.tolist()))
+    json.dump(cases, open(os.path.join(GOLD, "g5_tree_codec.json"), "w"))
+    print("g5", len(cases), "cases")
+
+
+# --------------------------------------------------------------------------- G6
+def synth_consumer_files(d, nq=60, ndoc=3000, kd=40, R=10, M=4, K=8, seed=0):
+    """Synthetic gt / dense / coarse / hn TSVs + mapping pkl in the reference's formats
+    (formats: SURVEY 8(b); writers: faiss_search.py:71-77, main_models.py:3760,4046-4053)."""
+    rng = np.random.default_rng(seed)
+    mapping = {i: tuple(int(x) for x in rng.integers(0, K, size=M)) for i in range(ndoc)}
+    with open(os.path.join(d, "rqmapping.pkl"), "wb") as f:
+        pickle.dump(mapping, f)
+    queries = [f"what is query number {i} about" for i in range(nq)]
+    gt, dense, coarse, hn = [], [], [], []
+    for i, q in enumerate(queries):
+        ngt = 1 + (i % 3 == 0)
+        g = [int(x) for x in rng.choice(ndoc, size=ngt, replace=False)]
+        gt.append(f"{q}\t{','.join(map(str, g))}")
+        # dense list: kd ids with descending scores; plant gt at a pseudo-random rank for 2/3 of queries
+        ids = [int(x) for x in rng.choice(ndoc, size=kd, replace=False) if x not in g][:kd - 2]
+        if i % 3 != 1:
+            ids.insert(int(rng.integers(0, min(len(ids), 25))), g[0])
+        while len(ids) < kd:
+            ids.append(-1 if i % 7 == 0 else int(rng.integers(0, ndoc)))  # faiss pads with -1 when k > N
+        sc = np.sort(rng.normal(80, 3, size=kd).astype(np.float32))[::-1]
+        if i % 7 == 0:
+            sc[np.array(ids) == -1] = -3.4028234663852886e+38
+        dense.append(f"{q}\t\t{','.join(str(x) for x in ids)}\t{','.join(str(float(s)) for s in sc)}")
+        # coarse: R distinct clusters; first ones drawn from the dense/gt docs so ranks are non-trivial
+        clus = []
+        cand = [mapping[g[0]]] if i % 4 != 3 else []
+        cand += [mapping[x] for x in ids[:15] if x >= 0]
+        for c in cand:
+            if c not in clus:
+                clus.append(c)
+        while len(clus) < R:
+            c = tuple(int(x) for x in rng.integers(0, K, size=M))
+            if c not in clus:
+                clus.append(c)
+        order = rng.permutation(len(clus))[:R]
+        clus = [list(clus[j]) for j in order]
+        cs = [float(x) for x in np.sort(rng.normal(-2, 0.5, size=R))[::-1]]
+        coarse.append(f"{q}\t{clus}\t{[list(mapping[x]) for x in g]}\t{cs}")
+        # hn (fine) file: docs that live in the beam clusters, sorted by score; some overlap with dense
+        members = [x for x in range(ndoc) if list(mapping[x]) in clus]
+        rng.shuffle(members)
+        fdocs = members[: int(rng.integers(5, 60))]
+        fs = np.sort(rng.normal(79, 3, size=len(fdocs)).astype(np.float32))[::-1]
+        gts = ",".join(str(float(x)) for x in rng.normal(80, 1, size=len(g)).astype(np.float32))
+        hn.append(f"{q}\t{gts}\t{','.join(map(str, fdocs))}\t{','.join(str(float(s)) for s in fs)}")
+    for name, lines in (("gt.tsv", gt), ("dense.tsv", dense), ("nci_coarse.tsv", coarse), ("nci_hn.tsv", hn)):
+        with open(os.path.join(d, name), "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+def g6_consumers():
+    """stdout + ofile of the UNMODIFIED reference evaluate.py / ensemble_marco.py on synthetic TSVs."""
+    out_dir = os.path.join(GOLD, "g6_consumers")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    synth_consumer_files(out_dir)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    runs = {
+        "evaluate_default": ["evaluate.py", "--dir_path", "{d}", "--gt_file", "gt.tsv", "--ance_file", "dense.tsv"],
+        "evaluate_recall5_20": ["evaluate.py", "--dir_path", "{d}", "--gt_file", "gt.tsv", "--ance_file", "dense.tsv",
+                                "--recall_num", "5,20", "--ofile", "{d}/eval_out.txt"],
+        "ensemble_default": ["ensemble_marco.py", "--dir_path", "{d}", "--mapping_file", "{d}/rqmapping.pkl",
+                             "--gt_file", "gt.tsv", "--ance_file", "dense.tsv", "--coarse_file", "nci_coarse.tsv",
+                             "--fine_file", "nci_hn.tsv", "--ofile", "{d}/ens_out.txt"],
+        "ensemble_grid": ["ensemble_marco.py", "--dir_path", "{d}", "--mapping_file", "{d}/rqmapping.pkl",
+                          "--gt_file", "gt.tsv", "--ance_file", "dense.tsv", "--coarse_file", "nci_coarse.tsv",
+                          "--fine_file", "nci_hn.tsv", "--alphas", "0.3,1.0", "--betas", "0.03,0.5",
+                          "--gammas", "0.02,0.5", "--recall_num", "1,10,100"],
+        "ensemble_nofine": ["ensemble_marco.py", "--dir_path", "{d}", "--mapping_file", "{d}/rqmapping.pkl",
+                            "--gt_file", "gt.tsv", "--ance_file", "dense.tsv", "--coarse_file", "nci_coarse.tsv"],
+    }
+    expected = {}
+    for name, argv in runs.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            for f in os.listdir(out_dir):
+                if f.endswith((".tsv", ".pkl")):
+                    shutil.copy(os.path.join(out_dir, f), tmp)
+            cmd = [sys.executable] + [a.replace("{d}", tmp) for a in argv]
+            cmd[1] = os.path.join(REF, cmd[1])
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=tmp)
+            assert r.returncode == 0, r.stderr[-2000:]
+            ofile = None
+            for f in ("eval_out.txt", "ens_out.txt"):
+                if os.path.exists(os.path.join(tmp, f)):
+                    ofile = open(os.path.join(tmp, f)).read()
+            expected[name] = dict(argv=argv, stdout=r.stdout, ofile=ofile)
+    json.dump(expected, open(os.path.join(out_dir, "expected.json"), "w"), indent=1)
+    print("g6", list(expected))
+
+
+# --------------------------------------------------------------------------- G7
+def g7_writers():
+    """Exact bytes of faiss_search.to_file (faiss_search.py:71-77) and LogTxtFile lines
+    (main_models.py:244-273) for the coarse / fine / hn tuples infer() logs."""
+    ref_import.setup()
+    import torch
+    import faiss_search
+    from main_models import LogTxtFile
+
+    out = {}
+    rng = np.random.default_rng(5)
+    dists = rng.normal(75, 10, size=(5, 7)).astype(np.float32)
+    dists[4, 5:] = -3.4028234663852886e+38
+    dists[0, 0] = 100.0
+    dists[1, 1] = np.float32(1e-7)
+    dists[2, 2] = np.float32(123456.789)
+    indices = rng.integers(0, 8841823, size=(5, 7)).astype(np.int64)
+    indices[4, 5:] = -1
+    with tempfile.TemporaryDirectory() as tmp:
+        qf = os.path.join(tmp, "q.tsv")
+        with open(qf, "w") as f:
+            for i in range(5):
+                f.write(f"query text {i} with \"quote\"\t{i},{i + 1}\n")
+        of = os.path.join(tmp, "o.tsv")
+        faiss_search.to_file(qf, of, dists, indices)
+        out["to_file"] = dict(raw_query=open(qf).read(), dists_hex=dists.tobytes().hex(), shape=list(dists.shape),
+                              indices=indices.tolist(), expected=open(of).read())
+        # LogTxtFile: tuples exactly as infer() builds them
+        final = os.path.join(tmp, "res_coarse.tsv")
+        for stale in ("/tmp/res_coarse.tsv_0", "/tmp/res_coarse.tsv_1"):
+            if os.path.exists(stale):
+                os.remove(stale)
+        scores32 = torch.tensor([-0.123456789, -1.5, -2.25], dtype=torch.float32)
+        lines0 = [("q a", [[1, 2, 3, 4], [5, 6, 7, 8]], [[1, 2, 3, 4]], [float(scores32[0]) / 5 ** 0.8, -0.75])]
+        lines1 = [("q b", [3, 1, 2], [9]),
+                  ("q c", ",".join(str(s.item()) for s in scores32), "5,6,7", ",".join(str(s.item()) for s in scores32[:2]))]
+        l0 = LogTxtFile(final, 0, 2, lambda: None)
+        l1 = LogTxtFile(final, 1, 2, lambda: None)
+        for ln in lines0:
+            l0.add(ln)
+        for ln in lines1:
+            l1.add(ln)
+        l1.wrapped_flush()
+        l0.wrapped_merge()
+        out["logtxt"] = dict(rank0=json.loads(json.dumps(lines0)), rank1=json.loads(json.dumps(lines1)),
+                             expected=open(final).read())
+    json.dump(out, open(os.path.join(GOLD, "g7_writers.json"), "w"), indent=1)
+    print("g7 ok")
+
+
+ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g7=g7_writers)
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or list(ALL)
+    for w in which:
+        ALL[w]()
