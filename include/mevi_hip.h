@@ -75,6 +75,20 @@ int mevi_topk_merge_f32(const float *scores, const int64_t *ids, int64_t nlists,
                         float *out_score, int64_t *out_id, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Residual-quantisation encode: codes[n, M] (int32, values in [0, K)).
+ * Replaces pq.get_rq_document_cluster / the index path of forward_rq with
+ * dist_mode 'l2' (MEVI/pq.py:281-305, 337-369, 124-131), which the reference
+ * evaluates on the CPU 128 rows at a time (MEVI/main_models.py:3207-3212).
+ *   x f32 [n, dim], codebook f32 [M, K, dim] (rqcodebook*.pt layout, pq.py:470)
+ *   per level: code = argmin_c sum_k (r_k - C[level][c][k])^2 (sequential fmaf
+ *   chain, lowest index on ties), then r -= C[level][code].
+ *   Requirements: dim % 4 == 0, M <= 8, 16-byte aligned x/codebook.
+ * Fully stream-ordered; no workspace.
+ * ---------------------------------------------------------------------- */
+int mevi_rq_encode_f32(const float *x, int64_t n, int64_t dim, const float *codebook, int64_t M,
+                       int64_t K, int32_t *codes, void *stream);
+
 /* Test / tuning hooks for the dense arm (not part of the drop-in surface):
  * force the chunk growth factor (0 = default) and read back statistics of the
  * last mevi_ip_topk_f32 call on this thread. */

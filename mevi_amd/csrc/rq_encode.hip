@@ -1,0 +1,188 @@
+// Residual-quantisation encode (K13): codes[n, M] = per level argmin_c sum_k (r_k - C[j][c][k])^2,
+// r <- r - C[j][code_j].
+//
+// Replaces pq.get_rq_document_cluster / forward_rq with dist_mode 'l2'
+// (MEVI/pq.py:281-305, 337-369; compute_scores :124-131), which the reference runs on
+// the CPU in batches of 128 (main_models.py:3207-3212).
+//
+// Direct-difference form on the VALU (NOT the |c|^2 - 2 x.c GEMM form): every distance is
+// the sequential f32 fmaf chain  d = fma(r_k - c_k, r_k - c_k, d), k = 0..dim-1, exactly what
+// oracle/mevi_oracle.c computes, so codes are bit-identical to the oracle; ties go to the
+// lowest centroid index.
+//
+// One launch per level.  A 256-thread workgroup owns 128 rows; each wave a 32-row x 32-
+// centroid tile with a 4x4 register tile per lane (16 independent chains), K-slabs of 32
+// staged through LDS (double buffered).  The residual is never stored: the staging step
+// re-derives it from X and the row's previous codes with the reference's operation order
+// ((x - c0) - c1) - ..., so a level costs one read of X (HBM) and the codebook stays in L2.
+// Bound: VALU (2 lane-ops per (row, centroid, k)); LDS traffic is halved four times over by
+// the register tile (8 b128 reads per 128 VALU instructions).
+
+#include "common.h"
+
+#include <math.h>
+
+namespace mevi {
+namespace {
+
+constexpr int RQ_ROWS = 128;  // rows per workgroup
+constexpr int RQ_CENTS = 32;  // centroids per chunk
+constexpr int RQ_KS = 32;     // k slab
+constexpr int RQ_LD = 36;     // floats per LDS row (16-byte aligned, conflict-free b128 reads)
+constexpr int RQ_MAXM = 8;    // levels supported by the in-register code history
+
+__global__ __launch_bounds__(256, 3) void rq_level_kernel(const float *__restrict__ X, long long n, int dim,
+                                                         const float *__restrict__ C, int M, int K, int level,
+                                                         int *__restrict__ codes) {
+  __shared__ __attribute__((aligned(16))) float xs[2][RQ_ROWS * RQ_LD];
+  __shared__ __attribute__((aligned(16))) float cs[2][RQ_CENTS * RQ_LD];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int ld = lane >> 3;  // row group 0..7   -> rows  32*wave + ld + 8*i
+  const int lc = lane & 7;   // cent group 0..7  -> cents lc + 8*j
+  const long long row0 = (long long)blockIdx.x * RQ_ROWS;
+
+  // staging duty: 4 float4 of the row slab (rows srow + 32*i), 1 float4 of the centroid slab
+  const int srow = t >> 3;
+  const int skq = (t & 7) * 4;
+  const float *xptr[4];
+  int prev[4][RQ_MAXM];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long long r = row0 + srow + 32 * i;
+    if (r > n - 1) r = n - 1;
+    xptr[i] = X + (size_t)r * dim + skq;
+#pragma unroll
+    for (int j = 0; j < RQ_MAXM; ++j) prev[i][j] = (j < level) ? codes[(size_t)r * M + j] : 0;
+  }
+  const size_t level_stride = (size_t)K * dim;
+  const int nslab = (dim + RQ_KS - 1) / RQ_KS;
+  const int nchunk = (K + RQ_CENTS - 1) / RQ_CENTS;
+
+  float4 rx[4], rc;
+  auto gload = [&](int chunk, int s) {
+    const int kk = s * RQ_KS + skq;
+    const bool in = kk < dim;  // dim % 4 == 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) {
+        v = *reinterpret_cast<const float4 *>(xptr[i] + s * RQ_KS);
+        for (int j = 0; j < level; ++j) {  // residual with the reference's operation order
+          const float4 c = *reinterpret_cast<const float4 *>(C + j * level_stride + (size_t)prev[i][j] * dim + kk);
+          v.x -= c.x; v.y -= c.y; v.z -= c.z; v.w -= c.w;
+        }
+      }
+      rx[i] = v;
+    }
+    const int cent = chunk * RQ_CENTS + srow;
+    rc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in && cent < K)
+      rc = *reinterpret_cast<const float4 *>(C + level * level_stride + (size_t)cent * dim + kk);
+  };
+  auto lstore = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&xs[b][(srow + 32 * i) * RQ_LD + skq]) = rx[i];
+    *reinterpret_cast<float4 *>(&cs[b][srow * RQ_LD + skq]) = rc;
+  };
+
+  float best_d[4];
+  int best_c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    best_d[i] = INFINITY;
+    best_c[i] = 0;
+  }
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    __syncthreads();  // previous chunk's readers are done with both buffers
+    gload(chunk, 0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+      if (s + 1 < nslab) gload(chunk, s + 1);
+      const float *px = &xs[s & 1][(32 * wave + ld) * RQ_LD];
+      const float *pc = &cs[s & 1][lc * RQ_LD];
+#pragma unroll
+      for (int k4 = 0; k4 < RQ_KS; k4 += 4) {
+        float4 xv[4], cv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(px + 8 * i * RQ_LD + k4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[j] = *reinterpret_cast<const float4 *>(pc + 8 * j * RQ_LD + k4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float d;
+            d = xv[i].x - cv[j].x; acc[i][j] = fmaf(d, d, acc[i][j]);
+            d = xv[i].y - cv[j].y; acc[i][j] = fmaf(d, d, acc[i][j]);
+            d = xv[i].z - cv[j].z; acc[i][j] = fmaf(d, d, acc[i][j]);
+            d = xv[i].w - cv[j].w; acc[i][j] = fmaf(d, d, acc[i][j]);
+          }
+      }
+      if (s + 1 < nslab) lstore((s + 1) & 1);
+      __syncthreads();
+    }
+    // running argmin: (distance, index) lexicographic, lowest index wins ties
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = chunk * RQ_CENTS + lc + 8 * j;
+        const float d = acc[i][j];
+        if (c < K && (d < best_d[i] || (d == best_d[i] && c < best_c[i]))) {
+          best_d[i] = d;
+          best_c[i] = c;
+        }
+      }
+  }
+  // reduce over the 8 lanes (lc) that share a row group
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      const float od = __shfl_xor(best_d[i], off);
+      const int oc = __shfl_xor(best_c[i], off);
+      if (od < best_d[i] || (od == best_d[i] && oc < best_c[i])) {
+        best_d[i] = od;
+        best_c[i] = oc;
+      }
+    }
+    const long long r = row0 + 32 * wave + ld + 8 * i;
+    if (lc == 0 && r < n) codes[(size_t)r * M + level] = best_c[i];
+  }
+}
+
+}  // namespace
+}  // namespace mevi
+
+using namespace mevi;
+
+extern "C" int mevi_rq_encode_f32(const float *x, int64_t n, int64_t dim, const float *codebook, int64_t M,
+                                  int64_t K, int32_t *codes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(n >= 0 && dim > 0 && M > 0 && K > 0, MEVI_ERR_INVALID_ARG, "rq_encode: bad shape");
+  if (n == 0) return MEVI_OK;
+  MEVI_REQUIRE(x && codebook && codes, MEVI_ERR_INVALID_ARG, "rq_encode: null pointer");
+  MEVI_REQUIRE(dim % 4 == 0, MEVI_ERR_UNSUPPORTED, "rq_encode: dim=%lld must be a multiple of 4", (long long)dim);
+  MEVI_REQUIRE(M <= RQ_MAXM, MEVI_ERR_UNSUPPORTED, "rq_encode: M=%lld > %d levels", (long long)M, RQ_MAXM);
+  MEVI_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)codebook % 16) == 0, MEVI_ERR_INVALID_ARG,
+               "rq_encode: x/codebook must be 16-byte aligned");
+  const int64_t nblk = (n + RQ_ROWS - 1) / RQ_ROWS;
+  MEVI_REQUIRE(nblk <= 0x7fffffffLL, MEVI_ERR_UNSUPPORTED, "rq_encode: too many rows");
+  for (int level = 0; level < (int)M; ++level) {
+    hipLaunchKernelGGL(rq_level_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x, (long long)n, (int)dim,
+                       codebook, (int)M, (int)K, level, codes);
+  }
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "mevi_topk_merge_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "mevi_topk_merge_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mevi_rq_encode_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "mevi_ip_topk_set_growth": (None, [c_double]),
     "mevi_ip_topk_set_profiling": (None, [c_int]),
     "mevi_ip_topk_get_stats": (None, [ctypes.POINTER(IpTopkStats)]),

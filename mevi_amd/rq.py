@@ -1,0 +1,178 @@
+"""Residual quantisation on MI355X: the 'rq' / 'l2' slice of the reference's
+`ProductQuantization` (MEVI/pq.py:15) that the eval scripts use, plus the cluster index
+the fine stage consumes.
+
+Reference surface mirrored (same names and argument meaning):
+  ProductQuantization(pq_type, subvector_num, subvector_bits, dist_mode, emb_size, ...)
+    .get_codebook()                                           pq.py:133-141
+    .initialize(index_file, doc_emb, rank, seed, pq_cluster_path, encode_batch_size)
+         -- only the "load rqcodebook*.pt" branch (pq.py:459-463) + broadcast (:484)
+    .get_document_cluster(doc_embeddings, rank, nrank, batch_size, return_mapping)  pq.py:217-247
+    .forward(vecs) -> index   (forward_rq, pq.py:337-369; proba/loss are training outputs)
+    .get_reconstruct_vector(index)                            pq.py:768-784
+Training (EMA / k-means / gumbel), 'pq' / 'opq' and 'ip' / 'iptol2' are out of scope.
+"""
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import hip
+
+
+def rq_encode(x, codebook):
+    """codes i32[n, M] of x f32[n, dim] against codebook f32[M, K, dim] (CUDA tensors)."""
+    hip.require_gpu()
+    assert x.is_cuda and codebook.is_cuda and x.dtype == torch.float32 and codebook.dtype == torch.float32
+    x = x.contiguous()
+    codebook = codebook.contiguous()
+    M, K, dim = codebook.shape
+    assert x.dim() == 2 and x.shape[1] == dim
+    codes = torch.empty((x.shape[0], M), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = hip.lib().mevi_rq_encode_f32(hip.ptr(x), x.shape[0], dim, hip.ptr(codebook), M, K,
+                                          hip.ptr(codes), hip.stream_ptr())
+    hip.check(st, "mevi_rq_encode_f32")
+    return codes
+
+
+class ClusterIndex:
+    """CSR form of the reference's `pq_doc_cluster: dict[tuple -> list[int]]` and
+    `pq_mapping: dict[int -> tuple]` (MEVI/main_models.py:3200-3220).
+
+    key(code) = sum_j code[j] * K**(M-1-j);  doc ids of a cluster are ascending, exactly the
+    order in which get_document_cluster appends them (pq.py:236-241)."""
+
+    def __init__(self, M, K, keys, offsets, doc_ids, codes=None):
+        self.M, self.K = M, K
+        self.keys = keys          # i64[n_clusters] sorted distinct keys
+        self.offsets = offsets    # i64[n_clusters + 1]
+        self.doc_ids = doc_ids    # i64[N]
+        self.codes = codes        # optional i32[N, M] (the mapping)
+
+    @staticmethod
+    def code_keys(codes, K):
+        codes = np.asarray(codes, dtype=np.int64)
+        M = codes.shape[-1]
+        w = K ** np.arange(M - 1, -1, -1, dtype=np.int64)
+        return (codes * w).sum(-1)
+
+    @classmethod
+    def from_codes(cls, codes, K, start=0):
+        codes = np.asarray(codes)
+        keys_all = cls.code_keys(codes, K)
+        order = np.argsort(keys_all, kind="stable")
+        sk = keys_all[order]
+        keys, first = np.unique(sk, return_index=True)
+        offsets = np.append(first, len(sk)).astype(np.int64)
+        return cls(codes.shape[1], K, keys, offsets, (order + start).astype(np.int64), codes.astype(np.int32))
+
+    @classmethod
+    def from_dict(cls, cluster, M, K):
+        """From the reference's pickled dict (rqclus*.pkl)."""
+        items = sorted((int(cls.code_keys(np.array(k), K)), v) for k, v in cluster.items())
+        keys = np.array([k for k, _ in items], dtype=np.int64)
+        sizes = np.array([len(v) for _, v in items], dtype=np.int64)
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        doc_ids = np.concatenate([np.asarray(v, dtype=np.int64) for _, v in items]) if items else np.zeros(0, np.int64)
+        return cls(M, K, keys, offsets, doc_ids)
+
+    def lookup(self, code):
+        """doc ids (ascending) of one cluster, empty array when the cluster owns no document."""
+        key = int(self.code_keys(np.asarray(code), self.K))
+        i = int(np.searchsorted(self.keys, key))
+        if i >= len(self.keys) or self.keys[i] != key:
+            return self.doc_ids[:0]
+        return self.doc_ids[self.offsets[i]:self.offsets[i + 1]]
+
+    def to_dicts(self):
+        """(cluster dict, mapping dict) in the reference's pickle layout."""
+        w = self.K ** np.arange(self.M - 1, -1, -1, dtype=np.int64)
+        cluster = {}
+        for i, key in enumerate(self.keys.tolist()):
+            code = tuple(int((key // int(wj)) % self.K) for wj in w)
+            cluster[code] = self.doc_ids[self.offsets[i]:self.offsets[i + 1]].tolist()
+        mapping = {d: c for c, ds in cluster.items() for d in ds}
+        return cluster, mapping
+
+
+class ProductQuantization:
+    def __init__(self, pq_type="rq", subvector_num=4, subvector_bits=5, dist_mode="l2", emb_size=768,
+                 pq_init_method="kmeans", pq_update_method="none", device=None, **unused):
+        if pq_type != "rq" or dist_mode != "l2":
+            raise NotImplementedError("only pq_type='rq', dist_mode='l2' is on the MEVI eval path")
+        self.pq_type, self.dist_mode = pq_type, dist_mode
+        self.subvector_num, self.subvector_bits = subvector_num, subvector_bits
+        self.subvector_cents = 2 ** subvector_bits
+        self.emb_size = self.last_dim = emb_size
+        self.pq_init_method = pq_init_method
+        self.device = torch.device(device if device is not None else "cuda")
+        self.codebook = torch.empty((subvector_num, self.subvector_cents, emb_size), dtype=torch.float32,
+                                    device=self.device)
+
+    def get_codebook(self):
+        return self.codebook
+
+    def fix(self):
+        pass  # nothing trains here
+
+    def load_codebook(self, tensor):
+        t = torch.as_tensor(np.asarray(tensor) if not torch.is_tensor(tensor) else tensor.detach(), dtype=torch.float32)
+        assert tuple(t.shape) == tuple(self.codebook.shape), (t.shape, self.codebook.shape)
+        self.codebook.copy_(t.to(self.device))
+
+    def initialize(self, index_file, doc_emb=None, rank=0, seed=0, pq_cluster_path=None, encode_batch_size=None):
+        """Rank 0 loads `rqcodebook{M}_{bits}.pt` (torch.save of the f32[M,K,dim] parameter),
+        then the codebook is broadcast (RCCL) when a process group exists."""
+        import os
+
+        import torch.distributed as dist
+
+        if rank == 0:
+            if index_file is None or not os.path.isfile(index_file):
+                raise FileNotFoundError(f"RQ codebook {index_file}: training a codebook is out of scope")
+            print("Intializing codebook with torch file...")
+            self.load_codebook(torch.load(index_file, map_location="cpu"))
+        if dist.is_available() and dist.is_initialized():
+            dist.broadcast(self.codebook, 0)
+
+    def forward(self, vecs, return_loss=False):
+        """index i32[n, M]; the reference's (proba, index, loss) triple minus the training outputs."""
+        return None, rq_encode(vecs.to(self.device, torch.float32), self.codebook), None
+
+    def get_document_cluster(self, doc_embeddings, rank, nrank, batch_size=1 << 20, return_mapping=False,
+                             as_index=False):
+        """Encode this rank's contiguous slice (rows // nrank each, last rank takes the rest:
+        pq.py:218-224) and group row ids by code tuple.  `batch_size` rows are resident on the
+        GPU at a time (the reference's 128-row CPU batches compute the same thing)."""
+        num_docs = doc_embeddings.shape[0]
+        per = num_docs // nrank
+        start = per * rank
+        ending = num_docs if rank + 1 == nrank else start + per
+        parts = []
+        for b0 in range(start, ending, batch_size):
+            b1 = min(b0 + batch_size, ending)
+            chunk = doc_embeddings[b0:b1]
+            chunk = chunk if torch.is_tensor(chunk) else torch.from_numpy(np.ascontiguousarray(chunk, dtype=np.float32))
+            parts.append(rq_encode(chunk.to(self.device, torch.float32), self.codebook).cpu())
+        codes = torch.cat(parts).numpy() if parts else np.zeros((0, self.subvector_num), np.int32)
+        index = ClusterIndex.from_codes(codes, self.subvector_cents, start=start)
+        print("Number of document clusters:", len(index.keys))
+        if as_index:
+            return index
+        cluster = defaultdict(list)
+        mapping = {}
+        for i, c in enumerate(codes.tolist()):
+            key = tuple(c)
+            cluster[key].append(i + start)
+            if return_mapping:
+                mapping[i + start] = key
+        return (dict(cluster), mapping) if return_mapping else dict(cluster)
+
+    def get_reconstruct_vector(self, index, codebook=None):
+        cb = self.codebook if codebook is None else codebook
+        index = index.to(cb.device).long()
+        out = torch.zeros(index.shape[:-1] + (cb.shape[-1],), dtype=torch.float32, device=cb.device)
+        for j in range(cb.shape[0]):
+            out = out + cb[j][index[..., j]]
+        return out

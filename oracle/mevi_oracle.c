@@ -133,6 +133,50 @@ int oracle_topk_merge_f32(const float *scores, const int64_t *ids, int64_t nlist
   return 0;
 }
 
+/* ----------------------------------------------------------------------------
+ * Residual quantisation encode.
+ * Restates pq.get_rq_document_cluster (MEVI/pq.py:281-305) == the index path of
+ * forward_rq (MEVI/pq.py:337-369) with dist_mode 'l2': compute_scores (pq.py:124-131)
+ * is -sum((a - b)**2, -1); index = argmax of it; the residual loses the chosen
+ * centroid after every level (rq_minus_centroids, pq.py:121-122).
+ * torch leaves the summation order of .sum(-1) and the tie order of .max unspecified;
+ * pinned here: d = fmaf chain over k = 0..dim-1 of (r_k - c_k)^2, lowest index on ties.
+ * neg_dist (optional, [n, M, K]) receives -d, i.e. forward_rq's `proba`.
+ * -------------------------------------------------------------------------- */
+int oracle_rq_encode_f32(const float *x, int64_t n, int64_t dim, const float *codebook, int64_t M,
+                         int64_t K, int32_t *codes, float *neg_dist) {
+  if (n < 0 || dim <= 0 || M <= 0 || K <= 0) return -1;
+#pragma omp parallel
+  {
+    float *r = (float *)malloc(sizeof(float) * (size_t)dim);
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      memcpy(r, x + i * dim, sizeof(float) * (size_t)dim);
+      for (int64_t j = 0; j < M; ++j) {
+        const float *cb = codebook + j * K * dim;
+        float best = INFINITY;
+        int32_t arg = 0;
+        for (int64_t c = 0; c < K; ++c) {
+          float d = 0.0f;
+          for (int64_t k = 0; k < dim; ++k) {
+            float diff = r[k] - cb[c * dim + k];
+            d = fmaf(diff, diff, d);
+          }
+          if (neg_dist) neg_dist[(i * M + j) * K + c] = -d;
+          if (d < best) {
+            best = d;
+            arg = (int32_t)c;
+          }
+        }
+        codes[i * M + j] = arg;
+        for (int64_t k = 0; k < dim; ++k) r[k] = r[k] - cb[(int64_t)arg * dim + k];
+      }
+    }
+    free(r);
+  }
+  return 0;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
