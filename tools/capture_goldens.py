@@ -247,8 +247,153 @@ def g7_writers():
     json.dump(out, open(os.path.join(GOLD, "g7_writers.json"), "w"), indent=1)
     print("g7 ok")
 
+# --------------------------------------------------------------------------- G1 / G2 / G3
+def _mevi_t5_config(T5Config, M, K, d_model=32, d_ff=64, heads=4, d_kv=8, layers=2, dec_layers=2,
+                    adaptor_layers=2, vocab=512):
+    """T5Config exactly as T5FineTuner builds it (main_models.py:1350-1389) for the eval flags of
+    marco_eval_nci_rq.sh, shrunk to fixture size."""
+    return T5Config(
+        vocab_size=vocab, num_layers=layers, num_decoder_layers=dec_layers, d_ff=d_ff, d_model=d_model,
+        num_heads=heads, decoder_start_token_id=0, output_past=True, d_kv=d_kv, dropout_rate=0.1,
+        decode_embedding=2, hierarchic_decode=0, decode_vocab_size=K * (M + 2) + 2, output_vocab_size=K,
+        tie_word_embeddings=0, tie_decode_embedding=1, contrastive=0, Rdrop=0.0, Rdrop_only_decoder=0,
+        Rdrop_loss="KL", adaptor_decode=1, adaptor_efficient=1, adaptor_layer_num=adaptor_layers,
+        embedding_distillation=0.0, weight_distillation=0.0, input_dropout=1, denoising=0,
+        multiple_decoder=0, decoder_num=1, train_batch_size=2, eval_batch_size=2, max_output_length=M + 2,
+        use_codebook=1, pq_loss="ce", pq_twin_loss="co", reserve_decoder=0, decoder_integration="series",
+        topk_minpooling=None)
 
-ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g7=g7_writers)
+
+def _synthetic_queries(rng, n, seqlen, vocab):
+    """token ids as the tokenizer contract produces them: tokens, eos=1, pad=0 (SURVEY 'Tokenizer contract')."""
+    ids = np.zeros((n, seqlen), np.int64)
+    mask = np.zeros((n, seqlen), np.int64)
+    for i in range(n):
+        L = int(np.clip(rng.poisson(9) + 2, 3, seqlen)) if i else seqlen   # first query fills the window
+        ids[i, :L - 1] = rng.integers(3, vocab, size=L - 1)
+        ids[i, L - 1] = 1
+        mask[i, :L] = 1
+    return ids, mask
+
+
+def g1_nci_generate():
+    """T5ForConditionalGeneration.generate(...) of the vendored MEVI fork with the kwargs infer() passes
+    (main_models.py:3612-3641): decoded tokens, scores, step-wise last-position logits, encoder states."""
+    ref_import.setup()
+    import torch
+    from transformers import T5Config, T5ForConditionalGeneration
+    from main_models import TreeBuilder, encode_single_newid
+
+    for (M, K, beams, seed) in [(4, 32, 10, 0), (3, 16, 4, 1), (4, 32, 4, 2)]:
+        torch.manual_seed(seed)
+        cfg = _mevi_t5_config(T5Config, M, K)
+        with io.StringIO() as buf, redirect_stdout(buf):
+            model = T5ForConditionalGeneration(cfg)
+        model.eval()
+        # make the tiny model less degenerate: random (not ones) norm scales, larger relative bias
+        with torch.no_grad():
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("layer_norm.weight") or "final_layer_norm" in n_:
+                    p_.copy_(1.0 + 0.2 * torch.randn_like(p_))
+                if "relative_attention_bias" in n_:
+                    p_.copy_(torch.randn_like(p_))
+                if n_.startswith("adaptor.") and n_.endswith("bias"):
+                    p_.copy_(0.05 * torch.randn_like(p_))
+        args = Namespace(kary=K, position=1, label_length_cutoff=M, max_output_length=M + 2)
+        builder = TreeBuilder(share_sons=True)
+        newids = [encode_single_newid(args, [i for _ in range(M)]) for i in range(K)]
+        for i in range(M):
+            builder.add_layer([ids[i] for ids in newids])
+        builder.add_layer([1])
+        root = builder.build()
+        rng = np.random.default_rng(seed + 50)
+        ids, mask = _synthetic_queries(rng, 4, 32, cfg.vocab_size)
+        step_logits = []
+        orig_forward = model.forward
+
+        def spy(*a, **k):
+            out = orig_forward(*a, **k)
+            step_logits.append(out[0][:, -1, :].detach().clone())
+            return out
+
+        model.forward = spy
+        kwargs = dict(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), use_cache=False,
+                      max_length=M + 2, length_penalty=0.8, num_return_sequences=beams, early_stopping=False,
+                      decode_embedding=2, decode_vocab_size=cfg.decode_vocab_size, decode_tree=root,
+                      output_hidden_states=True, output_scores=True, decoder_integration="series",
+                      decoder_attention_mask=torch.tensor([[1] * (M + 1) + [0]] * 4), num_beams=beams)
+        with torch.no_grad():
+            outs, scores, enc_h, dec_h = model.generate(**kwargs)
+        model.forward = orig_forward
+        sd = {k_: v_.detach().numpy() for k_, v_ in model.state_dict().items()}
+        np.savez(os.path.join(GOLD, f"g1_nci_M{M}_K{K}_R{beams}.npz"),
+                 input_ids=ids, attention_mask=mask, decoded=outs.numpy(), scores=np.array(scores, dtype=np.float64),
+                 enc_hidden=enc_h[::beams].numpy(),
+                 **{f"step{t}_logits": l.numpy() for t, l in enumerate(step_logits)},
+                 **{"w." + k_: v_ for k_, v_ in sd.items()},
+                 cfg=np.array(json.dumps(dict(M=M, K=K, beams=beams, d_model=cfg.d_model, d_ff=cfg.d_ff,
+                                              num_heads=cfg.num_heads, d_kv=cfg.d_kv, num_layers=cfg.num_layers,
+                                              num_decoder_layers=cfg.num_decoder_layers,
+                                              adaptor_layer_num=cfg.adaptor_layer_num, vocab_size=cfg.vocab_size,
+                                              layer_norm_epsilon=cfg.layer_norm_epsilon,
+                                              relative_attention_num_buckets=cfg.relative_attention_num_buckets))))
+        print("g1", M, K, beams, "decoded", tuple(outs.shape), "steps", len(step_logits), "score0", scores[0])
+
+
+def g2_t5_tower():
+    """T5Model forward as DocumentEncoder.encode does it (document_encoder.py:104-120): decoder_input_ids = 0,
+    reps = last_hidden_state[:, 0, :]; plus encoder/decoder per-layer hidden states."""
+    ref_import.setup()
+    import torch
+    from transformers import T5Config, T5Model
+
+    torch.manual_seed(7)
+    cfg = T5Config(vocab_size=512, d_model=32, d_ff=64, num_heads=4, d_kv=8, num_layers=2, num_decoder_layers=2,
+                   dropout_rate=0.1)
+    model = T5Model(cfg)
+    model.eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("layer_norm.weight"):
+                p_.copy_(1.0 + 0.2 * torch.randn_like(p_))
+            if "relative_attention_bias" in n_:
+                p_.copy_(torch.randn_like(p_))
+    rng = np.random.default_rng(77)
+    ids, mask = _synthetic_queries(rng, 8, 32, cfg.vocab_size)
+    with torch.no_grad():
+        out = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                    decoder_input_ids=torch.zeros((8, 1), dtype=torch.long), return_dict=True,
+                    output_hidden_states=True)
+    np.savez(os.path.join(GOLD, "g2_t5_tower.npz"), input_ids=ids, attention_mask=mask,
+             reps=out.last_hidden_state[:, 0, :].numpy(),
+             enc_last=out.encoder_last_hidden_state.numpy(),
+             **{f"enc_h{i}": h.numpy() for i, h in enumerate(out.encoder_hidden_states)},
+             **{f"dec_h{i}": h.numpy() for i, h in enumerate(out.decoder_hidden_states)},
+             **{"w." + k_: v_.detach().numpy() for k_, v_ in model.state_dict().items()},
+             cfg=np.array(json.dumps(dict(d_model=32, d_ff=64, num_heads=4, d_kv=8, num_layers=2,
+                                          num_decoder_layers=2, vocab_size=512, layer_norm_epsilon=cfg.layer_norm_epsilon,
+                                          relative_attention_num_buckets=cfg.relative_attention_num_buckets))))
+    print("g2 reps", tuple(out.last_hidden_state.shape))
+
+
+def g3_relative_buckets():
+    """T5Attention._relative_position_bucket tables (modeling_t5.py:241-304)."""
+    ref_import.setup()
+    import torch
+    from transformers.modeling_t5 import T5Attention
+
+    out = {}
+    for name, (ql, kl, bidir) in dict(enc32=(32, 32, True), dec6=(6, 6, False), enc200=(200, 200, True),
+                                      dec150=(150, 150, False)).items():
+        ctx = torch.arange(ql)[:, None]
+        mem = torch.arange(kl)[None, :]
+        out[name] = T5Attention._relative_position_bucket(mem - ctx, bidirectional=bidir, num_buckets=32).numpy()
+    np.savez_compressed(os.path.join(GOLD, "g3_relative_buckets.npz"), **out)
+    print("g3 ok")
+
+
+ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower,
+           g3=g3_relative_buckets)
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
