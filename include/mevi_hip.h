@@ -104,12 +104,6 @@ void mevi_ip_topk_set_growth(double growth);
 void mevi_ip_topk_set_profiling(int enable); /* record HIP events around every filter/compact launch */
 void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out);
 
-/* Diagnostics (kernel development only): variant 3 launches a build of the filter
- * kernel that records s_memtime stamps of one workgroup's phases; read them back
- * (512 x u64, host memory) with mevi_debug_read_stamps.  Variant 0 = product. */
-void mevi_debug_set_variant(int variant);
-int mevi_debug_read_stamps(unsigned long long *host_out);
-
 #ifdef __cplusplus
 }
 #endif

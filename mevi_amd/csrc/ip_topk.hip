@@ -24,7 +24,7 @@
 // and half 1 odd k); oracle/mevi_oracle.c computes the same chain on the CPU,
 // so parity is bit-exact.
 
-#include "common.h"
+#include "mfma_pp.h"
 
 #include <float.h>
 #include <math.h>
@@ -33,10 +33,6 @@
 namespace mevi {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128;          // docs per wave-group tile (MFMA A rows)
-constexpr int BK = 32;           // K slab
 constexpr int MAX_SORT = 16384;  // largest LDS sort (128 KiB of keys)
 
 struct TopkGeom {
@@ -63,66 +59,16 @@ static inline TopkGeom make_geom(int k) {
 }
 
 // ---------------------------------------------------------------------------
-// XCD-aware bijective block remap: blocks that share `bid % 8` share an XCD (L2),
-// so give each XCD a contiguous range of work items (doc tiles with all their
-// query tiles) -- the doc tile is then fetched from HBM once per XCD L2.
-__device__ inline int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + (bid >> 3);
-}
-
-// ---------------------------------------------------------------------------
-// ip_filter_kernel: f32-MFMA tile GEMM with a threshold-filter epilogue.
-//
-// One 512-thread workgroup per CU, two 4-wave groups.  Group g owns the 128-doc
-// tile (2*dpair+g); both share one query tile of QT = 64*NI rows.  Inside a group
-// wave (wm, wn) owns 64 docs x 32*NI queries = 2 x NI MFMA accumulators (32x32).
-// The two waves that share a SIMD belong to different groups and alternate roles:
-//   MFMA role    -- 16 k-steps x (2*NI) v_mfma_f32_32x32x2_f32 on slab s.  A wave
-//                   issues in order and the matrix pipe holds ONE MFMA (64 cycles),
-//                   so every other instruction sits in the shadow of an MFMA: the
-//                   stream is pinned (sched_group_barrier) to {MFMA, ds_read} x(2+NI),
-//                   {MFMA, global_load}, MFMA... per pair of k-steps; fragment reads
-//                   run two pairs ahead, the global loads of the slab this group
-//                   stages next are spread one per pair.
-//   staging role -- convert the staged registers into the LDS image of the next
-//                   slab (raised priority: a handful of ds_write2_b32).
-// Hand-over is early: the MFMA role executes its barrier once its last LDS read
-// has been issued (after pair 5 of 8), so the other group warms up (first LDS
-// reads) underneath the remaining MFMAs and the pipe does not idle at the switch.
-//   G0: [compute(s) + loads(s+1)] [lstore(s+1)] barrier ...
-//   G1: [lstore(s+1)] barrier [compute(s) + loads(s+2)] ...
-// LDS image: row-major [row][k], natural k order, odd row stride (33 floats) so
-// that both the b32 fragment reads (32 rows, same k) and the staging stores are
-// bank-conflict free.  MFMA lane half h consumes k = 2j + h, which makes each score
-// the sequential fmaf chain over k (bit-exact contract with the oracle).
-// Diagnostic build only (VARIANT 3): s_memtime stamps per wave of one workgroup.
-__device__ unsigned long long g_stamps[8 * 8 * 8];
-#define PP_STAMP(slot)                                                                          \
-  do {                                                                                          \
-    if (VARIANT == 3 && blockIdx.x == 4096 && s < 8) {                                          \
-      unsigned long long _t;                                                                    \
-      __builtin_amdgcn_sched_barrier(0);                                                        \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
-      __builtin_amdgcn_sched_barrier(0);                                                        \
-      if (lane == 0) g_stamps[((t >> 6) * 8 + s) * 8 + (slot)] = _t;                            \
-    }                                                                                           \
-  } while (0)
-
-constexpr int PP_THREADS = 512;
-constexpr int PP_LD = 33;  // floats per LDS row
-
-template <int NI, bool KTAIL, int VARIANT>
+// ip_filter_kernel: the shared f32-MFMA ping-pong tile loop (mfma_pp.h) with a threshold-
+// filter epilogue.  A = corpus rows (two 128-row tiles per workgroup), B = 128 queries.
+template <int NI, bool KTAIL>
 __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
     const float *__restrict__ Q, int nq, const float *__restrict__ D, long long doc_begin,
     long long doc_end, int dim, const float *__restrict__ tau, unsigned long long *__restrict__ buf,
     unsigned int *__restrict__ count, int S, int k, int cap, unsigned int id_base, int n_qtiles,
     int n_dpairs) {
-  constexpr int QT = 64 * NI;          // query rows per workgroup
-  constexpr int ROWS = 2 * BM + QT;    // LDS rows per buffer: A0[128] | A1[128] | B[QT]
-  constexpr int NLOAD = 4 + NI;        // float4 global loads per thread per slab
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 * ROWS * PP_LD floats
+  constexpr int QT = 64 * NI;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int nwg = n_qtiles * n_dpairs;
   const int wg = xcd_remap(blockIdx.x, nwg);
@@ -130,22 +76,16 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
   const int qtile = wg - dpair * n_qtiles;
 
   const int t = threadIdx.x;
-  const int grp = __builtin_amdgcn_readfirstlane(t >> 8);  // wave-uniform
+  const int grp = __builtin_amdgcn_readfirstlane(t >> 8);
   const int tg = t & 255;
   const int lane = t & 63;
   const int wave = tg >> 6;
-  const int wm = wave >> 1;
-  const int wn = wave & 1;
-  const int lrow = lane & 31;
-  const int half = lane >> 5;
-
-  const int srow = tg >> 3;
-  const int skq = (tg & 7) * 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = lane & 31, half = lane >> 5;
+  const int srow = tg >> 3, skq = (tg & 7) * 4;
   const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
   const int qrow0 = qtile * QT;
 
-  // staging duty of this thread: 4 float4 of its group's doc tile, NI float4 of the
-  // shared query tile (rows (QT/2)*grp + ...)
   const float *dptr[4];
   const float *qptr[NI];
 #pragma unroll
@@ -161,143 +101,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
     qptr[i] = Q + (size_t)qr * (size_t)dim + skq;
   }
 
-  float4 ra[4], rb[NI];
-  const int nslab = (dim + BK - 1) / BK;
-
-  auto gload_one = [&](int s, int i) {
-    int kk = s * BK;
-    if (KTAIL && kk + skq + 4 > dim) kk = dim - 4 - skq;  // stay in bounds; zeroed in lstore
-    if (i < 4) ra[i] = *reinterpret_cast<const float4 *>(dptr[i] + kk);
-    else rb[i - 4] = *reinterpret_cast<const float4 *>(qptr[i - 4] + kk);
-  };
-  auto gload = [&](int s) {
-#pragma unroll
-    for (int i = 0; i < NLOAD; ++i) gload_one(s, i);
-  };
-  auto lstore = [&](int s) {
-    float *base = lds + (s & 1) * ROWS * PP_LD;
-    float *sA = base + (grp * BM + srow) * PP_LD + skq;
-    float *sB = base + (2 * BM + (QT / 2) * grp + srow) * PP_LD + skq;
-    const bool zero = KTAIL && (s * BK + skq >= dim);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = ra[i];
-      if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      float *p = sA + 32 * i * PP_LD;
-      p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float4 v = rb[i];
-      if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      float *p = sB + 32 * i * PP_LD;
-      p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
-    }
-  };
-
   f32x16 acc[2][NI];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  auto compute = [&](int s, int gs, bool with_barrier) {
-    const float *base = lds + (s & 1) * ROWS * PP_LD;
-    const float *pa = base + (grp * BM + 64 * wm + lrow) * PP_LD + half;
-    const float *pb = base + (2 * BM + 32 * NI * wn + lrow) * PP_LD + half;
-    float av[2][16], bv[NI][16];
-    auto ld = [&](int pr) {
-#pragma unroll
-      for (int j = 2 * pr; j < 2 * pr + 2; ++j) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) av[mi][j] = pa[32 * mi * PP_LD + 2 * j];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bv[ni][j] = pb[32 * ni * PP_LD + 2 * j];
-      }
-    };
-    ld(0);
-    ld(1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int pr = 0; pr < 8; ++pr) {
-      if (pr + 2 < 8) ld(pr + 2);
-      if (gs >= 0 && pr < NLOAD) gload_one(gs, pr);
-#pragma unroll
-      for (int j = 2 * pr; j < 2 * pr + 2; ++j)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
-      // sched_group_barrier(mask, count, sync id): 0x008 MFMA, 0x100 DS read, 0x020 VMEM read
-      constexpr int NM = 4 * NI;  // MFMAs in this pair of k-steps
-      const bool rd = (pr + 2 < 8), gl = (gs >= 0 && pr < NLOAD);
-      if (rd) {
-#pragma unroll
-        for (int i = 0; i < 2 + NI; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-      }
-      if (gl) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-      if (rd && gl) __builtin_amdgcn_sched_group_barrier(0x008, NM - (2 + NI) - 1, 0);
-      else if (rd) __builtin_amdgcn_sched_group_barrier(0x008, NM - (2 + NI), 0);
-      else if (gl) __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
-      else __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-      // Early hand-over: after pair 5 every LDS read of this slab has been issued (the
-      // barrier's lgkmcnt(0) retires them), so the other group may start its phase now.
-      if (pr == 5) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (with_barrier) __syncthreads();
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // ---- prologue: slab 0 staged by everyone; G1 already has slab 1 in flight
-  gload(0);
-  lstore(0);
-  if (grp == 1 && nslab > 1) gload(1);
-  __syncthreads();
-
-  // Two role-specialised loops (wave-uniform branch; both execute 2*(nslab-1) barriers,
-  // one inside compute() and one after lstore()).
-  if (grp == 0) {
-    for (int s = 0; s + 1 < nslab; ++s) {
-      PP_STAMP(0);
-      compute(s, s + 1, true);
-      PP_STAMP(1);
-      __builtin_amdgcn_s_setprio(3);
-      lstore(s + 1);
-      __builtin_amdgcn_s_setprio(0);
-      PP_STAMP(2);
-      __syncthreads();
-      PP_STAMP(3);
-    }
-  } else {
-    for (int s = 0; s + 2 < nslab; ++s) {
-      PP_STAMP(0);
-      __builtin_amdgcn_s_setprio(3);
-      lstore(s + 1);
-      __builtin_amdgcn_s_setprio(0);
-      PP_STAMP(1);
-      __syncthreads();
-      PP_STAMP(2);
-      compute(s, s + 2, true);
-      PP_STAMP(3);
-    }
-    if (nslab >= 2) {
-      lstore(nslab - 1);
-      __syncthreads();
-      compute(nslab - 2, -1, true);
-    }
-  }
-  compute(nslab - 1, -1, false);  // last slab: nothing left to stage, both groups run together
+  pp_mainloop<NI, KTAIL>(dptr, qptr, dim, lds, acc);
 
   // ---- epilogue: threshold filter -------------------------------------------
   // C/D map of the 32x32 MFMA: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*half (doc)
@@ -493,7 +298,6 @@ static SearchState carve_state(char *&p, int64_t nq, const TopkGeom &g) {
 
 thread_local double g_growth = 0.0;
 thread_local int g_profile = 0;
-thread_local int g_variant = 0;  // 3: diagnostic stamp build
 thread_local mevi_ip_topk_stats g_stats = {0, 0, 0, 0.0, 0.0, 0.0};
 thread_local std::vector<hipEvent_t> g_events;  // triples: before filter, after filter, after compact
 
@@ -542,13 +346,12 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   double growth = g_growth > 0.0 ? g_growth : (double)(g.cap / (3 * g.k));
   if (growth < 1.0) growth = 1.0;
   const int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
-  const size_t pp_lds = (size_t)2 * (2 * BM + qt) * PP_LD * sizeof(float);
+  const size_t pp_lds = pp_lds_bytes<2>();
   const bool ktail = (dim % BK) != 0;
   const void *fn = nullptr;
-#define MEVI_PICK(NI_, T_, V_) fn = reinterpret_cast<const void *>(ip_filter_kernel<NI_, T_, V_>)
-  if (g_variant == 3 && !ktail) MEVI_PICK(2, false, 3);
-  else if (ktail) MEVI_PICK(2, true, 0);
-  else MEVI_PICK(2, false, 0);
+#define MEVI_PICK(NI_, T_) fn = reinterpret_cast<const void *>(ip_filter_kernel<NI_, T_>)
+  if (ktail) MEVI_PICK(2, true);
+  else MEVI_PICK(2, false);
 #undef MEVI_PICK
   // opt in to > 64 KiB dynamic LDS (per device; cheap, so done on every call)
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds) != hipSuccess) {
@@ -611,10 +414,7 @@ extern "C" size_t mevi_ip_topk_workspace_bytes(int64_t nq, int64_t dim, int64_t 
 
 extern "C" void mevi_ip_topk_set_growth(double growth) { g_growth = growth; }
 extern "C" void mevi_ip_topk_set_profiling(int enable) { g_profile = enable; }
-extern "C" void mevi_debug_set_variant(int v) { g_variant = v; }
-extern "C" int mevi_debug_read_stamps(unsigned long long *host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -4;
-}
+
 extern "C" void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out) {
   if (out) *out = g_stats;
 }

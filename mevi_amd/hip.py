@@ -36,8 +36,6 @@ _SIGNATURES = {
     "mevi_ip_topk_set_growth": (None, [c_double]),
     "mevi_ip_topk_set_profiling": (None, [c_int]),
     "mevi_ip_topk_get_stats": (None, [ctypes.POINTER(IpTopkStats)]),
-    "mevi_debug_set_variant": (None, [c_int]),
-    "mevi_debug_read_stamps": (c_int, [c_void_p]),
 }
 
 

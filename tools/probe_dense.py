@@ -18,12 +18,9 @@ q = torch.randn((nq, dim), device=dev, generator=g)
 d = torch.empty((nd, dim), device=dev)
 for a in range(0, nd, 1 << 20):
     d[a:a + (1 << 20)] = 0.05 * torch.randn((min(1 << 20, nd - a), dim), device=dev, generator=g) + 0.02
-import ctypes
-variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]  # 12: NI=2, 14: NI=4
 hip.lib().mevi_ip_topk_set_profiling(1)
-for it in range(3 * len(variants)):
-    v = variants[it % len(variants)]
-    hip.lib().mevi_debug_set_variant(ctypes.c_int(v))
+for it in range(3):
+    v = 0
     torch.cuda.synchronize()
     t = time.time()
     s, i = dense.ip_topk(q, d, k)
