@@ -89,6 +89,80 @@ int mevi_topk_merge_f32(const float *scores, const int64_t *ids, int64_t nlists,
 int mevi_rq_encode_f32(const float *x, int64_t n, int64_t dim, const float *codebook, int64_t M,
                        int64_t K, int32_t *codes, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Linear layer:  C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]
+ * Replaces every torch.nn.Linear / torch.matmul of the T5 stacks on the hot path:
+ * q/k/v/o and wi/wo (MEVI/transformers/modeling_t5.py:181-186, 217-220, 350-358, 412),
+ * the adaptor's nn.TransformerDecoderLayer projections and adaptor_linear
+ * (modeling_t5.py:1252-1255, 1677-1682).  W is the [out, in] weight of nn.Linear.
+ *   lda/ldw/ldc/ldr: row strides in floats; bias, residual may be NULL;
+ *   act: 0 = identity, 1 = ReLU (applied before the residual add).
+ *   Each output is the sequential f32 fmaf chain over k.
+ *   Requirements: K, lda, ldw multiples of 4; A, W 16-byte aligned.
+ * Fully stream-ordered; no workspace.
+ * ---------------------------------------------------------------------- */
+int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int64_t ldw, float *c, int64_t ldc,
+                     int64_t m, int64_t n, int64_t k, const float *bias, const float *residual,
+                     int64_t ldr, int act, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Small-shape T5 / adaptor operators (wave-per-row kernels).  Stream-ordered, no workspace.
+ * ---------------------------------------------------------------------- */
+/* T5LayerNorm: out = w * (x / sqrt(mean(x^2) + eps))  (MEVI/transformers/modeling_t5.py:155-171) */
+int mevi_rmsnorm_f32(const float *x, int64_t ldx, const float *w, float eps, int64_t rows, int64_t dim,
+                     float *out, int64_t ldo, void *stream);
+/* torch LayerNorm(x + y + cvec) * w + b, y / cvec optional: the post-LN residual blocks of
+ * nn.TransformerDecoderLayer (adaptor, modeling_t5.py:1252-1255); cvec carries the adaptor's
+ * constant cross-attention output (its memory is one learned vector, modeling_t5.py:1663). */
+int mevi_add_layernorm_f32(const float *x, int64_t ldx, const float *y, int64_t ldy, const float *cvec,
+                           const float *w, const float *b, float eps, int64_t rows, int64_t dim,
+                           float *out, int64_t ldo, void *stream);
+/* out[i] = table[idx[i]]: nn.Embedding (modeling_t5.py:718) and beam reorder (generation_utils.py:927-934) */
+int mevi_gather_rows_f32(const float *table, int64_t ldt, const int64_t *idx, int64_t n, int64_t dim,
+                         float *out, int64_t ldo, void *stream);
+int mevi_scale_f32(const float *x, float alpha, int64_t n, float *out, void *stream);
+/* softmax(scale*q.k^T + bias[h, q_pos0+t, j] + key mask + causal mask) . v for <= 64 keys
+ * (T5Attention.forward, modeling_t5.py:374-410: no 1/sqrt(d) scaling, fp32 softmax; also
+ * nn.MultiheadAttention of the adaptor with scale = head_dim^-0.5).
+ *   q[b, t, h*dh + d] via (q_bs, q_ts); k/v[b / kv_div, j, h*dh + d]; out like q.
+ *   key_mask i64 [nb / kv_div, tk] (1 = attend) or NULL; causal: key j allowed iff j <= q_pos0 + t. */
+int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, const float *k, int64_t k_bs, int64_t k_ts,
+                       const float *v, int64_t v_bs, int64_t v_ts, float *out, int64_t o_bs, int64_t o_ts,
+                       int64_t nb, int64_t tq, int64_t tk, int64_t heads, int64_t dh, int64_t kv_div,
+                       const float *bias, int64_t bias_rows, int64_t bias_ld, int64_t q_pos0,
+                       const int64_t *key_mask, int causal, float scale, void *stream);
+/* PAWA adaptive head on the valid columns only (modeling_t5.py:1607, 1677-1689):
+ * out[row, c] = sum_d s[row, d] * (t[row, c*dim + d] + e[c, d]),  t = adaptor_linear slice, e = lm_head rows */
+int mevi_adaptive_logits_f32(const float *s, int64_t lds, const float *t, int64_t ldt, const float *e,
+                             int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Constrained beam step over the shared-layer RQ tree (one decoding step).
+ * Replaces select_valid_embedding + log_softmax + prefix-tree mask + top-k + the Python
+ * candidate loop (modeling_t5.py:1578-1603,1689; generation_utils.py:783, 803-818, 851-945).
+ *   logits f32 [nq*nb, K+1]: col 0 = eos, cols 1..K = the K codes of this level
+ *   beam_scores f32 [nq, nb]
+ *   final_step == 0: out_scores/out_parent/out_code [nq, R] = the R best of
+ *       beam_score[r] + log_softmax(logits[r])[1 + c], descending, ties by lower r*K + c
+ *   final_step == 1: out_scores [nq, nb] = beam_score[r] + log_softmax(logits[r])[0] (eos closes)
+ * ---------------------------------------------------------------------- */
+int mevi_beam_step_f32(const float *logits, const float *beam_scores, int64_t nq, int64_t nb, int64_t K,
+                       int64_t R, int final_step, float *out_scores, int32_t *out_parent,
+                       int32_t *out_code, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Fine stage: in-cluster re-ranking (MEVI/main_models.py:3915-4014).
+ *   pair_dot: out[i] = <a[ia[i]], b[ib[i]]>, sequential f32 fmaf chain (same chain as
+ *             mevi_ip_topk_f32, so dense and fine scores of one pair are identical)
+ *   segment_sort_desc: every segment [seg_offsets[s], seg_offsets[s+1]) sorted by
+ *             (score desc, id asc); segments of at most 16384 entries.
+ * ---------------------------------------------------------------------- */
+int mevi_pair_dot_f32(const float *a, int64_t lda, const int64_t *ia, const float *b, int64_t ldb,
+                      const int64_t *ib, int64_t n, int64_t dim, float *out, void *stream);
+int mevi_segment_sort_desc_f32(const float *scores, const int64_t *ids, const int64_t *seg_offsets,
+                               int64_t nseg, int64_t max_seg_len, float *out_scores, int64_t *out_ids,
+                               void *stream);
+
 /* Test / tuning hooks for the dense arm (not part of the drop-in surface):
  * force the chunk growth factor (0 = default) and read back statistics of the
  * last mevi_ip_topk_f32 call on this thread. */

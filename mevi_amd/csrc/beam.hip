@@ -1,0 +1,100 @@
+// Constrained beam step over the shared-layer RQ tree (K10 / K11).
+//
+// Replaces, per decoding step, the reference's position mask + log_softmax + prefix-tree
+// mask + top-2R + Python candidate loop (MEVI/transformers/modeling_t5.py:1578-1603,1689;
+// generation_utils.py:783, 803-818, 851-945).  For the shared-sons tree every level-p node
+// has the same K children, so the step collapses to (SURVEY 8(a')):
+//     lsm      = log_softmax over {eos} U {K level-p codes}     (all other columns are exp(-1e9) = 0)
+//     cand[r,c] = beam_score[r] + lsm[r, c]                      (eos is cut by the tree)
+//     keep the R best of the nb*K candidates (descending, ties -> lower r*K + c)
+// Input logits hold only the valid columns: col 0 = eos, cols 1..K = codes of the level.
+// One workgroup per query: wave-per-beam logsumexp, 64-bit (score|index) keys, LDS bitonic sort.
+#include "common.h"
+
+#include <math.h>
+
+namespace mevi {
+namespace {
+
+__global__ __launch_bounds__(256) void beam_step_kernel(const float *__restrict__ logits,
+                                                       const float *__restrict__ beam_scores, int nb, int K,
+                                                       int R, int final_step, float *__restrict__ out_scores,
+                                                       int *__restrict__ out_parent, int *__restrict__ out_code) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // P keys, then nb floats x2
+  const int q = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ncol = K + 1;
+  const int ncand = nb * K;
+  int P = 64;
+  while (P < ncand) P <<= 1;
+  float *smax = reinterpret_cast<float *>(skeys + P);
+  float *slog = smax + nb;
+  const float *lq = logits + (size_t)q * nb * ncol;
+
+  for (int r = wave; r < nb; r += 4) {  // log-sum-exp of beam r over its K+1 valid columns
+    const float *row = lq + (size_t)r * ncol;
+    float m = -INFINITY;
+    for (int c = lane; c < ncol; c += 64) m = fmaxf(m, row[c]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float s = 0.f;
+    for (int c = lane; c < ncol; c += 64) s += expf(row[c] - m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+      smax[r] = m;
+      slog[r] = logf(s);
+    }
+  }
+  __syncthreads();
+  if (final_step) {  // hypothesis closes with eos: score + log_softmax[eos]
+    for (int r = t; r < nb; r += 256)
+      out_scores[(size_t)q * nb + r] = beam_scores[(size_t)q * nb + r] + ((lq[(size_t)r * ncol] - smax[r]) - slog[r]);
+    return;
+  }
+  for (int i = t; i < P; i += 256) {
+    unsigned long long key = 0ull;
+    if (i < ncand) {
+      const int r = i / K, c = i - r * K;
+      const float lsm = (lq[(size_t)r * ncol + 1 + c] - smax[r]) - slog[r];
+      key = make_key(beam_scores[(size_t)q * nb + r] + lsm, (unsigned int)i);
+    }
+    skeys[i] = key;
+  }
+  __syncthreads();
+  bitonic_sort_desc<256>(skeys, P, t);
+  for (int i = t; i < R; i += 256) {
+    const unsigned long long key = skeys[i];
+    const int flat = (int)key_id(key);
+    out_scores[(size_t)q * R + i] = key_score(key);
+    out_parent[(size_t)q * R + i] = flat / K;
+    out_code[(size_t)q * R + i] = flat % K;
+  }
+}
+
+}  // namespace
+}  // namespace mevi
+
+using namespace mevi;
+
+extern "C" int mevi_beam_step_f32(const float *logits, const float *beam_scores, int64_t nq, int64_t nb, int64_t K,
+                                  int64_t R, int final_step, float *out_scores, int32_t *out_parent,
+                                  int32_t *out_code, void *stream) {
+  MEVI_REQUIRE(nq >= 0 && nb > 0 && K > 0 && R > 0, MEVI_ERR_INVALID_ARG, "beam_step: bad shape");
+  if (nq == 0) return MEVI_OK;
+  MEVI_REQUIRE(logits && beam_scores && out_scores && (final_step || (out_parent && out_code)),
+               MEVI_ERR_INVALID_ARG, "beam_step: null pointer");
+  MEVI_REQUIRE(nb * K <= 16384, MEVI_ERR_UNSUPPORTED, "beam_step: nb*K=%lld > 16384", (long long)(nb * K));
+  MEVI_REQUIRE(final_step || nb * K >= R, MEVI_ERR_UNSUPPORTED,
+               "beam_step: fewer candidates (%lld) than beams (%lld)", (long long)(nb * K), (long long)R);
+  int P = 64;
+  while (P < nb * K) P <<= 1;
+  const size_t lds = (size_t)P * 8 + (size_t)nb * 8;
+  if (lds > 65536)
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(beam_step_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)nq), dim3(256), lds, (hipStream_t)stream, logits, beam_scores,
+                     (int)nb, (int)K, (int)R, final_step, out_scores, out_parent, out_code);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}

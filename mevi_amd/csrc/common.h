@@ -60,4 +60,25 @@ __host__ __device__ static inline uint32_t key_id(uint64_t key) {
   return 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
 }
 
+// In-LDS bitonic sort (descending) of P 64-bit keys by NT threads.
+template <int NT>
+__device__ inline void bitonic_sort_desc(unsigned long long *s, int P, int t) {
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < (P >> 1); i += NT) {
+        const int lo = 2 * i - (i & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = s[lo], b = s[hi];
+        if ((a < b) == desc) {
+          s[lo] = b;
+          s[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+
 }  // namespace mevi

@@ -1,0 +1,112 @@
+// C[M, N] = act(A[M, K] . W[N, K]^T + bias[N]) + residual[M, N]   (all f32, row-major, K contiguous)
+//
+// The linear layers of the T5 stacks: q/k/v/o projections and wi/wo of every block
+// (MEVI/transformers/modeling_t5.py:181-186, 217-220, 350-358, 412), the adaptor's packed
+// in_proj / out_proj / linear1 / linear2 (torch.nn.TransformerDecoderLayer, modeling_t5.py:1252-1255)
+// and adaptor_linear restricted to the valid columns (modeling_t5.py:1677-1682).
+// torch.nn.Linear stores W as [out, in], so both operands are K-contiguous: exactly the shape of
+// the shared ping-pong f32-MFMA loop (mfma_pp.h).  Every output is the sequential fmaf chain over k.
+#include "mfma_pp.h"
+
+namespace mevi {
+namespace {
+
+template <bool KTAIL>
+__global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_kernel(
+    const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
+    float *__restrict__ C, long long ldc, int M, int N, int K, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int act, int n_ntiles, int n_mpairs) {
+  constexpr int NI = 2;
+  constexpr int QT = 64 * NI;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int nwg = n_ntiles * n_mpairs;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int mpair = wg / n_ntiles;
+  const int ntile = wg - mpair * n_ntiles;
+
+  const int t = threadIdx.x;
+  const int grp = __builtin_amdgcn_readfirstlane(t >> 8);
+  const int tg = t & 255;
+  const int lane = t & 63;
+  const int wave = tg >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = lane & 31, half = lane >> 5;
+  const int srow = tg >> 3, skq = (tg & 7) * 4;
+  const int mrow0 = (mpair * 2 + grp) * BM;
+  const int nrow0 = ntile * QT;
+
+  const float *aptr[4];
+  const float *wptr[NI];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = mrow0 + srow + 32 * i;
+    if (r > M - 1) r = M - 1;
+    aptr[i] = A + (size_t)r * lda + skq;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int r = nrow0 + (QT / 2) * grp + srow + 32 * i;
+    if (r > N - 1) r = N - 1;
+    wptr[i] = W + (size_t)r * ldw + skq;
+  }
+
+  f32x16 acc[2][NI];
+  pp_mainloop<NI, KTAIL>(aptr, wptr, K, lds, acc);
+
+  // C/D map: col = lane&31 -> n (W row), row = (r&3) + 8*(r>>2) + 4*half -> m (A row)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = nrow0 + 32 * NI * wn + 32 * ni + lrow;
+    if (n >= N) continue;
+    const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow0 + 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < M) {
+          float v = acc[mi][ni][r];
+          if (bias) v += b;
+          if (act == 1) v = fmaxf(v, 0.f);
+          if (residual) v += residual[(size_t)m * ldr + n];
+          C[(size_t)m * ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace mevi
+
+using namespace mevi;
+
+extern "C" int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int64_t ldw, float *c, int64_t ldc,
+                                int64_t m, int64_t n, int64_t k, const float *bias, const float *residual,
+                                int64_t ldr, int act, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(m >= 0 && n >= 0 && k > 0, MEVI_ERR_INVALID_ARG, "gemm_nt: bad shape");
+  if (m == 0 || n == 0) return MEVI_OK;
+  MEVI_REQUIRE(a && w && c, MEVI_ERR_INVALID_ARG, "gemm_nt: null pointer");
+  MEVI_REQUIRE(k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, MEVI_ERR_UNSUPPORTED,
+               "gemm_nt: k, lda, ldw must be multiples of 4 (k=%lld lda=%lld ldw=%lld)", (long long)k,
+               (long long)lda, (long long)ldw);
+  MEVI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0, MEVI_ERR_INVALID_ARG,
+               "gemm_nt: a/w must be 16-byte aligned");
+  MEVI_REQUIRE(act == 0 || act == 1, MEVI_ERR_INVALID_ARG, "gemm_nt: act must be 0 (none) or 1 (relu)");
+  MEVI_REQUIRE(m < (1LL << 31) && n < (1LL << 31) && k < (1LL << 24), MEVI_ERR_UNSUPPORTED, "gemm_nt: too large");
+  const int64_t n_mpairs = (m + 2 * BM - 1) / (2 * BM), n_ntiles = (n + 127) / 128;
+  MEVI_REQUIRE(n_mpairs * n_ntiles <= 0x7fffffffLL, MEVI_ERR_UNSUPPORTED, "gemm_nt: grid too large");
+  const size_t lds_bytes = pp_lds_bytes<2>();
+  const bool ktail = (k % BK) != 0;
+  const void *fn = ktail ? reinterpret_cast<const void *>(gemm_nt_kernel<true>)
+                         : reinterpret_cast<const void *>(gemm_nt_kernel<false>);
+  MEVI_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  long long lda_ = lda, ldw_ = ldw, ldc_ = ldc, ldr_ = ldr;
+  int m_ = (int)m, n_ = (int)n, k_ = (int)k, nt = (int)n_ntiles, mp = (int)n_mpairs;
+  void *args[] = {(void *)&a, &lda_, (void *)&w, &ldw_, (void *)&c, &ldc_, &m_, &n_, &k_, (void *)&bias,
+                  (void *)&residual, &ldr_, &act, &nt, &mp};
+  MEVI_HIP_CHECK(hipLaunchKernel(fn, dim3((unsigned)(n_mpairs * n_ntiles)), dim3(PP_THREADS), args, lds_bytes, stream));
+  return MEVI_OK;
+}

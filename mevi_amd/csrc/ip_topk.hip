@@ -130,27 +130,6 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// In-LDS bitonic sort (descending) of P 64-bit keys by NT threads.
-template <int NT>
-__device__ inline void bitonic_sort_desc(unsigned long long *s, int P, int t) {
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = t; i < (P >> 1); i += NT) {
-        const int lo = 2 * i - (i & (stride - 1));
-        const int hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long a = s[lo], b = s[hi];
-        if ((a < b) == desc) {
-          s[lo] = b;
-          s[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void init_state_kernel(unsigned long long *buf, unsigned int *count,
                                                         float *tau, unsigned int *failed, long long nq,
                                                         int S, int k) {

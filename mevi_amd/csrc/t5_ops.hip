@@ -1,0 +1,273 @@
+// Small-shape T5 / adaptor operators (everything that is not a GEMM): wave-per-row kernels
+// with coalesced float4 access and wavefront (64-lane) reductions.  All f32.
+//
+//   rmsnorm          T5LayerNorm                      modeling_t5.py:155-171
+//   add_layernorm    torch LayerNorm(x + y + c)       nn.TransformerDecoderLayer post-LN (modeling_t5.py:1252-1255)
+//   gather_rows      nn.Embedding / beam reorder      modeling_t5.py:718, generation_utils.py:927-934
+//   attention        T5Attention / nn.MultiheadAttention for <= 64 keys
+//                    modeling_t5.py:374-410 (no 1/sqrt(d) scaling, additive bias + mask, fp32 softmax)
+//   adaptive_logits  PAWA head, valid columns only    modeling_t5.py:1607, 1677-1689
+//   scale            hidden * d_model^-0.5            modeling_t5.py:1607
+#include "common.h"
+
+#include <math.h>
+
+namespace mevi {
+namespace {
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+// one wave per row, 4 rows per workgroup
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float *__restrict__ x, long long ldx,
+                                                     const float *__restrict__ w, float eps, long long rows,
+                                                     int dim, float *__restrict__ out, long long ldo) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float4 *xr = reinterpret_cast<const float4 *>(x + r * ldx);
+  float ss = 0.f;
+  for (int i = lane; i < dim / 4; i += 64) {
+    const float4 v = xr[i];
+    ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+  }
+  ss = wave_sum(ss);
+  const float denom = sqrtf(ss / (float)dim + eps);
+  float4 *o = reinterpret_cast<float4 *>(out + r * ldo);
+  const float4 *wv = reinterpret_cast<const float4 *>(w);
+  for (int i = lane; i < dim / 4; i += 64) {
+    const float4 v = xr[i], g = wv[i];
+    o[i] = make_float4(g.x * (v.x / denom), g.y * (v.y / denom), g.z * (v.z / denom), g.w * (v.w / denom));
+  }
+}
+
+// out = LayerNorm(x + y + c) * w + b   (y, c optional; biased variance; eps inside the sqrt)
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ x, long long ldx,
+                                                           const float *__restrict__ y, long long ldy,
+                                                           const float *__restrict__ c,
+                                                           const float *__restrict__ w,
+                                                           const float *__restrict__ b, float eps,
+                                                           long long rows, int dim, float *__restrict__ out,
+                                                           long long ldo) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];  // 4 rows x dim
+  const int wv = threadIdx.x >> 6;
+  const long long r = (long long)blockIdx.x * 4 + wv;
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float *s = srow + (size_t)wv * dim;
+  float sum = 0.f;
+  for (int i = lane; i < dim; i += 64) {
+    float v = x[r * ldx + i];
+    if (y) v += y[r * ldy + i];
+    if (c) v += c[i];
+    s[i] = v;
+    sum += v;
+  }
+  const float mean = wave_sum(sum) / (float)dim;
+  float var = 0.f;
+  for (int i = lane; i < dim; i += 64) {
+    const float d = s[i] - mean;
+    var = fmaf(d, d, var);
+  }
+  var = wave_sum(var) / (float)dim;
+  const float inv = 1.0f / sqrtf(var + eps);
+  for (int i = lane; i < dim; i += 64) out[r * ldo + i] = (s[i] - mean) * inv * w[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void gather_rows_i64_kernel(const float *__restrict__ table, long long ldt,
+                                                             const long long *__restrict__ idx, long long n,
+                                                             int dim, float *__restrict__ out, long long ldo) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float4 *s = reinterpret_cast<const float4 *>(table + idx[r] * ldt);
+  float4 *d = reinterpret_cast<float4 *>(out + r * ldo);
+  for (int i = lane; i < dim / 4; i += 64) d[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float *__restrict__ x, float alpha, long long n,
+                                                   float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = x[i] * alpha;
+}
+
+struct AttnArgs {
+  const float *q, *k, *v;
+  float *out;
+  long long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  int nb, tq, tk, H, dh, kv_div;
+  const float *bias;   // [H, bias_rows, bias_ld] or null; row = q_pos0 + t, col = key
+  int bias_rows, bias_ld;
+  int q_pos0;
+  const long long *key_mask;  // [nb / kv_div, tk] (1 = attend) or null
+  int causal;                 // key j allowed iff j <= q_pos0 + t
+  float scale;                // multiplies q before the dot product (1 for T5)
+};
+
+// one wave per (batch, head, query token); lane j owns key j (tk <= 64)
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long total = (long long)a.nb * a.H * a.tq;
+  if (wid >= total) return;
+  const int lane = threadIdx.x & 63;
+  const int t = (int)(wid % a.tq);
+  const int h = (int)((wid / a.tq) % a.H);
+  const int b = (int)(wid / ((long long)a.tq * a.H));
+  const int bk = b / a.kv_div;
+  const float *q = a.q + (size_t)b * a.q_bs + (size_t)t * a.q_ts + (size_t)h * a.dh;
+  const int qpos = a.q_pos0 + t;
+
+  float s = -INFINITY;
+  if (lane < a.tk) {
+    const float *kr = a.k + (size_t)bk * a.k_bs + (size_t)lane * a.k_ts + (size_t)h * a.dh;
+    float acc = 0.f;
+    for (int d = 0; d < a.dh; d += 4) {
+      const float4 kv = *reinterpret_cast<const float4 *>(kr + d);
+      const float4 qv = *reinterpret_cast<const float4 *>(q + d);
+      acc = fmaf(qv.x * a.scale, kv.x, acc);
+      acc = fmaf(qv.y * a.scale, kv.y, acc);
+      acc = fmaf(qv.z * a.scale, kv.z, acc);
+      acc = fmaf(qv.w * a.scale, kv.w, acc);
+    }
+    float add = 0.f;
+    if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + lane];
+    if (a.key_mask && a.key_mask[(size_t)bk * a.tk + lane] == 0) add += -1e9f;
+    if (a.causal && lane > qpos) add += -1e9f;
+    s = acc + add;
+  }
+  const float m = wave_max(s);
+  const float e = (lane < a.tk) ? expf(s - m) : 0.f;
+  const float p = e / wave_sum(e);
+
+  float *o = a.out + (size_t)b * a.o_bs + (size_t)t * a.o_ts + (size_t)h * a.dh;
+  const float *vb = a.v + (size_t)bk * a.v_bs + (size_t)h * a.dh;
+  for (int d = lane; d < a.dh; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < a.tk; ++j) acc = fmaf(__shfl(p, j), vb[(size_t)j * a.v_ts + d], acc);
+    o[d] = acc;
+  }
+}
+
+// logits[row, c] = sum_d s[row, d] * (T[row, c*dim + d] + E[c, d]); one wave per (row, c)
+__global__ __launch_bounds__(256) void adaptive_logits_kernel(const float *__restrict__ s, long long lds_,
+                                                             const float *__restrict__ T, long long ldt,
+                                                             const float *__restrict__ E, long long rows,
+                                                             int ncol, int dim, float *__restrict__ out) {
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= rows * ncol) return;
+  const int lane = threadIdx.x & 63;
+  const long long r = wid / ncol;
+  const int c = (int)(wid - r * ncol);
+  const float4 *sv = reinterpret_cast<const float4 *>(s + r * lds_);
+  const float4 *tv = reinterpret_cast<const float4 *>(T + r * ldt + (size_t)c * dim);
+  const float4 *ev = reinterpret_cast<const float4 *>(E + (size_t)c * dim);
+  float acc = 0.f;
+  for (int i = lane; i < dim / 4; i += 64) {
+    const float4 a = sv[i], t4 = tv[i], e4 = ev[i];
+    acc = fmaf(a.x, t4.x + e4.x, acc);
+    acc = fmaf(a.y, t4.y + e4.y, acc);
+    acc = fmaf(a.z, t4.z + e4.z, acc);
+    acc = fmaf(a.w, t4.w + e4.w, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[r * ncol + c] = acc;
+}
+
+inline unsigned blocks4(long long waves) { return (unsigned)((waves + 3) / 4); }
+
+}  // namespace
+}  // namespace mevi
+
+using namespace mevi;
+
+extern "C" int mevi_rmsnorm_f32(const float *x, int64_t ldx, const float *w, float eps, int64_t rows, int64_t dim,
+                                float *out, int64_t ldo, void *stream) {
+  MEVI_REQUIRE(rows >= 0 && dim > 0 && dim % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, MEVI_ERR_INVALID_ARG,
+               "rmsnorm: dim/ld must be multiples of 4");
+  if (rows == 0) return MEVI_OK;
+  MEVI_REQUIRE(x && w && out, MEVI_ERR_INVALID_ARG, "rmsnorm: null pointer");
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(blocks4(rows)), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, w,
+                     eps, (long long)rows, (int)dim, out, (long long)ldo);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_add_layernorm_f32(const float *x, int64_t ldx, const float *y, int64_t ldy, const float *cvec,
+                                      const float *w, const float *b, float eps, int64_t rows, int64_t dim,
+                                      float *out, int64_t ldo, void *stream) {
+  MEVI_REQUIRE(rows >= 0 && dim > 0 && dim <= 8192, MEVI_ERR_INVALID_ARG, "add_layernorm: bad shape");
+  if (rows == 0) return MEVI_OK;
+  MEVI_REQUIRE(x && w && b && out, MEVI_ERR_INVALID_ARG, "add_layernorm: null pointer");
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3(blocks4(rows)), dim3(256), (size_t)4 * dim * sizeof(float),
+                     (hipStream_t)stream, x, (long long)ldx, y, (long long)ldy, cvec, w, b, eps, (long long)rows,
+                     (int)dim, out, (long long)ldo);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_gather_rows_f32(const float *table, int64_t ldt, const int64_t *idx, int64_t n, int64_t dim,
+                                    float *out, int64_t ldo, void *stream) {
+  MEVI_REQUIRE(n >= 0 && dim > 0 && dim % 4 == 0 && ldt % 4 == 0 && ldo % 4 == 0, MEVI_ERR_INVALID_ARG,
+               "gather_rows: dim/ld must be multiples of 4");
+  if (n == 0) return MEVI_OK;
+  MEVI_REQUIRE(table && idx && out, MEVI_ERR_INVALID_ARG, "gather_rows: null pointer");
+  hipLaunchKernelGGL(gather_rows_i64_kernel, dim3(blocks4(n)), dim3(256), 0, (hipStream_t)stream, table,
+                     (long long)ldt, reinterpret_cast<const long long *>(idx), (long long)n, (int)dim, out,
+                     (long long)ldo);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_scale_f32(const float *x, float alpha, int64_t n, float *out, void *stream) {
+  if (n <= 0) return MEVI_OK;
+  MEVI_REQUIRE(x && out, MEVI_ERR_INVALID_ARG, "scale: null pointer");
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, alpha,
+                     (long long)n, out);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, const float *k, int64_t k_bs,
+                                  int64_t k_ts, const float *v, int64_t v_bs, int64_t v_ts, float *out,
+                                  int64_t o_bs, int64_t o_ts, int64_t nb, int64_t tq, int64_t tk, int64_t heads,
+                                  int64_t dh, int64_t kv_div, const float *bias, int64_t bias_rows,
+                                  int64_t bias_ld, int64_t q_pos0, const int64_t *key_mask, int causal,
+                                  float scale, void *stream) {
+  MEVI_REQUIRE(nb >= 0 && tq > 0 && tk > 0 && heads > 0 && dh > 0 && kv_div > 0, MEVI_ERR_INVALID_ARG,
+               "attention: bad shape");
+  MEVI_REQUIRE(tk <= 64, MEVI_ERR_UNSUPPORTED, "attention: tk=%lld > 64 keys not supported", (long long)tk);
+  MEVI_REQUIRE(dh % 4 == 0 && q_bs % 4 == 0 && q_ts % 4 == 0 && k_bs % 4 == 0 && k_ts % 4 == 0,
+               MEVI_ERR_INVALID_ARG, "attention: dh and q/k strides must be multiples of 4");
+  if (nb == 0) return MEVI_OK;
+  MEVI_REQUIRE(q && k && v && out, MEVI_ERR_INVALID_ARG, "attention: null pointer");
+  MEVI_REQUIRE(!bias || q_pos0 + tq <= bias_rows, MEVI_ERR_INVALID_ARG, "attention: bias table too small");
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out;
+  a.q_bs = q_bs; a.q_ts = q_ts; a.k_bs = k_bs; a.k_ts = k_ts; a.v_bs = v_bs; a.v_ts = v_ts; a.o_bs = o_bs; a.o_ts = o_ts;
+  a.nb = (int)nb; a.tq = (int)tq; a.tk = (int)tk; a.H = (int)heads; a.dh = (int)dh; a.kv_div = (int)kv_div;
+  a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = (int)q_pos0;
+  a.key_mask = reinterpret_cast<const long long *>(key_mask); a.causal = causal; a.scale = scale;
+  hipLaunchKernelGGL(attention_kernel, dim3(blocks4(nb * heads * tq)), dim3(256), 0, (hipStream_t)stream, a);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_adaptive_logits_f32(const float *s, int64_t lds_, const float *t, int64_t ldt, const float *e,
+                                        int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream) {
+  MEVI_REQUIRE(rows >= 0 && ncol > 0 && dim > 0 && dim % 4 == 0 && lds_ % 4 == 0 && ldt % 4 == 0,
+               MEVI_ERR_INVALID_ARG, "adaptive_logits: bad shape");
+  if (rows == 0) return MEVI_OK;
+  MEVI_REQUIRE(s && t && e && out, MEVI_ERR_INVALID_ARG, "adaptive_logits: null pointer");
+  hipLaunchKernelGGL(adaptive_logits_kernel, dim3(blocks4(rows * ncol)), dim3(256), 0, (hipStream_t)stream, s,
+                     (long long)lds_, t, (long long)ldt, e, (long long)rows, (int)ncol, (int)dim, out);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}

@@ -5,7 +5,7 @@ there is no eager/CPU fallback anywhere in mevi_amd.
 """
 import ctypes
 import os
-from ctypes import c_double, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 import torch  # noqa: F401  (loads the HIP runtime the extension binds to)
 
@@ -33,6 +33,23 @@ _SIGNATURES = {
     "mevi_topk_merge_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mevi_rq_encode_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "mevi_gemm_nt_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                 c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mevi_rmsnorm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mevi_add_layernorm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float,
+                                       c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mevi_gather_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mevi_scale_f32": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_void_p]),
+    "mevi_attention_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                   c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                   c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_float, c_void_p]),
+    "mevi_adaptive_logits_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                         c_void_p, c_void_p]),
+    "mevi_beam_step_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
+    "mevi_pair_dot_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                  c_void_p, c_void_p]),
+    "mevi_segment_sort_desc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mevi_ip_topk_set_growth": (None, [c_double]),
     "mevi_ip_topk_set_profiling": (None, [c_int]),
     "mevi_ip_topk_get_stats": (None, [ctypes.POINTER(IpTopkStats)]),

@@ -1,0 +1,170 @@
+"""Thin tensor-level wrappers over the C ABI (include/mevi_hip.h).  torch supplies device memory
+and the current stream only; every function launches hand-written HIP kernels and raises
+MeviHipError when the extension or the GPU is missing."""
+import torch
+
+from . import hip
+
+
+def _f32(t):
+    assert t.is_cuda and t.dtype == torch.float32, (t.device, t.dtype)
+    return t
+
+
+def _rows2d(t):
+    """(pointer tensor, rows, cols, row stride) of a 2-D view whose last dim is contiguous."""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t, t.shape[0], t.shape[1], t.stride(0)
+
+
+def linear(x, weight, bias=None, residual=None, relu=False, out=None):
+    """out = act(x @ weight.T + bias) + residual   (x [M,K], weight [N,K] = nn.Linear layout)."""
+    x, M, K, lda = _rows2d(_f32(x))
+    w, N, K2, ldw = _rows2d(_f32(weight))
+    assert K == K2, (x.shape, weight.shape)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        ldr = residual.stride(0)
+    st = hip.lib().mevi_gemm_nt_f32(hip.ptr(x), lda, hip.ptr(w), ldw, hip.ptr(out), out.stride(0), M, N, K,
+                                    hip.ptr(bias) if bias is not None else None,
+                                    hip.ptr(residual) if residual is not None else None, ldr, 1 if relu else 0,
+                                    hip.stream_ptr())
+    hip.check(st, "mevi_gemm_nt_f32")
+    return out
+
+
+def rmsnorm(x, weight, eps, out=None):
+    x, M, D, ldx = _rows2d(_f32(x))
+    if out is None:
+        out = torch.empty((M, D), dtype=torch.float32, device=x.device)
+    st = hip.lib().mevi_rmsnorm_f32(hip.ptr(x), ldx, hip.ptr(weight), eps, M, D, hip.ptr(out), out.stride(0),
+                                    hip.stream_ptr())
+    hip.check(st, "mevi_rmsnorm_f32")
+    return out
+
+
+def add_layernorm(x, y, weight, bias, eps=1e-5, cvec=None, out=None):
+    x, M, D, ldx = _rows2d(_f32(x))
+    if out is None:
+        out = torch.empty((M, D), dtype=torch.float32, device=x.device)
+    ldy = 0
+    if y is not None:
+        assert y.shape == x.shape and y.stride(1) == 1
+        ldy = y.stride(0)
+    st = hip.lib().mevi_add_layernorm_f32(hip.ptr(x), ldx, hip.ptr(y) if y is not None else None, ldy,
+                                          hip.ptr(cvec) if cvec is not None else None, hip.ptr(weight), hip.ptr(bias),
+                                          eps, M, D, hip.ptr(out), out.stride(0), hip.stream_ptr())
+    hip.check(st, "mevi_add_layernorm_f32")
+    return out
+
+
+def gather_rows(table, idx, out=None):
+    table, _, D, ldt = _rows2d(_f32(table))
+    idx = idx.to(device=table.device, dtype=torch.int64).contiguous().view(-1)
+    n = idx.numel()
+    if out is None:
+        out = torch.empty((n, D), dtype=torch.float32, device=table.device)
+    st = hip.lib().mevi_gather_rows_f32(hip.ptr(table), ldt, hip.ptr(idx), n, D, hip.ptr(out), out.stride(0),
+                                        hip.stream_ptr())
+    hip.check(st, "mevi_gather_rows_f32")
+    return out
+
+
+def scale(x, alpha):
+    x = _f32(x).contiguous()
+    out = torch.empty_like(x)
+    st = hip.lib().mevi_scale_f32(hip.ptr(x), alpha, x.numel(), hip.ptr(out), hip.stream_ptr())
+    hip.check(st, "mevi_scale_f32")
+    return out
+
+
+def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=None, causal=False, scale=1.0):
+    """q [nb, tq, H*dh], k/v [nb/kv_div, tk, H*dh] (any batch/token strides, last dim contiguous)."""
+    for t in (q, k, v):
+        assert t.dim() == 3 and t.stride(2) == 1 and t.is_cuda and t.dtype == torch.float32
+    nb, tq, hd = q.shape
+    tk = k.shape[1]
+    dh = hd // heads
+    assert k.shape[0] * kv_div == nb and v.shape[:2] == k.shape[:2]
+    if out is None:
+        out = torch.empty((nb, tq, hd), dtype=torch.float32, device=q.device)
+    brows = bld = 0
+    if bias is not None:
+        assert bias.dim() == 3 and bias.is_contiguous() and bias.shape[0] == heads
+        brows, bld = bias.shape[1], bias.shape[2]
+    if key_mask is not None:
+        key_mask = key_mask.to(device=q.device, dtype=torch.int64).contiguous()
+        assert key_mask.shape == (nb // kv_div, tk)
+    st = hip.lib().mevi_attention_f32(
+        hip.ptr(q), q.stride(0), q.stride(1), hip.ptr(k), k.stride(0), k.stride(1), hip.ptr(v), v.stride(0),
+        v.stride(1), hip.ptr(out), out.stride(0), out.stride(1), nb, tq, tk, heads, dh, kv_div,
+        hip.ptr(bias) if bias is not None else None, brows, bld, q_pos0,
+        hip.ptr(key_mask) if key_mask is not None else None, 1 if causal else 0, scale, hip.stream_ptr())
+    hip.check(st, "mevi_attention_f32")
+    return out
+
+
+def adaptive_logits(s, t, e):
+    """logits[row, c] = sum_d s[row, d] * (t[row, c*dim + d] + e[c, d])."""
+    s, rows, dim, lds = _rows2d(_f32(s))
+    ncol = e.shape[0]
+    assert t.shape == (rows, ncol * dim) and t.stride(1) == 1 and e.is_contiguous()
+    out = torch.empty((rows, ncol), dtype=torch.float32, device=s.device)
+    st = hip.lib().mevi_adaptive_logits_f32(hip.ptr(s), lds, hip.ptr(t), t.stride(0), hip.ptr(e), rows, ncol, dim,
+                                            hip.ptr(out), hip.stream_ptr())
+    hip.check(st, "mevi_adaptive_logits_f32")
+    return out
+
+
+def beam_step(logits, beam_scores, K, R, final_step=False):
+    """logits [nq*nb, K+1] (col 0 eos), beam_scores [nq, nb] -> (scores, parent, code) [nq, R],
+    or final scores [nq, nb] when final_step."""
+    logits = _f32(logits).contiguous()
+    beam_scores = _f32(beam_scores).contiguous()
+    nq, nb = beam_scores.shape
+    assert logits.shape == (nq * nb, K + 1)
+    dev = logits.device
+    if final_step:
+        out = torch.empty((nq, nb), dtype=torch.float32, device=dev)
+        st = hip.lib().mevi_beam_step_f32(hip.ptr(logits), hip.ptr(beam_scores), nq, nb, K, R, 1, hip.ptr(out),
+                                          None, None, hip.stream_ptr())
+        hip.check(st, "mevi_beam_step_f32")
+        return out
+    sc = torch.empty((nq, R), dtype=torch.float32, device=dev)
+    parent = torch.empty((nq, R), dtype=torch.int32, device=dev)
+    code = torch.empty((nq, R), dtype=torch.int32, device=dev)
+    st = hip.lib().mevi_beam_step_f32(hip.ptr(logits), hip.ptr(beam_scores), nq, nb, K, R, 0, hip.ptr(sc),
+                                      hip.ptr(parent), hip.ptr(code), hip.stream_ptr())
+    hip.check(st, "mevi_beam_step_f32")
+    return sc, parent, code
+
+
+def pair_dot(a, ia, b, ib):
+    a, _, dim, lda = _rows2d(_f32(a))
+    b, _, dim2, ldb = _rows2d(_f32(b))
+    assert dim == dim2
+    ia = ia.to(device=a.device, dtype=torch.int64).contiguous()
+    ib = ib.to(device=a.device, dtype=torch.int64).contiguous()
+    n = ia.numel()
+    assert ib.numel() == n
+    out = torch.empty((n,), dtype=torch.float32, device=a.device)
+    st = hip.lib().mevi_pair_dot_f32(hip.ptr(a), lda, hip.ptr(ia), hip.ptr(b), ldb, hip.ptr(ib), n, dim,
+                                     hip.ptr(out), hip.stream_ptr())
+    hip.check(st, "mevi_pair_dot_f32")
+    return out
+
+
+def segment_sort_desc(scores, ids, seg_offsets, max_seg_len):
+    scores = _f32(scores).contiguous()
+    ids = ids.to(device=scores.device, dtype=torch.int64).contiguous()
+    seg = seg_offsets.to(device=scores.device, dtype=torch.int64).contiguous()
+    out_s = torch.empty_like(scores)
+    out_i = torch.empty_like(ids)
+    st = hip.lib().mevi_segment_sort_desc_f32(hip.ptr(scores), hip.ptr(ids), hip.ptr(seg), seg.numel() - 1,
+                                              int(max_seg_len), hip.ptr(out_s), hip.ptr(out_i), hip.stream_ptr())
+    hip.check(st, "mevi_segment_sort_desc_f32")
+    return out_s, out_i

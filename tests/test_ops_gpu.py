@@ -1,0 +1,157 @@
+"""GPU unit parity of the T5 / beam / fine-stage operators (through the C ABI) against plain
+torch fp32 on the CPU.  Tolerances are stated per test; GEMM, pair_dot and the sorts are exact
+(sequential fmaf chains / integer keys) and compared bit-for-bit with the C oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mevi_amd import ops
+from oracle import dense as odense
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain_gemm(a, w):
+    """C[m, n] = sequential fmaf chain over k (the oracle's dot)."""
+    L = odense.lib()
+    import ctypes
+    L.oracle_dot_f32.restype = ctypes.c_float
+    L.oracle_dot_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    out = np.empty((a.shape[0], w.shape[0]), np.float32)
+    for i in range(a.shape[0]):
+        for j in range(w.shape[0]):
+            out[i, j] = L.oracle_dot_f32(a[i].ctypes.data, w[j].ctypes.data, a.shape[1])
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 50, 64), (300, 130, 100), (5, 768, 768), (257, 129, 36)])
+def test_linear_bit_exact_chain(cuda, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    out = ops.linear(torch.from_numpy(a).to(cuda), torch.from_numpy(w).to(cuda)).cpu().numpy()
+    if M * N <= 40000:
+        assert np.array_equal(out.view(np.uint32), _chain_gemm(a, w).view(np.uint32))
+    assert np.abs(out - a @ w.T).max() <= 2e-4
+
+
+def test_linear_epilogues_and_strides(cuda):
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy(rng.standard_normal((200, 96)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal((160, 96)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(160).astype(np.float32))
+    r = torch.from_numpy(rng.standard_normal((200, 160)).astype(np.float32))
+    ref = F.relu(a @ w.T + b) + r
+    out = ops.linear(a.to(cuda), w.to(cuda), bias=b.to(cuda), residual=r.to(cuda), relu=True)
+    assert (out.cpu() - ref).abs().max() <= 1e-4
+    # strided views: A is a column slice, output goes into a slice of a wider buffer
+    big = torch.zeros((200, 400), device=cuda)
+    wide = torch.from_numpy(rng.standard_normal((200, 192)).astype(np.float32)).to(cuda)
+    ops.linear(wide[:, 96:], w.to(cuda), out=big[:, 40:200])
+    assert (big[:, 40:200].cpu() - wide[:, 96:].cpu() @ w.T).abs().max() <= 1e-4
+    assert big[:, :40].abs().max() == 0 and big[:, 200:].abs().max() == 0
+
+
+def test_rmsnorm_layernorm_gather_scale(cuda):
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.standard_normal((37, 768)).astype(np.float32) * 3)
+    w = torch.from_numpy(rng.standard_normal(768).astype(np.float32))
+    ref = w * (x / torch.sqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert (ops.rmsnorm(x.to(cuda), w.to(cuda), 1e-6).cpu() - ref).abs().max() <= 2e-6 * ref.abs().max()
+    y = torch.from_numpy(rng.standard_normal((37, 768)).astype(np.float32))
+    c = torch.from_numpy(rng.standard_normal(768).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(768).astype(np.float32))
+    ref = F.layer_norm(x + y + c, (768,), w, b, 1e-5)
+    got = ops.add_layernorm(x.to(cuda), y.to(cuda), w.to(cuda), b.to(cuda), 1e-5, cvec=c.to(cuda)).cpu()
+    assert (got - ref).abs().max() <= 1e-5
+    ref = F.layer_norm(x, (768,), w, b, 1e-5)
+    assert (ops.add_layernorm(x.to(cuda), None, w.to(cuda), b.to(cuda)).cpu() - ref).abs().max() <= 1e-5
+    idx = torch.from_numpy(rng.integers(0, 37, size=100))
+    assert torch.equal(ops.gather_rows(x.to(cuda), idx.to(cuda)).cpu(), x[idx])
+    assert torch.equal(ops.scale(x.to(cuda), 768 ** -0.5).cpu(), x * (768 ** -0.5))
+
+
+@pytest.mark.parametrize("nb,tq,tk,H,dh,kv_div,causal,scale", [
+    (6, 32, 32, 12, 64, 1, False, 1.0),     # encoder self-attention
+    (20, 1, 32, 12, 64, 10, False, 1.0),    # decoder cross-attention: 10 beams share a query's K/V
+    (20, 1, 5, 12, 64, 1, True, 1.0),       # decoder self-attention with cache (q at position 4)
+    (8, 1, 3, 8, 96, 1, True, 96 ** -0.5),  # adaptor nn.MultiheadAttention, head dim 96
+])
+def test_attention(cuda, nb, tq, tk, H, dh, kv_div, causal, scale):
+    rng = np.random.default_rng(nb * tk)
+    q = torch.from_numpy(rng.standard_normal((nb, tq, H * dh)).astype(np.float32))
+    k = torch.from_numpy(rng.standard_normal((nb // kv_div, tk, H * dh)).astype(np.float32)) * 0.3
+    v = torch.from_numpy(rng.standard_normal((nb // kv_div, tk, H * dh)).astype(np.float32))
+    q_pos0 = tk - tq if causal else 0
+    bias = torch.from_numpy(rng.standard_normal((H, q_pos0 + tq, tk)).astype(np.float32))
+    mask = torch.ones((nb // kv_div, tk), dtype=torch.int64)
+    if not causal:
+        for b in range(mask.shape[0]):
+            mask[b, rng.integers(3, tk + 1):] = 0
+    qh = q.view(nb, tq, H, dh).transpose(1, 2) * scale
+    kh = k.repeat_interleave(kv_div, 0).view(nb, tk, H, dh).transpose(1, 2)
+    vh = v.repeat_interleave(kv_div, 0).view(nb, tk, H, dh).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) + bias[None, :, q_pos0:q_pos0 + tq, :]
+    s = s + (1.0 - mask.repeat_interleave(kv_div, 0)[:, None, None, :].float()) * -1e9
+    if causal:
+        s = s + (1.0 - torch.tril(torch.ones(tk, tk))[q_pos0:q_pos0 + tq])[None, None] * -1e9
+    ref = (F.softmax(s, -1) @ vh).transpose(1, 2).reshape(nb, tq, H * dh)
+    got = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), H, kv_div=kv_div, bias=bias.to(cuda), q_pos0=q_pos0,
+                        key_mask=mask.to(cuda), causal=causal, scale=scale).cpu()
+    assert (got - ref).abs().max() <= 2e-5
+
+
+def test_adaptive_logits(cuda):
+    rng = np.random.default_rng(3)
+    rows, ncol, dim = 23, 33, 768
+    s = torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32)) * 0.05
+    t = torch.from_numpy(rng.standard_normal((rows, ncol * dim)).astype(np.float32))
+    e = torch.from_numpy(rng.standard_normal((ncol, dim)).astype(np.float32))
+    ref = torch.einsum("rd,rcd->rc", s, t.view(rows, ncol, dim) + e[None])
+    got = ops.adaptive_logits(s.to(cuda), t.to(cuda), e.to(cuda)).cpu()
+    assert (got - ref).abs().max() <= 5e-5
+
+
+@pytest.mark.parametrize("nq,nb,K,R", [(7, 1, 32, 10), (7, 10, 32, 10), (3, 10, 256, 10), (5, 4, 16, 4)])
+def test_beam_step(cuda, nq, nb, K, R):
+    rng = np.random.default_rng(nq + nb + K)
+    logits = torch.from_numpy(rng.standard_normal((nq * nb, K + 1)).astype(np.float32) * 3)
+    bs = torch.from_numpy(-rng.random((nq, nb)).astype(np.float32) * 5)
+    lsm = F.log_softmax(logits, -1).view(nq, nb, K + 1)
+    cand = (bs[:, :, None] + lsm[:, :, 1:]).reshape(nq, nb * K)
+    sc, parent, code = ops.beam_step(logits.to(cuda), bs.to(cuda), K, R)
+    top = torch.topk(cand, R, dim=1)
+    assert (sc.cpu() - top.values).abs().max() <= 2e-6
+    flat = parent.cpu().long() * K + code.cpu().long()
+    picked = torch.gather(cand, 1, flat)                       # same candidates up to f32-rounding ties
+    assert (picked - top.values).abs().max() <= 2e-6
+    fin = ops.beam_step(logits.to(cuda), bs.to(cuda), K, R, final_step=True).cpu()
+    assert (fin - (bs + lsm[:, :, 0])).abs().max() <= 2e-6
+
+
+def test_pair_dot_and_segment_sort(cuda):
+    import ctypes
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((50, 768)).astype(np.float32)
+    B = rng.standard_normal((400, 768)).astype(np.float32)
+    ia = rng.integers(0, 50, size=1000)
+    ib = rng.integers(0, 400, size=1000)
+    got = ops.pair_dot(torch.from_numpy(A).to(cuda), torch.from_numpy(ia).to(cuda), torch.from_numpy(B).to(cuda),
+                       torch.from_numpy(ib).to(cuda)).cpu().numpy()
+    L = odense.lib()
+    L.oracle_dot_f32.restype = ctypes.c_float
+    L.oracle_dot_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    ref = np.array([L.oracle_dot_f32(A[i].ctypes.data, B[j].ctypes.data, 768) for i, j in zip(ia, ib)], np.float32)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))          # bit-exact chain
+    # segments incl. empty ones, duplicates (ties -> ascending id)
+    lens = [0, 5, 1, 300, 0, 64, 630]
+    seg = np.concatenate([[0], np.cumsum(lens)])
+    sc = np.round(rng.standard_normal(seg[-1]).astype(np.float32), 1)
+    ids = rng.permutation(100000)[: seg[-1]].astype(np.int64)
+    os_, oi_ = ops.segment_sort_desc(torch.from_numpy(sc).to(cuda), torch.from_numpy(ids).to(cuda),
+                                     torch.from_numpy(seg).to(cuda), max(lens))
+    os_, oi_ = os_.cpu().numpy(), oi_.cpu().numpy()
+    for a, b in zip(seg[:-1], seg[1:]):
+        order = np.lexsort((ids[a:b], -sc[a:b]))
+        assert np.array_equal(oi_[a:b], ids[a:b][order]) and np.array_equal(os_[a:b], sc[a:b][order])
