@@ -149,11 +149,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 
   float *o = a.out + (size_t)b * a.o_bs + (size_t)t * a.o_ts + (size_t)h * a.dh;
   const float *vb = a.v + (size_t)bk * a.v_bs + (size_t)h * a.dh;
-  for (int d = lane; d < a.dh; d += 64) {
-    float acc = 0.f;
-    for (int j = 0; j < a.tk; ++j) acc = fmaf(__shfl(p, j), vb[(size_t)j * a.v_ts + d], acc);
-    o[d] = acc;
+  // every lane takes part in the shuffles (a lane outside dh must still SOURCE p for its key)
+  float acc0 = 0.f, acc1 = 0.f;  // output dims lane and lane + 64 (dh <= 128)
+  for (int j = 0; j < a.tk; ++j) {
+    const float pj = __shfl(p, j);
+    if (lane < a.dh) acc0 = fmaf(pj, vb[(size_t)j * a.v_ts + lane], acc0);
+    if (lane + 64 < a.dh) acc1 = fmaf(pj, vb[(size_t)j * a.v_ts + lane + 64], acc1);
   }
+  if (lane < a.dh) o[lane] = acc0;
+  if (lane + 64 < a.dh) o[lane + 64] = acc1;
 }
 
 // logits[row, c] = sum_d s[row, d] * (T[row, c*dim + d] + E[c, d]); one wave per (row, c)
@@ -244,6 +248,7 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   MEVI_REQUIRE(nb >= 0 && tq > 0 && tk > 0 && heads > 0 && dh > 0 && kv_div > 0, MEVI_ERR_INVALID_ARG,
                "attention: bad shape");
   MEVI_REQUIRE(tk <= 64, MEVI_ERR_UNSUPPORTED, "attention: tk=%lld > 64 keys not supported", (long long)tk);
+  MEVI_REQUIRE(dh <= 128, MEVI_ERR_UNSUPPORTED, "attention: head dim %lld > 128 not supported", (long long)dh);
   MEVI_REQUIRE(dh % 4 == 0 && q_bs % 4 == 0 && q_ts % 4 == 0 && k_bs % 4 == 0 && k_ts % 4 == 0,
                MEVI_ERR_INVALID_ARG, "attention: dh and q/k strides must be multiples of 4");
   if (nb == 0) return MEVI_OK;

@@ -1,0 +1,174 @@
+"""NCI-RQ seq2seq arm: T5 encoder + 6-layer decoder + PAWA adaptive head + constrained beam search.
+
+Mirrors `T5ForConditionalGeneration.generate(...)` as infer() calls it (MEVI/main_models.py:3612-3663;
+MEVI/transformers/generation_utils.py:116-577, 709-1011; modeling_t5.py:1561-1689) for the configuration
+every script uses: decode_embedding=2, adaptor_decode=adaptor_efficient=1, the shared-sons codebook tree,
+num_beams = num_return_sequences.  The search is the validated restatement of SURVEY 8(a'):
+
+  enc = Encoder(input_ids, mask)                      once per query
+  for level p in 0..M-1:  logits (last position, valid columns) -> beam_step -> top-R prefixes
+  final = score + log_softmax(level-M logits)[eos];   result = final / (M+1)**length_penalty
+
+Differences from the reference that do not change the function computed: KV-cached decoder and
+adaptor (reference: use_cache=False), only the last position and only the K+1 valid columns of the
+adaptive head are evaluated (reference materialises [B*R, t, d, V]), cross K/V once per query.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .t5 import DecoderStack, EncoderStack, T5Dims, _dev
+
+
+class NCIConfig(T5Dims):
+    def __init__(self, M=4, K=32, adaptor_layer_num=4, num_decoder_layers=6, **kw):
+        super().__init__(num_decoder_layers=num_decoder_layers, **kw)
+        self.M, self.K, self.adaptor_layers = M, K, adaptor_layer_num
+        self.V = K * (M + 2) + 2            # decode_vocab_size (main_models.py:1337-1339)
+        self.T = M + 1                      # decoder positions actually evaluated (tokens 0..M)
+
+
+class Adaptor:
+    """nn.TransformerDecoder(TransformerDecoderLayer(d, nhead=8), L) over the decode-token embeddings
+    (modeling_t5.py:1252-1255, 1650-1665), one position at a time with cached K|V.  Its memory is the
+    single learned vector adaptor_embeddings, so each layer's cross-attention output is a constant:
+    softmax over one key is 1  =>  c_l = out_proj(v_proj(memory))."""
+
+    NHEAD = 8
+
+    def __init__(self, w, cfg, device):
+        self.cfg, self.dev = cfg, device
+        d = cfg.d_model
+        mem = _dev(w, "adaptor_embeddings", device).reshape(1, d)
+        self.layers = []
+        for l in range(cfg.adaptor_layers):
+            p = f"adaptor.layers.{l}"
+            L = {k: _dev(w, f"{p}.{k}", device) for k in (
+                "self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+                "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias")}
+            xw, xb = _dev(w, f"{p}.multihead_attn.in_proj_weight", device), _dev(w, f"{p}.multihead_attn.in_proj_bias", device)
+            v = ops.linear(mem, xw[2 * d:].contiguous(), bias=xb[2 * d:].contiguous())
+            L["cross_const"] = ops.linear(v, _dev(w, f"{p}.multihead_attn.out_proj.weight", device),
+                                          bias=_dev(w, f"{p}.multihead_attn.out_proj.bias", device)).reshape(d).contiguous()
+            L["wq"], L["bq"] = L["self_attn.in_proj_weight"][:d].contiguous(), L["self_attn.in_proj_bias"][:d].contiguous()
+            L["wkv"], L["bkv"] = L["self_attn.in_proj_weight"][d:].contiguous(), L["self_attn.in_proj_bias"][d:].contiguous()
+            self.layers.append(L)
+
+    def new_cache(self, rows):
+        return [torch.empty((rows, self.cfg.T, 2 * self.cfg.d_model), dtype=torch.float32, device=self.dev)
+                for _ in self.layers]
+
+    def step(self, x, t, cache):
+        d = self.cfg.d_model
+        n = x.shape[0]
+        for L, kvc in zip(self.layers, cache):
+            q = ops.linear(x, L["wq"], bias=L["bq"])
+            ops.linear(x, L["wkv"], bias=L["bkv"], out=kvc[:, t, :])
+            ctx = ops.attention(q.view(n, 1, d), kvc[:, :t + 1, :d], kvc[:, :t + 1, d:], self.NHEAD,
+                                q_pos0=t, causal=True, scale=(d // self.NHEAD) ** -0.5)
+            sa = ops.linear(ctx.view(n, d), L["self_attn.out_proj.weight"], bias=L["self_attn.out_proj.bias"])
+            x = ops.add_layernorm(x, sa, L["norm1.weight"], L["norm1.bias"])
+            x = ops.add_layernorm(x, None, L["norm2.weight"], L["norm2.bias"], cvec=L["cross_const"])
+            ff = ops.linear(ops.linear(x, L["linear1.weight"], bias=L["linear1.bias"], relu=True),
+                            L["linear2.weight"], bias=L["linear2.bias"])
+            x = ops.add_layernorm(x, ff, L["norm3.weight"], L["norm3.bias"])
+        return x
+
+
+class NCIModel:
+    """`generate()` mirrors the reference call; weights use the reference's state_dict names
+    (T5ForConditionalGeneration: shared, encoder.*, decoder.*, decode_embeddings, adaptor*, lm_head)."""
+
+    def __init__(self, weights, cfg=None, device=None, **kw):
+        self.dev = torch.device(device if device is not None else "cuda")
+        self.cfg = cfg if cfg is not None else NCIConfig(**kw)
+        c = self.cfg
+        self.shared = _dev(weights, "shared.weight", self.dev)
+        self.dec_emb = _dev(weights, "decode_embeddings.weight", self.dev)
+        self.encoder = EncoderStack(weights, c, self.dev)
+        self.decoder = DecoderStack(weights, c, self.dev, max_len=c.T)
+        self.adaptor = Adaptor(weights, c, self.dev)
+        # adaptive head restricted to the valid columns of every position:
+        # column 0 = eos (token 1), columns 1..K = tokens 2 + p*K + (c-1)     (modeling_t5.py:1578-1603)
+        aw = _dev(weights, "adaptor_linear.weight", self.dev).view(c.d_model, c.V, c.d_model)   # [d, V, e]
+        lm = _dev(weights, "lm_head.weight", self.dev)
+        self.head_w, self.head_e = [], []
+        for p in range(c.M + 1):
+            cols = torch.tensor([1] + list(range(2 + p * c.K, 2 + (p + 1) * c.K)), device=self.dev)
+            # rows ordered (column, d): W_p[c*d_model + d, e] = adaptor_linear.weight[d*V + v_c, e]
+            self.head_w.append(aw[:, cols, :].permute(1, 0, 2).reshape((c.K + 1) * c.d_model, c.d_model).contiguous())
+            self.head_e.append(lm[cols].contiguous())
+        del aw
+
+    # -- one decoding position for all live beams -----------------------------------------------
+    def _logits(self, tokens, t, dcache, acache, xkv, mask, kv_div):
+        c = self.cfg
+        tok = ops.gather_rows(self.dec_emb, tokens)
+        seq = ops.scale(self.decoder.step(tok, t, dcache, xkv, mask, kv_div), c.d_model ** -0.5)
+        a = self.adaptor.step(tok, t, acache)
+        tmat = ops.linear(a, self.head_w[t])                       # [n, (K+1)*d]
+        return ops.adaptive_logits(seq, tmat, self.head_e[t])      # [n, K+1]
+
+    @torch.no_grad()
+    def generate(self, input_ids, attention_mask, num_beams=10, num_return_sequences=None, length_penalty=0.8,
+                 max_length=None, **reference_kwargs):
+        """Returns (decoded i64[B*R, M+2], scores list[float] (descending per query),
+        enc_last_hidden_state f32[B*R, S, d] view, None) like the reference's 4-tuple; the last slot
+        (dec_hidden) is only read when query_encoder='nci' and is not produced (SURVEY 8(a') note iii)."""
+        c = self.cfg
+        R = num_beams
+        assert num_return_sequences in (None, R) and R <= c.K, "needs num_beams == num_return_sequences <= K"
+        assert max_length in (None, c.M + 2)
+        ids = input_ids.to(self.dev, torch.int64).contiguous()
+        mask = attention_mask.to(self.dev, torch.int64).contiguous()
+        B = ids.shape[0]
+        enc = self.encoder.forward(self.shared, ids, mask)
+        xkv = self.decoder.cross_kv(enc)
+
+        nb = 1
+        tokens = torch.zeros(B, dtype=torch.int64, device=self.dev)          # decoder_start_token_id = 0
+        scores = torch.zeros((B, 1), dtype=torch.float32, device=self.dev)
+        codes = torch.zeros((B, 1, 0), dtype=torch.int64, device=self.dev)
+        dcache, acache = self.decoder.new_cache(B), self.adaptor.new_cache(B)
+        base = torch.arange(B, device=self.dev)[:, None]
+        for p in range(c.M):
+            logits = self._logits(tokens, p, dcache, acache, xkv, mask, nb)
+            scores, parent, code = ops.beam_step(logits, scores, c.K, R)
+            parent, code = parent.long(), code.long()
+            rows = (base * nb + parent).reshape(-1)                           # surviving parents, [B*R]
+            dcache = [ops.gather_rows(k.view(k.shape[0], -1), rows).view(B * R, c.T, -1) for k in dcache]
+            acache = [ops.gather_rows(k.view(k.shape[0], -1), rows).view(B * R, c.T, -1) for k in acache]
+            codes = torch.cat([torch.gather(codes, 1, parent[:, :, None].expand(-1, -1, codes.shape[2])),
+                               code[:, :, None]], dim=2)
+            tokens = (2 + p * c.K + code).reshape(-1)
+            nb = R
+        logits = self._logits(tokens, c.M, dcache, acache, xkv, mask, nb)
+        final = ops.beam_step(logits, scores, c.K, R, final_step=True)        # [B, R]
+        hyp = final.double() / (c.M + 1) ** length_penalty                    # BeamHypotheses.add: len = M+1
+        order = torch.argsort(hyp, dim=1, descending=True, stable=True)
+        hyp = torch.gather(hyp, 1, order)
+        codes = torch.gather(codes, 1, order[:, :, None].expand(-1, -1, c.M))
+        toks = 2 + torch.arange(c.M, device=self.dev) * c.K + codes
+        decoded = torch.cat([torch.zeros((B, R, 1), dtype=torch.int64, device=self.dev), toks,
+                             torch.ones((B, R, 1), dtype=torch.int64, device=self.dev)], dim=2).view(B * R, c.M + 2)
+        return decoded, hyp.reshape(-1).tolist(), enc, None
+
+
+def decode_token(decoded, K):
+    """main_models.decode_token for codebook models (MEVI/main_models.py:117-136): strip bos/eos, undo
+    the per-position offset, clamp negatives to 0 -> codes i64[n, M]."""
+    seqs = decoded[:, 1:-1] - 2
+    seqs = seqs - torch.arange(seqs.shape[1], device=seqs.device) * K
+    return seqs.clamp(min=0)
+
+
+def dec_2d(dec, size):
+    """main_utils.dec_2d (MEVI/main_utils.py:38-47)."""
+    if torch.is_tensor(dec):
+        return dec.reshape(-1, size, dec.shape[-1])
+    return [dec[i:i + size] for i in range(0, len(dec), size)]
+
+
+def load_npz_weights(npz, prefix="w."):
+    return {k[len(prefix):]: torch.from_numpy(np.asarray(npz[k])) for k in npz.files if k.startswith(prefix)}

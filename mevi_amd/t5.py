@@ -1,0 +1,193 @@
+"""T5 stacks on MI355X: encoder, KV-cached decoder step, twin-tower query encoder.
+
+Arithmetic follows the MEVI-modified T5 (MEVI/transformers/modeling_t5.py): pre-RMSNorm residual
+blocks (T5Block :494-580), attention without 1/sqrt(d) scaling and with the layer-0 relative
+position bias shared by all layers (T5Attention :203-418, T5Stack :781-785), bias-free
+relu(x Wi^T) Wo^T feed-forward (:174-186), final RMSNorm (:806).  Every matmul is the f32-MFMA
+GEMM (ops.linear), everything else the wave-per-row kernels of csrc/t5_ops.hip.
+
+Reference surfaces mirrored:
+  DocumentEncoder.encode / encode_query   MEVI/document_encoder.py:104-123  -> TwinTower
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def relative_position_bucket(rel, bidirectional, num_buckets=32, max_distance=128):
+    """T5 bucket of rel = memory_pos - query_pos (modeling_t5.py:241-289); the log runs in float32."""
+    rel = np.asarray(rel, dtype=np.int64)
+    n = num_buckets
+    ret = np.zeros_like(rel)
+    if bidirectional:
+        n //= 2
+        ret = ret + (rel > 0) * n
+        rel = np.abs(rel)
+    else:
+        rel = np.maximum(-rel, 0)
+    max_exact = n // 2
+    scale = np.float32(n - max_exact) / np.float32(math.log(max_distance / max_exact))
+    big = max_exact + (np.log(np.maximum(rel, 1).astype(np.float32) / np.float32(max_exact))
+                       / np.float32(math.log(max_distance / max_exact)) * np.float32(n - max_exact)).astype(np.int64)
+    del scale
+    return ret + np.where(rel < max_exact, rel, np.minimum(big, n - 1))
+
+
+def bias_table(rel_weight, qlen, klen, bidirectional, num_buckets=32):
+    """[H, qlen, klen] additive bias from relative_attention_bias.weight [buckets, H] (compute_bias :291-304)."""
+    b = relative_position_bucket(np.arange(klen)[None, :] - np.arange(qlen)[:, None], bidirectional, num_buckets)
+    idx = torch.from_numpy(b).to(rel_weight.device)
+    return rel_weight[idx].permute(2, 0, 1).contiguous()
+
+
+class T5Dims:
+    def __init__(self, d_model=768, d_ff=3072, num_heads=12, d_kv=64, num_layers=12, num_decoder_layers=12,
+                 layer_norm_epsilon=1e-6, relative_attention_num_buckets=32, **unused):
+        self.d_model, self.d_ff, self.num_heads, self.d_kv = d_model, d_ff, num_heads, d_kv
+        self.num_layers, self.num_decoder_layers = num_layers, num_decoder_layers
+        self.eps, self.buckets = layer_norm_epsilon, relative_attention_num_buckets
+        self.inner = num_heads * d_kv
+
+
+def _dev(w, key, device):
+    t = w[key]
+    t = t if torch.is_tensor(t) else torch.from_numpy(np.asarray(t))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class EncoderStack:
+    """T5Stack(is_decoder=False).  Weights: the reference's state_dict names under `prefix`."""
+
+    def __init__(self, w, dims, device, prefix="encoder", max_len=64):
+        self.d, self.dev = dims, device
+        self.layers = []
+        for l in range(dims.num_layers):
+            p = f"{prefix}.block.{l}.layer"
+            sa = f"{p}.0.SelfAttention"
+            self.layers.append(dict(
+                ln0=_dev(w, f"{p}.0.layer_norm.weight", device),
+                wqkv=torch.cat([_dev(w, f"{sa}.{n}.weight", device) for n in "qkv"]).contiguous(),
+                wo=_dev(w, f"{sa}.o.weight", device),
+                ln1=_dev(w, f"{p}.1.layer_norm.weight", device),
+                wi=_dev(w, f"{p}.1.DenseReluDense.wi.weight", device),
+                wo2=_dev(w, f"{p}.1.DenseReluDense.wo.weight", device)))
+        self.final_ln = _dev(w, f"{prefix}.final_layer_norm.weight", device)
+        self.rel = _dev(w, f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight", device)
+        self._bias = {}
+
+    def bias(self, S):
+        if S not in self._bias:
+            self._bias[S] = bias_table(self.rel, S, S, True, self.d.buckets)
+        return self._bias[S]
+
+    def forward(self, embeddings, input_ids, attention_mask):
+        """input_ids/attention_mask i64[B, S] (S <= 64) -> last hidden state f32[B, S, d_model]."""
+        d = self.d
+        B, S = input_ids.shape
+        x = ops.gather_rows(embeddings, input_ids.reshape(-1))
+        bias = self.bias(S)
+        for L in self.layers:
+            h = ops.rmsnorm(x, L["ln0"], d.eps)
+            qkv = ops.linear(h, L["wqkv"]).view(B, S, 3 * d.inner)
+            ctx = ops.attention(qkv[:, :, :d.inner], qkv[:, :, d.inner:2 * d.inner], qkv[:, :, 2 * d.inner:],
+                                d.num_heads, bias=bias, key_mask=attention_mask)
+            x = ops.linear(ctx.view(B * S, d.inner), L["wo"], residual=x)
+            h = ops.rmsnorm(x, L["ln1"], d.eps)
+            x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
+        return ops.rmsnorm(x, self.final_ln, d.eps).view(B, S, d.d_model)
+
+
+class DecoderStack:
+    """T5Stack(is_decoder=True) evaluated one position at a time with a KV cache.
+
+    The reference runs use_cache=False and recomputes the whole prefix for every beam at every
+    step (main_models.py:3615); under the causal mask the cached form is the same function
+    (SURVEY 8(a') note iv).  Cross-attention K/V are projected once per QUERY, not per beam."""
+
+    def __init__(self, w, dims, device, prefix="decoder", n_layers=None, max_len=8):
+        self.d, self.dev = dims, device
+        n_layers = dims.num_decoder_layers if n_layers is None else n_layers
+        self.layers = []
+        for l in range(n_layers):
+            p = f"{prefix}.block.{l}.layer"
+            sa, xa = f"{p}.0.SelfAttention", f"{p}.1.EncDecAttention"
+            self.layers.append(dict(
+                ln0=_dev(w, f"{p}.0.layer_norm.weight", device),
+                wq=_dev(w, f"{sa}.q.weight", device),
+                wkv=torch.cat([_dev(w, f"{sa}.k.weight", device), _dev(w, f"{sa}.v.weight", device)]).contiguous(),
+                wo=_dev(w, f"{sa}.o.weight", device),
+                ln1=_dev(w, f"{p}.1.layer_norm.weight", device),
+                xq=_dev(w, f"{xa}.q.weight", device),
+                xkv=torch.cat([_dev(w, f"{xa}.k.weight", device), _dev(w, f"{xa}.v.weight", device)]).contiguous(),
+                xo=_dev(w, f"{xa}.o.weight", device),
+                ln2=_dev(w, f"{p}.2.layer_norm.weight", device),
+                wi=_dev(w, f"{p}.2.DenseReluDense.wi.weight", device),
+                wo2=_dev(w, f"{p}.2.DenseReluDense.wo.weight", device)))
+        self.final_ln = _dev(w, f"{prefix}.final_layer_norm.weight", device)
+        rel = _dev(w, f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight", device)
+        self.self_bias = bias_table(rel, max_len, max_len, False, dims.buckets)   # [H, T, T]
+        self.max_len = max_len
+
+    def cross_kv(self, enc):
+        """Per-layer cross-attention K|V of the encoder states: list of f32[B, S, 2*inner]."""
+        B, S, dm = enc.shape
+        flat = enc.reshape(B * S, dm)
+        return [ops.linear(flat, L["xkv"]).view(B, S, 2 * self.d.inner) for L in self.layers]
+
+    def new_cache(self, rows):
+        return [torch.empty((rows, self.max_len, 2 * self.d.inner), dtype=torch.float32, device=self.dev)
+                for _ in self.layers]
+
+    def step(self, x, t, cache, xkv, enc_mask, kv_div):
+        """x f32[n, d_model]: embeddings of the token at position t of every row; cache[l] f32[n, T, 2*inner]
+        holds self-attention K|V of positions < t (position t is written here); rows r attend to the
+        encoder states of query r // kv_div.  Returns the final-normed hidden state f32[n, d_model]."""
+        d = self.d
+        n = x.shape[0]
+        for L, kvc, xc in zip(self.layers, cache, xkv):
+            h = ops.rmsnorm(x, L["ln0"], d.eps)
+            q = ops.linear(h, L["wq"])
+            ops.linear(h, L["wkv"], out=kvc[:, t, :])
+            ctx = ops.attention(q.view(n, 1, d.inner), kvc[:, :t + 1, :d.inner], kvc[:, :t + 1, d.inner:],
+                                d.num_heads, bias=self.self_bias, q_pos0=t, causal=True)
+            x = ops.linear(ctx.view(n, d.inner), L["wo"], residual=x)
+            h = ops.rmsnorm(x, L["ln1"], d.eps)
+            q = ops.linear(h, L["xq"])
+            ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :, :d.inner], xc[:, :, d.inner:], d.num_heads,
+                                kv_div=kv_div, key_mask=enc_mask)
+            x = ops.linear(ctx.view(n, d.inner), L["xo"], residual=x)
+            h = ops.rmsnorm(x, L["ln2"], d.eps)
+            x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
+        return ops.rmsnorm(x, self.final_ln, d.eps)
+
+
+class TwinTower:
+    """The query tower of the dense arm: T5Model encoder + one decoder step on token 0,
+    reps = last_hidden_state[:, 0, :], normalize=False (DocumentEncoder.encode, document_encoder.py:104-120).
+
+    `encode_query(qry)` takes the reference's {'input_ids', 'attention_mask'} mapping."""
+
+    def __init__(self, weights, dims=None, device=None, batch_size=512, **cfg):
+        self.dev = torch.device(device if device is not None else "cuda")
+        self.d = dims if dims is not None else T5Dims(**cfg)
+        self.shared = _dev(weights, "shared.weight", self.dev)
+        self.encoder = EncoderStack(weights, self.d, self.dev)
+        self.decoder = DecoderStack(weights, self.d, self.dev, max_len=1)
+        self.batch_size = batch_size
+
+    def encode_query(self, qry):
+        ids = qry["input_ids"].to(self.dev, torch.int64)
+        mask = qry["attention_mask"].to(self.dev, torch.int64)
+        outs = []
+        for a in range(0, ids.shape[0], self.batch_size):
+            i, m = ids[a:a + self.batch_size].contiguous(), mask[a:a + self.batch_size].contiguous()
+            enc = self.encoder.forward(self.shared, i, m)
+            B = i.shape[0]
+            x = ops.gather_rows(self.shared, torch.zeros(B, dtype=torch.int64, device=self.dev))
+            outs.append(self.decoder.step(x, 0, self.decoder.new_cache(B), self.decoder.cross_kv(enc), m, 1))
+        return torch.cat(outs) if outs else torch.empty((0, self.d.d_model), device=self.dev)
+
+    encode = encode_query

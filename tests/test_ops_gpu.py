@@ -77,6 +77,8 @@ def test_rmsnorm_layernorm_gather_scale(cuda):
     (20, 1, 32, 12, 64, 10, False, 1.0),    # decoder cross-attention: 10 beams share a query's K/V
     (20, 1, 5, 12, 64, 1, True, 1.0),       # decoder self-attention with cache (q at position 4)
     (8, 1, 3, 8, 96, 1, True, 96 ** -0.5),  # adaptor nn.MultiheadAttention, head dim 96
+    (8, 32, 32, 4, 8, 1, False, 1.0),       # tiny heads (fixture models): fewer output dims than keys
+    (6, 1, 6, 8, 4, 1, True, 0.5),
 ])
 def test_attention(cuda, nb, tq, tk, H, dh, kv_div, causal, scale):
     rng = np.random.default_rng(nb * tk)
