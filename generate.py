@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Query-embedding CLI -- same argv and output file as the reference's MEVI/generate.py:283-311
+(`--gen_query`): raw little-endian f32 [n_queries, dim].  One process per GPU (`--gpus "0,1,..."`),
+contiguous query ranges per rank (generate.py:74-82), per-rank files concatenated by rank 0.
+The T5-ANCE tower runs on the HIP kernels (mevi_amd.t5.TwinTower); tokenisation stays an HF call.
+"""
+import argparse
+import os
+import socket
+
+import numpy as np
+import pandas as pd
+
+
+def get_tokenizer(model_path):
+    from transformers import AutoTokenizer
+
+    return AutoTokenizer.from_pretrained(model_path)
+
+
+def rank_range(n, rank, nrank):
+    """[start, end) of `rank`: n // nrank rows each, the first n % nrank ranks take one more (generate.py:74-82)."""
+    base, extra = divmod(n, nrank)
+    start = base * rank + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def load_document_encoder(model_path, ckpt_path, device):
+    import torch
+
+    from mevi_amd.evalrun import load_tower_weights
+    from mevi_amd.t5 import TwinTower
+
+    weights, dims = load_tower_weights(model_path)
+    if ckpt_path is not None:  # fine-tuned tower inside a training checkpoint (generate.py:200-211)
+        sd = torch.load(ckpt_path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        pre = "document_encoder.lm_q."
+        weights.update({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+    return TwinTower(weights, dims=dims, device=device)
+
+
+def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path, output_path, batch_size, dim, gpus,
+                        query_length=32, tokenizer=None):
+    import torch
+    import torch.distributed as dist
+
+    nrank = len(gpus)
+    if nrank > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=nrank)
+    device = torch.device(f"cuda:{gpus[rank]}")
+    torch.cuda.set_device(device)
+    encoder = load_document_encoder(model_path, ckpt_path, device)
+    tokenizer = tokenizer or get_tokenizer(tokenizer_path)
+    df = pd.read_csv(query_file, names=["query", "oldid"], encoding="utf-8", header=None, sep="\t")["query"]
+    start, end = rank_range(len(df), rank, nrank)
+    cur_path = output_path[:-4] + f"_{rank}.bin" if nrank > 1 else output_path
+    out = np.memmap(cur_path, dtype=np.float32, mode="w+", shape=(end - start, dim))
+    for s in range(start, end, batch_size):
+        e = min(s + batch_size, end)
+        tok = tokenizer.batch_encode_plus(list(df[s:e]), max_length=query_length, padding="max_length",
+                                          truncation=True, return_tensors="pt")
+        out[s - start:e - start] = encoder.encode_query(tok).cpu().numpy()
+    out.flush()
+    if nrank > 1:
+        dist.barrier()
+        if rank == 0:
+            allq = np.memmap(output_path, dtype=np.float32, mode="w+", shape=(len(df), dim))
+            at = 0
+            for r in range(nrank):
+                part = np.memmap(output_path[:-4] + f"_{r}.bin", dtype=np.float32, mode="r").reshape(-1, dim)
+                allq[at:at + part.shape[0]] = part
+                at += part.shape[0]
+            allq.flush()
+            for r in range(nrank):
+                os.remove(output_path[:-4] + f"_{r}.bin")
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--query_file", type=str, default=None)
+    parser.add_argument("--model_path", type=str, required=True)
+    parser.add_argument("--tokenizer_path", type=str, required=True)
+    parser.add_argument("--query_embedding_path", type=str, default=None)
+    parser.add_argument("--ckpt_path", type=str, default=None)
+    parser.add_argument("--batch_size", type=int, default=128)
+    parser.add_argument("--dim", type=int, default=768)
+    parser.add_argument("--gpus", type=str, default=None)
+    parser.add_argument("--gen_query", action="store_true", default=False)
+    parser.add_argument("--timing_infer_step", type=int, default=0)
+    args = parser.parse_args()
+    gpus = [int(g) for g in args.gpus.split(",")] if args.gpus is not None else [0]
+    if not args.gen_query:
+        raise SystemExit("only --gen_query is built (document embedding generation is SURVEY 8(f) 'next')")
+    assert args.query_file is not None and args.query_embedding_path is not None, \
+        "Need to specify source path and target path!"
+    common = (args.query_file, args.model_path, args.ckpt_path, args.tokenizer_path, args.query_embedding_path,
+              args.batch_size, args.dim, gpus)
+    if len(gpus) > 1:
+        import torch.multiprocessing as mp
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(_free_port())
+        mp.spawn(gen_query_embedding, nprocs=len(gpus), args=common)
+    else:
+        gen_query_embedding(0, *common)

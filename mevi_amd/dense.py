@@ -82,23 +82,28 @@ def shard_range(n_rows, rank, world_size):
     return start, min(start + per, n_rows)
 
 
-def sharded_ip_topk(query, local_docs, k, id_offset, group=None):
+def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=None, merge=None):
     """Row-sharded search: local top-k with global ids, all-gather, merge.
 
     Every rank passes the full (replicated) query matrix and its own shard; every
     rank returns the identical merged (scores, ids), independent of shard count.
+    `local_search` / `merge` default to the HIP kernels; they are injection points for the
+    CPU (gloo) test of the collective plumbing and are never set by product code.
     """
     import torch.distributed as dist
 
-    s, i = ip_topk(query, local_docs, k, id_offset=id_offset)
+    local_search = local_search or ip_topk
+    merge = merge or topk_merge
+    s, i = local_search(query, local_docs, k, id_offset=id_offset)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return s, i
     world = dist.get_world_size(group)
-    all_s = torch.empty((world,) + tuple(s.shape), dtype=s.dtype, device=s.device)
-    all_i = torch.empty((world,) + tuple(i.shape), dtype=i.dtype, device=i.device)
-    dist.all_gather_into_tensor(all_s, s, group=group)
-    dist.all_gather_into_tensor(all_i, i, group=group)
-    return topk_merge(all_s, all_i, k)
+    nq = s.shape[0]
+    all_s = torch.empty((world * nq, k), dtype=s.dtype, device=s.device)   # rank-major concatenation
+    all_i = torch.empty((world * nq, k), dtype=i.dtype, device=i.device)
+    dist.all_gather_into_tensor(all_s, s.contiguous(), group=group)
+    dist.all_gather_into_tensor(all_i, i.contiguous(), group=group)
+    return merge(all_s.view(world, nq, k), all_i.view(world, nq, k), k)
 
 
 def search(query, doc, dim, topk, param="Flat", device=None):

@@ -1,0 +1,251 @@
+"""Eval driver of the seq2seq arm: what `python main.py --mode eval ...` (marco_eval_nci_rq.sh)
+does in the reference -- main.inference / partial_inference (MEVI/main.py:267-337),
+T5FineTunerWithValidation.on_validation_epoch_start / infer / validation_epoch_end
+(MEVI/main_models.py:4215-4273, 3555-4098, 4290-4393) and handle_infer_results (:4100-4201).
+
+Per process (one per GPU, queries split by rank like DistributedSampler(shuffle=False)):
+  NCI beam search (mevi_amd.nci) -> coarse log + ranks -> twin-tower query embedding (mevi_amd.t5)
+  -> in-cluster re-ranking (mevi_amd.fine) -> fine / hard-negative logs -> rank-merged TSVs + metrics.
+"""
+import os
+import pickle
+import time
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import fine as mfine
+from . import hip
+from .io import RankLog
+from .nci import NCIModel, config_from_weights, decode_token
+from .rq import ClusterIndex, ProductQuantization
+from .t5 import T5Dims, TwinTower
+
+
+# ---- loading -------------------------------------------------------------------------------
+def load_nci_weights(path):
+    """The NCI checkpoint: a Lightning ckpt ('state_dict' with 'model.' prefixes) or a bare state dict;
+    same key handling as try_load_ckpt's nci_path branch (MEVI/main.py:232-248)."""
+    sd = torch.load(path, map_location="cpu")
+    if "state_dict" in sd:
+        sd = sd["state_dict"]
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("model."):
+            k = k[6:]
+        if torch.is_tensor(v):
+            out[k] = v
+    if "lm_head.weight" not in out and "decode_embeddings.weight" in out:  # tie_decode_embedding=1
+        out["lm_head.weight"] = out["decode_embeddings.weight"]
+    return out
+
+
+def load_tower_weights(model_dir):
+    """T5-ANCE directory in HF layout (config.json + pytorch_model.bin), as DocumentEncoder.build ->
+    AutoModel.from_pretrained reads it (MEVI/document_encoder.py:176-188)."""
+    import json
+
+    cfg = json.load(open(os.path.join(model_dir, "config.json")))
+    sd = torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu")
+    if "encoder.embed_tokens.weight" in sd and "shared.weight" not in sd:
+        sd["shared.weight"] = sd["encoder.embed_tokens.weight"]
+    dims = T5Dims(d_model=cfg["d_model"], d_ff=cfg["d_ff"], num_heads=cfg["num_heads"], d_kv=cfg["d_kv"],
+                  num_layers=cfg["num_layers"], num_decoder_layers=cfg.get("num_decoder_layers", cfg["num_layers"]),
+                  layer_norm_epsilon=cfg.get("layer_norm_epsilon", 1e-6),
+                  relative_attention_num_buckets=cfg.get("relative_attention_num_buckets", 32))
+    return sd, dims
+
+
+def load_queries(data_dir, n_test=-1, fname="dev_mevi_dedup.tsv"):
+    """dev_mevi_dedup.tsv: `query \\t id,id,...` (main_utils.load_data_infer, MEVI/main_utils.py:271-278)."""
+    df = pd.read_csv(os.path.join(data_dir, fname), names=["query", "oldid"], encoding="utf-8", header=None,
+                     sep="\t", converters={"oldid": lambda x: [int(v) for v in x.split(",")]})
+    assert not df.isnull().values.any()
+    if n_test is not None and n_test >= 0:
+        df = df[:n_test]
+    return df
+
+
+def rank_slice(n, rank, nrank):
+    """Indices DistributedSampler(shuffle=False) gives `rank`: every nrank-th item of the list padded to
+    a multiple of nrank by repeating its head (MEVI/main.py:318-322); duplicates are de-duplicated by the
+    query-keyed dicts downstream."""
+    total = (n + nrank - 1) // nrank * nrank
+    idx = list(range(n)) + list(range(total - n))
+    return idx[rank:total:nrank]
+
+
+class EvalRun:
+    def __init__(self, args, tokenizer=None, rank=0, nrank=1, barrier=None, device=None):
+        self.args, self.rank, self.nrank = args, rank, nrank
+        self.barrier = barrier or (lambda: None)
+        hip.require_gpu()
+        self.dev = torch.device(device if device is not None else "cuda")
+        a = args
+        self.M, self.K, self.R = a.subvector_num, 2 ** a.subvector_bits, a.num_return_sequences
+        nci_w = load_nci_weights(a.nci_ckpt)
+        self.cfg = config_from_weights(nci_w, self.M, self.K)   # shapes of the checkpoint are authoritative
+        d_model = self.cfg.d_model
+        self.nci = NCIModel(nci_w, cfg=self.cfg, device=self.dev)
+        del nci_w
+        tower_dir = os.path.join(a.ckpt_dir, "t5-ance")
+        tw, tdims = load_tower_weights(tower_dir)
+        self.tower = TwinTower(tw, dims=tdims, device=self.dev)
+        if tokenizer is None:
+            from transformers import AutoTokenizer  # host-side tokenisation stays an HF call (boundary)
+
+            tokenizer = AutoTokenizer.from_pretrained(tower_dir)
+        self.tokenizer = tokenizer
+        # corpus embeddings resident in HBM (the reference keeps a CPU memmap and copies per cluster)
+        n_docs = os.path.getsize(a.embedding_path) // (4 * d_model)
+        emb = np.memmap(a.embedding_path, dtype=np.float32, mode="r", shape=(n_docs, d_model))
+        self.emb = torch.empty((n_docs, d_model), dtype=torch.float32, device=self.dev)
+        step = 1 << 20
+        for s in range(0, n_docs, step):
+            self.emb[s:s + step] = torch.from_numpy(np.array(emb[s:s + step]))
+        # RQ codebook + cluster index (pickles if present, else encode on the GPU and write them)
+        self.pq = ProductQuantization("rq", self.M, a.subvector_bits, "l2", d_model, device=self.dev)
+        self.pq.initialize(a.pq_path, rank=0)
+        map_path = a.pq_cluster_path.replace("clus", "mapping")
+        if os.path.exists(a.pq_cluster_path) and os.path.exists(map_path):
+            with open(a.pq_cluster_path, "rb") as f:
+                self.index = ClusterIndex.from_dict(pickle.load(f), self.M, self.K)
+            with open(map_path, "rb") as f:
+                self.mapping = pickle.load(f)
+        else:
+            self.index = self.pq.get_document_cluster(self.emb, 0, 1, as_index=True)
+            cluster, self.mapping = self.index.to_dicts()
+            if rank == 0:
+                with open(a.pq_cluster_path, "wb") as f:
+                    pickle.dump(cluster, f)
+                with open(map_path, "wb") as f:
+                    pickle.dump(self.mapping, f)
+            self.barrier()
+        print("Number of all pq document clusters:", len(self.index.keys))
+        self.fine = mfine.FineStage(self.emb, self.index)
+        prefix = a.custom_save_path[:-4]
+        self.coarse_log = RankLog(f"{prefix}_coarse.tsv", rank, nrank, self.barrier)
+        self.fine_log = RankLog(f"{prefix}_fine.tsv", rank, nrank, self.barrier)
+        self.hn_log = RankLog(f"{prefix}_hn{a.save_hard_neg}.tsv", rank, nrank, self.barrier) if a.save_hard_neg else None
+
+    def tokenize(self, queries):
+        out = self.tokenizer.batch_encode_plus(list(queries), max_length=32, padding="max_length", truncation=True,
+                                               return_tensors="pt")
+        return out["input_ids"], out["attention_mask"]
+
+    @torch.no_grad()
+    def infer(self, texts, doc_ids):
+        """One batch: returns [(text, ndoc, coarse ranks, fine ranks)] like infer() with recall_level='both'."""
+        a, R = self.args, self.R
+        ids, mask = self.tokenize(texts)
+        decoded, scores, _, _ = self.nci.generate(ids, mask, num_beams=R, num_return_sequences=R,
+                                                  length_penalty=a.length_penalty, max_length=self.M + 2)
+        B = len(texts)
+        codes = decode_token(decoded, self.K).view(B, R, self.M).cpu().numpy()
+        scores = np.array(scores).reshape(B, R)
+        qemb = self.tower.encode_query({"input_ids": ids, "attention_mask": mask})
+        ranked, ndoc = self.fine.rerank(qemb, codes)
+        gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None else None
+        results = []
+        for i, text in enumerate(texts):
+            d = codes[i].tolist()
+            gt_codes = [list(self.mapping[g]) for g in doc_ids[i]]
+            self.coarse_log.add((text, d, gt_codes, scores[i].tolist()))
+            cr = tuple(d.index(g) if g in d else None for g in gt_codes)
+            docs, sc = ranked[i]
+            self.fine_log.add((text, docs, doc_ids[i]))
+            if self.hn_log is not None:
+                n = a.save_hard_neg
+                self.hn_log.add((text, mfine.f32_repr(gt_s[i]), ",".join(map(str, docs[:n])), mfine.f32_repr(sc[:n])))
+            results.append((text, int(ndoc[i]), cr, mfine.fine_ranks(docs, doc_ids[i])))
+        return results
+
+    def run(self, df):
+        a = self.args
+        idx = rank_slice(len(df), self.rank, self.nrank)
+        cache = []
+        bs = max(1, a.eval_batch_size)
+        for s in range(0, len(idx), bs):
+            rows = df.iloc[idx[s:s + bs]]
+            cache += self.infer(rows["query"].tolist(), rows["oldid"].tolist())
+        return self.finish(cache)
+
+    # ---- handle_infer_results / validation_epoch_end ----------------------------------------
+    def finish(self, cache):
+        a = self.args
+        self.coarse_log.merge()
+        self.fine_log.merge()
+        part = f"/tmp/{os.path.basename(a.custom_save_path)}.results_{self.rank}"
+        with open(part, "wb") as f:
+            pickle.dump(cache, f)
+        self.barrier()
+        if self.hn_log is not None:
+            self.hn_log.merge()
+        out = None
+        if self.rank == 0:
+            allres = []
+            for r in range(self.nrank):
+                p = f"/tmp/{os.path.basename(a.custom_save_path)}.results_{r}"
+                with open(p, "rb") as f:
+                    allres += pickle.load(f)
+                os.remove(p)
+            out = summarize(allres, a.recall_num, self.R)
+            write_metrics(out, a.metric_path, self.R, len(self.index.keys))
+        self.barrier()
+        return out
+
+
+def _acc(v, tables):
+    found = [x for x in v if x is not None]
+    best = min(found) if found else None
+    for recall, mrr, hit in [tables]:
+        for k in recall:
+            if found:
+                recall[k] += sum(x < k for x in found) / len(v)
+                mrr[k] += 1 / (best + 1) if best < k else 0
+                hit[k] += best < k
+    return found, best
+
+
+def summarize(results, recall_num, R):
+    """recall / mrr / hitrate at recall_num for the fine list, cluster_* at the cut-offs <= R, mean ndoc."""
+    queries = {q: (length, findex, cindex) for (q, length, cindex, findex) in results}
+    fine = tuple({k: 0 for k in recall_num} for _ in range(3))
+    ccut = sorted(k for k in recall_num if k <= R)
+    if not ccut or ccut[-1] != R:
+        ccut.append(R)
+    coarse = tuple({k: 0 for k in ccut} for _ in range(3))
+    nsamples = 0
+    for q, (length, findex, cindex) in queries.items():
+        _acc(findex, fine)
+        _acc(cindex, coarse)
+        nsamples += length
+    n = len(queries)
+    for t in fine + coarse:
+        for k in t:
+            t[k] /= n
+    return dict(recall=fine[0], mrr=fine[1], hitrate=fine[2], cluster_recall=coarse[0], cluster_mrr=coarse[1],
+                cluster_hitrate=coarse[2], ndoc=nsamples / n, nqueries=n)
+
+
+def write_metrics(out, metric_path, R, npqclus):
+    lines = []
+    for name in ("recall", "mrr", "hitrate"):
+        lines += [f"{name}{k} {v}" for k, v in out[name].items()]
+    for name in ("cluster_recall", "cluster_hitrate"):
+        lines += [f"{name}{k} {v}" for k, v in out[name].items()]
+    lines.append(f"ndocs@cluster{R}: {out['ndoc']}")
+    print(f"npqclus: {npqclus}")
+    print("\n".join(lines))
+    if metric_path:
+        os.makedirs(os.path.dirname(os.path.abspath(metric_path)), exist_ok=True)
+        with open(metric_path, "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+def default_metric_path(args):
+    logs = args.logs_dir or os.path.join(args.data_dir, "logs")
+    t = args.time_str or time.strftime("%Y%m%d%H%M%S")
+    tag = f"mevi_{args.dataset}_{args.query_type}_{args.model_info}_k{2 ** args.subvector_bits}"
+    return os.path.join(logs, f"{tag}_metrics_{t}.txt")

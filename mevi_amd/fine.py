@@ -1,0 +1,100 @@
+"""Coarse + fine stages of `infer()` after the beam search (MEVI/main_models.py:3736-4098).
+
+coarse  -- log (text, clusters, gt codes, scores); rank of every gt cluster in the beam list;
+           ndoc = sum of the beam clusters' sizes                              (:3758-3780)
+fine    -- twin-tower query embedding . embeddings of the documents inside the beam clusters,
+           concatenated in beam order, sorted descending; gt-document scores; hard-negative log
+           line truncated to save_hard_neg                                      (:3781-4089)
+
+The reference walks Python dicts and a CPU memmap per cluster with one H2D copy and one matmul per
+<= 1024 rows; here the cluster -> doc list is a CSR index, all (query, doc) pairs of a batch are
+scored by ONE pair_dot launch on the HBM-resident embedding matrix and ordered by ONE segmented
+sort.  Order: score descending, ties by ascending doc id (torch.sort leaves ties unspecified).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .rq import ClusterIndex
+
+MAX_SEGMENT = 16384
+
+
+def f32_repr(values):
+    """','.join(str(x.item()) for x in f32 tensor): the reference's way of printing scores."""
+    return ",".join(map(repr, np.asarray(values, dtype=np.float32).astype(np.float64).tolist()))
+
+
+class FineStage:
+    def __init__(self, doc_embeddings, cluster_index: ClusterIndex):
+        assert doc_embeddings.is_cuda and doc_embeddings.dtype == torch.float32 and doc_embeddings.dim() == 2
+        self.emb = doc_embeddings
+        self.index = cluster_index
+        self.dev = doc_embeddings.device
+
+    def candidates(self, beam_codes):
+        """beam_codes i64[B, R, M] -> (cand_doc_ids i64[total], cand_query i64[total], seg i64[B+1], ndoc i64[B])
+        with each query's candidates in beam order (cluster after cluster, ids ascending inside)."""
+        idx = self.index
+        codes = np.asarray(beam_codes, dtype=np.int64)
+        B, R, _ = codes.shape
+        keys = ClusterIndex.code_keys(codes, idx.K).reshape(-1)
+        pos = np.searchsorted(idx.keys, keys)
+        pos_c = np.minimum(pos, max(len(idx.keys) - 1, 0))
+        found = (pos < len(idx.keys)) & (idx.keys[pos_c] == keys) if len(idx.keys) else np.zeros_like(keys, bool)
+        start = np.where(found, idx.offsets[pos_c], 0)
+        size = np.where(found, idx.offsets[pos_c + 1] - idx.offsets[pos_c], 0)
+        total = int(size.sum())
+        first = np.cumsum(size) - size
+        flat = np.arange(total, dtype=np.int64) - np.repeat(first, size) + np.repeat(start, size)
+        cand = idx.doc_ids[flat]
+        cand_q = np.repeat(np.repeat(np.arange(B, dtype=np.int64), R), size)
+        ndoc = size.reshape(B, R).sum(1)
+        seg = np.concatenate([[0], np.cumsum(ndoc)]).astype(np.int64)
+        return cand, cand_q, seg, ndoc
+
+    def rerank(self, query_emb, beam_codes):
+        """query_emb f32[B, dim] (CUDA).  Returns per query: (doc ids list[int], scores f32 ndarray), and ndoc."""
+        cand, cand_q, seg, ndoc = self.candidates(beam_codes)
+        B = len(ndoc)
+        if len(cand) == 0:
+            return [([], np.zeros(0, np.float32)) for _ in range(B)], ndoc
+        cand_t = torch.from_numpy(cand).to(self.dev)
+        sc = ops.pair_dot(query_emb, torch.from_numpy(cand_q).to(self.dev), self.emb, cand_t)
+        longest = int(ndoc.max())
+        if longest <= MAX_SEGMENT:
+            s_sorted, i_sorted = ops.segment_sort_desc(sc, cand_t, torch.from_numpy(seg), longest)
+        else:
+            # a beam cluster list above the LDS sort capacity: order the flat list by
+            # (segment, -score, id) with one device sort (rare: > 16384 candidates for one query)
+            segid = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int64), ndoc)).to(self.dev)
+            o = torch.argsort(cand_t, stable=True)
+            o = o[torch.argsort(-sc[o], stable=True)]
+            o = o[torch.argsort(segid[o], stable=True)]
+            s_sorted, i_sorted = sc[o], cand_t[o]
+        s_sorted, i_sorted = s_sorted.cpu().numpy(), i_sorted.cpu().numpy()
+        out = [(i_sorted[a:b].tolist(), s_sorted[a:b]) for a, b in zip(seg[:-1], seg[1:])]
+        return out, ndoc
+
+    def gt_scores(self, query_emb, gt_doc_ids):
+        """q . emb[gt] for the hard-negative log line (main_models.py:4024-4045): list of f32 arrays."""
+        lens = [len(g) for g in gt_doc_ids]
+        if sum(lens) == 0:
+            return [np.zeros(0, np.float32) for _ in lens]
+        ib = torch.tensor([d for g in gt_doc_ids for d in g], dtype=torch.int64, device=self.dev)
+        ia = torch.from_numpy(np.repeat(np.arange(len(lens), dtype=np.int64), lens)).to(self.dev)
+        sc = ops.pair_dot(query_emb, ia, self.emb, ib).cpu().numpy()
+        return np.split(sc, np.cumsum(lens)[:-1])
+
+
+def coarse_ranks(beam_codes, gt_codes):
+    """index of every gt cluster in the query's beam list, None when absent (main_models.py:3773-3774)."""
+    d = [list(map(int, c)) for c in beam_codes]
+    return tuple(d.index(list(map(int, g))) if list(map(int, g)) in d else None for g in gt_codes)
+
+
+def fine_ranks(sorted_docs, gt_doc_ids):
+    pos = {}
+    for i, p in enumerate(sorted_docs):
+        pos.setdefault(p, i)
+    return tuple(pos.get(g) for g in gt_doc_ids)

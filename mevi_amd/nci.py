@@ -28,6 +28,26 @@ class NCIConfig(T5Dims):
         self.T = M + 1                      # decoder positions actually evaluated (tokens 0..M)
 
 
+def config_from_weights(w, M, K):
+    """Read the architecture off the checkpoint's tensor shapes (the reference takes it from
+    --model_info, MEVI/main.py:755-773; the shapes are authoritative for a given checkpoint)."""
+    def count(prefix):
+        n = 0
+        while f"{prefix}.{n}.layer.0.layer_norm.weight" in w:
+            n += 1
+        return n
+
+    heads = w["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].shape[1]
+    inner = w["encoder.block.0.layer.0.SelfAttention.q.weight"].shape[0]
+    na = 0
+    while f"adaptor.layers.{na}.norm1.weight" in w:
+        na += 1
+    return NCIConfig(M=M, K=K, adaptor_layer_num=na, d_model=w["shared.weight"].shape[1],
+                     d_ff=w["encoder.block.0.layer.1.DenseReluDense.wi.weight"].shape[0], num_heads=heads,
+                     d_kv=inner // heads, num_layers=count("encoder.block"), num_decoder_layers=count("decoder.block"),
+                     relative_attention_num_buckets=w["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].shape[0])
+
+
 class Adaptor:
     """nn.TransformerDecoder(TransformerDecoderLayer(d, nhead=8), L) over the decode-token embeddings
     (modeling_t5.py:1252-1255, 1650-1665), one position at a time with cached K|V.  Its memory is the

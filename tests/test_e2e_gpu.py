@@ -1,0 +1,172 @@
+"""End-to-end on the GPU: the eval driver (main.py's EvalRun) and the dense CLI chain on a miniature
+of config C4, checked against a CPU restatement of infer() built from the oracle pieces, then fed to
+the consumers exactly like marco_ensemble.sh does."""
+import json
+import os
+import pickle
+import subprocess
+import sys
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense as odense
+from oracle import rq as orq
+from oracle import t5 as ot5
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+class FakeTokenizer:
+    """Deterministic stand-in for the SentencePiece tokenizer (tokenisation is the boundary)."""
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def batch_encode_plus(self, texts, max_length=32, padding="max_length", truncation=True, return_tensors="pt"):
+        ids = np.zeros((len(texts), max_length), np.int64)
+        mask = np.zeros((len(texts), max_length), np.int64)
+        for i, t in enumerate(texts):
+            toks = [3 + (hash_(w) % (self.vocab - 3)) for w in t.split()][: max_length - 1] + [1]
+            ids[i, :len(toks)] = toks
+            mask[i, :len(toks)] = 1
+        return {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+
+
+def hash_(w):
+    h = 2166136261
+    for ch in w.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+@pytest.fixture(scope="module")
+def mini(tmp_path_factory):
+    d = tmp_path_factory.mktemp("marco")
+    g = np.load(os.path.join(GOLD, "g1_nci_M4_K32_R10.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    W = ot5.load_weights(g)
+    tw = np.load(os.path.join(GOLD, "g2_t5_tower.npz"))
+    TW = ot5.load_weights(tw)
+    tcfg = json.loads(str(tw["cfg"]))
+    os.makedirs(d / "ckpts" / "t5-ance")
+    os.makedirs(d / "origin")
+    os.makedirs(d / "ance")
+    torch.save({"state_dict": {"model." + k: v for k, v in W.items()}}, d / "ckpts" / "nci.ckpt")
+    torch.save(TW, d / "ckpts" / "t5-ance" / "pytorch_model.bin")
+    json.dump(dict(d_model=32, d_ff=64, num_heads=4, d_kv=8, num_layers=2, num_decoder_layers=2), open(d / "ckpts" / "t5-ance" / "config.json", "w"))
+    rng = np.random.default_rng(0)
+    dim, M, K = 32, 4, 32
+    queries = [" ".join(f"w{rng.integers(0, 50)}" for _ in range(rng.integers(3, 12))) + f" q{i}" for i in range(23)]
+    # corpus built around the clusters the (random-weight) model actually emits, so that the fine
+    # stage has documents to rank: doc = sum_j C[j][code_j] + noise for beam code paths + random paths
+    enc = FakeTokenizer(512).batch_encode_plus(queries)
+    dec, _, _ = ot5.nci_generate(W, cfg, enc["input_ids"], enc["attention_mask"], 10)
+    beam_codes = ot5.decode_token(dec, K).numpy()
+    C = (rng.standard_normal((M, K, dim)) * (1.0 / np.arange(1, M + 1))[:, None, None]).astype(np.float32)
+    C[0] *= 3.0
+    paths = np.concatenate([np.repeat(beam_codes[::3], 6, axis=0), rng.integers(0, K, size=(2000, M))])
+    rng.shuffle(paths)
+    N = len(paths)
+    emb = sum(C[j][paths[:, j]] for j in range(M)).astype(np.float32) + 0.01 * rng.standard_normal((N, dim)).astype(np.float32)
+    emb.tofile(d / "ance" / "docemb.bin")
+    torch.save(torch.nn.Parameter(torch.from_numpy(C)), d / "ance" / "rqcodebook4_5.pt")
+    gts = [[int(x) for x in rng.choice(N, size=1 + i % 2, replace=False)] for i in range(len(queries))]
+    with open(d / "origin" / "dev_mevi_dedup.tsv", "w") as f:
+        for q, g_ in zip(queries, gts):
+            f.write(f"{q}\t{','.join(map(str, g_))}\n")
+    args = Namespace(subvector_num=M, subvector_bits=5, num_return_sequences=10, adaptor_layer_num=2, model_info="base",
+                     nci_ckpt=str(d / "ckpts" / "nci.ckpt"), ckpt_dir=str(d / "ckpts"), embedding_path=str(d / "ance" / "docemb.bin"),
+                     pq_path=str(d / "ance" / "rqcodebook4_5.pt"), pq_cluster_path=str(d / "ance" / "rqclus4_5.pkl"),
+                     custom_save_path=str(d / "ance" / "nci_result_rq45_top10.tsv"), save_hard_neg=N, length_penalty=0.8,
+                     eval_batch_size=4, recall_num=[1, 5, 10, 20, 50, 100], metric_path=str(d / "logs" / "m.txt"),
+                     data_dir=str(d / "origin"), n_test=-1)
+    return dict(dir=d, args=args, W=W, cfg=cfg, TW=TW, tcfg=tcfg, emb=emb, C=C, queries=queries, gts=gts, N=N)
+
+
+def test_eval_driver_matches_cpu_restatement(cuda, mini):
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    a = mini["args"]
+    tok = FakeTokenizer(512)
+    run = EvalRun(a, tokenizer=tok, device=cuda)
+    out = run.run(load_queries(a.data_dir))
+    prefix = a.custom_save_path[:-4]
+    coarse = [l.rstrip("\n").split("\t") for l in open(prefix + "_coarse.tsv")]
+    fine = [l.rstrip("\n").split("\t") for l in open(prefix + "_fine.tsv")]
+    hn = [l.rstrip("\n").split("\t") for l in open(f"{prefix}_hn{a.save_hard_neg}.tsv")]
+    assert len(coarse) == len(fine) == len(hn) == len(mini["queries"])
+    # ---- CPU restatement of infer() from the oracle pieces
+    enc = tok.batch_encode_plus(mini["queries"])
+    ids, mask = enc["input_ids"], enc["attention_mask"]
+    dec, sc, _ = ot5.nci_generate(mini["W"], mini["cfg"], ids, mask, 10)
+    codes = ot5.decode_token(dec, 32).view(len(ids), 10, 4).numpy()
+    sc = sc.numpy().reshape(len(ids), 10)
+    qemb = ot5.tower_encode(mini["TW"], mini["tcfg"], ids, mask).numpy()
+    cluster, mapping = orq.cluster_dict(orq.rq_encode(mini["emb"], mini["C"]))
+    assert pickle.load(open(a.pq_cluster_path, "rb")) == cluster          # GPU RQ encode wrote the reference's pickles
+    assert pickle.load(open(a.pq_cluster_path.replace("clus", "mapping"), "rb")) == mapping
+    nd = 0
+    for i, q in enumerate(mini["queries"]):
+        assert coarse[i][0] == fine[i][0] == hn[i][0] == q
+        assert eval(coarse[i][1]) == codes[i].tolist()                      # identical beam clusters
+        assert np.abs(np.array(eval(coarse[i][3])) - sc[i]).max() <= 1e-5
+        assert eval(coarse[i][2]) == [list(mapping[g]) for g in mini["gts"][i]]
+        docs = [d for c in codes[i].tolist() for d in cluster.get(tuple(c), [])]
+        nd += len(docs)
+        got_docs = eval(fine[i][1])
+        assert sorted(got_docs) == sorted(docs) and eval(fine[i][2]) == mini["gts"][i]
+        if docs:
+            ref = mini["emb"][docs] @ qemb[i]
+            got_s = np.array([float(x) for x in hn[i][3].split(",")])
+            order = np.argsort(-ref, kind="stable")
+            assert np.abs(got_s - ref[order]).max() <= 2e-4
+            assert [int(x) for x in hn[i][2].split(",")] == got_docs
+            gaps = np.abs(np.diff(ref[order]))
+            firm = np.concatenate([[True], gaps > 1e-3]) & np.concatenate([gaps > 1e-3, [True]])
+            assert all(got_docs[j] == docs[order[j]] for j in np.nonzero(firm)[0])
+        gs = np.array([float(x) for x in hn[i][1].split(",")])
+        assert np.abs(gs - mini["emb"][mini["gts"][i]] @ qemb[i]).max() <= 2e-4
+    assert nd > 50, "fixture should populate beam clusters"
+    assert abs(out["ndoc"] - nd / len(mini["queries"])) < 1e-9
+    assert os.path.exists(a.metric_path) and "ndocs@cluster10" in open(a.metric_path).read()
+
+
+def test_dense_cli_and_ensemble_chain(cuda, mini, tmp_path):
+    """faiss_search.py (C1-style plumbing on the GPU) -> evaluate.py -> ensemble_marco.py on the files above."""
+    d, a = mini["dir"], mini["args"]
+    enc = FakeTokenizer(512).batch_encode_plus(mini["queries"])
+    from mevi_amd.t5 import TwinTower
+    from mevi_amd.evalrun import load_tower_weights
+
+    tw, dims = load_tower_weights(os.path.join(a.ckpt_dir, "t5-ance"))
+    q = TwinTower(tw, dims=dims, device=cuda).encode_query(enc).cpu().numpy()
+    q.tofile(d / "ance" / "query_emb.bin")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = str(d / "ance" / "dense.txt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "faiss_search.py"), "--query_path", str(d / "ance" / "query_emb.bin"),
+                        "--doc_path", a.embedding_path, "--output_path", out, "--raw_query_path",
+                        str(d / "origin" / "dev_mevi_dedup.tsv"), "--dim", "32", "--topk", "100", "--param", "HNSW256"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "Param HNSW256 trained: True." in r.stdout and "int64 (23, 100) float32 (23, 100)" in r.stdout
+    es, ei = odense.ip_topk_exact(q, mini["emb"], 100)
+    lines = [l.rstrip("\n").split("\t") for l in open(out)]
+    for i, l in enumerate(lines):
+        assert l[0] == mini["queries"][i] and l[1] == ""
+        assert [int(x) for x in l[2].split(",")] == ei[i].tolist()
+        assert [np.float32(x) for x in l[3].split(",")] == es[i].tolist()       # bit-exact scores through the TSV
+    prefix = a.custom_save_path[:-4]
+    if not os.path.exists(prefix + "_coarse.tsv"):
+        pytest.skip("eval driver test did not run")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "ensemble_marco.py"), "--mapping_file",
+                        a.pq_cluster_path.replace("clus", "mapping"), "--gt_file", str(d / "origin" / "dev_mevi_dedup.tsv"),
+                        "--ance_file", out, "--coarse_file", prefix + "_coarse.tsv", "--fine_file",
+                        f"{prefix}_hn{a.save_hard_neg}.tsv", "--ofile", str(tmp_path / "ens.txt")],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "ANCE Pred" in r.stdout and "Fine Pred" in r.stdout and "score + 0.6 / (0.03 * crank + 1)" in r.stdout

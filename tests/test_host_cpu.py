@@ -1,0 +1,154 @@
+"""CPU tests of host logic: CLI argv surfaces, rank partitioning rules, token codec / tree goldens (G5),
+metric aggregation, and the sharded dense arm's collective plumbing on gloo (world_size 2)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+EVAL_ARGV = """--n_gpu 8 --mode eval --query_type gtq --co_neg_from clus --model_info base --id_class bert_k30_c30_1
+--dataset marco --Rdrop 0. --eval_batch_size 2 --encode_batch_size 1024 --document_encoder ance --recall_level both
+--qtower encmask_dec --query_embed_accum attenpool --pq_loss ce --pq_type rq --codebook 1 --subvector_num 4
+--subvector_bits 5 --use_gumbel_softmax 0 --pq_softmax_tau 1 --pq_hard_softmax_topk 1 --pq_negative none --fixnci
+--fixpq --document_encoder_from_pretrained 0 --not_load_document_encoder 0 --no_nci_loss 1 --query_encoder twin
+--num_return_sequences 10 --save_hard_neg 8841823 --pq_path D/ance/rqcodebook4_5.pt --pq_cluster_path D/ance/rqclus4_5.pkl
+--nci_ckpt D/ckpts/nci.ckpt --data_dir D/origin --newid_dir D/ance --document_path D/ance/all_document --ckpt_dir D/ckpts
+--embedding_path D/ance/docemb.bin --custom_save_path D/ance/nci_result_rq45_top10.tsv""".split()
+
+
+def test_main_accepts_every_flag_of_marco_eval_nci_rq_sh():
+    import main
+
+    a = main.parsers_parser(EVAL_ARGV)
+    main.check_supported(a)
+    assert a.n_gpu == list(range(8)) and a.num_return_sequences == 10 and a.save_hard_neg == 8841823
+    assert a.subvector_num == 4 and a.subvector_bits == 5 and a.length_penalty == 0.8
+    assert ("--fixnci", None) in a.ignored_flags and ("--Rdrop", "0.") in a.ignored_flags
+    assert main.parsers_parser(["--mode", "eval", "--data_dir", "x", "--n_gpu", "[2,5]"]).n_gpu == [2, 5]
+    with pytest.raises(SystemExit):
+        main.check_supported(main.parsers_parser(["--mode", "train", "--data_dir", "x"]))
+    with pytest.raises(SystemExit):   # NQ / AR2 towers are out of scope
+        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--document_encoder", "ar2"]))
+
+
+def test_cli_argument_surfaces_match_reference():
+    for script, flags in {
+        "faiss_search.py": ["--query_path", "--doc_path", "--output_path", "--raw_query_path", "--dim", "--topk", "--param"],
+        "generate.py": ["--query_file", "--model_path", "--tokenizer_path", "--query_embedding_path", "--ckpt_path",
+                        "--batch_size", "--dim", "--gpus", "--gen_query", "--timing_infer_step"],
+        "evaluate.py": ["--dir_path", "--gt_file", "--ance_file", "--recall_num", "--ofile"],
+        "ensemble_marco.py": ["--dir_path", "--gt_file", "--ance_file", "--fine_file", "--coarse_file", "--mapping_file",
+                              "--alphas", "--betas", "--gammas", "--recall_num", "--ofile"],
+    }.items():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, script), "--help"], capture_output=True, text=True,
+                           env=dict(os.environ, PYTHONPATH=ROOT))
+        assert r.returncode == 0, r.stderr[-500:]
+        for f in flags:
+            assert f in r.stdout, (script, f)
+
+
+def test_rank_partition_rules():
+    import generate
+    from mevi_amd.dense import shard_range
+    from mevi_amd.evalrun import rank_slice
+
+    # generate.py:74-82 -- the first n % nrank ranks take one more row, ranges are contiguous
+    for n, w in [(6980, 8), (10, 3), (5, 8)]:
+        r = [generate.rank_range(n, i, w) for i in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        sizes = [b - a for a, b in r]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    # dense arm: ceil(N / W) rows per rank
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert shard_range(8841823, 7, 8) == (7 * 1105228, 8841823)
+    # DistributedSampler(shuffle=False): strided, padded by repeating the head
+    assert rank_slice(10, 0, 4) == [0, 4, 8] and rank_slice(10, 3, 4) == [3, 7, 1]
+    from torch.utils.data import DistributedSampler
+
+    for n, w in [(10, 4), (23, 8), (7, 2)]:
+        for r in range(w):
+            assert rank_slice(n, r, w) == list(DistributedSampler(range(n), num_replicas=w, rank=r, shuffle=False))
+
+
+def test_token_codec_against_reference_golden():
+    from mevi_amd.nci import dec_2d, decode_token
+
+    for case in json.load(open(os.path.join(GOLD, "g5_tree_codec.json"))):
+        M, K = case["M"], case["K"]
+        enc = torch.tensor(case["encoded"])
+        assert enc.tolist() == [[2 + p * K + c for p, c in enumerate(row)] + [1] for row in case["codes"]]
+        assert case["encoded_from_str"] == enc[0].tolist()
+        assert case["tree_levels"] == [[2 + p * K + c for c in range(K)] for p in range(M)] + [[1]]
+        seqs = torch.cat([torch.zeros((len(enc), 1), dtype=torch.long), enc], 1)
+        got = decode_token(seqs, K)
+        assert got.tolist() == case["decoded"] == case["codes"] and case["eos_is_none"]
+        assert dec_2d(got, 3).tolist() == case["dec_2d"]
+        assert dec_2d(list(range(7)), 3) == [[0, 1, 2], [3, 4, 5], [6]]
+
+
+def test_metric_aggregation_matches_consumer_semantics():
+    from mevi_amd.evalrun import summarize
+
+    res = [("q1", 12, (0, None), (3, None)), ("q2", 0, (None,), (None,)), ("q3", 5, (7,), (0,)),
+           ("q1", 12, (0, None), (3, None))]            # DistributedSampler padding duplicates q1
+    out = summarize(res, [1, 5, 10, 20], 10)
+    assert out["nqueries"] == 3 and abs(out["ndoc"] - 17 / 3) < 1e-12
+    assert out["recall"][5] == (0.5 + 0 + 1) / 3 and out["mrr"][5] == (1 / 4 + 0 + 1) / 3 and out["recall"][1] == 1 / 3
+    assert out["cluster_recall"][10] == (0.5 + 0 + 1) / 3 and out["cluster_recall"][5] == 0.5 / 3
+    assert list(out["cluster_recall"]) == [1, 5, 10]
+
+
+def _gloo_worker(rank, world, port, q, d, k, ret):
+    import torch.distributed as dist
+
+    from mevi_amd import dense
+    from oracle import dense as od
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = dense.shard_range(len(d), rank, world)
+
+    def local(qq, dd, kk, id_offset=0):     # CPU stand-ins for the two device steps (checker = the oracle)
+        s, i = od.ip_topk_exact(qq.numpy(), dd.numpy(), kk, id_offset)
+        return torch.from_numpy(s), torch.from_numpy(i)
+
+    def merge(s, i, kk):
+        ms, mi = od.topk_merge(s.numpy(), i.numpy(), kk)
+        return torch.from_numpy(ms), torch.from_numpy(mi)
+
+    s, i = dense.sharded_ip_topk(torch.from_numpy(q), torch.from_numpy(d[a:b]), k, id_offset=a,
+                                 local_search=local, merge=merge)
+    ret[rank] = (s.numpy(), i.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_dense_exchange_on_gloo_world2():
+    """The N > 1 path of the dense arm: shard ranges, global ids, all-gather of per-shard top-k and the
+    merge must give every rank the un-sharded answer.  gloo / CPU: the device kernels are replaced by the
+    oracle through the injection points of sharded_ip_topk, the collective plumbing is the product's."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from oracle import dense as od
+
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((9, 32)).astype(np.float32)
+    d = rng.standard_normal((501, 32)).astype(np.float32)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_gloo_worker, nprocs=2, args=(2, port, q, d, 20, ret))
+    es, ei = od.ip_topk_exact(q, d, 20)
+    for r in range(2):
+        assert np.array_equal(ret[r][1], ei) and np.array_equal(ret[r][0], es)

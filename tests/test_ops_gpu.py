@@ -157,3 +157,51 @@ def test_pair_dot_and_segment_sort(cuda):
     for a, b in zip(seg[:-1], seg[1:]):
         order = np.lexsort((ids[a:b], -sc[a:b]))
         assert np.array_equal(oi_[a:b], ids[a:b][order]) and np.array_equal(os_[a:b], sc[a:b][order])
+
+
+def test_fine_stage_matches_reference_procedure(cuda):
+    """FineStage.rerank vs a literal restatement of the reference loop (dict lookup per beam cluster,
+    scores concatenated in beam order, sorted descending) with the oracle's fmaf-chain scores."""
+    import ctypes
+    from mevi_amd.fine import FineStage, coarse_ranks, fine_ranks, f32_repr
+    from mevi_amd.rq import ClusterIndex
+    from oracle import rq as orq
+
+    rng = np.random.default_rng(12)
+    N, dim, M, K, B, R = 3000, 64, 3, 6, 9, 5
+    emb = rng.standard_normal((N, dim)).astype(np.float32)
+    codes = rng.integers(0, K, size=(N, M)).astype(np.int32)
+    cluster, mapping = orq.cluster_dict(codes)
+    q = rng.standard_normal((B, dim)).astype(np.float32)
+    beams = rng.integers(0, K, size=(B, R, M))
+    beams[0] = codes[rng.integers(0, N, size=R)]                # populated clusters
+    beams[1, :, :] = K - 1                                       # likely rare/empty clusters repeated
+    fs = FineStage(torch.from_numpy(emb).to(cuda), ClusterIndex.from_codes(codes, K))
+    out, ndoc = fs.rerank(torch.from_numpy(q).to(cuda), beams)
+    L = odense.lib()
+    L.oracle_dot_f32.restype = ctypes.c_float
+    L.oracle_dot_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    for b in range(B):
+        docs, sc = [], []
+        seen = set()
+        for r in range(R):
+            key = tuple(int(x) for x in beams[b, r])
+            cur = cluster.get(key)
+            if cur is None:
+                continue
+            # NOTE: a cluster repeated in the beam list is scored again by the reference as well
+            docs += cur
+            sc += [L.oracle_dot_f32(q[b].ctypes.data, emb[d].ctypes.data, dim) for d in cur]
+            seen.add(key)
+        assert ndoc[b] == len(docs)
+        order = np.lexsort((np.array(docs, dtype=np.int64), -np.array(sc, dtype=np.float32))) if docs else []
+        assert out[b][0] == [docs[i] for i in order]
+        assert np.array_equal(out[b][1].view(np.uint32), np.array([sc[i] for i in order], np.float32).view(np.uint32))
+    gts = [[int(x) for x in rng.integers(0, N, size=1 + b % 2)] for b in range(B)]
+    gs = fs.gt_scores(torch.from_numpy(q).to(cuda), gts)
+    for b in range(B):
+        ref = np.array([L.oracle_dot_f32(q[b].ctypes.data, emb[d].ctypes.data, dim) for d in gts[b]], np.float32)
+        assert np.array_equal(gs[b].view(np.uint32), ref.view(np.uint32))
+    assert coarse_ranks(beams[0], [beams[0][2], [K, K, K]]) == (list(map(list, beams[0].tolist())).index(beams[0][2].tolist()), None)
+    assert fine_ranks([5, 3, 9, 3], [9, 3, 7]) == (2, 1, None)
+    assert f32_repr(np.array([0.1, 100.0], np.float32)) == "0.10000000149011612,100.0"
