@@ -31,9 +31,13 @@ constexpr int RQ_KS = 32;     // k slab
 constexpr int RQ_LD = 36;     // floats per LDS row (16-byte aligned, conflict-free b128 reads)
 constexpr int RQ_MAXM = 8;    // levels supported by the in-register code history
 
-__global__ __launch_bounds__(256, 3) void rq_level_kernel(const float *__restrict__ X, long long n, int dim,
-                                                         const float *__restrict__ C, int M, int K, int level,
+// LEVEL is a template parameter so the code-history loops unroll and stay in registers
+// (a runtime-indexed history array lands in scratch: 20x slower).
+template <int LEVEL>
+__global__ __launch_bounds__(256, 2) void rq_level_kernel(const float *__restrict__ X, long long n, int dim,
+                                                         const float *__restrict__ C, int M, int K,
                                                          int *__restrict__ codes) {
+  constexpr int level = LEVEL;
   __shared__ __attribute__((aligned(16))) float xs[2][RQ_ROWS * RQ_LD];
   __shared__ __attribute__((aligned(16))) float cs[2][RQ_CENTS * RQ_LD];
 
@@ -48,14 +52,14 @@ __global__ __launch_bounds__(256, 3) void rq_level_kernel(const float *__restric
   const int srow = t >> 3;
   const int skq = (t & 7) * 4;
   const float *xptr[4];
-  int prev[4][RQ_MAXM];
+  int prev[4][LEVEL > 0 ? LEVEL : 1];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     long long r = row0 + srow + 32 * i;
     if (r > n - 1) r = n - 1;
     xptr[i] = X + (size_t)r * dim + skq;
 #pragma unroll
-    for (int j = 0; j < RQ_MAXM; ++j) prev[i][j] = (j < level) ? codes[(size_t)r * M + j] : 0;
+    for (int j = 0; j < LEVEL; ++j) prev[i][j] = codes[(size_t)r * M + j];
   }
   const size_t level_stride = (size_t)K * dim;
   const int nslab = (dim + RQ_KS - 1) / RQ_KS;
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(256, 3) void rq_level_kernel(const float *__restric
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (in) {
         v = *reinterpret_cast<const float4 *>(xptr[i] + s * RQ_KS);
-        for (int j = 0; j < level; ++j) {  // residual with the reference's operation order
+#pragma unroll
+        for (int j = 0; j < LEVEL; ++j) {  // residual with the reference's operation order
           const float4 c = *reinterpret_cast<const float4 *>(C + j * level_stride + (size_t)prev[i][j] * dim + kk);
           v.x -= c.x; v.y -= c.y; v.z -= c.z; v.w -= c.w;
         }
@@ -111,8 +116,8 @@ __global__ __launch_bounds__(256, 3) void rq_level_kernel(const float *__restric
       if (s + 1 < nslab) gload(chunk, s + 1);
       const float *px = &xs[s & 1][(32 * wave + ld) * RQ_LD];
       const float *pc = &cs[s & 1][lc * RQ_LD];
-#pragma unroll
-      for (int k4 = 0; k4 < RQ_KS; k4 += 4) {
+#pragma unroll 2
+      for (int k4 = 0; k4 < RQ_KS; k4 += 4) {  // limited unroll: a full unroll hoists 64 float4 reads and spills
         float4 xv[4], cv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(px + 8 * i * RQ_LD + k4);
@@ -180,8 +185,16 @@ extern "C" int mevi_rq_encode_f32(const float *x, int64_t n, int64_t dim, const 
   const int64_t nblk = (n + RQ_ROWS - 1) / RQ_ROWS;
   MEVI_REQUIRE(nblk <= 0x7fffffffLL, MEVI_ERR_UNSUPPORTED, "rq_encode: too many rows");
   for (int level = 0; level < (int)M; ++level) {
-    hipLaunchKernelGGL(rq_level_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x, (long long)n, (int)dim,
-                       codebook, (int)M, (int)K, level, codes);
+#define MEVI_RQ_LEVEL(L)                                                                                   \
+  case L:                                                                                                  \
+    hipLaunchKernelGGL(rq_level_kernel<L>, dim3((unsigned)nblk), dim3(256), 0, stream, x, (long long)n,    \
+                       (int)dim, codebook, (int)M, (int)K, codes);                                         \
+    break;
+    switch (level) {
+      MEVI_RQ_LEVEL(0) MEVI_RQ_LEVEL(1) MEVI_RQ_LEVEL(2) MEVI_RQ_LEVEL(3)
+      MEVI_RQ_LEVEL(4) MEVI_RQ_LEVEL(5) MEVI_RQ_LEVEL(6) MEVI_RQ_LEVEL(7)
+    }
+#undef MEVI_RQ_LEVEL
   }
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
