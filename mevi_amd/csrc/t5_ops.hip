@@ -160,6 +160,57 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   if (lane + 64 < a.dh) o[lane + 64] = acc1;
 }
 
+// Self-attention of one (batch, head) per workgroup: Q, K, V tiles [tk x dh] staged ONCE in LDS
+// (the wave-per-query kernel above re-reads K and V from L2 for every query row: 32x the traffic
+// at S = 32).  K rows are padded by one float so that lane = key reads are bank-conflict free.
+// Same arithmetic as attention_kernel (fmaf chain over d, expf softmax, fmaf chain over keys).
+__global__ __launch_bounds__(256) void attention_tile_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int dh = a.dh, tk = a.tk, ldk = dh + 1;
+  float *sq = sm;                    // [tk][dh]
+  float *sk = sq + tk * dh;          // [tk][dh + 1]
+  float *sv = sk + tk * ldk;         // [tk][dh]
+  const float *qg = a.q + (size_t)b * a.q_bs + (size_t)h * dh;
+  const float *kg = a.k + (size_t)b * a.k_bs + (size_t)h * dh;
+  const float *vg = a.v + (size_t)b * a.v_bs + (size_t)h * dh;
+  for (int i = t; i < tk * dh; i += 256) {
+    const int r = i / dh, d = i - r * dh;
+    sq[i] = qg[(size_t)r * a.q_ts + d] * a.scale;
+    sk[r * ldk + d] = kg[(size_t)r * a.k_ts + d];
+    sv[i] = vg[(size_t)r * a.v_ts + d];
+  }
+  __syncthreads();
+  for (int tq = wave; tq < a.tq; tq += 4) {
+    const int qpos = a.q_pos0 + tq;
+    float s = -INFINITY;
+    if (lane < tk) {
+      float acc = 0.f;
+      const float *qr = sq + tq * dh;
+      const float *kr = sk + lane * ldk;
+      for (int d = 0; d < dh; ++d) acc = fmaf(qr[d], kr[d], acc);
+      float add = 0.f;
+      if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + lane];
+      if (a.key_mask && a.key_mask[(size_t)b * tk + lane] == 0) add += -1e9f;
+      if (a.causal && lane > qpos) add += -1e9f;
+      s = acc + add;
+    }
+    const float m = wave_max(s);
+    const float e = (lane < tk) ? expf(s - m) : 0.f;
+    const float p = e / wave_sum(e);
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int j = 0; j < tk; ++j) {
+      const float pj = __shfl(p, j);
+      if (lane < dh) acc0 = fmaf(pj, sv[j * dh + lane], acc0);
+      if (lane + 64 < dh) acc1 = fmaf(pj, sv[j * dh + lane + 64], acc1);
+    }
+    float *o = a.out + (size_t)b * a.o_bs + (size_t)tq * a.o_ts + (size_t)h * dh;
+    if (lane < dh) o[lane] = acc0;
+    if (lane + 64 < dh) o[lane + 64] = acc1;
+  }
+}
+
 // logits[row, c] = sum_d s[row, d] * (T[row, c*dim + d] + E[c, d]); one wave per (row, c)
 __global__ __launch_bounds__(256) void adaptive_logits_kernel(const float *__restrict__ s, long long lds_,
                                                              const float *__restrict__ T, long long ldt,
@@ -260,7 +311,12 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   a.nb = (int)nb; a.tq = (int)tq; a.tk = (int)tk; a.H = (int)heads; a.dh = (int)dh; a.kv_div = (int)kv_div;
   a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = (int)q_pos0;
   a.key_mask = reinterpret_cast<const long long *>(key_mask); a.causal = causal; a.scale = scale;
-  hipLaunchKernelGGL(attention_kernel, dim3(blocks4(nb * heads * tq)), dim3(256), 0, (hipStream_t)stream, a);
+  const size_t tile_lds = (size_t)tk * (3 * dh + 1) * sizeof(float);
+  if (kv_div == 1 && tq == tk && tq >= 8 && tile_lds <= 65536) {  // self-attention over a whole sequence
+    hipLaunchKernelGGL(attention_tile_kernel, dim3((unsigned)(nb * heads)), dim3(256), tile_lds, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(attention_kernel, dim3(blocks4(nb * heads * tq)), dim3(256), 0, (hipStream_t)stream, a);
+  }
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

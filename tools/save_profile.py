@@ -1,6 +1,8 @@
 """Copy a rocprofv3 --stats kernel summary from gpurun_out/ into profiles/ (names trimmed)."""
 import csv, glob, sys
-src = glob.glob((sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/stats") + "/**/*kernel_stats.csv", recursive=True)[0]
+import os
+src = max(glob.glob((sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/stats") + "/**/*kernel_stats.csv", recursive=True),
+          key=os.path.getmtime)
 dst = sys.argv[2]
 rows = list(csv.reader(open(src)))
 with open(dst, "w", newline="") as f:
