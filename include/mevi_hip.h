@@ -63,6 +63,22 @@ int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, int64_t nd,
                      float *out_score, int64_t *out_id, void *workspace,
                      size_t workspace_bytes, void *stream);
 
+/* Indexed form of the same search (same results, bit for bit): the corpus shard is pre-split once
+ * into (hi, lo) bfloat16 pairs (the analogue of faiss `index.add`, MEVI/faiss_search.py:19); a search
+ * then selects k + margin candidates per query with three bf16 MFMAs per product (16x the f32 MFMA
+ * rate each), re-scores them with the exact f32 fmaf chain, and PROVES per query that no other row can
+ * enter the top-k (|approx - exact| <= 2.5e-4 * ||q|| * max||d||); unproven queries are re-run through
+ * the exact f32 path.  `docs` (f32) is still needed for the exact re-scoring.
+ *   index buffer: mevi_ip_index_bytes(nd, dim) bytes, 256-byte aligned, filled by mevi_ip_index_build_f32.
+ * Synchronising like mevi_ip_topk_f32. */
+size_t mevi_ip_index_bytes(int64_t nd, int64_t dim);
+int mevi_ip_index_build_f32(const float *docs, int64_t nd, int64_t dim, void *index, size_t index_bytes,
+                            void *stream);
+size_t mevi_ip_topk_indexed_workspace_bytes(int64_t nq, int64_t dim, int64_t k);
+int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float *docs, const void *index, int64_t nd,
+                             int64_t dim, int64_t k, int64_t id_offset, float *out_score, int64_t *out_id,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* Merge `nlists` per-shard top-k lists into one (the step after the RCCL
  * all-gather of the row-sharded dense arm; new in this build).
  *   scores f32 [nlists, nq, k_in], ids i64 [nlists, nq, k_in] (id -1 = padding)

@@ -24,7 +24,7 @@
 // and half 1 odd k); oracle/mevi_oracle.c computes the same chain on the CPU,
 // so parity is bit-exact.
 
-#include "mfma_pp.h"
+#include "mfma_pp_bf16x3.h"
 
 #include <float.h>
 #include <math.h>
@@ -205,11 +205,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
 // top-k rows of the fallback state -> rows idx[r] of the main state
 __global__ __launch_bounds__(256) void scatter_top_kernel(const unsigned long long *__restrict__ src,
                                                          const int *__restrict__ idx, int nrows, int S,
-                                                         int k, unsigned long long *__restrict__ dst) {
+                                                         int k, unsigned long long *__restrict__ dst, int dst_ld) {
   const int r = blockIdx.x;
   if (r >= nrows) return;
   const unsigned long long *s = src + (size_t)r * S;
-  unsigned long long *d = dst + (size_t)idx[r] * S;
+  unsigned long long *d = dst + (size_t)idx[r] * dst_ld;
   for (int i = threadIdx.x; i < k; i += blockDim.x) d[i] = s[i];
 }
 
@@ -247,6 +247,170 @@ __global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ sc
       out_score[off] = key_score(key);
       out_id[off] = (long long)key_id(key);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bf16x3 pre-filter (see mfma_pp_bf16x3.h): split, approximate filter, exact re-score + verify.
+
+constexpr float X3_C_ERR = 2.5e-4f;  // |approx - chain| <= X3_C_ERR * ||q|| * ||d||   (derivation: DESIGN.md 4.1b)
+
+// f32 rows -> slab-interleaved (hi | lo) bf16 image + row L2 norms + max norm.  One wave per row.
+__global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ x, long long n, int dim, int dimp,
+                                                   unsigned short *__restrict__ out, float *__restrict__ norms,
+                                                   unsigned int *__restrict__ max_norm_bits) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float *xr = x + (size_t)r * dim;
+  unsigned short *o = out + (size_t)r * dimp * 2;
+  float ss = 0.f;
+  for (int s = 0; s < dimp / 32; ++s) {
+    if (lane < 32) {
+      const int k = s * 32 + lane;
+      const float v = k < dim ? xr[k] : 0.f;
+      const __bf16 hi = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)hi);
+      o[s * 64 + lane] = __builtin_bit_cast(unsigned short, hi);
+      o[s * 64 + 32 + lane] = __builtin_bit_cast(unsigned short, lo);
+      ss = fmaf(v, v, ss);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  if (lane == 0) {
+    const float nrm = sqrtf(ss) * 1.000001f;  // round up: the bound must hold for the real norm
+    norms[r] = nrm;
+    if (max_norm_bits) atomicMax(max_norm_bits, __float_as_uint(nrm));  // non-negative floats order as uints
+  }
+}
+
+// Approximate scores (bf16x3) + threshold filter: same epilogue as ip_filter_kernel, A = split corpus
+// rows (two 128-row tiles), B = 256 split queries.  Keys carry the APPROXIMATE score.
+__global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_x3_kernel(
+    const float *__restrict__ Qs, int nq, const float *__restrict__ Ds, long long doc_begin, long long doc_end,
+    int dimp, const float *__restrict__ tau, unsigned long long *__restrict__ buf,
+    unsigned int *__restrict__ count, int S, int k, int cap, unsigned int id_base, int n_qtiles, int n_dpairs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nwg = n_qtiles * n_dpairs;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int dpair = wg / n_qtiles;
+  const int qtile = wg - dpair * n_qtiles;
+  const int t = threadIdx.x;
+  const int grp = __builtin_amdgcn_readfirstlane(t >> 8);
+  const int tg = t & 255;
+  const int lane = t & 63;
+  const int wave = tg >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = lane & 31, half = lane >> 5;
+  const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
+  const int qrow0 = qtile * X3_QT;
+  // DMA duty of this lane: LDS rows 64*w8 + 8*i + (lane>>3); rows [0,256) are the two corpus tiles, [256,512) queries
+  const int w8 = t >> 6;
+  const float *rowptr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lr = 64 * w8 + 8 * i + (lane >> 3);
+    if (lr < 2 * BM) {
+      long long dr = doc_begin + (long long)dpair * 2 * BM + lr;
+      if (dr > doc_end - 1) dr = doc_end - 1;
+      rowptr[i] = Ds + (size_t)dr * (size_t)dimp;
+    } else {
+      int qr = qrow0 + (lr - 2 * BM);
+      if (qr > nq - 1) qr = nq - 1;
+      rowptr[i] = Qs + (size_t)qr * (size_t)dimp;
+    }
+  }
+  f32x16 acc[2][4];
+  pp_mainloop_bf16x3(rowptr, dimp / 32, lds, acc);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int qi = qrow0 + 128 * wn + 32 * ni + lrow;
+    const bool qok = qi < nq;
+    const float tq = qok ? tau[qi] : INFINITY;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[mi][ni][r];
+        if (v > tq) {
+          const long long dr = drow0 + 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (dr < doc_end) {
+            const unsigned int slot = atomicAdd(&count[qi], 1u);
+            if (slot < (unsigned int)cap) buf[(size_t)qi * S + k + slot] = make_key(v, id_base + (unsigned int)dr);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Exact re-scoring of the kp approximate survivors of one query, exact top-k, and the proof that
+// nothing outside the survivors can belong to it:
+//   every non-survivor has approx <= a_last (the kp-th approximate score), hence
+//   chain <= a_last + eps_q;  if a_last + eps_q < e_k (the exact k-th score) the list is exact.
+// One workgroup per query; one lane per candidate, sequential fmaf chain over k (the oracle's chain),
+// rows staged through LDS in 32-wide slabs.
+__global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ Q, const float *__restrict__ D,
+                                                     int dim, unsigned long long *__restrict__ buf, int S, int k,
+                                                     int kp, unsigned int id_base, const float *__restrict__ qnorm,
+                                                     const unsigned int *__restrict__ dmax_bits,
+                                                     unsigned int *__restrict__ failed,
+                                                     unsigned long long *__restrict__ out_top, int out_ld) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // P keys, then staging floats
+  const int q = blockIdx.x, t = threadIdx.x;
+  int P = 64;
+  while (P < kp) P <<= 1;
+  float *sd = reinterpret_cast<float *>(skeys + P);  // [256][36]
+  float *sq = sd + 256 * 36;                         // [32]
+  unsigned int *sid = reinterpret_cast<unsigned int *>(sq + 32);  // [256]
+  unsigned long long *row = buf + (size_t)q * S;
+  const unsigned long long last = row[kp - 1];
+  const float *qr = Q + (size_t)q * dim;
+  const int srow = t >> 3, spc = (t & 7) * 4;
+  const int nslab = (dim + 31) / 32;
+  for (int base = 0; base < P; base += 256) {
+    const int c = base + t;
+    const unsigned long long key = (c < kp) ? row[c] : 0ull;
+    const bool valid = key != 0ull;
+    sid[t] = valid ? key_id(key) - id_base : 0u;
+    float acc = 0.f;
+    for (int s = 0; s < nslab; ++s) {
+      __syncthreads();
+      const int kk = s * 32 + spc;
+      const bool in = kk < dim;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = srow + 32 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) v = *reinterpret_cast<const float4 *>(D + (size_t)sid[rr] * dim + kk);
+        *reinterpret_cast<float4 *>(sd + rr * 36 + spc) = v;
+      }
+      if (t < 32) sq[t] = (s * 32 + t < dim) ? qr[s * 32 + t] : 0.f;
+      __syncthreads();
+      const float *dr = sd + t * 36;
+#pragma unroll
+      for (int k4 = 0; k4 < 32; k4 += 4) {
+        const float4 x = *reinterpret_cast<const float4 *>(dr + k4);
+        acc = fmaf(sq[k4], x.x, acc);
+        acc = fmaf(sq[k4 + 1], x.y, acc);
+        acc = fmaf(sq[k4 + 2], x.z, acc);
+        acc = fmaf(sq[k4 + 3], x.w, acc);
+      }
+    }
+    skeys[c] = valid ? make_key(acc, key_id(key)) : 0ull;
+    __syncthreads();
+  }
+  bitonic_sort_desc<256>(skeys, P, t);
+  for (int i = t; i < k; i += 256) out_top[(size_t)q * out_ld + i] = skeys[i];
+  if (t == 0) {
+    bool ok = true;
+    if (last != 0ull) {  // the survivor list is full: there are documents outside it
+      const unsigned long long kth = skeys[k - 1];
+      const float eps = X3_C_ERR * qnorm[q] * __uint_as_float(*dmax_bits);
+      ok = (kth != 0ull) && (key_score(last) + eps < key_score(kth));
+    }
+    if (!ok) failed[q] = 1u;  // keeps an overflow flag set by compact_kernel during the approximate pass
   }
 }
 
@@ -304,7 +468,7 @@ static void profile_collect() {
 // Walk docs [0, nd) in chunks; returns number of filter launches, <0 on error.
 static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, int dim,
                         const TopkGeom &g, uint32_t id_base, const SearchState &st, bool guaranteed,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool x3 = false) {
   const long long total = nq * (long long)g.k;
   const long long init_n = total > nq ? total : nq;
   hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, stream,
@@ -320,16 +484,17 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   // MFMAs per phase) was measured at the same MFMA-pipe utilisation (85.6 % vs 85.4 %)
   // and pads nq further, so only NI = 2 is instantiated.
   const int ni = 2;
-  const int qt = 64 * ni;
+  const int qt = x3 ? X3_QT : 64 * ni;
   const int n_qtiles = (int)((nq + qt - 1) / qt);
   double growth = g_growth > 0.0 ? g_growth : (double)(g.cap / (3 * g.k));
   if (growth < 1.0) growth = 1.0;
   const int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
-  const size_t pp_lds = pp_lds_bytes<2>();
+  const size_t pp_lds = x3 ? x3_lds_bytes() : pp_lds_bytes<2>();
   const bool ktail = (dim % BK) != 0;
   const void *fn = nullptr;
 #define MEVI_PICK(NI_, T_) fn = reinterpret_cast<const void *>(ip_filter_kernel<NI_, T_>)
-  if (ktail) MEVI_PICK(2, true);
+  if (x3) fn = reinterpret_cast<const void *>(ip_filter_x3_kernel);  // Q, D = split images, dim = padded dim
+  else if (ktail) MEVI_PICK(2, true);
   else MEVI_PICK(2, false);
 #undef MEVI_PICK
   // opt in to > 64 KiB dynamic LDS (per device; cheap, so done on every call)
@@ -450,7 +615,8 @@ extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, i
     int64_t fl = run_pass(qsub, nf, docs, nd, (int)dim, g, (uint32_t)id_offset, fb, true, stream);
     if (fl < 0) return MEVI_ERR_HIP;
     g_stats.n_fallback_chunks = fl;
-    hipLaunchKernelGGL(scatter_top_kernel, dim3((unsigned)nf), dim3(256), 0, stream, fb.buf, fidx, (int)nf, g.S, g.k, st.buf);
+    hipLaunchKernelGGL(scatter_top_kernel, dim3((unsigned)nf), dim3(256), 0, stream, fb.buf, fidx, (int)nf, g.S, g.k, st.buf,
+                       g.S);
     // idx (host) must outlive the async H2D copy
     MEVI_HIP_CHECK(hipStreamSynchronize(stream));
     profile_collect();
@@ -458,6 +624,148 @@ extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, i
   const long long total = nq * (long long)k;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, st.buf, g.S,
                      g.k, (long long)nq, out_score, reinterpret_cast<long long *>(out_id));
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Indexed (bf16x3 pre-filtered) search.  Index = split corpus image + row norms + max norm.
+namespace {
+struct IndexView {
+  const float *split;         // [nd, dimp] floats holding (hi | lo) bf16 slabs
+  const float *norms;         // [nd]
+  const unsigned int *dmax;   // max row norm (float bits)
+};
+inline int64_t pad32(int64_t d) { return (d + 31) / 32 * 32; }
+inline size_t index_split_bytes(int64_t nd, int64_t dim) { return align_up((size_t)nd * pad32(dim) * 4, 256); }
+inline IndexView view_index(const void *index, int64_t nd, int64_t dim) {
+  const char *p = reinterpret_cast<const char *>(index);
+  IndexView v;
+  v.split = reinterpret_cast<const float *>(p);
+  v.norms = reinterpret_cast<const float *>(p + index_split_bytes(nd, dim));
+  v.dmax = reinterpret_cast<const unsigned int *>(p + index_split_bytes(nd, dim) + align_up((size_t)nd * 4, 256));
+  return v;
+}
+inline int x3_kprime(int k) {  // survivors kept per query: k plus a margin for the approximation error
+  int extra = k / 4 < 128 ? 128 : k / 4;
+  return (k + extra + 63) / 64 * 64;
+}
+}  // namespace
+
+extern "C" size_t mevi_ip_index_bytes(int64_t nd, int64_t dim) {
+  if (nd < 0 || dim <= 0) return 0;
+  return index_split_bytes(nd, dim) + align_up((size_t)nd * 4, 256) + 256;
+}
+
+extern "C" int mevi_ip_index_build_f32(const float *docs, int64_t nd, int64_t dim, void *index, size_t index_bytes,
+                                       void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(nd >= 0 && dim > 0, MEVI_ERR_INVALID_ARG, "ip_index_build: bad shape");
+  MEVI_REQUIRE(index && index_bytes >= mevi_ip_index_bytes(nd, dim), MEVI_ERR_WORKSPACE, "ip_index_build: index buffer too small");
+  MEVI_REQUIRE(((uintptr_t)index % 256) == 0, MEVI_ERR_INVALID_ARG, "ip_index_build: index must be 256-byte aligned");
+  IndexView v = view_index(index, nd, dim);
+  MEVI_HIP_CHECK(hipMemsetAsync(const_cast<unsigned int *>(v.dmax), 0, 4, stream));
+  if (nd > 0) {
+    MEVI_REQUIRE(docs, MEVI_ERR_INVALID_ARG, "ip_index_build: null docs");
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((nd + 3) / 4)), dim3(256), 0, stream, docs, (long long)nd, (int)dim,
+                       (int)pad32(dim), reinterpret_cast<unsigned short *>(const_cast<float *>(v.split)),
+                       const_cast<float *>(v.norms), const_cast<unsigned int *>(v.dmax));
+  }
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" size_t mevi_ip_topk_indexed_workspace_bytes(int64_t nq, int64_t dim, int64_t k) {
+  if (nq <= 0 || k <= 0 || k > 4096 || dim <= 0) return 0;
+  const TopkGeom gp = make_geom(x3_kprime((int)k));
+  // approx state (K' geometry) + exact top lists + split queries + norms, then the exact-path workspace for the fallback
+  return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)nq * pad32(dim) * 4, 256) +
+         align_up((size_t)nq * 4, 256) + mevi_ip_topk_workspace_bytes(nq, dim, k) + 256;
+}
+
+extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float *docs, const void *index, int64_t nd,
+                                        int64_t dim, int64_t k, int64_t id_offset, float *out_score,
+                                        int64_t *out_id, void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  g_stats = {0, 0, 0, 0.0, 0.0, 0.0};
+  for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
+  g_events.clear();
+  MEVI_REQUIRE(nq >= 0 && nd >= 0 && dim > 0 && k > 0, MEVI_ERR_INVALID_ARG, "ip_topk_indexed: bad shape");
+  if (nq == 0) return MEVI_OK;
+  MEVI_REQUIRE(q && out_score && out_id && index && (docs || nd == 0), MEVI_ERR_INVALID_ARG, "ip_topk_indexed: null pointer");
+  MEVI_REQUIRE(dim % 4 == 0 && k <= 4096, MEVI_ERR_UNSUPPORTED, "ip_topk_indexed: dim %% 4 != 0 or k > 4096");
+  MEVI_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)docs % 16) == 0 && ((uintptr_t)index % 256) == 0,
+               MEVI_ERR_INVALID_ARG, "ip_topk_indexed: misaligned pointer");
+  MEVI_REQUIRE(id_offset >= 0 && id_offset + nd < 0xFFFFFFFFLL && nq < (1LL << 31), MEVI_ERR_UNSUPPORTED,
+               "ip_topk_indexed: ids / nq out of range");
+  const size_t need = mevi_ip_topk_indexed_workspace_bytes(nq, dim, k);
+  MEVI_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 256) == 0, MEVI_ERR_WORKSPACE,
+               "ip_topk_indexed: workspace %zu bytes < required %zu (or misaligned)", workspace_bytes, need);
+
+  const int kp = x3_kprime((int)k);
+  const TopkGeom gp = make_geom(kp), g = make_geom((int)k);
+  const int64_t dimp = pad32(dim);
+  IndexView iv = view_index(index, nd, dim);
+  char *p = reinterpret_cast<char *>(workspace);
+  SearchState st = carve_state(p, nq, gp);
+  unsigned long long *top = reinterpret_cast<unsigned long long *>(p);  // [nq, k] exact keys
+  p += align_up((size_t)nq * k * 8, 256);
+  float *qsplit = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * dimp * 4, 256);
+  float *qnorm = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * 4, 256);
+  void *exact_ws = p;
+  const size_t exact_ws_bytes = mevi_ip_topk_workspace_bytes(nq, dim, k);
+
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, (long long)nq, (int)dim,
+                     (int)dimp, reinterpret_cast<unsigned short *>(qsplit), qnorm, (unsigned int *)nullptr);
+  int64_t launches = run_pass(qsplit, nq, iv.split, nd, (int)dimp, gp, (uint32_t)id_offset, st, false, stream, true);
+  if (launches < 0) return MEVI_ERR_HIP;
+  g_stats.n_chunks = launches;
+  g_stats.filter_flops *= (double)dim / (double)dimp;  // algorithmic flops count dim, not the padding
+  // exact re-scoring + verification
+  int P = 64;
+  while (P < kp) P <<= 1;
+  const size_t rs_lds = (size_t)P * 8 + (256 * 36 + 32 + 256) * 4;
+  if (rs_lds > 65536)
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds));
+  hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(256), rs_lds, stream, q, docs, (int)dim, st.buf, gp.S,
+                     (int)k, kp, (unsigned int)id_offset, qnorm, iv.dmax, st.failed, top, (int)k);
+  MEVI_HIP_CHECK(hipGetLastError());
+  std::vector<unsigned int> failed((size_t)nq);
+  MEVI_HIP_CHECK(hipMemcpyAsync(failed.data(), st.failed, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+  MEVI_HIP_CHECK(hipStreamSynchronize(stream));
+  profile_collect();
+  // approx-state overflow (adversarial order) is flagged by compact_kernel in the same array (bitwise or: both set 1)
+  std::vector<int> idx;
+  for (int64_t i = 0; i < nq; ++i)
+    if (failed[(size_t)i]) idx.push_back((int)i);
+  if (!idx.empty()) {  // unproven or overflowed queries: exact f32 search of just those, scattered into `top`
+    const int64_t nf = (int64_t)idx.size();
+    g_stats.n_failed_queries = nf;
+    char *e = reinterpret_cast<char *>(exact_ws);
+    SearchState fb = carve_state(e, nq, g);
+    e += state_bytes(nq, g);  // skip the second state of the exact workspace layout
+    float *qsub = reinterpret_cast<float *>(e);
+    e += align_up((size_t)nq * dim * 4, 256);
+    int *fidx = reinterpret_cast<int *>(e);
+    (void)exact_ws_bytes;
+    MEVI_HIP_CHECK(hipMemcpyAsync(fidx, idx.data(), (size_t)nf * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nf), dim3(256), 0, stream, q, fidx, (int)nf, (int)dim, qsub);
+    const double keep_flops = g_stats.filter_flops;
+    int64_t fl = run_pass(qsub, nf, docs, nd, (int)dim, g, (uint32_t)id_offset, fb, true, stream);
+    g_stats.filter_flops = keep_flops;
+    if (fl < 0) return MEVI_ERR_HIP;
+    g_stats.n_fallback_chunks = fl;
+    hipLaunchKernelGGL(scatter_top_kernel, dim3((unsigned)nf), dim3(256), 0, stream, fb.buf, fidx, (int)nf, g.S, g.k, top,
+                       (int)k);
+    MEVI_HIP_CHECK(hipStreamSynchronize(stream));
+    profile_collect();
+  }
+  const long long total = nq * (long long)k;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, top, (int)k, (int)k,
+                     (long long)nq, out_score, reinterpret_cast<long long *>(out_id));
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

@@ -48,6 +48,46 @@ def ip_topk(query, docs, k, id_offset=0):
     return out_s, out_i
 
 
+class DenseIndex:
+    """A corpus shard prepared for searching -- the analogue of faiss `index.add(doc)`
+    (MEVI/faiss_search.py:19): keeps the f32 rows and their (hi, lo) bfloat16 split image.
+    `search` returns exactly what `ip_topk` returns (bit for bit), ~3x faster: candidates are
+    selected with bf16 MFMAs, re-scored with the exact f32 chain and proven complete per query."""
+
+    def __init__(self, docs):
+        hip.require_gpu()
+        assert docs.is_cuda and docs.dtype == torch.float32 and docs.dim() == 2
+        self.docs = docs.contiguous()
+        nd, dim = self.docs.shape
+        L = hip.lib()
+        nbytes = L.mevi_ip_index_bytes(nd, dim)
+        self.index = torch.empty(nbytes, dtype=torch.uint8, device=docs.device)
+        with torch.cuda.device(docs.device):
+            st = L.mevi_ip_index_build_f32(hip.ptr(self.docs), nd, dim, hip.ptr(self.index), nbytes, hip.stream_ptr())
+        hip.check(st, "mevi_ip_index_build_f32")
+
+    def search(self, query, k, id_offset=0):
+        assert query.is_cuda and query.dtype == torch.float32 and query.dim() == 2 and query.shape[1] == self.docs.shape[1]
+        query = query.contiguous()
+        nq, dim = query.shape
+        nd = self.docs.shape[0]
+        L = hip.lib()
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=query.device)
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=query.device)
+        if nq == 0:
+            return out_s, out_i
+        ws_bytes = L.mevi_ip_topk_indexed_workspace_bytes(nq, dim, k)
+        if ws_bytes == 0:
+            raise hip.MeviHipError(f"ip_topk_indexed: unsupported shape nq={nq} dim={dim} k={k}")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=query.device)
+        with torch.cuda.device(query.device):
+            st = L.mevi_ip_topk_indexed_f32(hip.ptr(query), nq, hip.ptr(self.docs), hip.ptr(self.index), nd, dim, k,
+                                            id_offset, hip.ptr(out_s), hip.ptr(out_i), hip.ptr(ws), ws_bytes,
+                                            hip.stream_ptr())
+        hip.check(st, "mevi_ip_topk_indexed_f32")
+        return out_s, out_i
+
+
 def topk_merge(scores, ids, k_out):
     """Merge per-shard lists: scores f32[nlists,nq,k_in], ids i64[nlists,nq,k_in] -> [nq,k_out]."""
     hip.require_gpu()
@@ -92,9 +132,13 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
     """
     import torch.distributed as dist
 
-    local_search = local_search or ip_topk
     merge = merge or topk_merge
-    s, i = local_search(query, local_docs, k, id_offset=id_offset)
+    if local_search is not None:
+        s, i = local_search(query, local_docs, k, id_offset=id_offset)
+    elif isinstance(local_docs, DenseIndex):
+        s, i = local_docs.search(query, k, id_offset=id_offset)
+    else:
+        s, i = ip_topk(query, local_docs, k, id_offset=id_offset)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return s, i
     world = dist.get_world_size(group)
@@ -119,5 +163,5 @@ def search(query, doc, dim, topk, param="Flat", device=None):
     print(f"Param {param} trained: True.")  # reference prints index.is_trained
     q = _as_device_f32(np.asarray(query).reshape(-1, dim) if isinstance(query, np.ndarray) else query, device)
     d = _as_device_f32(np.asarray(doc).reshape(-1, dim) if isinstance(doc, np.ndarray) else doc, device)
-    s, i = ip_topk(q, d, topk)
+    s, i = DenseIndex(d).search(q, topk)      # index.add(doc); index.search(query, topk)
     return s.cpu().numpy(), i.cpu().numpy()

@@ -29,6 +29,11 @@ _SIGNATURES = {
     "mevi_ip_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mevi_ip_topk_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mevi_ip_index_bytes": (c_size_t, [c_int64, c_int64]),
+    "mevi_ip_index_build_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "mevi_ip_topk_indexed_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "mevi_ip_topk_indexed_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mevi_topk_merge_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "mevi_topk_merge_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -17,11 +17,23 @@ def _run(q, d, k, cuda, id_offset=0):
     return s.cpu().numpy(), i.cpu().numpy()
 
 
+def _run_indexed(q, d, k, cuda, id_offset=0):
+    idx = dense.DenseIndex(torch.from_numpy(d).to(cuda))
+    s, i = idx.search(torch.from_numpy(q).to(cuda), k, id_offset=id_offset)
+    torch.cuda.synchronize()
+    return s.cpu().numpy(), i.cpu().numpy()
+
+
 def _check(q, d, k, cuda, id_offset=0):
+    """Both the exact-f32 path and the indexed (bf16x3 pre-filter + exact re-score) path, bit for bit."""
     s, i = _run(q, d, k, cuda, id_offset)
     es, ei = odense.ip_topk_exact(q, d, k, id_offset)
     np.testing.assert_array_equal(i, ei)
     np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
+    if d.shape[0] > 0:
+        s2, i2 = _run_indexed(q, d, k, cuda, id_offset)
+        np.testing.assert_array_equal(i2, ei)
+        np.testing.assert_array_equal(s2.view(np.uint32), es.view(np.uint32))
     return s, i
 
 
@@ -119,9 +131,11 @@ def test_growth_override_changes_chunking_not_results(cuda):
     try:
         L.mevi_ip_topk_set_growth(0.0)
         a = _check(q, d, 20, cuda)
+        _run(q, d, 20, cuda)
         n0 = _stats().n_chunks
         L.mevi_ip_topk_set_growth(1.0)
         b = _check(q, d, 20, cuda)
+        _run(q, d, 20, cuda)
         n1 = _stats().n_chunks
     finally:
         L.mevi_ip_topk_set_growth(0.0)
@@ -138,6 +152,28 @@ def test_blas_restatement_agrees_to_rounding(cuda):
     bs, bi = odense.ip_topk_blas(q, d, 100)
     assert np.abs(s - bs).max() <= 1e-3          # |score| ~ 100, f32 eps * sum|a*b|
     assert (i == bi).mean() > 0.99               # only near-ties may swap
+
+
+def test_indexed_prefilter_proves_most_queries_and_falls_back_for_the_rest(cuda):
+    """Random data: the bf16x3 bound proves (nearly) every query.  Near-duplicate scores beyond the
+    margin (many rows within eps of the k-th score) cannot be proven -> exact fallback, same answer."""
+    rng = np.random.default_rng(31)
+    q = rng.standard_normal((300, 768), dtype=np.float32)
+    d = rng.standard_normal((40000, 768), dtype=np.float32)
+    s, i = _run_indexed(q, d, 100, cuda)
+    es, ei = odense.ip_topk_exact(q, d, 100)
+    np.testing.assert_array_equal(i, ei)
+    assert _stats().n_failed_queries <= 3
+    # 5000 copies of one row + noise far below the error bound: the top-50 cannot be proven from 256 survivors
+    base = rng.standard_normal((1, 64), dtype=np.float32)
+    d2 = np.concatenate([base + 1e-6 * rng.standard_normal((5000, 64)).astype(np.float32),
+                         rng.standard_normal((3000, 64), dtype=np.float32)])
+    q2 = np.concatenate([base * 2, rng.standard_normal((7, 64), dtype=np.float32)])
+    s, i = _run_indexed(q2, d2, 50, cuda)
+    es, ei = odense.ip_topk_exact(q2, d2, 50)
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
+    assert _stats().n_failed_queries >= 1
 
 
 def test_rejects_bad_arguments(cuda):

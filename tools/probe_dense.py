@@ -7,6 +7,7 @@ import torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mevi_amd import dense, hip  # noqa: E402
+INDEXED = os.environ.get("INDEXED", "1") == "1"
 
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 6980
@@ -19,11 +20,12 @@ d = torch.empty((nd, dim), device=dev)
 for a in range(0, nd, 1 << 20):
     d[a:a + (1 << 20)] = 0.05 * torch.randn((min(1 << 20, nd - a), dim), device=dev, generator=g) + 0.02
 hip.lib().mevi_ip_topk_set_profiling(1)
+index = dense.DenseIndex(d) if INDEXED else None
 for it in range(3):
     v = 0
     torch.cuda.synchronize()
     t = time.time()
-    s, i = dense.ip_topk(q, d, k)
+    s, i = (index.search(q, k) if INDEXED else dense.ip_topk(q, d, k))
     torch.cuda.synchronize()
     dt = time.time() - t
     st = hip.IpTopkStats()
