@@ -189,6 +189,8 @@ typedef struct mevi_ip_topk_stats {
   double filter_ms;          /* sum of ip_filter_kernel durations (HIP events on the call's stream; profiling on) */
   double compact_ms;         /* sum of compact_kernel durations (profiling on) */
   double filter_flops;       /* algorithmic flops of those filter launches: 2 * nq * rows * dim */
+  double max_err_ratio;      /* indexed search: largest observed |bf16x3 approx - exact| / (|q| |d|) among survivors */
+  double err_bound;          /* indexed search: the bound the proof uses (must dominate max_err_ratio) */
 } mevi_ip_topk_stats;
 void mevi_ip_topk_set_growth(double growth);
 void mevi_ip_topk_set_profiling(int enable); /* record HIP events around every filter/compact launch */

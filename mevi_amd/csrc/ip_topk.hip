@@ -28,6 +28,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <string.h>
 #include <vector>
 
 namespace mevi {
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ sc
 // ---------------------------------------------------------------------------
 // bf16x3 pre-filter (see mfma_pp_bf16x3.h): split, approximate filter, exact re-score + verify.
 
-constexpr float X3_C_ERR = 2.5e-4f;  // |approx - chain| <= X3_C_ERR * ||q|| * ||d||   (derivation: DESIGN.md 4.1b)
+constexpr float X3_C_ERR = 4.0e-4f;  // |approx - chain| <= X3_C_ERR * ||q|| * ||d||   (derivation: DESIGN.md 4.1b)
 
 // f32 rows -> slab-interleaved (hi | lo) bf16 image + row L2 norms + max norm.  One wave per row.
 __global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ x, long long n, int dim, int dimp,
@@ -356,7 +357,9 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
                                                      int kp, unsigned int id_base, const float *__restrict__ qnorm,
                                                      const unsigned int *__restrict__ dmax_bits,
                                                      unsigned int *__restrict__ failed,
-                                                     unsigned long long *__restrict__ out_top, int out_ld) {
+                                                     unsigned long long *__restrict__ out_top, int out_ld,
+                                                     const float *__restrict__ dnorm,
+                                                     unsigned int *__restrict__ err_ratio_bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // P keys, then staging floats
   const int q = blockIdx.x, t = threadIdx.x;
   int P = 64;
@@ -369,7 +372,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
   const float *qr = Q + (size_t)q * dim;
   const int srow = t >> 3, spc = (t & 7) * 4;
   const int nslab = (dim + 31) / 32;
-  for (int base = 0; base < P; base += 256) {
+  for (int i = kp + t; i < P; i += 256) skeys[i] = 0ull;
+  for (int base = 0; base < kp; base += 256) {
     const int c = base + t;
     const unsigned long long key = (c < kp) ? row[c] : 0ull;
     const bool valid = key != 0ull;
@@ -398,7 +402,11 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
         acc = fmaf(sq[k4 + 3], x.w, acc);
       }
     }
-    skeys[c] = valid ? make_key(acc, key_id(key)) : 0ull;
+    if (c < P) skeys[c] = valid ? make_key(acc, key_id(key)) : 0ull;
+    if (valid && err_ratio_bits) {  // observed |approx - exact| / (||q|| ||d||): must stay far below X3_C_ERR
+      const float den = qnorm[q] * dnorm[sid[t]];
+      if (den > 0.f) atomicMax(err_ratio_bits, __float_as_uint(fabsf(key_score(key) - acc) / den));
+    }
     __syncthreads();
   }
   bitonic_sort_desc<256>(skeys, P, t);
@@ -441,7 +449,7 @@ static SearchState carve_state(char *&p, int64_t nq, const TopkGeom &g) {
 
 thread_local double g_growth = 0.0;
 thread_local int g_profile = 0;
-thread_local mevi_ip_topk_stats g_stats = {0, 0, 0, 0.0, 0.0, 0.0};
+thread_local mevi_ip_topk_stats g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0};
 thread_local std::vector<hipEvent_t> g_events;  // triples: before filter, after filter, after compact
 
 static void profile_mark(hipStream_t stream) {
@@ -486,7 +494,7 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   const int ni = 2;
   const int qt = x3 ? X3_QT : 64 * ni;
   const int n_qtiles = (int)((nq + qt - 1) / qt);
-  double growth = g_growth > 0.0 ? g_growth : (double)(g.cap / (3 * g.k));
+  double growth = g_growth > 0.0 ? g_growth : (double)g.cap / (3.0 * g.k);  // expected survivors per chunk ~ cap/3
   if (growth < 1.0) growth = 1.0;
   const int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
   const size_t pp_lds = x3 ? x3_lds_bytes() : pp_lds_bytes<2>();
@@ -567,7 +575,7 @@ extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, i
                                 int64_t k, int64_t id_offset, float *out_score, int64_t *out_id,
                                 void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  g_stats = {0, 0, 0, 0.0, 0.0, 0.0};
+  g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
   g_events.clear();
   MEVI_REQUIRE(nq >= 0 && nd >= 0 && dim > 0 && k > 0, MEVI_ERR_INVALID_ARG,
@@ -680,14 +688,14 @@ extern "C" size_t mevi_ip_topk_indexed_workspace_bytes(int64_t nq, int64_t dim, 
   const TopkGeom gp = make_geom(x3_kprime((int)k));
   // approx state (K' geometry) + exact top lists + split queries + norms, then the exact-path workspace for the fallback
   return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)nq * pad32(dim) * 4, 256) +
-         align_up((size_t)nq * 4, 256) + mevi_ip_topk_workspace_bytes(nq, dim, k) + 256;
+         align_up((size_t)(nq + 1) * 4, 256) + mevi_ip_topk_workspace_bytes(nq, dim, k) + 256;
 }
 
 extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float *docs, const void *index, int64_t nd,
                                         int64_t dim, int64_t k, int64_t id_offset, float *out_score,
                                         int64_t *out_id, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  g_stats = {0, 0, 0, 0.0, 0.0, 0.0};
+  g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
   g_events.clear();
   MEVI_REQUIRE(nq >= 0 && nd >= 0 && dim > 0 && k > 0, MEVI_ERR_INVALID_ARG, "ip_topk_indexed: bad shape");
@@ -712,8 +720,8 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   p += align_up((size_t)nq * k * 8, 256);
   float *qsplit = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * dimp * 4, 256);
-  float *qnorm = reinterpret_cast<float *>(p);
-  p += align_up((size_t)nq * 4, 256);
+  float *qnorm = reinterpret_cast<float *>(p);  // [nq] + 1 slot for the observed error ratio
+  p += align_up((size_t)(nq + 1) * 4, 256);
   void *exact_ws = p;
   const size_t exact_ws_bytes = mevi_ip_topk_workspace_bytes(nq, dim, k);
 
@@ -730,13 +738,23 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   if (rs_lds > 65536)
     MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds));
+  unsigned int *err_bits = reinterpret_cast<unsigned int *>(qnorm + nq);  // spare slot behind the norms (256-byte padded)
+  MEVI_HIP_CHECK(hipMemsetAsync(err_bits, 0, 4, stream));
   hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(256), rs_lds, stream, q, docs, (int)dim, st.buf, gp.S,
-                     (int)k, kp, (unsigned int)id_offset, qnorm, iv.dmax, st.failed, top, (int)k);
+                     (int)k, kp, (unsigned int)id_offset, qnorm, iv.dmax, st.failed, top, (int)k, iv.norms, err_bits);
+  unsigned int err_host = 0;
+  MEVI_HIP_CHECK(hipMemcpyAsync(&err_host, err_bits, 4, hipMemcpyDeviceToHost, stream));
   MEVI_HIP_CHECK(hipGetLastError());
   std::vector<unsigned int> failed((size_t)nq);
   MEVI_HIP_CHECK(hipMemcpyAsync(failed.data(), st.failed, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
   MEVI_HIP_CHECK(hipStreamSynchronize(stream));
   profile_collect();
+  {
+    float r;
+    memcpy(&r, &err_host, 4);
+    g_stats.max_err_ratio = r;
+    g_stats.err_bound = X3_C_ERR;
+  }
   // approx-state overflow (adversarial order) is flagged by compact_kernel in the same array (bitwise or: both set 1)
   std::vector<int> idx;
   for (int64_t i = 0; i < nq; ++i)

@@ -44,6 +44,10 @@ def lib():
         L.oracle_topk_merge_f32.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                             c_void_p, c_void_p]
         L.oracle_num_threads.restype = c_int
+        L.oracle_heap_update_f32.restype = c_int
+        L.oracle_heap_update_f32.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+        L.oracle_heap_finalize_f32.restype = c_int
+        L.oracle_heap_finalize_f32.argtypes = [c_int64, c_int64, c_void_p, c_void_p, c_void_p]
         _lib = L
     return _lib
 
@@ -74,31 +78,22 @@ def topk_merge(scores, ids, k_out):
     return out_s, out_i
 
 
-def ip_topk_blas(query, docs, k, id_offset=0, block=65536):
-    """faiss-style Flat-IP: blocked sgemm + running top-k (ties by ascending id)."""
+def ip_topk_blas(query, docs, k, id_offset=0, block=16384):
+    """faiss-style Flat-IP on the CPU, the way faiss evaluates it: blocked sgemm (numpy -> BLAS, all host
+    threads) and per-query heaps of the k best updated block by block (oracle_heap_update_f32, OpenMP over
+    queries).  Ties by ascending id.  Summation order is BLAS's."""
     q = np.ascontiguousarray(query, dtype=np.float32)
     d = np.asarray(docs, dtype=np.float32)
     nq = q.shape[0]
-    best_s = np.full((nq, 0), 0, np.float32)
-    best_i = np.full((nq, 0), 0, np.int64)
+    L = lib()
+    heap_s = np.empty((nq, k), np.float32)
+    heap_i = np.empty((nq, k), np.int64)
+    heap_n = np.zeros(nq, np.int64)
     for b0 in range(0, d.shape[0], block):
-        sc = q @ d[b0:b0 + block].T
-        ids = np.broadcast_to(np.arange(b0, b0 + sc.shape[1], dtype=np.int64) + id_offset, sc.shape)
-        cs = np.concatenate([best_s, sc], axis=1)
-        ci = np.concatenate([best_i, ids], axis=1)
-        if cs.shape[1] > k:
-            part = np.argpartition(-cs, k - 1, axis=1)[:, :k]
-            cs = np.take_along_axis(cs, part, 1)
-            ci = np.take_along_axis(ci, part, 1)
-        best_s, best_i = cs, ci
-    order = np.lexsort((best_i, -best_s), axis=1)
-    best_s = np.take_along_axis(best_s, order, 1)
-    best_i = np.take_along_axis(best_i, order, 1)
-    if best_s.shape[1] < k:
-        pad = k - best_s.shape[1]
-        best_s = np.concatenate([best_s, np.full((nq, pad), -FLT_MAX, np.float32)], 1)
-        best_i = np.concatenate([best_i, np.full((nq, pad), -1, np.int64)], 1)
-    return best_s, best_i
+        sc = np.ascontiguousarray(q @ d[b0:b0 + block].T)
+        L.oracle_heap_update_f32(_p(sc), nq, sc.shape[1], id_offset + b0, k, _p(heap_s), _p(heap_i), _p(heap_n))
+    L.oracle_heap_finalize_f32(nq, k, _p(heap_s), _p(heap_i), _p(heap_n))
+    return heap_s, heap_i
 
 
 def num_threads():

@@ -107,6 +107,64 @@ int oracle_ip_topk_f32(const float *q, int64_t nq, const float *docs, int64_t nd
   return 0;
 }
 
+/* faiss-style evaluation of Flat-IP: the caller computes a block of scores with BLAS sgemm
+ * (scores[nq, nb] = Q . D[b0:b0+nb]^T); this routine folds the block into per-query min-heaps of the k
+ * best (faiss HeapResultHandler), OpenMP over queries.  heap_n[q] = filled slots.  Finish with
+ * oracle_heap_finalize_f32 (sorts each heap: score desc, id asc; pads -FLT_MAX / -1). */
+int oracle_heap_update_f32(const float *scores, int64_t nq, int64_t nb, int64_t id0, int64_t k,
+                           float *heap_s, int64_t *heap_i, int64_t *heap_n) {
+#pragma omp parallel for schedule(static)
+  for (int64_t q = 0; q < nq; ++q) {
+    hit_t *h = (hit_t *)malloc(sizeof(hit_t) * (size_t)k);
+    int64_t n = heap_n[q];
+    for (int64_t j = 0; j < n; ++j) {
+      h[j].s = heap_s[q * k + j];
+      h[j].id = heap_i[q * k + j];
+    }
+    const float *row = scores + q * nb;
+    for (int64_t d = 0; d < nb; ++d) {
+      hit_t c;
+      c.s = row[d] + 0.0f;
+      c.id = id0 + d;
+      if (!(c.s > -INFINITY)) continue;
+      if (n < k) {
+        h[n++] = c;
+        if (n == k)
+          for (int64_t i = k / 2 - 1; i >= 0; --i) heap_sift_down(h, k, i);
+      } else if (hit_before(&c, &h[0])) {
+        h[0] = c;
+        heap_sift_down(h, k, 0);
+      }
+    }
+    for (int64_t j = 0; j < n; ++j) {
+      heap_s[q * k + j] = h[j].s;
+      heap_i[q * k + j] = h[j].id;
+    }
+    heap_n[q] = n;
+    free(h);
+  }
+  return 0;
+}
+
+int oracle_heap_finalize_f32(int64_t nq, int64_t k, float *heap_s, int64_t *heap_i, const int64_t *heap_n) {
+#pragma omp parallel for schedule(static)
+  for (int64_t q = 0; q < nq; ++q) {
+    hit_t *h = (hit_t *)malloc(sizeof(hit_t) * (size_t)k);
+    int64_t n = heap_n[q];
+    for (int64_t j = 0; j < n; ++j) {
+      h[j].s = heap_s[q * k + j];
+      h[j].id = heap_i[q * k + j];
+    }
+    qsort(h, (size_t)n, sizeof(hit_t), hit_cmp);
+    for (int64_t j = 0; j < k; ++j) {
+      heap_s[q * k + j] = j < n ? h[j].s : -FLT_MAX;
+      heap_i[q * k + j] = j < n ? h[j].id : -1;
+    }
+    free(h);
+  }
+  return 0;
+}
+
 /* Merge nlists per-shard lists (scores [nlists,nq,k_in], ids, id<0 = padding) into
  * [nq,k_out]; same ordering rule.  New in the build: what a single
  * un-sharded search would have returned. */

@@ -57,6 +57,21 @@ def test_shard_count_invariance_at_full_size(c2):
     assert torch.equal(mi, i) and torch.equal(ms.view(torch.int32), s.view(torch.int32))
 
 
+def test_indexed_prefilter_equals_exact_path_at_full_size(c2):
+    """The bf16x3 pre-filtered search must return the exact-f32 search's lists bit for bit, with (nearly)
+    every query proven by the error bound rather than by the fallback."""
+    from mevi_amd import hip
+
+    docs, query, s, i = c2
+    index = dense.DenseIndex(docs)
+    s2, i2 = index.search(query, bench.TOPK)
+    st = hip.IpTopkStats()
+    hip.lib().mevi_ip_topk_get_stats(st)
+    assert torch.equal(i2, i) and torch.equal(s2.view(torch.int32), s.view(torch.int32))
+    assert st.n_failed_queries <= 0.01 * bench.N_QUERIES
+    assert st.max_err_ratio <= st.err_bound / 8
+
+
 def test_scores_are_exact_chains_and_lists_are_complete(c2):
     docs, query, s, i = c2
     rows = torch.tensor([0, 17, 3333, 6979], device=docs.device)
