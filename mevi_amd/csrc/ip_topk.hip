@@ -73,8 +73,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
 
   const int nwg = n_qtiles * n_dpairs;
   const int wg = xcd_remap(blockIdx.x, nwg);
-  const int dpair = wg / n_qtiles;
-  const int qtile = wg - dpair * n_qtiles;
+  int dpair, qtile;
+  supertile_order<4, 8>(wg, n_dpairs, n_qtiles, dpair, qtile);
 
   const int t = threadIdx.x;
   const int grp = __builtin_amdgcn_readfirstlane(t >> 8);
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_x3_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nwg = n_qtiles * n_dpairs;
   const int wg = xcd_remap(blockIdx.x, nwg);
-  const int dpair = wg / n_qtiles;
-  const int qtile = wg - dpair * n_qtiles;
+  int dpair, qtile;
+  supertile_order<4, 8>(wg, n_dpairs, n_qtiles, dpair, qtile);
   const int t = threadIdx.x;
   const int grp = __builtin_amdgcn_readfirstlane(t >> 8);
   const int tg = t & 255;

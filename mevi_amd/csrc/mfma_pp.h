@@ -50,6 +50,25 @@ __device__ inline int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// Work-item order inside an XCD's contiguous range: super-tiles of SD A-tiles x SQ B-tiles, so that the
+// ~32 workgroups resident on one XCD share BOTH operands through its 4 MiB L2 (a plain row-major order
+// shares the A tile only and re-reads every B tile from the Infinity Cache).  Bijective for any shape.
+template <int SD, int SQ>
+__device__ inline void supertile_order(int wg, int n_a, int n_b, int &a_tile, int &b_tile) {
+  const int band_size = SD * n_b;
+  const int band = wg / band_size;
+  const int r = wg - band * band_size;
+  const int sd = min(SD, n_a - band * SD);
+  const int n_groups = (n_b + SQ - 1) / SQ;
+  int g = r / (sd * SQ);
+  if (g > n_groups - 1) g = n_groups - 1;
+  const int r2 = r - g * sd * SQ;
+  const int sq = (g == n_groups - 1) ? n_b - g * SQ : SQ;
+  const int d_in = r2 / sq;
+  a_tile = band * SD + d_in;
+  b_tile = g * SQ + (r2 - d_in * sq);
+}
+
 // aptr[i]: this thread's staging pointers into its group's A tile (row srow+32i, + skq),
 // bptr[i]: into the shared B tile (row (QT/2)*grp + srow + 32i, + skq); rows pre-clamped.
 // acc[mi][ni]: 32x32 accumulators of wave (wm, wn): A rows 64*wm + 32*mi + ..., B rows
