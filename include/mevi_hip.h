@@ -161,6 +161,8 @@ int mevi_adaptive_logits_f32(const float *s, int64_t lds, const float *t, int64_
  *   final_step == 0: out_scores/out_parent/out_code [nq, R] = the R best of
  *       beam_score[r] + log_softmax(logits[r])[1 + c], descending, ties by lower r*K + c
  *   final_step == 1: out_scores [nq, nb] = beam_score[r] + log_softmax(logits[r])[0] (eos closes)
+ *   final_step == 2: pq.beam_search step -- logits f32 [nq*nb, K] (no eos column), candidates
+ *       beam_score[r] * softmax(logits[r])[c], outputs as for 0
  * ---------------------------------------------------------------------- */
 int mevi_beam_step_f32(const float *logits, const float *beam_scores, int64_t nq, int64_t nb, int64_t K,
                        int64_t R, int final_step, float *out_scores, int32_t *out_parent,
@@ -178,6 +180,15 @@ int mevi_pair_dot_f32(const float *a, int64_t lda, const int64_t *ia, const floa
 int mevi_segment_sort_desc_f32(const float *scores, const int64_t *ids, const int64_t *seg_offsets,
                                int64_t nseg, int64_t max_seg_len, float *out_scores, int64_t *out_ids,
                                void *stream);
+
+/* Pieces of pq.beam_search (MEVI/pq.py:613-713; only reached with doc_multiclus > 1): the score row
+ * -sum_k (x_k - c_k)^2 of every row against the K centroids of one level, and the residual hand-down
+ * out[r] = x[src[r]] - centroids[code[r]].  The top-R step is mevi_beam_step_f32 with final_step = 2
+ * (logits = the K score columns, candidate = beam_prob * softmax). */
+int mevi_rq_neg_dist_f32(const float *x, int64_t n, int64_t dim, const float *centroids, int64_t K,
+                         float *neg_dist, void *stream);
+int mevi_gather_sub_f32(const float *x, const int64_t *src, const float *centroids, const int32_t *code,
+                        int64_t n, int64_t dim, float *out, void *stream);
 
 /* Test / tuning hooks for the dense arm (not part of the drop-in surface):
  * force the chunk growth factor (0 = default) and read back statistics of the

@@ -16,6 +16,8 @@
 namespace mevi {
 namespace {
 
+// mode 0: NCI step (K+1 columns, col 0 = eos, log-domain);  mode 1: NCI final step;
+// mode 2: pq.beam_search step (K columns of -distance): cand = beam_prob[r] * softmax(row)[c]  (pq.py:660-676)
 __global__ __launch_bounds__(256) void beam_step_kernel(const float *__restrict__ logits,
                                                        const float *__restrict__ beam_scores, int nb, int K,
                                                        int R, int final_step, float *__restrict__ out_scores,
@@ -23,7 +25,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float *__restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // P keys, then nb floats x2
   const int q = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int ncol = K + 1;
+  const int ncol = (final_step == 2) ? K : K + 1;
   const int ncand = nb * K;
   int P = 64;
   while (P < ncand) P <<= 1;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float *__restrict_
     }
   }
   __syncthreads();
-  if (final_step) {  // hypothesis closes with eos: score + log_softmax[eos]
+  if (final_step == 1) {  // hypothesis closes with eos: score + log_softmax[eos]
     for (int r = t; r < nb; r += 256)
       out_scores[(size_t)q * nb + r] = beam_scores[(size_t)q * nb + r] + ((lq[(size_t)r * ncol] - smax[r]) - slog[r]);
     return;
@@ -56,8 +58,13 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float *__restrict_
     unsigned long long key = 0ull;
     if (i < ncand) {
       const int r = i / K, c = i - r * K;
-      const float lsm = (lq[(size_t)r * ncol + 1 + c] - smax[r]) - slog[r];
-      key = make_key(beam_scores[(size_t)q * nb + r] + lsm, (unsigned int)i);
+      if (final_step == 2) {
+        const float p = expf(lq[(size_t)r * ncol + c] - smax[r]) / expf(slog[r]);
+        key = make_key(beam_scores[(size_t)q * nb + r] * p, (unsigned int)i);
+      } else {
+        const float lsm = (lq[(size_t)r * ncol + 1 + c] - smax[r]) - slog[r];
+        key = make_key(beam_scores[(size_t)q * nb + r] + lsm, (unsigned int)i);
+      }
     }
     skeys[i] = key;
   }
@@ -82,10 +89,11 @@ extern "C" int mevi_beam_step_f32(const float *logits, const float *beam_scores,
                                   int32_t *out_code, void *stream) {
   MEVI_REQUIRE(nq >= 0 && nb > 0 && K > 0 && R > 0, MEVI_ERR_INVALID_ARG, "beam_step: bad shape");
   if (nq == 0) return MEVI_OK;
-  MEVI_REQUIRE(logits && beam_scores && out_scores && (final_step || (out_parent && out_code)),
+  MEVI_REQUIRE(final_step >= 0 && final_step <= 2, MEVI_ERR_INVALID_ARG, "beam_step: mode must be 0, 1 or 2");
+  MEVI_REQUIRE(logits && beam_scores && out_scores && (final_step == 1 || (out_parent && out_code)),
                MEVI_ERR_INVALID_ARG, "beam_step: null pointer");
   MEVI_REQUIRE(nb * K <= 16384, MEVI_ERR_UNSUPPORTED, "beam_step: nb*K=%lld > 16384", (long long)(nb * K));
-  MEVI_REQUIRE(final_step || nb * K >= R, MEVI_ERR_UNSUPPORTED,
+  MEVI_REQUIRE(final_step == 1 || nb * K >= R, MEVI_ERR_UNSUPPORTED,
                "beam_step: fewer candidates (%lld) than beams (%lld)", (long long)(nb * K), (long long)R);
   int P = 64;
   while (P < nb * K) P <<= 1;

@@ -33,10 +33,12 @@ constexpr int RQ_MAXM = 8;    // levels supported by the in-register code histor
 
 // LEVEL is a template parameter so the code-history loops unroll and stay in registers
 // (a runtime-indexed history array lands in scratch: 20x slower).
-template <int LEVEL>
+// STORE = true: write -distance to neg_dist[row, c] instead of taking the argmin (pq.beam_search needs
+// the whole score row: compute_scores, pq.py:124-131); X is then an explicit residual matrix (LEVEL 0).
+template <int LEVEL, bool STORE>
 __global__ __launch_bounds__(256, 2) void rq_level_kernel(const float *__restrict__ X, long long n, int dim,
                                                          const float *__restrict__ C, int M, int K,
-                                                         int *__restrict__ codes) {
+                                                         int *__restrict__ codes, float *__restrict__ neg_dist) {
   constexpr int level = LEVEL;
   __shared__ __attribute__((aligned(16))) float xs[2][RQ_ROWS * RQ_LD];
   __shared__ __attribute__((aligned(16))) float cs[2][RQ_CENTS * RQ_LD];
@@ -137,6 +139,18 @@ __global__ __launch_bounds__(256, 2) void rq_level_kernel(const float *__restric
       if (s + 1 < nslab) lstore((s + 1) & 1);
       __syncthreads();
     }
+    if (STORE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long r = row0 + 32 * wave + ld + 8 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = chunk * RQ_CENTS + lc + 8 * j;
+          if (r < n && c < K) neg_dist[(size_t)r * K + c] = -acc[i][j];
+        }
+      }
+      continue;
+    }
     // running argmin: (distance, index) lexicographic, lowest index wins ties
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -150,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void rq_level_kernel(const float *__restric
         }
       }
   }
+  if (STORE) return;
   // reduce over the 8 lanes (lc) that share a row group
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -164,6 +179,22 @@ __global__ __launch_bounds__(256, 2) void rq_level_kernel(const float *__restric
     }
     const long long r = row0 + 32 * wave + ld + 8 * i;
     if (lc == 0 && r < n) codes[(size_t)r * M + level] = best_c[i];
+  }
+}
+
+// out[r] = X[src[r]] - C[code[r]]: the residual hand-down of pq.beam_search (pq.py:690-693). One wave per row.
+__global__ __launch_bounds__(256) void gather_sub_kernel(const float *__restrict__ X, const long long *__restrict__ src,
+                                                        const float *__restrict__ C, const int *__restrict__ code,
+                                                        long long n, int dim, float *__restrict__ out) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float4 *x = reinterpret_cast<const float4 *>(X + (size_t)src[r] * dim);
+  const float4 *c = reinterpret_cast<const float4 *>(C + (size_t)code[r] * dim);
+  float4 *o = reinterpret_cast<float4 *>(out + (size_t)r * dim);
+  for (int i = lane; i < dim / 4; i += 64) {
+    const float4 a = x[i], b = c[i];
+    o[i] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
   }
 }
 
@@ -187,8 +218,8 @@ extern "C" int mevi_rq_encode_f32(const float *x, int64_t n, int64_t dim, const 
   for (int level = 0; level < (int)M; ++level) {
 #define MEVI_RQ_LEVEL(L)                                                                                   \
   case L:                                                                                                  \
-    hipLaunchKernelGGL(rq_level_kernel<L>, dim3((unsigned)nblk), dim3(256), 0, stream, x, (long long)n,    \
-                       (int)dim, codebook, (int)M, (int)K, codes);                                         \
+    hipLaunchKernelGGL((rq_level_kernel<L, false>), dim3((unsigned)nblk), dim3(256), 0, stream, x,         \
+                       (long long)n, (int)dim, codebook, (int)M, (int)K, codes, (float *)nullptr);         \
     break;
     switch (level) {
       MEVI_RQ_LEVEL(0) MEVI_RQ_LEVEL(1) MEVI_RQ_LEVEL(2) MEVI_RQ_LEVEL(3)
@@ -196,6 +227,30 @@ extern "C" int mevi_rq_encode_f32(const float *x, int64_t n, int64_t dim, const 
     }
 #undef MEVI_RQ_LEVEL
   }
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_rq_neg_dist_f32(const float *x, int64_t n, int64_t dim, const float *centroids, int64_t K,
+                                    float *neg_dist, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(n >= 0 && dim > 0 && K > 0 && dim % 4 == 0, MEVI_ERR_INVALID_ARG, "rq_neg_dist: bad shape");
+  if (n == 0) return MEVI_OK;
+  MEVI_REQUIRE(x && centroids && neg_dist, MEVI_ERR_INVALID_ARG, "rq_neg_dist: null pointer");
+  const int64_t nblk = (n + RQ_ROWS - 1) / RQ_ROWS;
+  hipLaunchKernelGGL((rq_level_kernel<0, true>), dim3((unsigned)nblk), dim3(256), 0, stream, x, (long long)n, (int)dim,
+                     centroids, 1, (int)K, (int *)nullptr, neg_dist);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_gather_sub_f32(const float *x, const int64_t *src, const float *centroids, const int32_t *code,
+                                   int64_t n, int64_t dim, float *out, void *stream_) {
+  MEVI_REQUIRE(n >= 0 && dim > 0 && dim % 4 == 0, MEVI_ERR_INVALID_ARG, "gather_sub: bad shape");
+  if (n == 0) return MEVI_OK;
+  MEVI_REQUIRE(x && src && centroids && code && out, MEVI_ERR_INVALID_ARG, "gather_sub: null pointer");
+  hipLaunchKernelGGL(gather_sub_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), x,
+                     reinterpret_cast<const long long *>(src), centroids, code, (long long)n, (int)dim, out);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

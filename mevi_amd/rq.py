@@ -169,6 +169,48 @@ class ProductQuantization:
                 mapping[i + start] = key
         return (dict(cluster), mapping) if return_mapping else dict(cluster)
 
+    @torch.no_grad()
+    def beam_search(self, doc_emb, num_return_sequences, num_beams=None, do_sample=False, return_proba=False):
+        """Top-R code paths per row (pq.beam_search, MEVI/pq.py:613-713, rq_topk_score='prod'): per level
+        softmax(-distance) times the running beam probability, top-R over beams x K.  Returns labels
+        i32[bs, R, M] (and probabilities f32[bs, R])."""
+        assert not do_sample and num_beams in (None, num_return_sequences)
+        L = hip.lib()
+        R, M, K, dim = num_return_sequences, self.subvector_num, self.subvector_cents, self.emb_size
+        x = doc_emb.to(self.device, torch.float32).contiguous()
+        bs = x.shape[0]
+        resid, nb = x, 1
+        scores = torch.ones((bs, 1), dtype=torch.float32, device=self.device)
+        labels = torch.zeros((bs, 1, 0), dtype=torch.int32, device=self.device)
+        base = torch.arange(bs, device=self.device)[:, None]
+        for j in range(M):
+            nd = torch.empty((bs * nb, K), dtype=torch.float32, device=self.device)
+            hip.check(L.mevi_rq_neg_dist_f32(hip.ptr(resid), bs * nb, dim, hip.ptr(self.codebook[j]), K, hip.ptr(nd),
+                                             hip.stream_ptr()), "mevi_rq_neg_dist_f32")
+            if R < nb * K:
+                sc = torch.empty((bs, R), dtype=torch.float32, device=self.device)
+                parent = torch.empty((bs, R), dtype=torch.int32, device=self.device)
+                code = torch.empty((bs, R), dtype=torch.int32, device=self.device)
+                hip.check(L.mevi_beam_step_f32(hip.ptr(nd), hip.ptr(scores), bs, nb, K, R, 2, hip.ptr(sc),
+                                               hip.ptr(parent), hip.ptr(code), hip.stream_ptr()), "mevi_beam_step_f32")
+                nb_new = R
+            else:  # fewer candidates than beams: keep them all, in (beam, code) order
+                sc = (scores[:, :, None] * torch.softmax(nd.view(bs, nb, K), -1)).reshape(bs, nb * K)
+                parent = torch.arange(nb, device=self.device, dtype=torch.int32).repeat_interleave(K)[None].expand(bs, -1).contiguous()
+                code = torch.arange(K, device=self.device, dtype=torch.int32).repeat(nb)[None].expand(bs, -1).contiguous()
+                nb_new = nb * K
+            labels = torch.cat([torch.gather(labels, 1, parent.long()[:, :, None].expand(-1, -1, labels.shape[2])),
+                                code[:, :, None]], dim=2)
+            if j != M - 1:
+                src = (base * nb + parent.long()).reshape(-1).contiguous()
+                nxt = torch.empty((bs * nb_new, dim), dtype=torch.float32, device=self.device)
+                hip.check(L.mevi_gather_sub_f32(hip.ptr(resid), hip.ptr(src), hip.ptr(self.codebook[j]),
+                                                hip.ptr(code.reshape(-1).contiguous()), bs * nb_new, dim, hip.ptr(nxt),
+                                                hip.stream_ptr()), "mevi_gather_sub_f32")
+                resid = nxt
+            scores, nb = sc, nb_new
+        return (labels, scores) if return_proba else labels
+
     def get_reconstruct_vector(self, index, codebook=None):
         cb = self.codebook if codebook is None else codebook
         index = index.to(cb.device).long()

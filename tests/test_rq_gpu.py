@@ -73,3 +73,20 @@ def test_document_cluster_matches_reference_layout(cuda):
     assert c2 == cluster and m2 == mapping
     rec = pq.get_reconstruct_vector(torch.from_numpy(g["codes"][:32]).to(cuda))
     assert np.array_equal(rec.cpu().numpy(), g["reconstruct32"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g4_rq_*.npz"))))
+def test_pq_beam_search_matches_reference_golden(cuda, path):
+    """pq.beam_search (doc_multiclus > 1 path): labels identical to the reference.  Probabilities are
+    softmax(-distance) with |distance| up to 1.5e3, so ONE f32 ulp of a distance (1.2e-4) already moves a
+    probability by 1.2e-4 relative; tolerance 1e-3 absolute (the oracle itself sits 6e-5 from the reference)."""
+    g = np.load(path)
+    M, K, dim = g["C"].shape
+    pq = rq.ProductQuantization("rq", M, int(np.log2(K)), "l2", dim, device=cuda)
+    pq.load_codebook(g["C"])
+    for R in (5, 10):
+        if f"beam{R}_labels" not in g:
+            continue
+        lab, sc = pq.beam_search(torch.from_numpy(g["X"][:64]), R, return_proba=True)
+        assert np.array_equal(lab.cpu().numpy(), g[f"beam{R}_labels"])
+        assert np.abs(sc.cpu().numpy() - g[f"beam{R}_scores"]).max() <= 1e-3
