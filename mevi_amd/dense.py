@@ -122,32 +122,78 @@ def shard_range(n_rows, rank, world_size):
     return start, min(start + per, n_rows)
 
 
-def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=None, merge=None):
-    """Row-sharded search: local top-k with global ids, all-gather, merge.
+def truncated_list_len(k, world):
+    """Entries each shard contributes in the first round of a sharded search.  With rows spread evenly a
+    shard holds Binomial(k, 1/world) of the global top-k: mean k/world, deviation < sqrt(k/world); eight
+    deviations of head-room make a second round rare, and the proof in merge_truncated catches the rest."""
+    if world <= 1:
+        return k
+    share = (k + world - 1) // world
+    return min(k, share + 8 * int(np.ceil(np.sqrt(share))) + 16)
 
-    Every rank passes the full (replicated) query matrix and its own shard; every
-    rank returns the identical merged (scores, ids), independent of shard count.
-    `local_search` / `merge` default to the HIP kernels; they are injection points for the
-    CPU (gloo) test of the collective plumbing and are never set by product code.
+
+def merge_truncated(all_s, all_i, k, merge=None):
+    """Merge per-shard lists that may have been TRUNCATED to k_local < k entries and decide, per query,
+    whether the merged top-k is provably the un-sharded answer.
+
+    all_s f32[world, nq, k_local], all_i i64[world, nq, k_local] (id -1 = padding: that shard is exhausted).
+    A shard's unseen rows all rank after its last returned entry, so the merged list is exact unless some
+    shard's LAST entry made it into the merged top-k (then deeper rows of that shard might belong too).
+    Returns (scores [nq, k], ids [nq, k], unproven bool[nq])."""
+    merge = merge or topk_merge
+    world, nq, kl = all_s.shape
+    ms, mi = merge(all_s, all_i, k)
+    last_s, last_i = all_s[:, :, kl - 1], all_i[:, :, kl - 1]          # [world, nq]
+    kth_s, kth_i = ms[:, k - 1], mi[:, k - 1]                           # [nq]
+    # kth_i == -1: fewer than k rows exist in total -> every returned row is already in the list
+    in_topk = (last_i >= 0) & (kth_i[None] >= 0) & (
+        (last_s > kth_s[None]) | ((last_s == kth_s[None]) & (last_i <= kth_i[None])))
+    truncated = kl < k
+    unproven = in_topk.any(0) if truncated else torch.zeros(nq, dtype=torch.bool, device=ms.device)
+    return ms, mi, unproven
+
+
+def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=None, merge=None):
+    """Row-sharded search: local top lists with global ids, all-gather, merge.
+
+    Every rank passes the full (replicated) query matrix and its own shard; every rank returns the
+    identical merged (scores, ids), equal to the un-sharded search whatever the shard count.
+    Round 1 exchanges only k_local = ~2k/world entries per shard (per-rank re-scoring, compaction and
+    the all-gather shrink with the world size); queries whose merged list cannot be proven complete
+    (a shard's last entry reached the global top-k) are repeated with full k-entry lists -- every rank
+    takes the same decision from the same gathered data.
+    `local_search` / `merge` default to the HIP kernels; they are injection points for the CPU (gloo)
+    test of the collective plumbing and are never set by product code.
     """
     import torch.distributed as dist
 
-    merge = merge or topk_merge
-    if local_search is not None:
-        s, i = local_search(query, local_docs, k, id_offset=id_offset)
-    elif isinstance(local_docs, DenseIndex):
-        s, i = local_docs.search(query, k, id_offset=id_offset)
-    else:
-        s, i = ip_topk(query, local_docs, k, id_offset=id_offset)
+    def local(q, kk):
+        if local_search is not None:
+            return local_search(q, local_docs, kk, id_offset=id_offset)
+        if isinstance(local_docs, DenseIndex):
+            return local_docs.search(q, kk, id_offset=id_offset)
+        return ip_topk(q, local_docs, kk, id_offset=id_offset)
+
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return s, i
+        return local(query, k)
     world = dist.get_world_size(group)
-    nq = s.shape[0]
-    all_s = torch.empty((world * nq, k), dtype=s.dtype, device=s.device)   # rank-major concatenation
-    all_i = torch.empty((world * nq, k), dtype=i.dtype, device=i.device)
-    dist.all_gather_into_tensor(all_s, s.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_i, i.contiguous(), group=group)
-    return merge(all_s.view(world, nq, k), all_i.view(world, nq, k), k)
+
+    def exchange(q, kk):
+        s, i = local(q, kk)
+        n = s.shape[0]
+        all_s = torch.empty((world * n, kk), dtype=s.dtype, device=s.device)   # rank-major concatenation
+        all_i = torch.empty((world * n, kk), dtype=i.dtype, device=i.device)
+        dist.all_gather_into_tensor(all_s, s.contiguous(), group=group)
+        dist.all_gather_into_tensor(all_i, i.contiguous(), group=group)
+        return all_s.view(world, n, kk), all_i.view(world, n, kk)
+
+    kl = truncated_list_len(k, world)
+    ms, mi, unproven = merge_truncated(*exchange(query, kl), k, merge=merge)
+    redo = torch.nonzero(unproven).flatten()
+    if redo.numel() > 0:                       # identical on every rank
+        rs, ri, _ = merge_truncated(*exchange(query[redo].contiguous(), k), k, merge=merge)
+        ms[redo], mi[redo] = rs, ri
+    return ms, mi
 
 
 def search(query, doc, dim, topk, param="Flat", device=None):

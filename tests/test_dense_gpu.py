@@ -108,6 +108,44 @@ def test_id_offset_and_shard_merge_equals_unsharded(cuda):
         np.testing.assert_array_equal(oi_, full_i)
 
 
+def test_truncated_shard_lists_are_proven_or_redone(cuda):
+    """Round 1 of the sharded search exchanges k_local < k entries per shard.  Even shards prove every
+    query; a shard that owns most of a query's top-k (skewed corpus) must be detected as unproven."""
+    rng = np.random.default_rng(17)
+    nq, nd, dim, k, world = 40, 16000, 64, 200, 8
+    q = rng.standard_normal((nq, dim), dtype=np.float32)
+    d = rng.standard_normal((nd, dim), dtype=np.float32)
+    q[1:] -= np.outer(q[1:] @ q[0], q[0]) / (q[0] @ q[0])   # only query 0 sees the skew
+    d[:1500] += 0.8 * q[0]                      # query 0's neighbours all live in shard 0
+    full_s, full_i = _run(q, d, k, cuda)
+    kl = dense.truncated_list_len(k, world)
+    assert kl == 25 + 8 * 5 + 16 and dense.truncated_list_len(k, 1) == k and dense.truncated_list_len(10, 8) == 10
+    ls, li = [], []
+    for r in range(world):
+        a, b = dense.shard_range(nd, r, world)
+        s, i = _run_indexed(q, d[a:b], kl, cuda, id_offset=a)
+        ls.append(s)
+        li.append(i)
+    ms, mi, unproven = dense.merge_truncated(torch.from_numpy(np.stack(ls)).to(cuda), torch.from_numpy(np.stack(li)).to(cuda), k)
+    unproven = unproven.cpu().numpy()
+    assert unproven[0] and unproven.sum() <= 3
+    ok = ~unproven
+    np.testing.assert_array_equal(mi.cpu().numpy()[ok], full_i[ok])            # proven queries are exact
+    np.testing.assert_array_equal(ms.cpu().numpy()[ok].view(np.uint32), full_s[ok].view(np.uint32))
+    assert not np.array_equal(mi.cpu().numpy()[0], full_i[0])                  # and the flagged one really was wrong
+    # redo of the flagged queries with full lists
+    redo = np.nonzero(unproven)[0]
+    ls, li = [], []
+    for r in range(world):
+        a, b = dense.shard_range(nd, r, world)
+        s, i = _run_indexed(q[redo], d[a:b], k, cuda, id_offset=a)
+        ls.append(s)
+        li.append(i)
+    rs, ri, still = dense.merge_truncated(torch.from_numpy(np.stack(ls)).to(cuda), torch.from_numpy(np.stack(li)).to(cuda), k)
+    assert not still.any()
+    np.testing.assert_array_equal(ri.cpu().numpy(), full_i[redo])
+
+
 def test_adversarial_row_order_takes_guaranteed_path(cuda):
     # rows sorted by ascending score for every query: each chunk floods the
     # candidate list -> overflow -> flagged queries are recomputed exactly.

@@ -115,7 +115,10 @@ def _gloo_worker(rank, world, port, q, d, k, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     a, b = dense.shard_range(len(d), rank, world)
 
+    rounds = []
+
     def local(qq, dd, kk, id_offset=0):     # CPU stand-ins for the two device steps (checker = the oracle)
+        rounds.append((qq.shape[0], kk))
         s, i = od.ip_topk_exact(qq.numpy(), dd.numpy(), kk, id_offset)
         return torch.from_numpy(s), torch.from_numpy(i)
 
@@ -125,7 +128,7 @@ def _gloo_worker(rank, world, port, q, d, k, ret):
 
     s, i = dense.sharded_ip_topk(torch.from_numpy(q), torch.from_numpy(d[a:b]), k, id_offset=a,
                                  local_search=local, merge=merge)
-    ret[rank] = (s.numpy(), i.numpy())
+    ret[rank] = (s.numpy(), i.numpy(), rounds)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -142,13 +145,22 @@ def test_sharded_dense_exchange_on_gloo_world2():
 
     rng = np.random.default_rng(3)
     q = rng.standard_normal((9, 32)).astype(np.float32)
-    d = rng.standard_normal((501, 32)).astype(np.float32)
+    d = rng.standard_normal((2001, 32)).astype(np.float32)
+    d[:400] += 1.5 * q[0]     # query 0's top-300 sits in rank 0's shard: round 1 (k_local < k) must be redone
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_gloo_worker, nprocs=2, args=(2, port, q, d, 20, ret))
+    mp.spawn(_gloo_worker, nprocs=2, args=(2, port, q, d, 20, ret))   # k_local = k: single round
     es, ei = od.ip_topk_exact(q, d, 20)
     for r in range(2):
         assert np.array_equal(ret[r][1], ei) and np.array_equal(ret[r][0], es)
+    import mevi_amd.dense as md
+    assert md.truncated_list_len(20, 2) == 20 and md.truncated_list_len(300, 2) == 150 + 8 * 13 + 16
+    mp.spawn(_gloo_worker, nprocs=2, args=(2, port + 1, q, d, 300, ret))  # truncated round + redo for query 0
+    es, ei = od.ip_topk_exact(q, d, 300)
+    for r in range(2):
+        assert np.array_equal(ret[r][1], ei) and np.array_equal(ret[r][0], es)
+        rounds = ret[r][2]                           # all queries truncated, then the skewed few with full lists
+        assert rounds[0] == (9, 270) and len(rounds) == 2 and rounds[1][1] == 300 and 1 <= rounds[1][0] <= 3
