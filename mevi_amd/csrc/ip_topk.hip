@@ -306,24 +306,22 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_x3_kernel(
   const int lrow = lane & 31, half = lane >> 5;
   const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
   const int qrow0 = qtile * X3_QT;
-  // DMA duty of this lane: LDS rows 64*w8 + 8*i + (lane>>3); rows [0,256) are the two corpus tiles, [256,512) queries
-  const int w8 = t >> 6;
-  const float *rowptr[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int lr = 64 * w8 + 8 * i + (lane >> 3);
-    if (lr < 2 * BM) {
-      long long dr = doc_begin + (long long)dpair * 2 * BM + lr;
-      if (dr > doc_end - 1) dr = doc_end - 1;
-      rowptr[i] = Ds + (size_t)dr * (size_t)dimp;
-    } else {
-      int qr = qrow0 + (lr - 2 * BM);
-      if (qr > nq - 1) qr = nq - 1;
-      rowptr[i] = Qs + (size_t)qr * (size_t)dimp;
-    }
+  // DMA duty of this wave: waves 0-3 stage the two corpus tiles (LDS rows [0,256)), waves 4-7 the query tile
+  const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const float *src;
+  long long rows_left;
+  if (w8 < 4) {
+    const long long first = doc_begin + (long long)dpair * 2 * BM;
+    src = Ds + (size_t)first * (size_t)dimp;
+    rows_left = doc_end - first;
+  } else {
+    src = Qs + (size_t)qrow0 * (size_t)dimp;
+    rows_left = nq - qrow0;
   }
+  if (rows_left > 2 * BM) rows_left = 2 * BM;
+  const unsigned int src_bytes = (unsigned int)(rows_left * dimp * 4);
   f32x16 acc[2][4];
-  pp_mainloop_bf16x3(rowptr, dimp / 32, lds, acc);
+  pp_mainloop_bf16x3(src, src_bytes, dimp * 4, dimp / 32, lds, acc);
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int qi = qrow0 + 128 * wn + 32 * ni + lrow;
