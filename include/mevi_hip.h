@@ -63,14 +63,17 @@ int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, int64_t nd,
                      float *out_score, int64_t *out_id, void *workspace,
                      size_t workspace_bytes, void *stream);
 
-/* Indexed form of the same search (same results, bit for bit): the corpus shard is pre-split once
- * into (hi, lo) bfloat16 pairs (the analogue of faiss `index.add`, MEVI/faiss_search.py:19); a search
- * then selects k + margin candidates per query with three bf16 MFMAs per product (16x the f32 MFMA
- * rate each), re-scores them with the exact f32 fmaf chain, and PROVES per query that no other row can
- * enter the top-k (|approx - exact| <= 2.5e-4 * ||q|| * max||d||); unproven queries are re-run through
- * the exact f32 path.  `docs` (f32) is still needed for the exact re-scoring.
+/* Indexed form of the same search (same results, bit for bit): the corpus shard is converted once into
+ * a centred, scaled float16 image f16((d - mu) * S) (the analogue of faiss `index.add`,
+ * MEVI/faiss_search.py:19; mu = column mean of the shard); a search then selects k + margin candidates
+ * per query with ONE f16 MFMA per product (16x the f32 MFMA rate), re-scores them with the exact f32
+ * fmaf chain, and PROVES per query that no other row can enter the top-k:
+ *   |approx + q.mu - exact| <= ||q|| * (c1 * max||d - mu|| + c2 * max||d||),
+ *   c1 = 2^-10 + 2^-22 + 4 dim 2^-24 (f16 roundings + accumulation), c2 = dim 2^-24 (the exact chain);
+ * unproven queries are re-run through the exact f32 path.  `docs` (f32) is still needed for the exact
+ * re-scoring.
  *   index buffer: mevi_ip_index_bytes(nd, dim) bytes, 256-byte aligned, filled by mevi_ip_index_build_f32.
- * Synchronising like mevi_ip_topk_f32. */
+ *   dim % 4 == 0.  Synchronising like mevi_ip_topk_f32. */
 size_t mevi_ip_index_bytes(int64_t nd, int64_t dim);
 int mevi_ip_index_build_f32(const float *docs, int64_t nd, int64_t dim, void *index, size_t index_bytes,
                             void *stream);
@@ -200,8 +203,8 @@ typedef struct mevi_ip_topk_stats {
   double filter_ms;          /* sum of ip_filter_kernel durations (HIP events on the call's stream; profiling on) */
   double compact_ms;         /* sum of compact_kernel durations (profiling on) */
   double filter_flops;       /* algorithmic flops of those filter launches: 2 * nq * rows * dim */
-  double max_err_ratio;      /* indexed search: largest observed |bf16x3 approx - exact| / (|q| |d|) among survivors */
-  double err_bound;          /* indexed search: the bound the proof uses (must dominate max_err_ratio) */
+  double max_err_ratio;      /* indexed search: largest observed |f16 approx - exact| / proven bound among survivors */
+  double err_bound;          /* indexed search: 1.0 (max_err_ratio is relative to the bound the proof uses) */
 } mevi_ip_topk_stats;
 void mevi_ip_topk_set_growth(double growth);
 void mevi_ip_topk_set_profiling(int enable); /* record HIP events around every filter/compact launch */

@@ -24,7 +24,7 @@
 // and half 1 odd k); oracle/mevi_oracle.c computes the same chain on the CPU,
 // so parity is bit-exact.
 
-#include "mfma_pp_bf16x3.h"
+#include "mfma_pp_f16.h"
 
 #include <float.h>
 #include <math.h>
@@ -252,44 +252,163 @@ __global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ sc
 }
 
 // ---------------------------------------------------------------------------
-// bf16x3 pre-filter (see mfma_pp_bf16x3.h): split, approximate filter, exact re-score + verify.
+// f16 pre-filter (see mfma_pp_f16.h): centred + scaled f16 images, approximate filter, exact re-score + proof.
 
-constexpr float X3_C_ERR = 4.0e-4f;  // |approx - chain| <= X3_C_ERR * ||q|| * ||d||   (derivation: DESIGN.md 4.1b)
+constexpr double H1_U = 1.0 / 2048.0;  // f16 unit roundoff
+// |acc/(S_q S_d) - q.(d - mu)| <= h1_c1 * ||q|| * ||d - mu||   (derivation: mfma_pp_f16.h)
+static inline float h1_c1(int64_t dimp) {
+  return (float)((2.0 * H1_U + H1_U * H1_U + 4.0 * (double)dimp / 16777216.0 + 2e-7) * 1.001);
+}
+// |chain_f32(q, d) - q.d| <= h1_c2 * ||q|| * ||d||   (n sequential fmaf: gamma_n = n u / (1 - n u), u = 2^-24)
+static inline float h1_c2(int64_t dim) { return (float)((double)dim / 16777216.0 * 1.01); }
 
-// f32 rows -> slab-interleaved (hi | lo) bf16 image + row L2 norms + max norm.  One wave per row.
-__global__ __launch_bounds__(256) void split_kernel(const float *__restrict__ x, long long n, int dim, int dimp,
-                                                   unsigned short *__restrict__ out, float *__restrict__ norms,
-                                                   unsigned int *__restrict__ max_norm_bits) {
+// power of two S with m * S in [2^14, 2^15) (m > 0), exponent clamped so S and 1/S stay finite normal floats
+__device__ __forceinline__ float pow2_scale(float m) {
+  if (!(m > 0.f)) return 1.f;
+  int e;
+  (void)frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
+  int s = 15 - e;
+  s = s > 100 ? 100 : (s < -100 ? -100 : s);
+  return ldexpf(1.f, s);
+}
+
+// column sums of the shard in f64 (mu = sum / n); 256 threads = 256 columns per pass, 512 rows per workgroup
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, long long n, int dim,
+                                                    double *__restrict__ sum) {
+  const long long r0 = (long long)blockIdx.x * 512;
+  const long long r1 = r0 + 512 < n ? r0 + 512 : n;
+  for (int c = threadIdx.x; c < dim; c += 256) {
+    double a = 0.0;
+    for (long long r = r0; r < r1; ++r) a += (double)x[(size_t)r * dim + c];
+    atomicAdd(&sum[c], a);
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const double *__restrict__ sum, long long n, int dim, int dimp,
+                                                  float *__restrict__ mu) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < dimp) mu[c] = (c < dim && n > 0) ? (float)(sum[c] / (double)n) : 0.f;
+}
+
+// per row: ||d - mu|| (stored, rounded up), and shard maxima bits[0] = max ||d - mu||, bits[1] = max ||d||,
+// bits[2] = max |d_k - mu_k|.  One wave per row.
+__global__ __launch_bounds__(256) void doc_stats_kernel(const float *__restrict__ x, long long n, int dim,
+                                                       const float *__restrict__ mu, float *__restrict__ norms_c,
+                                                       unsigned int *__restrict__ bits) {
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
   const int lane = threadIdx.x & 63;
   const float *xr = x + (size_t)r * dim;
-  unsigned short *o = out + (size_t)r * dimp * 2;
-  float ss = 0.f;
-  for (int s = 0; s < dimp / 32; ++s) {
-    if (lane < 32) {
-      const int k = s * 32 + lane;
-      const float v = k < dim ? xr[k] : 0.f;
-      const __bf16 hi = (__bf16)v;
-      const __bf16 lo = (__bf16)(v - (float)hi);
-      o[s * 64 + lane] = __builtin_bit_cast(unsigned short, hi);
-      o[s * 64 + 32 + lane] = __builtin_bit_cast(unsigned short, lo);
-      ss = fmaf(v, v, ss);
-    }
+  float sc = 0.f, sr = 0.f, mx = 0.f;
+  for (int k = lane * 4; k < dim; k += 256) {
+    const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+    const float4 m = *reinterpret_cast<const float4 *>(mu + k);
+    const float c0 = v.x - m.x, c1 = v.y - m.y, c2 = v.z - m.z, c3 = v.w - m.w;
+    sc = fmaf(c0, c0, fmaf(c1, c1, fmaf(c2, c2, fmaf(c3, c3, sc))));
+    sr = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, sr))));
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(c0), fabsf(c1))), fmaxf(fabsf(c2), fabsf(c3)));
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  for (int off = 32; off > 0; off >>= 1) {
+    sc += __shfl_xor(sc, off);
+    sr += __shfl_xor(sr, off);
+    mx = fmaxf(mx, __shfl_xor(mx, off));
+  }
   if (lane == 0) {
-    const float nrm = sqrtf(ss) * 1.000001f;  // round up: the bound must hold for the real norm
-    norms[r] = nrm;
-    if (max_norm_bits) atomicMax(max_norm_bits, __float_as_uint(nrm));  // non-negative floats order as uints
+    const float nc = sqrtf(sc) * 1.00001f, nr = sqrtf(sr) * 1.00001f;  // round up: bounds must hold for the real norms
+    norms_c[r] = nc;
+    atomicMax(&bits[0], __float_as_uint(nc));  // non-negative floats order as uints
+    atomicMax(&bits[1], __float_as_uint(nr));
+    atomicMax(&bits[2], __float_as_uint(mx));
   }
 }
 
-// Approximate scores (bf16x3) + threshold filter: same epilogue as ip_filter_kernel, A = split corpus
-// rows (two 128-row tiles), B = 256 split queries.  Keys carry the APPROXIMATE score.
-__global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_x3_kernel(
-    const float *__restrict__ Qs, int nq, const float *__restrict__ Ds, long long doc_begin, long long doc_end,
+__global__ void doc_scale_kernel(const unsigned int *__restrict__ bits, float *__restrict__ scal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float s = pow2_scale(__uint_as_float(bits[2]));
+    scal[0] = s;
+    scal[1] = 1.f / s;
+  }
+}
+
+// docs -> f16((d - mu) * S_d), row-major [n, dimp], zero padded.  One wave per row.
+__global__ __launch_bounds__(256) void split_docs_f16_kernel(const float *__restrict__ x, long long n, int dim, int dimp,
+                                                            const float *__restrict__ mu,
+                                                            const float *__restrict__ scal,
+                                                            _Float16 *__restrict__ out) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float *xr = x + (size_t)r * dim;
+  _Float16 *o = out + (size_t)r * dimp;
+  const float s = scal[0];
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  for (int k = lane * 4; k < dimp; k += 256) {
+    h4 h = {0, 0, 0, 0};
+    if (k < dim) {
+      const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+      const float4 m = *reinterpret_cast<const float4 *>(mu + k);
+      h[0] = (_Float16)((v.x - m.x) * s);
+      h[1] = (_Float16)((v.y - m.y) * s);
+      h[2] = (_Float16)((v.z - m.z) * s);
+      h[3] = (_Float16)((v.w - m.w) * s);
+    }
+    *reinterpret_cast<h4 *>(o + k) = h;
+  }
+}
+
+// queries -> f16(q * S_q) with a power of two S_q per row; qnorm = ||q|| (rounded up), qinv = 1 / (S_q S_d),
+// qshift = q.mu in f64 (approx + qshift estimates q.d).  One wave per row.
+__global__ __launch_bounds__(256) void split_queries_f16_kernel(const float *__restrict__ x, long long n, int dim,
+                                                               int dimp, const float *__restrict__ mu,
+                                                               const float *__restrict__ doc_scal,
+                                                               _Float16 *__restrict__ out, float *__restrict__ qnorm,
+                                                               float *__restrict__ qinv, double *__restrict__ qshift) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float *xr = x + (size_t)r * dim;
+  _Float16 *o = out + (size_t)r * dimp;
+  float ss = 0.f, mx = 0.f;
+  double sh = 0.0;
+  for (int k = lane * 4; k < dim; k += 256) {
+    const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+    const float4 m = *reinterpret_cast<const float4 *>(mu + k);
+    ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    sh += (double)v.x * m.x + (double)v.y * m.y + (double)v.z * m.z + (double)v.w * m.w;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ss += __shfl_xor(ss, off);
+    mx = fmaxf(mx, __shfl_xor(mx, off));
+    sh += __shfl_xor(sh, off);
+  }
+  const float s = pow2_scale(mx);
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  for (int k = lane * 4; k < dimp; k += 256) {
+    h4 h = {0, 0, 0, 0};
+    if (k < dim) {
+      const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+      h[0] = (_Float16)(v.x * s);
+      h[1] = (_Float16)(v.y * s);
+      h[2] = (_Float16)(v.z * s);
+      h[3] = (_Float16)(v.w * s);
+    }
+    *reinterpret_cast<h4 *>(o + k) = h;
+  }
+  if (lane == 0) {
+    qnorm[r] = sqrtf(ss) * 1.00001f;
+    qinv[r] = (1.f / s) * doc_scal[1];
+    qshift[r] = sh;
+  }
+}
+
+// Approximate scores (f16) + threshold filter: same epilogue as ip_filter_kernel, A = f16 corpus rows (two
+// 128-row tiles), B = 256 f16 queries.  Keys carry the RAW accumulator (= S_q S_d x the centred approximate
+// score): per query that is a monotone image of the approximate score, which is all tau and the ranking need.
+__global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
+    const float *__restrict__ Qh, int nq, const float *__restrict__ Dh, long long doc_begin, long long doc_end,
     int dimp, const float *__restrict__ tau, unsigned long long *__restrict__ buf,
     unsigned int *__restrict__ count, int S, int k, int cap, unsigned int id_base, int n_qtiles, int n_dpairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -305,23 +424,24 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_x3_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const int lrow = lane & 31, half = lane >> 5;
   const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
-  const int qrow0 = qtile * X3_QT;
+  const int qrow0 = qtile * H1_QT;
+  const int row_bytes = dimp * 2;
   // DMA duty of this wave: waves 0-3 stage the two corpus tiles (LDS rows [0,256)), waves 4-7 the query tile
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
-  const float *src;
+  const char *src;
   long long rows_left;
   if (w8 < 4) {
     const long long first = doc_begin + (long long)dpair * 2 * BM;
-    src = Ds + (size_t)first * (size_t)dimp;
+    src = reinterpret_cast<const char *>(Dh) + (size_t)first * (size_t)row_bytes;
     rows_left = doc_end - first;
   } else {
-    src = Qs + (size_t)qrow0 * (size_t)dimp;
+    src = reinterpret_cast<const char *>(Qh) + (size_t)qrow0 * (size_t)row_bytes;
     rows_left = nq - qrow0;
   }
   if (rows_left > 2 * BM) rows_left = 2 * BM;
-  const unsigned int src_bytes = (unsigned int)(rows_left * dimp * 4);
+  const unsigned int src_bytes = (unsigned int)(rows_left * row_bytes);
   f32x16 acc[2][4];
-  pp_mainloop_bf16x3(src, src_bytes, dimp * 4, dimp / 32, lds, acc);
+  pp_mainloop_f16(src, src_bytes, row_bytes, dimp / 32, lds, acc);
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int qi = qrow0 + 128 * wn + 32 * ni + lrow;
@@ -345,18 +465,21 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_x3_kernel(
 }
 
 // Exact re-scoring of the kp approximate survivors of one query, exact top-k, and the proof that
-// nothing outside the survivors can belong to it:
-//   every non-survivor has approx <= a_last (the kp-th approximate score), hence
-//   chain <= a_last + eps_q;  if a_last + eps_q < e_k (the exact k-th score) the list is exact.
-// One workgroup per query; one lane per candidate, sequential fmaf chain over k (the oracle's chain),
-// rows staged through LDS in 32-wide slabs.
+// nothing outside the survivors can belong to it.  With a = acc * qinv (the centred approximate score),
+//   chain(q, d) <= a + q.mu + eps_q,   eps_q = ||q|| * (c1 * max||d - mu|| + c2 * max||d||)
+// for every document of the shard; every non-survivor has acc <= acc_last (the kp-th raw accumulator), so if
+//   acc_last * qinv + q.mu + eps_q < e_k   (the exact k-th score; compared in f64)
+// the list is exact.  One workgroup per query; one lane per candidate, sequential fmaf chain over k (the
+// oracle's chain), rows staged through LDS in 32-wide slabs.
 __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ Q, const float *__restrict__ D,
                                                      int dim, unsigned long long *__restrict__ buf, int S, int k,
                                                      int kp, unsigned int id_base, const float *__restrict__ qnorm,
+                                                     const float *__restrict__ qinv,
+                                                     const double *__restrict__ qshift, float c1, float c2,
                                                      const unsigned int *__restrict__ dmax_bits,
                                                      unsigned int *__restrict__ failed,
                                                      unsigned long long *__restrict__ out_top, int out_ld,
-                                                     const float *__restrict__ dnorm,
+                                                     const float *__restrict__ dnorm_c,
                                                      unsigned int *__restrict__ err_ratio_bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // P keys, then staging floats
   const int q = blockIdx.x, t = threadIdx.x;
@@ -401,9 +524,10 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
       }
     }
     if (c < P) skeys[c] = valid ? make_key(acc, key_id(key)) : 0ull;
-    if (valid && err_ratio_bits) {  // observed |approx - exact| / (||q|| ||d||): must stay far below X3_C_ERR
-      const float den = qnorm[q] * dnorm[sid[t]];
-      if (den > 0.f) atomicMax(err_ratio_bits, __float_as_uint(fabsf(key_score(key) - acc) / den));
+    if (valid && err_ratio_bits) {  // observed |approx - exact| / its bound: must stay far below 1
+      const double den = (double)qnorm[q] * ((double)c1 * dnorm_c[sid[t]] + (double)c2 * __uint_as_float(dmax_bits[1]));
+      const double est = (double)key_score(key) * (double)qinv[q] + qshift[q];
+      if (den > 0.0) atomicMax(err_ratio_bits, __float_as_uint((float)(fabs(est - (double)acc) / den)));
     }
     __syncthreads();
   }
@@ -413,8 +537,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
     bool ok = true;
     if (last != 0ull) {  // the survivor list is full: there are documents outside it
       const unsigned long long kth = skeys[k - 1];
-      const float eps = X3_C_ERR * qnorm[q] * __uint_as_float(*dmax_bits);
-      ok = (kth != 0ull) && (key_score(last) + eps < key_score(kth));
+      const double eps = (double)qnorm[q] * ((double)c1 * __uint_as_float(dmax_bits[0]) + (double)c2 * __uint_as_float(dmax_bits[1]));
+      ok = (kth != 0ull) && ((double)key_score(last) * (double)qinv[q] + qshift[q] + eps < (double)key_score(kth));
     }
     if (!ok) failed[q] = 1u;  // keeps an overflow flag set by compact_kernel during the approximate pass
   }
@@ -474,7 +598,7 @@ static void profile_collect() {
 // Walk docs [0, nd) in chunks; returns number of filter launches, <0 on error.
 static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, int dim,
                         const TopkGeom &g, uint32_t id_base, const SearchState &st, bool guaranteed,
-                        hipStream_t stream, bool x3 = false) {
+                        hipStream_t stream, bool h1 = false) {
   const long long total = nq * (long long)g.k;
   const long long init_n = total > nq ? total : nq;
   hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, stream,
@@ -490,16 +614,16 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   // MFMAs per phase) was measured at the same MFMA-pipe utilisation (85.6 % vs 85.4 %)
   // and pads nq further, so only NI = 2 is instantiated.
   const int ni = 2;
-  const int qt = x3 ? X3_QT : 64 * ni;
+  const int qt = h1 ? H1_QT : 64 * ni;
   const int n_qtiles = (int)((nq + qt - 1) / qt);
   double growth = g_growth > 0.0 ? g_growth : (double)g.cap / (3.0 * g.k);  // expected survivors per chunk ~ cap/3
   if (growth < 1.0) growth = 1.0;
   const int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
-  const size_t pp_lds = x3 ? x3_lds_bytes() : pp_lds_bytes<2>();
+  const size_t pp_lds = h1 ? h1_lds_bytes() : pp_lds_bytes<2>();
   const bool ktail = (dim % BK) != 0;
   const void *fn = nullptr;
 #define MEVI_PICK(NI_, T_) fn = reinterpret_cast<const void *>(ip_filter_kernel<NI_, T_>)
-  if (x3) fn = reinterpret_cast<const void *>(ip_filter_x3_kernel);  // Q, D = split images, dim = padded dim
+  if (h1) fn = reinterpret_cast<const void *>(ip_filter_h1_kernel);  // Q, D = f16 images, dim = padded dim
   else if (ktail) MEVI_PICK(2, true);
   else MEVI_PICK(2, false);
 #undef MEVI_PICK
@@ -635,24 +759,35 @@ extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, i
 }
 
 // ---------------------------------------------------------------------------
-// Indexed (bf16x3 pre-filtered) search.  Index = split corpus image + row norms + max norm.
+// Indexed (f16 pre-filtered) search.  Index = centred f16 corpus image + centred row norms + column mean +
+// shard scalars.
 namespace {
 struct IndexView {
-  const float *split;         // [nd, dimp] floats holding (hi | lo) bf16 slabs
-  const float *norms;         // [nd]
-  const unsigned int *dmax;   // max row norm (float bits)
+  const float *image;        // [nd, dimp] f16 (held as raw bytes)
+  const float *norms_c;      // [nd]  ||d - mu||
+  const float *mu;           // [dimp]
+  const unsigned int *bits;  // [0] max ||d - mu||, [1] max ||d||, [2] max |d_k - mu_k|   (float bits)
+  const float *scal;         // [0] S_d, [1] 1 / S_d
+  double *colsum;            // [dimp] build scratch
 };
 inline int64_t pad32(int64_t d) { return (d + 31) / 32 * 32; }
-inline size_t index_split_bytes(int64_t nd, int64_t dim) { return align_up((size_t)nd * pad32(dim) * 4, 256); }
+inline size_t index_image_bytes(int64_t nd, int64_t dim) { return align_up((size_t)nd * pad32(dim) * 2, 256); }
 inline IndexView view_index(const void *index, int64_t nd, int64_t dim) {
   const char *p = reinterpret_cast<const char *>(index);
   IndexView v;
-  v.split = reinterpret_cast<const float *>(p);
-  v.norms = reinterpret_cast<const float *>(p + index_split_bytes(nd, dim));
-  v.dmax = reinterpret_cast<const unsigned int *>(p + index_split_bytes(nd, dim) + align_up((size_t)nd * 4, 256));
+  v.image = reinterpret_cast<const float *>(p);
+  p += index_image_bytes(nd, dim);
+  v.norms_c = reinterpret_cast<const float *>(p);
+  p += align_up((size_t)nd * 4, 256);
+  v.mu = reinterpret_cast<const float *>(p);
+  p += align_up((size_t)pad32(dim) * 4, 256);
+  v.bits = reinterpret_cast<const unsigned int *>(p);
+  v.scal = reinterpret_cast<const float *>(p + 16);
+  p += 256;
+  v.colsum = reinterpret_cast<double *>(const_cast<char *>(p));
   return v;
 }
-inline int x3_kprime(int k) {  // survivors kept per query: k plus a margin for the approximation error
+inline int h1_kprime(int k) {  // survivors kept per query: k plus a margin for the approximation error
   int extra = k / 4 < 128 ? 128 : k / 4;
   return (k + extra + 63) / 64 * 64;
 }
@@ -660,33 +795,49 @@ inline int x3_kprime(int k) {  // survivors kept per query: k plus a margin for 
 
 extern "C" size_t mevi_ip_index_bytes(int64_t nd, int64_t dim) {
   if (nd < 0 || dim <= 0) return 0;
-  return index_split_bytes(nd, dim) + align_up((size_t)nd * 4, 256) + 256;
+  return index_image_bytes(nd, dim) + align_up((size_t)nd * 4, 256) + align_up((size_t)pad32(dim) * 4, 256) + 256 +
+         align_up((size_t)pad32(dim) * 8, 256);
 }
 
 extern "C" int mevi_ip_index_build_f32(const float *docs, int64_t nd, int64_t dim, void *index, size_t index_bytes,
                                        void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   MEVI_REQUIRE(nd >= 0 && dim > 0, MEVI_ERR_INVALID_ARG, "ip_index_build: bad shape");
+  MEVI_REQUIRE(dim % 4 == 0, MEVI_ERR_UNSUPPORTED, "ip_index_build: dim %% 4 != 0");
   MEVI_REQUIRE(index && index_bytes >= mevi_ip_index_bytes(nd, dim), MEVI_ERR_WORKSPACE, "ip_index_build: index buffer too small");
-  MEVI_REQUIRE(((uintptr_t)index % 256) == 0, MEVI_ERR_INVALID_ARG, "ip_index_build: index must be 256-byte aligned");
+  MEVI_REQUIRE(((uintptr_t)index % 256) == 0 && ((uintptr_t)docs % 16) == 0, MEVI_ERR_INVALID_ARG,
+               "ip_index_build: index must be 256-byte, docs 16-byte aligned");
   IndexView v = view_index(index, nd, dim);
-  MEVI_HIP_CHECK(hipMemsetAsync(const_cast<unsigned int *>(v.dmax), 0, 4, stream));
+  const int dimp = (int)pad32(dim);
+  // mean, maxima, scale and the scratch sums all start from zero (an empty shard keeps mu = 0, S_d = 1)
+  MEVI_HIP_CHECK(hipMemsetAsync(const_cast<float *>(v.mu), 0,
+                                align_up((size_t)dimp * 4, 256) + 256 + align_up((size_t)dimp * 8, 256), stream));
   if (nd > 0) {
     MEVI_REQUIRE(docs, MEVI_ERR_INVALID_ARG, "ip_index_build: null docs");
-    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((nd + 3) / 4)), dim3(256), 0, stream, docs, (long long)nd, (int)dim,
-                       (int)pad32(dim), reinterpret_cast<unsigned short *>(const_cast<float *>(v.split)),
-                       const_cast<float *>(v.norms), const_cast<unsigned int *>(v.dmax));
+    const unsigned rows4 = (unsigned)((nd + 3) / 4);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((nd + 511) / 512)), dim3(256), 0, stream, docs, (long long)nd,
+                       (int)dim, v.colsum);
+    hipLaunchKernelGGL(mean_kernel, dim3((unsigned)((dimp + 255) / 256)), dim3(256), 0, stream, v.colsum, (long long)nd,
+                       (int)dim, dimp, const_cast<float *>(v.mu));
+    hipLaunchKernelGGL(doc_stats_kernel, dim3(rows4), dim3(256), 0, stream, docs, (long long)nd, (int)dim, v.mu,
+                       const_cast<float *>(v.norms_c), const_cast<unsigned int *>(v.bits));
   }
+  hipLaunchKernelGGL(doc_scale_kernel, dim3(1), dim3(64), 0, stream, v.bits, const_cast<float *>(v.scal));
+  if (nd > 0)
+    hipLaunchKernelGGL(split_docs_f16_kernel, dim3((unsigned)((nd + 3) / 4)), dim3(256), 0, stream, docs, (long long)nd,
+                       (int)dim, dimp, v.mu, v.scal, reinterpret_cast<_Float16 *>(const_cast<float *>(v.image)));
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }
 
 extern "C" size_t mevi_ip_topk_indexed_workspace_bytes(int64_t nq, int64_t dim, int64_t k) {
   if (nq <= 0 || k <= 0 || k > 4096 || dim <= 0) return 0;
-  const TopkGeom gp = make_geom(x3_kprime((int)k));
-  // approx state (K' geometry) + exact top lists + split queries + norms, then the exact-path workspace for the fallback
-  return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)nq * pad32(dim) * 4, 256) +
-         align_up((size_t)(nq + 1) * 4, 256) + mevi_ip_topk_workspace_bytes(nq, dim, k) + 256;
+  const TopkGeom gp = make_geom(h1_kprime((int)k));
+  // approx state (K' geometry) + exact top lists + f16 queries + per-query norm / scale / shift, then the
+  // exact-path workspace for the fallback
+  return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)nq * pad32(dim) * 2, 256) +
+         2 * align_up((size_t)(nq + 1) * 4, 256) + align_up((size_t)nq * 8, 256) +
+         mevi_ip_topk_workspace_bytes(nq, dim, k) + 256;
 }
 
 extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float *docs, const void *index, int64_t nd,
@@ -708,7 +859,7 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   MEVI_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 256) == 0, MEVI_ERR_WORKSPACE,
                "ip_topk_indexed: workspace %zu bytes < required %zu (or misaligned)", workspace_bytes, need);
 
-  const int kp = x3_kprime((int)k);
+  const int kp = h1_kprime((int)k);
   const TopkGeom gp = make_geom(kp), g = make_geom((int)k);
   const int64_t dimp = pad32(dim);
   IndexView iv = view_index(index, nd, dim);
@@ -716,16 +867,21 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   SearchState st = carve_state(p, nq, gp);
   unsigned long long *top = reinterpret_cast<unsigned long long *>(p);  // [nq, k] exact keys
   p += align_up((size_t)nq * k * 8, 256);
-  float *qsplit = reinterpret_cast<float *>(p);
-  p += align_up((size_t)nq * dimp * 4, 256);
+  float *qimage = reinterpret_cast<float *>(p);  // [nq, dimp] f16
+  p += align_up((size_t)nq * dimp * 2, 256);
   float *qnorm = reinterpret_cast<float *>(p);  // [nq] + 1 slot for the observed error ratio
   p += align_up((size_t)(nq + 1) * 4, 256);
+  float *qinv = reinterpret_cast<float *>(p);   // [nq] 1 / (S_q S_d)
+  p += align_up((size_t)(nq + 1) * 4, 256);
+  double *qshift = reinterpret_cast<double *>(p);  // [nq] q.mu
+  p += align_up((size_t)nq * 8, 256);
   void *exact_ws = p;
   const size_t exact_ws_bytes = mevi_ip_topk_workspace_bytes(nq, dim, k);
+  const float c1 = h1_c1(dimp), c2 = h1_c2(dim);
 
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, (long long)nq, (int)dim,
-                     (int)dimp, reinterpret_cast<unsigned short *>(qsplit), qnorm, (unsigned int *)nullptr);
-  int64_t launches = run_pass(qsplit, nq, iv.split, nd, (int)dimp, gp, (uint32_t)id_offset, st, false, stream, true);
+  hipLaunchKernelGGL(split_queries_f16_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, (long long)nq,
+                     (int)dim, (int)dimp, iv.mu, iv.scal, reinterpret_cast<_Float16 *>(qimage), qnorm, qinv, qshift);
+  int64_t launches = run_pass(qimage, nq, iv.image, nd, (int)dimp, gp, (uint32_t)id_offset, st, false, stream, true);
   if (launches < 0) return MEVI_ERR_HIP;
   g_stats.n_chunks = launches;
   g_stats.filter_flops *= (double)dim / (double)dimp;  // algorithmic flops count dim, not the padding
@@ -739,7 +895,8 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   unsigned int *err_bits = reinterpret_cast<unsigned int *>(qnorm + nq);  // spare slot behind the norms (256-byte padded)
   MEVI_HIP_CHECK(hipMemsetAsync(err_bits, 0, 4, stream));
   hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(256), rs_lds, stream, q, docs, (int)dim, st.buf, gp.S,
-                     (int)k, kp, (unsigned int)id_offset, qnorm, iv.dmax, st.failed, top, (int)k, iv.norms, err_bits);
+                     (int)k, kp, (unsigned int)id_offset, qnorm, qinv, qshift, c1, c2, iv.bits, st.failed, top, (int)k,
+                     iv.norms_c, err_bits);
   unsigned int err_host = 0;
   MEVI_HIP_CHECK(hipMemcpyAsync(&err_host, err_bits, 4, hipMemcpyDeviceToHost, stream));
   MEVI_HIP_CHECK(hipGetLastError());
@@ -751,7 +908,7 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
     float r;
     memcpy(&r, &err_host, 4);
     g_stats.max_err_ratio = r;
-    g_stats.err_bound = X3_C_ERR;
+    g_stats.err_bound = 1.0;  // the ratio is observed error / proven bound
   }
   // approx-state overflow (adversarial order) is flagged by compact_kernel in the same array (bitwise or: both set 1)
   std::vector<int> idx;

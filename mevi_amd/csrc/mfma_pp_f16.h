@@ -1,0 +1,161 @@
+// f16 tile loop of the pre-filter (ip_topk.hip, ip_filter_h1_kernel).
+//
+// Operands are f16 images of the f32 rows, row-major, row = dimp halves (dimp = dim padded to 32):
+//   docs    : f16((d - mu) * S_d)      mu = column mean of the shard, S_d one power of two for the shard
+//   queries : f16(q * S_q)             S_q a power of two per query
+//   acc = sum_k a_k * b_k              ONE v_mfma_f32_32x32x16_f16 per 16 k, f32 accumulate
+//
+// acc / (S_q S_d) APPROXIMATES the f32 dot product q.(d - mu) with the rigorous bound
+//   |acc/(S_q S_d) - sum_k q_k (d_k - mu_k)| <= C1(dim) * ||q|| * ||d - mu||,
+//   C1 = (2u + u^2) + 4 * dimp * 2^-24 + 2e-7,   u = 2^-11 (f16 unit roundoff)
+// (both operands rounded once: (1+u)^2 - 1 per product, Cauchy-Schwarz over the row; products of two
+// f16 are exact in f32; 4 * 2^-24 per accumulation step allows the matrix core to truncate instead of
+// rounding; 2e-7 covers elements that fall below the f16 normal range -- with a row maximum scaled to
+// [2^14, 2^15) those are < 2^-29 of it -- and the rounding of d - mu).  The result is only ever used to
+// SELECT candidates that are then re-scored exactly (ip_topk.hip: rescore_kernel holds the proof).
+//
+// Geometry: 512 threads = 8 waves, all computing (staging is DMA); block tile 256 A rows x 256 B rows;
+// wave w8 = 4*grp + 2*wm + wn owns A rows 128*grp + 64*wm + [0,64) x B rows 128*wn + [0,128) = 2 x 4
+// accumulators of 32x32.  LDS rows are A0[0,128) | A1[128,256) | B[256,512).
+//
+// The K loop advances in UNITS of 32 k = 64 bytes per row = four 16-byte pieces (piece c = k 8c..8c+7); a
+// unit is two MFMA k-steps j = 0,1, the lane (row, half) of a fragment reads piece 2j + half.
+// Staging is LDS-DMA in its MUBUF form (buffer_load_dwordx4 ... lds): no staging registers, no ds_write,
+// and -- unlike global_load_lds, which the compiler books on lgkmcnt as an out-of-order FLAT event,
+// degrading every `s_waitcnt lgkmcnt(N)` of the fragment pipeline to lgkmcnt(0) -- it counts on vmcnt
+// only.  One wave-instruction moves 1 KiB = 16 rows x 64 B; the LDS destination is linear (M0 base +
+// lane*16), so the bank swizzle is applied on the SOURCE address and again on the read:
+//   logical piece c of row r lives in slot c ^ ((r >> 2) & 3).
+// ds_read_b128 is serviced in lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} (+32): with 64-byte rows
+// the 16 rows of a group then cover all 16 slots of the 256-byte bank line -> conflict free.
+// A wave stages 64 rows of ONE operand per unit (4 pieces), so its buffer descriptor is wave-uniform:
+// `src` = first row of the wave's operand tile (docs: waves 0-3, queries: waves 4-7), `src_bytes` = bytes
+// from there to the end of the operand (rows past it read as 0 and are masked in the epilogue).
+//
+// Pipeline (per wave, unit u, window W_u = barrier u-1 .. barrier u; F0/F1 = fragment register sets):
+//   PA: ds_read F0 <- (u, j=0)   | 8 MFMA on F1 = (u-1, j=1) | 2 DMA pieces of unit u+3
+//   PB: ds_read F1 <- (u, j=1)   | 8 MFMA on F0 = (u,   j=0) | 2 DMA pieces of unit u+3
+//   s_waitcnt lgkmcnt(0) vmcnt(8); s_barrier   -- unit u+1 landed (units u+2, u+3 = 8 pieces stay in flight),
+//                                                 every wave has finished READING unit u
+// so an LDS round trip is covered by 8 MFMAs of the same wave, a DMA piece has two full windows to land
+// and the memory queue is never drained.  Buffer (u+3)&3 = (u-1)&3 is free from barrier u-1 on.
+#pragma once
+
+#include "mfma_pp.h"
+
+namespace mevi {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int H1_QT = 256;  // B rows per workgroup
+constexpr int H1_ROWS = 2 * BM + H1_QT;
+constexpr int H1_LD = 16;   // floats (64 B) per LDS row of one unit
+constexpr int H1_NBUF = 4;  // units resident in LDS: one being read, three landing
+constexpr int H1_UNIT = H1_ROWS * H1_LD;  // floats per unit buffer (32 KiB)
+constexpr size_t h1_lds_bytes() { return (size_t)H1_NBUF * H1_UNIT * sizeof(float); }
+
+__device__ __forceinline__ void pp_mainloop_f16(const void *src, unsigned int src_bytes, int row_bytes, int nunits,
+                                                float *lds, f32x16 (&acc)[2][4]) {
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = w8 >> 2, wm = (w8 >> 1) & 1, wn = w8 & 1;
+  const int lrow = lane & 31;
+  const int half = lane >> 5;
+  // DMA piece i of this wave fills LDS rows 64*w8 + 16*i + (lane>>2), slot lane&3, which holds logical piece
+  // c = (lane&3) ^ ((row>>2)&3), (row>>2)&3 = (lane>>4)&3
+  const int cpiece = (lane & 3) ^ ((lane >> 4) & 3);
+  int voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) voff[i] = (64 * (w8 & 3) + 16 * i + (lane >> 2)) * row_bytes + cpiece * 16;
+
+  // pieces [p0, p0+2) of unit u; units past the end get an empty descriptor (no fetch), so the number of
+  // pieces in flight -- what the counted vmcnt relies on -- is the same in every window
+  auto dma2 = [&](int u, int p0) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(src), 0, u < nunits ? (int)src_bytes : 0, 0x00020000);
+    float *base = lds + (u & (H1_NBUF - 1)) * H1_UNIT + (64 * w8) * H1_LD;
+#pragma unroll
+    for (int i = p0; i < p0 + 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(base + 16 * i * H1_LD), 16,
+                                               voff[i], u * 64, 0, 0);
+  };
+
+  const int sw = (lrow >> 2) & 3;  // fragment rows are lrow + multiples of 32
+  int cj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) cj[j] = ((2 * j + half) ^ sw) * 4;  // float offset of this lane's piece, k-step j
+  const int offa = (grp * BM + 64 * wm + lrow) * H1_LD;
+  const int offb = (2 * BM + 128 * wn + lrow) * H1_LD;
+  struct Frag {
+    f16x8 a[2], b[4];
+  };
+  auto read = [&](int u, int j, Frag &f) {
+    const float *p = lds + (u & (H1_NBUF - 1)) * H1_UNIT + cj[j];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) f.a[mi] = *reinterpret_cast<const f16x8 *>(p + offa + 32 * mi * H1_LD);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) f.b[ni] = *reinterpret_cast<const f16x8 *>(p + offb + 32 * ni * H1_LD);
+  };
+  auto mma = [&](const Frag &f) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
+  };
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  Frag F0, F1;
+
+  auto window = [&](int u, bool first) {
+    read(u, 0, F0);
+    if (!first) mma(F1);
+    dma2(u + 3, 0);
+    if (!first) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    read(u, 1, F1);
+    mma(F0);
+    dma2(u + 3, 2);
+    // first MFMA ahead of the reads: its wait covers the fragments issued a group ago, not these
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // unit u+1 landed once at most the 8 pieces of units u+2, u+3 are outstanding; own reads of unit u done
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  dma2(0, 0);
+  dma2(0, 2);
+  dma2(1, 0);
+  dma2(1, 2);
+  dma2(2, 0);
+  dma2(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // unit 0 landed
+  __builtin_amdgcn_sched_barrier(0);
+  window(0, true);
+  for (int u = 1; u < nunits; ++u) window(u, false);
+  mma(F1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the empty tail pieces: nothing may target LDS past the loop
+}
+
+}  // namespace mevi

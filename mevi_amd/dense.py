@@ -52,7 +52,7 @@ class DenseIndex:
     """A corpus shard prepared for searching -- the analogue of faiss `index.add(doc)`
     (MEVI/faiss_search.py:19): keeps the f32 rows and their (hi, lo) bfloat16 split image.
     `search` returns exactly what `ip_topk` returns (bit for bit), ~3x faster: candidates are
-    selected with bf16 MFMAs, re-scored with the exact f32 chain and proven complete per query."""
+    selected with f16 MFMAs, re-scored with the exact f32 chain and proven complete per query."""
 
     def __init__(self, docs):
         hip.require_gpu()

@@ -25,7 +25,7 @@ def _run_indexed(q, d, k, cuda, id_offset=0):
 
 
 def _check(q, d, k, cuda, id_offset=0):
-    """Both the exact-f32 path and the indexed (bf16x3 pre-filter + exact re-score) path, bit for bit."""
+    """Both the exact-f32 path and the indexed (f16 pre-filter + exact re-score) path, bit for bit."""
     s, i = _run(q, d, k, cuda, id_offset)
     es, ei = odense.ip_topk_exact(q, d, k, id_offset)
     np.testing.assert_array_equal(i, ei)
@@ -193,7 +193,7 @@ def test_blas_restatement_agrees_to_rounding(cuda):
 
 
 def test_indexed_prefilter_proves_most_queries_and_falls_back_for_the_rest(cuda):
-    """Random data: the bf16x3 bound proves (nearly) every query.  Near-duplicate scores beyond the
+    """Random data: the f16 bound proves (nearly) every query.  Near-duplicate scores beyond the
     margin (many rows within eps of the k-th score) cannot be proven -> exact fallback, same answer."""
     rng = np.random.default_rng(31)
     q = rng.standard_normal((300, 768), dtype=np.float32)

@@ -58,7 +58,7 @@ def test_shard_count_invariance_at_full_size(c2):
 
 
 def test_indexed_prefilter_equals_exact_path_at_full_size(c2):
-    """The bf16x3 pre-filtered search must return the exact-f32 search's lists bit for bit, with (nearly)
+    """The f16 pre-filtered search must return the exact-f32 search's lists bit for bit, with (nearly)
     every query proven by the error bound rather than by the fallback."""
     from mevi_amd import hip
 
