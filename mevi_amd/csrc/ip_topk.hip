@@ -60,6 +60,76 @@ static inline TopkGeom make_geom(int k) {
 }
 
 // ---------------------------------------------------------------------------
+// Threshold-filter epilogue of one wave tile (64 corpus rows x 32*NI queries, acc[2][NI]).
+// C/D map of the 32x32 MFMA: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*half (doc).
+// Every score above the query's current threshold becomes a candidate key in the query's buffer.
+// Slots are handed out by ONE atomic per query column and wave tile (the two lanes of a column pool
+// their counts), all NI of them in flight together, instead of one returning atomic per candidate:
+//   pass 1  count the passing elements per lane and column
+//   atomics base slot per column
+//   pass 2  store the keys (plain stores; accumulators no lane passes in are skipped wave-wide)
+template <int NI>
+__device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], int q0, int nq, long long d0, long long doc_end,
+                                          const float *__restrict__ tau, unsigned long long *__restrict__ buf,
+                                          unsigned int *__restrict__ count, int S, int k, int cap,
+                                          unsigned int id_base) {
+  const int lane = threadIdx.x & 63;
+  const int lrow = lane & 31, half = lane >> 5;
+  if (d0 + 64 > doc_end) {  // ragged last tile (wave-uniform): rows past the shard never pass
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (d0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half >= doc_end) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] = -INFINITY;
+        }
+  }
+  float tq[NI];
+  unsigned int n[NI], base[NI];
+  bool any[2][NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int qi = q0 + 32 * ni + lrow;
+    tq[ni] = qi < nq ? tau[qi] : INFINITY;
+    n[ni] = 0u;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      unsigned int c = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c += acc[mi][ni][r] > tq[ni] ? 1u : 0u;
+      any[mi][ni] = __any(c != 0u);
+      n[ni] += c;
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const unsigned int other = __shfl_xor(n[ni], 32);
+    base[ni] = 0u;
+    if (half == 0 && n[ni] + other != 0u) base[ni] = atomicAdd(&count[q0 + 32 * ni + lrow], n[ni] + other);
+    n[ni] = other;  // kept for the upper half's offset
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const unsigned int b = __shfl(base[ni], lrow);
+    unsigned int slot = half == 0 ? b : b + n[ni];  // lower half's candidates first, then the upper half's
+    unsigned long long *dst = buf + (size_t)(q0 + 32 * ni + lrow) * S + k;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      if (!any[mi][ni]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[mi][ni][r];
+        if (v > tq[ni]) {
+          if (slot < (unsigned int)cap)
+            dst[slot] = make_key(v, id_base + (unsigned int)(d0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half));
+          ++slot;
+        }
+      }
+    }
+  }
+}
+
 // ip_filter_kernel: the shared f32-MFMA ping-pong tile loop (mfma_pp.h) with a threshold-
 // filter epilogue.  A = corpus rows (two 128-row tiles per workgroup), B = 128 queries.
 template <int NI, bool KTAIL>
@@ -82,7 +152,6 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
   const int lane = t & 63;
   const int wave = tg >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lrow = lane & 31, half = lane >> 5;
   const int srow = tg >> 3, skq = (tg & 7) * 4;
   const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
   const int qrow0 = qtile * QT;
@@ -105,30 +174,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
   f32x16 acc[2][NI];
   pp_mainloop<NI, KTAIL>(dptr, qptr, dim, lds, acc);
 
-  // ---- epilogue: threshold filter -------------------------------------------
-  // C/D map of the 32x32 MFMA: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*half (doc)
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int qi = qrow0 + 32 * NI * wn + 32 * ni + lrow;
-    const bool qok = qi < nq;
-    const float tq = qok ? tau[qi] : INFINITY;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[mi][ni][r];
-        if (v > tq) {
-          const long long dr = drow0 + 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (dr < doc_end) {
-            const unsigned int slot = atomicAdd(&count[qi], 1u);
-            if (slot < (unsigned int)cap) {
-              buf[(size_t)qi * S + k + slot] = make_key(v, id_base + (unsigned int)dr);
-            }
-          }
-        }
-      }
-    }
-  }
+  emit_tile<NI>(acc, qrow0 + 32 * NI * wn, nq, drow0 + 64 * wm, doc_end, tau, buf, count, S, k, cap, id_base);
 }
 
 __global__ __launch_bounds__(256) void init_state_kernel(unsigned long long *buf, unsigned int *count,
@@ -422,7 +468,6 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
   const int lane = t & 63;
   const int wave = tg >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lrow = lane & 31, half = lane >> 5;
   const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
   const int qrow0 = qtile * H1_QT;
   const int row_bytes = dimp * 2;
@@ -442,26 +487,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
   const unsigned int src_bytes = (unsigned int)(rows_left * row_bytes);
   f32x16 acc[2][4];
   pp_mainloop_f16(src, src_bytes, row_bytes, dimp / 32, lds, acc);
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int qi = qrow0 + 128 * wn + 32 * ni + lrow;
-    const bool qok = qi < nq;
-    const float tq = qok ? tau[qi] : INFINITY;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[mi][ni][r];
-        if (v > tq) {
-          const long long dr = drow0 + 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (dr < doc_end) {
-            const unsigned int slot = atomicAdd(&count[qi], 1u);
-            if (slot < (unsigned int)cap) buf[(size_t)qi * S + k + slot] = make_key(v, id_base + (unsigned int)dr);
-          }
-        }
-      }
-    }
-  }
+  emit_tile<4>(acc, qrow0 + 128 * wn, nq, drow0 + 64 * wm, doc_end, tau, buf, count, S, k, cap, id_base);
 }
 
 // Exact re-scoring of the kp approximate survivors of one query, exact top-k, and the proof that
