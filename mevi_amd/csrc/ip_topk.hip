@@ -62,15 +62,17 @@ static inline TopkGeom make_geom(int k) {
 // ---------------------------------------------------------------------------
 // Threshold-filter epilogue of one wave tile (64 corpus rows x 32*NI queries, acc[2][NI]).
 // C/D map of the 32x32 MFMA: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*half (doc).
-// Every score above the query's current threshold becomes a candidate key in the query's buffer.
+// Every score above the query's current threshold tq[ni] (= tau of column q0 + 32*ni + lane&31, +inf past
+// nq; loaded by the caller, early) becomes a candidate key in the query's buffer.
 // Slots are handed out by ONE atomic per query column and wave tile (the two lanes of a column pool
 // their counts), all NI of them in flight together, instead of one returning atomic per candidate:
-//   pass 1  count the passing elements per lane and column
+//   pass 1  per accumulator: max of its 16 values (v_max3) -> skipped wave-wide when no lane beats its
+//           threshold; otherwise count the passing elements per lane
 //   atomics base slot per column
-//   pass 2  store the keys (plain stores; accumulators no lane passes in are skipped wave-wide)
+//   pass 2  store the keys of the accumulators that had any (plain stores)
 template <int NI>
-__device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], int q0, int nq, long long d0, long long doc_end,
-                                          const float *__restrict__ tau, unsigned long long *__restrict__ buf,
+__device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq)[NI], int q0, long long d0,
+                                          long long doc_end, unsigned long long *__restrict__ buf,
                                           unsigned int *__restrict__ count, int S, int k, int cap,
                                           unsigned int id_base) {
   const int lane = threadIdx.x & 63;
@@ -85,22 +87,24 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], int q0, int nq, 
           for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] = -INFINITY;
         }
   }
-  float tq[NI];
-  unsigned int n[NI], base[NI];
-  bool any[2][NI];
+  unsigned int c[2][NI], n[NI], base[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int qi = q0 + 32 * ni + lrow;
-    tq[ni] = qi < nq ? tau[qi] : INFINITY;
-    n[ni] = 0u;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      unsigned int c = 0u;
+      const f32x16 &a = acc[mi][ni];
+      float m = fmaxf(fmaxf(a[0], a[1]), a[2]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c += acc[mi][ni][r] > tq[ni] ? 1u : 0u;
-      any[mi][ni] = __any(c != 0u);
-      n[ni] += c;
+      for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, a[r]), a[r + 1]);
+      m = fmaxf(m, a[15]);
+      unsigned int cc = 0u;
+      if (__any(m > tq[ni])) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cc += a[r] > tq[ni] ? 1u : 0u;
+      }
+      c[mi][ni] = cc;
     }
+    n[ni] = c[0][ni] + c[1][ni];
   }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -116,7 +120,7 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], int q0, int nq, 
     unsigned long long *dst = buf + (size_t)(q0 + 32 * ni + lrow) * S + k;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      if (!any[mi][ni]) continue;
+      if (!__any(c[mi][ni] != 0u)) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[mi][ni][r];
@@ -127,6 +131,17 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], int q0, int nq, 
         }
       }
     }
+  }
+}
+
+// thresholds of the NI query columns of this lane
+template <int NI>
+__device__ __forceinline__ void load_tq(float (&tq)[NI], const float *__restrict__ tau, int q0, int nq) {
+  const int lrow = threadIdx.x & 31;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int qi = q0 + 32 * ni + lrow;
+    tq[ni] = qi < nq ? tau[qi] : INFINITY;
   }
 }
 
@@ -149,7 +164,6 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
   const int t = threadIdx.x;
   const int grp = __builtin_amdgcn_readfirstlane(t >> 8);
   const int tg = t & 255;
-  const int lane = t & 63;
   const int wave = tg >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int srow = tg >> 3, skq = (tg & 7) * 4;
@@ -174,7 +188,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_kernel(
   f32x16 acc[2][NI];
   pp_mainloop<NI, KTAIL>(dptr, qptr, dim, lds, acc);
 
-  emit_tile<NI>(acc, qrow0 + 32 * NI * wn, nq, drow0 + 64 * wm, doc_end, tau, buf, count, S, k, cap, id_base);
+  float tq[NI];
+  load_tq<NI>(tq, tau, qrow0 + 32 * NI * wn, nq);
+  emit_tile<NI>(acc, tq, qrow0 + 32 * NI * wn, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base);
 }
 
 __global__ __launch_bounds__(256) void init_state_kernel(unsigned long long *buf, unsigned int *count,
@@ -453,41 +469,63 @@ __global__ __launch_bounds__(256) void split_queries_f16_kernel(const float *__r
 // Approximate scores (f16) + threshold filter: same epilogue as ip_filter_kernel, A = f16 corpus rows (two
 // 128-row tiles), B = 256 f16 queries.  Keys carry the RAW accumulator (= S_q S_d x the centred approximate
 // score): per query that is a monotone image of the approximate score, which is all tau and the ranking need.
+// Persistent: gridDim.x (a multiple of 8) workgroups; the workgroups of one XCD (blockIdx & 7) walk that XCD's
+// contiguous range of work items side by side, so at any time they sit in one super-tile and share both
+// operands through the XCD's L2.
 __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
     const float *__restrict__ Qh, int nq, const float *__restrict__ Dh, long long doc_begin, long long doc_end,
     int dimp, const float *__restrict__ tau, unsigned long long *__restrict__ buf,
     unsigned int *__restrict__ count, int S, int k, int cap, unsigned int id_base, int n_qtiles, int n_dpairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nwg = n_qtiles * n_dpairs;
-  const int wg = xcd_remap(blockIdx.x, nwg);
-  int dpair, qtile;
-  supertile_order<4, 8>(wg, n_dpairs, n_qtiles, dpair, qtile);
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int range_base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;  // as xcd_remap
+  const int range_len = q8 + (xcd < r8 ? 1 : 0);
+  int item = blockIdx.x >> 3;  // next work item of this workgroup inside the XCD's range
   const int t = threadIdx.x;
-  const int grp = __builtin_amdgcn_readfirstlane(t >> 8);
-  const int tg = t & 255;
-  const int lane = t & 63;
-  const int wave = tg >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
-  const int qrow0 = qtile * H1_QT;
-  const int row_bytes = dimp * 2;
-  // DMA duty of this wave: waves 0-3 stage the two corpus tiles (LDS rows [0,256)), waves 4-7 the query tile
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
-  const char *src;
-  long long rows_left;
-  if (w8 < 4) {
-    const long long first = doc_begin + (long long)dpair * 2 * BM;
-    src = reinterpret_cast<const char *>(Dh) + (size_t)first * (size_t)row_bytes;
-    rows_left = doc_end - first;
-  } else {
-    src = reinterpret_cast<const char *>(Qh) + (size_t)qrow0 * (size_t)row_bytes;
-    rows_left = nq - qrow0;
-  }
-  if (rows_left > 2 * BM) rows_left = 2 * BM;
-  const unsigned int src_bytes = (unsigned int)(rows_left * row_bytes);
-  f32x16 acc[2][4];
-  pp_mainloop_f16(src, src_bytes, row_bytes, dimp / 32, lds, acc);
-  emit_tile<4>(acc, qrow0 + 128 * wn, nq, drow0 + 64 * wm, doc_end, tau, buf, count, S, k, cap, id_base);
+  const int grp = w8 >> 2, wm = (w8 >> 1) & 1, wn = w8 & 1;
+  const int row_bytes = dimp * 2;
+  // tiles fetched ahead of their epilogue: (dpair, qtile) FIFO, at most two entries
+  int pend_d[2], pend_q[2], n_pend = 0;
+
+  auto next = [&](H1Src &s) -> bool {
+    if (item >= range_len) return false;
+    int dpair, qtile;
+    supertile_order<4, 8>(range_base + item, n_dpairs, n_qtiles, dpair, qtile);
+    item += per_xcd;
+    pend_d[n_pend] = dpair;
+    pend_q[n_pend] = qtile;
+    ++n_pend;
+    // DMA duty of this wave: waves 0-3 stage the two corpus tiles (LDS rows [0,256)), waves 4-7 the query tile
+    long long rows_left;
+    if (w8 < 4) {
+      const long long first = doc_begin + (long long)dpair * 2 * BM;
+      s.src = reinterpret_cast<const char *>(Dh) + (size_t)first * (size_t)row_bytes;
+      rows_left = doc_end - first;
+    } else {
+      const int qrow0 = qtile * H1_QT;
+      s.src = reinterpret_cast<const char *>(Qh) + (size_t)qrow0 * (size_t)row_bytes;
+      rows_left = nq - qrow0;
+    }
+    if (rows_left > 2 * BM) rows_left = 2 * BM;
+    s.bytes = (unsigned int)(rows_left * row_bytes);
+    return true;
+  };
+  float tq[4];
+  auto begin = [&]() {  // start of the tile at the head of the FIFO: fetch its thresholds under the main loop
+    load_tq<4>(tq, tau, pend_q[0] * H1_QT + 128 * wn, nq);
+  };
+  auto emit = [&](f32x16 (&acc)[2][4]) {
+    const int dpair = pend_d[0], qtile = pend_q[0];
+    pend_d[0] = pend_d[1];
+    pend_q[0] = pend_q[1];
+    --n_pend;
+    const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
+    emit_tile<4>(acc, tq, qtile * H1_QT + 128 * wn, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base);
+  };
+  h1_tile_stream(row_bytes, dimp / 32, lds, next, begin, emit);
 }
 
 // Exact re-scoring of the kp approximate survivors of one query, exact top-k, and the proof that
@@ -658,6 +696,13 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
     set_error("ip_topk: cannot raise dynamic LDS to %zu bytes", pp_lds);
     return -1;
   }
+  int n_cu = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8)
+      n_cu = v;
+  }
   int64_t seen = 0, launches = 0;
   while (seen < nd) {
     int64_t chunk = cap_docs;
@@ -680,7 +725,12 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       const float *tau_c = st.tau;
       void *args[] = {(void *)&Q, &nq_i, (void *)&D, &d0, &d1, &dim, (void *)&tau_c, (void *)&st.buf,
                       (void *)&st.count, (void *)&g.S, (void *)&g.k, (void *)&g.cap, &id_base, &n_qt, &n_dp};
-      if (hipLaunchKernel(fn, dim3((unsigned)nwg), dim3(PP_THREADS), args, pp_lds, stream) != hipSuccess) {
+      unsigned grid = (unsigned)nwg;
+      if (h1) {  // persistent: one workgroup per CU (128 KiB of LDS each), a multiple of 8 so every XCD gets its share
+        const int64_t per_xcd = (nwg + 7) / 8 < n_cu / 8 ? (nwg + 7) / 8 : n_cu / 8;
+        grid = (unsigned)(8 * per_xcd);
+      }
+      if (hipLaunchKernel(fn, dim3(grid), dim3(PP_THREADS), args, pp_lds, stream) != hipSuccess) {
         set_error("ip_topk: filter kernel launch failed");
         return -1;
       }
@@ -797,7 +847,9 @@ struct IndexView {
   double *colsum;            // [dimp] build scratch
 };
 inline int64_t pad32(int64_t d) { return (d + 31) / 32 * 32; }
-inline size_t index_image_bytes(int64_t nd, int64_t dim) { return align_up((size_t)nd * pad32(dim) * 2, 256); }
+// k extent of the f16 images: whole 32-wide units, at least three (h1_tile_stream prefetches three units ahead)
+inline int64_t pad_k(int64_t d) { return pad32(d) < 96 ? 96 : pad32(d); }
+inline size_t index_image_bytes(int64_t nd, int64_t dim) { return align_up((size_t)nd * pad_k(dim) * 2, 256); }
 inline IndexView view_index(const void *index, int64_t nd, int64_t dim) {
   const char *p = reinterpret_cast<const char *>(index);
   IndexView v;
@@ -806,7 +858,7 @@ inline IndexView view_index(const void *index, int64_t nd, int64_t dim) {
   v.norms_c = reinterpret_cast<const float *>(p);
   p += align_up((size_t)nd * 4, 256);
   v.mu = reinterpret_cast<const float *>(p);
-  p += align_up((size_t)pad32(dim) * 4, 256);
+  p += align_up((size_t)pad_k(dim) * 4, 256);
   v.bits = reinterpret_cast<const unsigned int *>(p);
   v.scal = reinterpret_cast<const float *>(p + 16);
   p += 256;
@@ -821,8 +873,8 @@ inline int h1_kprime(int k) {  // survivors kept per query: k plus a margin for 
 
 extern "C" size_t mevi_ip_index_bytes(int64_t nd, int64_t dim) {
   if (nd < 0 || dim <= 0) return 0;
-  return index_image_bytes(nd, dim) + align_up((size_t)nd * 4, 256) + align_up((size_t)pad32(dim) * 4, 256) + 256 +
-         align_up((size_t)pad32(dim) * 8, 256);
+  return index_image_bytes(nd, dim) + align_up((size_t)nd * 4, 256) + align_up((size_t)pad_k(dim) * 4, 256) + 256 +
+         align_up((size_t)pad_k(dim) * 8, 256);
 }
 
 extern "C" int mevi_ip_index_build_f32(const float *docs, int64_t nd, int64_t dim, void *index, size_t index_bytes,
@@ -834,7 +886,7 @@ extern "C" int mevi_ip_index_build_f32(const float *docs, int64_t nd, int64_t di
   MEVI_REQUIRE(((uintptr_t)index % 256) == 0 && ((uintptr_t)docs % 16) == 0, MEVI_ERR_INVALID_ARG,
                "ip_index_build: index must be 256-byte, docs 16-byte aligned");
   IndexView v = view_index(index, nd, dim);
-  const int dimp = (int)pad32(dim);
+  const int dimp = (int)pad_k(dim);
   // mean, maxima, scale and the scratch sums all start from zero (an empty shard keeps mu = 0, S_d = 1)
   MEVI_HIP_CHECK(hipMemsetAsync(const_cast<float *>(v.mu), 0,
                                 align_up((size_t)dimp * 4, 256) + 256 + align_up((size_t)dimp * 8, 256), stream));
@@ -861,7 +913,7 @@ extern "C" size_t mevi_ip_topk_indexed_workspace_bytes(int64_t nq, int64_t dim, 
   const TopkGeom gp = make_geom(h1_kprime((int)k));
   // approx state (K' geometry) + exact top lists + f16 queries + per-query norm / scale / shift, then the
   // exact-path workspace for the fallback
-  return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)nq * pad32(dim) * 2, 256) +
+  return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)nq * pad_k(dim) * 2, 256) +
          2 * align_up((size_t)(nq + 1) * 4, 256) + align_up((size_t)nq * 8, 256) +
          mevi_ip_topk_workspace_bytes(nq, dim, k) + 256;
 }
@@ -887,7 +939,7 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
 
   const int kp = h1_kprime((int)k);
   const TopkGeom gp = make_geom(kp), g = make_geom((int)k);
-  const int64_t dimp = pad32(dim);
+  const int64_t dimp = pad_k(dim);
   IndexView iv = view_index(index, nd, dim);
   char *p = reinterpret_cast<char *>(workspace);
   SearchState st = carve_state(p, nq, gp);

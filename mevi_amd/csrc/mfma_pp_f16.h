@@ -1,6 +1,7 @@
 // f16 tile loop of the pre-filter (ip_topk.hip, ip_filter_h1_kernel).
 //
 // Operands are f16 images of the f32 rows, row-major, row = dimp halves (dimp = dim padded to 32):
+// (dimp >= 96: a tile spans at least three 32-wide units, see h1_tile_stream)
 //   docs    : f16((d - mu) * S_d)      mu = column mean of the shard, S_d one power of two for the shard
 //   queries : f16(q * S_q)             S_q a power of two per query
 //   acc = sum_k a_k * b_k              ONE v_mfma_f32_32x32x16_f16 per 16 k, f32 accumulate
@@ -32,13 +33,19 @@
 // `src` = first row of the wave's operand tile (docs: waves 0-3, queries: waves 4-7), `src_bytes` = bytes
 // from there to the end of the operand (rows past it read as 0 and are masked in the epilogue).
 //
-// Pipeline (per wave, unit u, window W_u = barrier u-1 .. barrier u; F0/F1 = fragment register sets):
-//   PA: ds_read F0 <- (u, j=0)   | 8 MFMA on F1 = (u-1, j=1) | 2 DMA pieces of unit u+3
-//   PB: ds_read F1 <- (u, j=1)   | 8 MFMA on F0 = (u,   j=0) | 2 DMA pieces of unit u+3
-//   s_waitcnt lgkmcnt(0) vmcnt(8); s_barrier   -- unit u+1 landed (units u+2, u+3 = 8 pieces stay in flight),
-//                                                 every wave has finished READING unit u
+// Pipeline (per wave; the unit stream runs ACROSS tiles, g = stream position, u = unit within the tile;
+// window W_g = barrier g-1 .. barrier g; F0/F1 = fragment register sets):
+//   PA: ds_read F0 <- (g, j=0)   | 8 MFMA on F1 = (g-1, j=1) | 2 DMA pieces of stream unit g+3
+//   PB: ds_read F1 <- (g, j=1)   | 8 MFMA on F0 = (g,   j=0) | 2 DMA pieces of stream unit g+3
+//   s_waitcnt lgkmcnt(0) vmcnt(8); s_barrier   -- unit g+1 landed (units g+2, g+3 = 8 pieces stay in flight),
+//                                                 every wave has finished READING unit g
 // so an LDS round trip is covered by 8 MFMAs of the same wave, a DMA piece has two full windows to land
-// and the memory queue is never drained.  Buffer (u+3)&3 = (u-1)&3 is free from barrier u-1 on.
+// and the memory queue is never drained.  Buffer (g+3)&3 = (g-1)&3 is free from barrier g-1 on.
+// The workgroup is PERSISTENT: it walks a list of tiles, and the last three windows of a tile already stage
+// the first three units of the next one, so the fill latency of a tile (a cold 4 us round trip through
+// L2/HBM) is paid once per workgroup, not once per tile, and the staging of tile t+1 proceeds under the
+// epilogue of tile t.  (Other vector-memory operations of the epilogue only ever make the counted wait
+// stricter: vmcnt completes in order.)
 #pragma once
 
 #include "mfma_pp.h"
@@ -54,8 +61,21 @@ constexpr int H1_NBUF = 4;  // units resident in LDS: one being read, three land
 constexpr int H1_UNIT = H1_ROWS * H1_LD;  // floats per unit buffer (32 KiB)
 constexpr size_t h1_lds_bytes() { return (size_t)H1_NBUF * H1_UNIT * sizeof(float); }
 
-__device__ __forceinline__ void pp_mainloop_f16(const void *src, unsigned int src_bytes, int row_bytes, int nunits,
-                                                float *lds, f32x16 (&acc)[2][4]) {
+// What one wave stages for a tile: the 64 rows [0, 64) from `src` on, rows `row_bytes` apart, valid up to
+// `bytes` (wave-uniform).
+struct H1Src {
+  const void *src;
+  unsigned int bytes;
+};
+
+// next(H1Src &) -> bool : fetch this wave's source of the workgroup's next tile (false: no more tiles); it is
+//                         called one tile AHEAD of the tile being computed
+// begin()               : the oldest fetched tile starts computing (load what its epilogue will need)
+// emit(acc)             : epilogue of that tile (tiles complete in the order next() returned them)
+// nunits >= 3 (the images are padded to at least 96 k).
+template <class Next, class Begin, class Emit>
+__device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float *lds, Next next, Begin begin,
+                                               Emit emit) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -69,12 +89,18 @@ __device__ __forceinline__ void pp_mainloop_f16(const void *src, unsigned int sr
 #pragma unroll
   for (int i = 0; i < 4; ++i) voff[i] = (64 * (w8 & 3) + 16 * i + (lane >> 2)) * row_bytes + cpiece * 16;
 
-  // pieces [p0, p0+2) of unit u; units past the end get an empty descriptor (no fetch), so the number of
-  // pieces in flight -- what the counted vmcnt relies on -- is the same in every window
-  auto dma2 = [&](int u, int p0) {
+  H1Src cur, nxt;
+  if (!next(cur)) return;  // no tile for this workgroup (uniform)
+  bool have_nxt = next(nxt);
+  if (!have_nxt) nxt.bytes = 0u, nxt.src = cur.src;
+
+  // pieces [p0, p0+2) of unit u of tile `s`, into stream buffer gb; an exhausted stream has bytes = 0 (empty
+  // descriptor, no fetch), so the number of pieces in flight -- what the counted vmcnt relies on -- is the
+  // same in every window
+  auto dma2 = [&](const H1Src &s, int u, int gb, int p0) {
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(src), 0, u < nunits ? (int)src_bytes : 0, 0x00020000);
-    float *base = lds + (u & (H1_NBUF - 1)) * H1_UNIT + (64 * w8) * H1_LD;
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.src), 0, (int)s.bytes, 0x00020000);
+    float *base = lds + (gb & (H1_NBUF - 1)) * H1_UNIT + (64 * w8) * H1_LD;
 #pragma unroll
     for (int i = p0; i < p0 + 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(base + 16 * i * H1_LD), 16,
@@ -90,13 +116,14 @@ __device__ __forceinline__ void pp_mainloop_f16(const void *src, unsigned int sr
   struct Frag {
     f16x8 a[2], b[4];
   };
-  auto read = [&](int u, int j, Frag &f) {
-    const float *p = lds + (u & (H1_NBUF - 1)) * H1_UNIT + cj[j];
+  auto read = [&](int gb, int j, Frag &f) {
+    const float *p = lds + (gb & (H1_NBUF - 1)) * H1_UNIT + cj[j];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) f.a[mi] = *reinterpret_cast<const f16x8 *>(p + offa + 32 * mi * H1_LD);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) f.b[ni] = *reinterpret_cast<const f16x8 *>(p + offb + 32 * ni * H1_LD);
   };
+  f32x16 acc[2][4];
   auto mma = [&](const Frag &f) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -105,19 +132,19 @@ __device__ __forceinline__ void pp_mainloop_f16(const void *src, unsigned int sr
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
   };
 
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
   Frag F0, F1;
+  int g = 0;  // stream position of the unit being computed (buffer g & 3)
 
   auto window = [&](int u, bool first) {
-    read(u, 0, F0);
+    // stream unit g+3: unit u+3 of this tile, or unit u+3-nunits of the next one
+    const bool spill = u + 3 >= nunits;
+    H1Src tgt;
+    tgt.src = spill ? nxt.src : cur.src;
+    tgt.bytes = spill ? nxt.bytes : cur.bytes;
+    const int tu = spill ? u + 3 - nunits : u + 3;
+    read(g, 0, F0);
     if (!first) mma(F1);
-    dma2(u + 3, 0);
+    dma2(tgt, tu, g + 3, 0);
     if (!first) {
       __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -127,9 +154,9 @@ __device__ __forceinline__ void pp_mainloop_f16(const void *src, unsigned int sr
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    read(u, 1, F1);
+    read(g, 1, F1);
     mma(F0);
-    dma2(u + 3, 2);
+    dma2(tgt, tu, g + 3, 2);
     // first MFMA ahead of the reads: its wait covers the fragments issued a group ago, not these
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
@@ -139,22 +166,36 @@ __device__ __forceinline__ void pp_mainloop_f16(const void *src, unsigned int sr
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     __builtin_amdgcn_sched_barrier(0);
-    // unit u+1 landed once at most the 8 pieces of units u+2, u+3 are outstanding; own reads of unit u done
+    // unit g+1 landed once at most the 8 pieces of units g+2, g+3 are outstanding; own reads of unit g done
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ++g;
   };
 
-  dma2(0, 0);
-  dma2(0, 2);
-  dma2(1, 0);
-  dma2(1, 2);
-  dma2(2, 0);
-  dma2(2, 2);
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    dma2(cur, u, u, 0);
+    dma2(cur, u, u, 2);
+  }
   asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // unit 0 landed
   __builtin_amdgcn_sched_barrier(0);
-  window(0, true);
-  for (int u = 1; u < nunits; ++u) window(u, false);
-  mma(F1);
+  while (true) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    begin();
+    window(0, true);
+    for (int u = 1; u < nunits; ++u) window(u, false);
+    mma(F1);
+    emit(acc);
+    if (!have_nxt) break;
+    cur = nxt;
+    have_nxt = next(nxt);
+    if (!have_nxt) nxt.bytes = 0u;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the empty tail pieces: nothing may target LDS past the loop
 }
 
