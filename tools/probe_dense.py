@@ -8,6 +8,8 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mevi_amd import dense, hip  # noqa: E402
 INDEXED = os.environ.get("INDEXED", "1") == "1"
+if os.environ.get("MEVI_PROBE_LIB"):  # A/B timing of another build of the library on the same device
+    hip.LIB = os.path.abspath(os.environ["MEVI_PROBE_LIB"])
 
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 6980
