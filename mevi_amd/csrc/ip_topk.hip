@@ -66,10 +66,10 @@ static inline TopkGeom make_geom(int k) {
 // nq; loaded by the caller, early) becomes a candidate key in the query's buffer.
 // Slots are handed out by ONE atomic per query column and wave tile (the two lanes of a column pool
 // their counts), all NI of them in flight together, instead of one returning atomic per candidate:
-//   pass 1  per accumulator: max of its 16 values (v_max3) -> skipped wave-wide when no lane beats its
-//           threshold; otherwise count the passing elements per lane
+//   pass 1  per accumulator: maxima of its register quads (v_max3) -> quads no lane beats its threshold in are
+//           skipped wave-wide; in the others count the passing elements per lane
 //   atomics base slot per column
-//   pass 2  store the keys of the accumulators that had any (plain stores)
+//   pass 2  store the keys of the quads that had any (plain stores)
 template <int NI>
 __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq)[NI], int q0, long long d0,
                                           long long doc_end, unsigned long long *__restrict__ buf,
@@ -87,24 +87,34 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq
           for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] = -INFINITY;
         }
   }
-  unsigned int c[2][NI], n[NI], base[NI];
+  // pass 1: per accumulator the maxima of its four register quads (rows 8i .. 8i+3 of the lane's half) and,
+  // where some lane beats its threshold, the number of passing elements per lane.  qmask: bit 4*(mi*NI+ni)+i
+  // set when some lane of the wave passes in quad i of accumulator (mi, ni) -- a wave-uniform work list for
+  // pass 2, which is then a handful of scalar tests instead of a vector compare per element.
+  unsigned int n[NI], base[NI];
+  unsigned int qmask = 0u;
+  static_assert(2 * NI * 4 <= 32, "quad mask must fit one SGPR");
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
+    n[ni] = 0u;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const f32x16 &a = acc[mi][ni];
-      float m = fmaxf(fmaxf(a[0], a[1]), a[2]);
+      float qm[4];
 #pragma unroll
-      for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, a[r]), a[r + 1]);
-      m = fmaxf(m, a[15]);
-      unsigned int cc = 0u;
+      for (int i = 0; i < 4; ++i) qm[i] = fmaxf(fmaxf(fmaxf(a[4 * i], a[4 * i + 1]), a[4 * i + 2]), a[4 * i + 3]);
+      const float m = fmaxf(fmaxf(fmaxf(qm[0], qm[1]), qm[2]), qm[3]);
       if (__any(m > tq[ni])) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cc += a[r] > tq[ni] ? 1u : 0u;
+        for (int i = 0; i < 4; ++i) {
+          if (__any(qm[i] > tq[ni])) {
+            qmask |= 1u << (4 * (mi * NI + ni) + i);
+#pragma unroll
+            for (int r = 4 * i; r < 4 * i + 4; ++r) n[ni] += a[r] > tq[ni] ? 1u : 0u;
+          }
+        }
       }
-      c[mi][ni] = cc;
     }
-    n[ni] = c[0][ni] + c[1][ni];
   }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -113,6 +123,8 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq
     if (half == 0 && n[ni] + other != 0u) base[ni] = atomicAdd(&count[q0 + 32 * ni + lrow], n[ni] + other);
     n[ni] = other;  // kept for the upper half's offset
   }
+  // key = ord(score) << 32 | ~id;  ~(id0 + c) = ~id0 - c
+  const unsigned int nid0 = 0xFFFFFFFFu - (id_base + (unsigned int)(d0 + 4 * half));
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const unsigned int b = __shfl(base[ni], lrow);
@@ -120,14 +132,19 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq
     unsigned long long *dst = buf + (size_t)(q0 + 32 * ni + lrow) * S + k;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      if (!__any(c[mi][ni] != 0u)) continue;
+      if (((qmask >> (4 * (mi * NI + ni))) & 15u) == 0u) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[mi][ni][r];
-        if (v > tq[ni]) {
-          if (slot < (unsigned int)cap)
-            dst[slot] = make_key(v, id_base + (unsigned int)(d0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half));
-          ++slot;
+      for (int i = 0; i < 4; ++i) {
+        if (((qmask >> (4 * (mi * NI + ni) + i)) & 1u) == 0u) continue;
+#pragma unroll
+        for (int r = 4 * i; r < 4 * i + 4; ++r) {
+          const float v = acc[mi][ni][r];
+          if (v > tq[ni]) {
+            if (slot < (unsigned int)cap)
+              dst[slot] = ((unsigned long long)f32_to_ord(v) << 32) |
+                          (unsigned long long)(nid0 - (unsigned int)(32 * mi + (r & 3) + 8 * (r >> 2)));
+            ++slot;
+          }
         }
       }
     }
@@ -637,6 +654,7 @@ thread_local double g_growth = 0.0;
 thread_local int g_profile = 0;
 thread_local mevi_ip_topk_stats g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0};
 thread_local std::vector<hipEvent_t> g_events;  // triples: before filter, after filter, after compact
+thread_local std::vector<long long> g_chunk_rows;  // rows of the launch each triple brackets (profiling on)
 
 static void profile_mark(hipStream_t stream) {
   if (!g_profile) return;
@@ -654,7 +672,10 @@ static void profile_collect() {
     (void)hipEventElapsedTime(&c, g_events[i + 1], g_events[i + 2]);
     g_stats.filter_ms += f;
     g_stats.compact_ms += c;
+    if (getenv("MEVI_IP_TOPK_TRACE") && i / 3 < g_chunk_rows.size())  // per-launch breakdown on stderr
+      fprintf(stderr, "ip_topk launch %zu: %lld rows  filter %.3f ms  compact %.3f ms\n", i / 3, g_chunk_rows[i / 3], f, c);
   }
+  g_chunk_rows.clear();
   for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
   g_events.clear();
 }
@@ -740,6 +761,7 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
                        st.count, st.tau, st.failed, g.S, g.k, g.cap);
     profile_mark(stream);
     g_stats.filter_flops += 2.0 * (double)nq * (double)chunk * (double)dim;
+    if (g_profile) g_chunk_rows.push_back((long long)chunk);
     seen += chunk;
     ++launches;
   }
