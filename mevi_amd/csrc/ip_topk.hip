@@ -504,16 +504,17 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
   const int grp = w8 >> 2, wm = (w8 >> 1) & 1, wn = w8 & 1;
   const int row_bytes = dimp * 2;
-  // tiles fetched ahead of their epilogue: (dpair, qtile) FIFO, at most two entries
-  int pend_d[2], pend_q[2], n_pend = 0;
+  // tiles fetched ahead of their epilogue: (dpair, qtile) FIFO of at most two entries, head and tail in
+  // scalars (an indexed array would live in scratch and drain the DMA queue on every access)
+  int head_d = 0, head_q = 0, tail_d = 0, tail_q = 0, n_pend = 0;
 
   auto next = [&](H1Src &s) -> bool {
     if (item >= range_len) return false;
     int dpair, qtile;
     supertile_order<4, 8>(range_base + item, n_dpairs, n_qtiles, dpair, qtile);
     item += per_xcd;
-    pend_d[n_pend] = dpair;
-    pend_q[n_pend] = qtile;
+    if (n_pend == 0) head_d = dpair, head_q = qtile;
+    else tail_d = dpair, tail_q = qtile;
     ++n_pend;
     // DMA duty of this wave: waves 0-3 stage the two corpus tiles (LDS rows [0,256)), waves 4-7 the query tile
     long long rows_left;
@@ -532,12 +533,11 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
   };
   float tq[4];
   auto begin = [&]() {  // start of the tile at the head of the FIFO: fetch its thresholds under the main loop
-    load_tq<4>(tq, tau, pend_q[0] * H1_QT + 128 * wn, nq);
+    load_tq<4>(tq, tau, head_q * H1_QT + 128 * wn, nq);
   };
   auto emit = [&](f32x16 (&acc)[2][4]) {
-    const int dpair = pend_d[0], qtile = pend_q[0];
-    pend_d[0] = pend_d[1];
-    pend_q[0] = pend_q[1];
+    const int dpair = head_d, qtile = head_q;
+    head_d = tail_d, head_q = tail_q;
     --n_pend;
     const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
     emit_tile<4>(acc, tq, qtile * H1_QT + 128 * wn, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base);
