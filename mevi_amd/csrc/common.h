@@ -60,25 +60,51 @@ __host__ __device__ static inline uint32_t key_id(uint64_t key) {
   return 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
 }
 
+// One compare-exchange stage of an in-LDS bitonic network over P 64-bit keys, NT threads.  A thread loads
+// the keys of four pairs before it compares and stores them: the LDS round trips of a stage overlap instead
+// of chaining (a plain loop re-reads the array it has just written, so every iteration waits for the last).
+// MERGE: every pair orders descending (the merge stages of a descending sort); otherwise the direction
+// follows the bitonic sort's block parity, (lo & size) == 0 -> descending.
+template <int NT, bool MERGE>
+__device__ __forceinline__ void bitonic_stage(unsigned long long *s, int P, int size, int stride, int t) {
+  const int npairs = P >> 1;
+  for (int i0 = t; i0 < npairs; i0 += 4 * NT) {
+    unsigned long long a[4], b[4];
+    int lo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * NT;
+      lo[u] = i < npairs ? 2 * i - (i & (stride - 1)) : -1;
+      if (lo[u] >= 0) {
+        a[u] = s[lo[u]];
+        b[u] = s[lo[u] + stride];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (lo[u] >= 0) {
+        const bool desc = MERGE || ((lo[u] & size) == 0);
+        if ((a[u] < b[u]) == desc) {
+          s[lo[u]] = b[u];
+          s[lo[u] + stride] = a[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // In-LDS bitonic sort (descending) of P 64-bit keys by NT threads.
 template <int NT>
 __device__ inline void bitonic_sort_desc(unsigned long long *s, int P, int t) {
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = t; i < (P >> 1); i += NT) {
-        const int lo = 2 * i - (i & (stride - 1));
-        const int hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long a = s[lo], b = s[hi];
-        if ((a < b) == desc) {
-          s[lo] = b;
-          s[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) bitonic_stage<NT, false>(s, P, size, stride, t);
 }
 
+// Merge stages only: s[0, P) bitonic (descending then ascending, or any rotation) -> sorted descending.
+template <int NT>
+__device__ inline void bitonic_merge_desc(unsigned long long *s, int P, int t) {
+  for (int stride = P >> 1; stride > 0; stride >>= 1) bitonic_stage<NT, true>(s, P, P, stride, t);
+}
 
 }  // namespace mevi

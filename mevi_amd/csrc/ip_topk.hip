@@ -10,7 +10,7 @@
 //     written: the epilogue compares every accumulator with the query's running
 //     threshold tau[q] (its current k-th best score) and appends the few
 //     survivors to a per-query candidate list with one atomic each.
-//   * compact_kernel    -- one workgroup per query: bitonic-sorts current top-k
+//   * compact_kernel    -- per query: radix-selects the k largest of current top-k
 //     + new candidates in LDS (64-bit score|id keys), keeps the best k, raises
 //     tau[q].
 //   The corpus is walked in geometrically growing chunks (each chunk doubles
@@ -227,31 +227,118 @@ __global__ __launch_bounds__(256) void init_state_kernel(unsigned long long *buf
   }
 }
 
-__global__ __launch_bounds__(256) void compact_kernel(unsigned long long *__restrict__ buf,
-                                                     unsigned int *__restrict__ count,
-                                                     float *__restrict__ tau,
-                                                     unsigned int *__restrict__ failed, int S, int k,
-                                                     int cap) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
-  const int q = blockIdx.x;
+// One query: keep the k largest of its (k survivors + c new candidates) keys, refresh tau, reset the
+// candidate count.  This is a SELECTION, not a sort: an MSB-first radix select (8-bit digits, LDS histogram)
+// finds the k-th largest key T, the keys above it are written back in arbitrary order and T itself goes to
+// slot k-1 (consumers read the k-th key there; nothing else relies on order -- the lists are sorted once, by
+// sort_lists_kernel or after the exact re-scoring).  A bitonic sort of the 4096-key case cost 78 LDS-bound
+// stages (1.3 ms per chunk for 6980 queries); the select reads the keys about five times.
+// Keys are unique (score, id) pairs except the empty key 0, so "above T" are exactly k-1 keys when T != 0.
+__device__ __forceinline__ void compact_query(unsigned long long *skeys, unsigned int *hist,
+                                              unsigned long long *__restrict__ row, unsigned int *__restrict__ count,
+                                              float *__restrict__ tau, unsigned int *__restrict__ failed, int q, int k,
+                                              int cap) {
   const int t = threadIdx.x;
   const unsigned int c_raw = count[q];
-  if (c_raw == 0u) return;  // nothing new for this query (uniform per block)
+  if (c_raw == 0u) return;  // nothing new for this query (uniform per workgroup)
   const int c = c_raw > (unsigned int)cap ? cap : (int)c_raw;
   const int n = k + c;
-  int P = 512;
-  while (P < n) P <<= 1;
-  unsigned long long *row = buf + (size_t)q * S;
-  for (int i = t; i < P; i += 256) skeys[i] = (i < n) ? row[i] : 0ull;
+  for (int i = t; i < n; i += 256) skeys[i] = row[i];
+  // hist[256..259]: prefix lo, prefix hi, rank still needed inside the prefix bucket, bucket size
+  unsigned long long prefix = 0ull;
+  unsigned int need = (unsigned int)k;
+  int shift = 56;
+  for (; shift >= 0; shift -= 8) {
+    hist[t] = 0u;
+    __syncthreads();
+    for (int i = t; i < n; i += 256) {
+      const unsigned long long key = skeys[i];
+      if (shift == 56 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (t < 64) {  // wave 0: the digit d where the count of larger digits first reaches `need`
+      const unsigned int h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+      const unsigned int g = h0 + h1 + h2 + h3;
+      unsigned int above = g;  // inclusive suffix sum over lanes >= t
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_down(above, off);
+        if (t + off < 64) above += o;
+      }
+      const unsigned int excl = above - g;  // keys in groups of larger digits
+      if (excl < need && need <= above) {   // exactly one lane
+        unsigned int cum = excl;
+        int d = 4 * t + 3;
+        unsigned int hd = h3;
+        if (cum + h3 < need) { cum += h3; d = 4 * t + 2; hd = h2;
+          if (cum + h2 < need) { cum += h2; d = 4 * t + 1; hd = h1;
+            if (cum + h1 < need) { cum += h1; d = 4 * t; hd = h0; } } }
+        hist[256] = (unsigned int)d;
+        hist[257] = need - cum;  // rank inside bucket d
+        hist[258] = hd;
+      }
+    }
+    __syncthreads();
+    prefix = (prefix << 8) | (unsigned long long)hist[256];
+    need = hist[257];
+    const unsigned int bucket = hist[258];
+    __syncthreads();
+    if (bucket == 1u) break;  // T is the only key with this prefix (uniform)
+  }
+  // T: all 64 bits fixed (shift < 0 after the last pass), or the unique key whose top bits equal `prefix`
+  unsigned long long T = prefix;
+  if (shift >= 0) {
+    if (shift > 0) {
+      for (int i = t; i < n; i += 256)
+        if ((skeys[i] >> shift) == prefix) {
+          hist[256] = (unsigned int)skeys[i];
+          hist[257] = (unsigned int)(skeys[i] >> 32);
+        }
+      __syncthreads();
+      T = ((unsigned long long)hist[257] << 32) | (unsigned long long)hist[256];
+      __syncthreads();
+    }
+  }
+  if (t == 0) hist[259] = 0u;
   __syncthreads();
-  bitonic_sort_desc<256>(skeys, P, t);
-  for (int i = t; i < k; i += 256) row[i] = skeys[i];
+  for (int i = t; i < n; i += 256) {
+    const unsigned long long key = skeys[i];
+    if (key > T) row[atomicAdd(&hist[259], 1u)] = key;
+  }
+  __syncthreads();
+  const int m = (int)hist[259];  // k-1 if T != 0; the number of non-empty keys (< k) if T == 0
+  for (int i = m + t; i < k; i += 256) row[i] = (i == k - 1) ? T : 0ull;
   if (t == 0) {
-    const unsigned long long kth = skeys[k - 1];
-    tau[q] = (kth != 0ull) ? key_score(kth) : -INFINITY;
+    tau[q] = (T != 0ull) ? key_score(T) : -INFINITY;
     count[q] = 0u;
     if (c_raw > (unsigned int)cap) failed[q] = 1u;
   }
+  __syncthreads();  // skeys / hist are reused by the workgroup's next query
+}
+
+// Workgroups walk the queries with a grid stride (S * 8 + 2 KiB of LDS each).
+__global__ __launch_bounds__(256) void compact_kernel(unsigned long long *__restrict__ buf,
+                                                     unsigned int *__restrict__ count,
+                                                     float *__restrict__ tau,
+                                                     unsigned int *__restrict__ failed, int nq, int S, int k,
+                                                     int cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  unsigned int *hist = reinterpret_cast<unsigned int *>(skeys + S);
+  for (int q = blockIdx.x; q < nq; q += gridDim.x)
+    compact_query(skeys, hist, buf + (size_t)q * S, count, tau, failed, q, k, cap);
+}
+
+// Sort every query's list (row[0, k)) descending: the last step of a pass whose lists are read as ranked output.
+__global__ __launch_bounds__(256) void sort_lists_kernel(unsigned long long *__restrict__ buf, int S, int k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  const int t = threadIdx.x;
+  unsigned long long *row = buf + (size_t)blockIdx.x * S;
+  int P = 64;
+  while (P < k) P <<= 1;
+  for (int i = t; i < P; i += 256) skeys[i] = (i < k) ? row[i] : 0ull;
+  __syncthreads();
+  bitonic_sort_desc<256>(skeys, P, t);
+  for (int i = t; i < k; i += 256) row[i] = skeys[i];
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long *__restrict__ buf, int S,
@@ -370,35 +457,43 @@ __global__ __launch_bounds__(256) void mean_kernel(const double *__restrict__ su
 }
 
 // per row: ||d - mu|| (stored, rounded up), and shard maxima bits[0] = max ||d - mu||, bits[1] = max ||d||,
-// bits[2] = max |d_k - mu_k|.  One wave per row.
+// bits[2] = max |d_k - mu_k|.  One wave per row, 16 rows per wave, one atomic per workgroup and maximum
+// (every row hitting the same three words serialises the whole pass).
 __global__ __launch_bounds__(256) void doc_stats_kernel(const float *__restrict__ x, long long n, int dim,
                                                        const float *__restrict__ mu, float *__restrict__ norms_c,
                                                        unsigned int *__restrict__ bits) {
-  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n) return;
-  const int lane = threadIdx.x & 63;
-  const float *xr = x + (size_t)r * dim;
-  float sc = 0.f, sr = 0.f, mx = 0.f;
-  for (int k = lane * 4; k < dim; k += 256) {
-    const float4 v = *reinterpret_cast<const float4 *>(xr + k);
-    const float4 m = *reinterpret_cast<const float4 *>(mu + k);
-    const float c0 = v.x - m.x, c1 = v.y - m.y, c2 = v.z - m.z, c3 = v.w - m.w;
-    sc = fmaf(c0, c0, fmaf(c1, c1, fmaf(c2, c2, fmaf(c3, c3, sc))));
-    sr = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, sr))));
-    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(c0), fabsf(c1))), fmaxf(fabsf(c2), fabsf(c3)));
+  __shared__ float red[3][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r0 = ((long long)blockIdx.x * 4 + wave) * 16;
+  float mc = 0.f, mr = 0.f, mx = 0.f;
+  for (long long r = r0; r < r0 + 16 && r < n; ++r) {
+    const float *xr = x + (size_t)r * dim;
+    float sc = 0.f, sr = 0.f;
+    for (int k = lane * 4; k < dim; k += 256) {
+      const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+      const float4 m = *reinterpret_cast<const float4 *>(mu + k);
+      const float c0 = v.x - m.x, c1 = v.y - m.y, c2 = v.z - m.z, c3 = v.w - m.w;
+      sc = fmaf(c0, c0, fmaf(c1, c1, fmaf(c2, c2, fmaf(c3, c3, sc))));
+      sr = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, sr))));
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(c0), fabsf(c1))), fmaxf(fabsf(c2), fabsf(c3)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sc += __shfl_xor(sc, off);
+      sr += __shfl_xor(sr, off);
+    }
+    const float nc = sqrtf(sc) * 1.00001f, nr = sqrtf(sr) * 1.00001f;  // round up: bounds must hold for the real norms
+    if (lane == 0) norms_c[r] = nc;
+    mc = fmaxf(mc, nc);
+    mr = fmaxf(mr, nr);
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    sc += __shfl_xor(sc, off);
-    sr += __shfl_xor(sr, off);
-    mx = fmaxf(mx, __shfl_xor(mx, off));
-  }
-  if (lane == 0) {
-    const float nc = sqrtf(sc) * 1.00001f, nr = sqrtf(sr) * 1.00001f;  // round up: bounds must hold for the real norms
-    norms_c[r] = nc;
-    atomicMax(&bits[0], __float_as_uint(nc));  // non-negative floats order as uints
-    atomicMax(&bits[1], __float_as_uint(nr));
-    atomicMax(&bits[2], __float_as_uint(mx));
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (lane == 0) red[0][wave] = mc, red[1][wave] = mr, red[2][wave] = mx;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float v = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+    atomicMax(&bits[threadIdx.x], __float_as_uint(v));  // non-negative floats order as uints
   }
 }
 
@@ -688,10 +783,11 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   const long long init_n = total > nq ? total : nq;
   hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, stream,
                      st.buf, st.count, st.tau, st.failed, (long long)nq, g.S, g.k);
-  if ((size_t)g.S * 8 > 65536) {  // dynamic LDS beyond 64 KiB must be opted into
+  const size_t compact_lds = (size_t)g.S * 8 + 2048;  // keys + histogram
+  if (compact_lds > 65536) {  // dynamic LDS beyond 64 KiB must be opted into
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(compact_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, g.S * 8) != hipSuccess) {
-      set_error("ip_topk: cannot raise dynamic LDS to %d bytes", g.S * 8);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)compact_lds) != hipSuccess) {
+      set_error("ip_topk: cannot raise dynamic LDS to %zu bytes", compact_lds);
       return -1;
     }
   }
@@ -757,14 +853,20 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       }
     }
     profile_mark(stream);
-    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nq), dim3(256), (size_t)g.S * 8, stream, st.buf,
-                       st.count, st.tau, st.failed, g.S, g.k, g.cap);
+    {
+      const int nq_i = (int)nq;
+      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)(nq < 8 * n_cu ? nq : 8 * n_cu)), dim3(256), compact_lds, stream,
+                         st.buf, st.count, st.tau, st.failed, nq_i, g.S, g.k, g.cap);
+    }
     profile_mark(stream);
     g_stats.filter_flops += 2.0 * (double)nq * (double)chunk * (double)dim;
     if (g_profile) g_chunk_rows.push_back((long long)chunk);
     seen += chunk;
     ++launches;
   }
+  if (!h1)  // exact passes hand their lists out as ranked results (the f16 pass is re-scored and sorted later)
+    hipLaunchKernelGGL(sort_lists_kernel, dim3((unsigned)nq), dim3(256), (size_t)next_pow2(g.k < 64 ? 64 : g.k) * 8, stream,
+                       st.buf, g.S, g.k);
   if (hipGetLastError() != hipSuccess) {
     set_error("ip_topk: kernel launch failed");
     return -1;
@@ -914,12 +1016,11 @@ extern "C" int mevi_ip_index_build_f32(const float *docs, int64_t nd, int64_t di
                                 align_up((size_t)dimp * 4, 256) + 256 + align_up((size_t)dimp * 8, 256), stream));
   if (nd > 0) {
     MEVI_REQUIRE(docs, MEVI_ERR_INVALID_ARG, "ip_index_build: null docs");
-    const unsigned rows4 = (unsigned)((nd + 3) / 4);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((nd + 511) / 512)), dim3(256), 0, stream, docs, (long long)nd,
                        (int)dim, v.colsum);
     hipLaunchKernelGGL(mean_kernel, dim3((unsigned)((dimp + 255) / 256)), dim3(256), 0, stream, v.colsum, (long long)nd,
                        (int)dim, dimp, const_cast<float *>(v.mu));
-    hipLaunchKernelGGL(doc_stats_kernel, dim3(rows4), dim3(256), 0, stream, docs, (long long)nd, (int)dim, v.mu,
+    hipLaunchKernelGGL(doc_stats_kernel, dim3((unsigned)((nd + 63) / 64)), dim3(256), 0, stream, docs, (long long)nd, (int)dim, v.mu,
                        const_cast<float *>(v.norms_c), const_cast<unsigned int *>(v.bits));
   }
   hipLaunchKernelGGL(doc_scale_kernel, dim3(1), dim3(64), 0, stream, v.bits, const_cast<float *>(v.scal));
