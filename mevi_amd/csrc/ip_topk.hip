@@ -640,81 +640,113 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
   h1_tile_stream(row_bytes, dimp / 32, lds, next, begin, emit);
 }
 
-// Exact re-scoring of the kp approximate survivors of one query, exact top-k, and the proof that
-// nothing outside the survivors can belong to it.  With a = acc * qinv (the centred approximate score),
+// Exact re-scoring of the kp approximate survivors of every query, exact top-k, and the proof that nothing
+// outside the survivors can belong to it.  With a = acc * qinv (the centred approximate score),
 //   chain(q, d) <= a + q.mu + eps_q,   eps_q = ||q|| * (c1 * max||d - mu|| + c2 * max||d||)
-// for every document of the shard; every non-survivor has acc <= acc_last (the kp-th raw accumulator), so if
+// for every document of the shard; every non-survivor has acc <= acc_last (the kp-th raw accumulator = the
+// final tau of the approximate pass), so if
 //   acc_last * qinv + q.mu + eps_q < e_k   (the exact k-th score; compared in f64)
-// the list is exact.  One workgroup per query; one lane per candidate, sequential fmaf chain over k (the
-// oracle's chain), rows staged through LDS in 32-wide slabs.
-__global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ Q, const float *__restrict__ D,
-                                                     int dim, unsigned long long *__restrict__ buf, int S, int k,
-                                                     int kp, unsigned int id_base, const float *__restrict__ qnorm,
-                                                     const float *__restrict__ qinv,
-                                                     const double *__restrict__ qshift, float c1, float c2,
-                                                     const unsigned int *__restrict__ dmax_bits,
-                                                     unsigned int *__restrict__ failed,
-                                                     unsigned long long *__restrict__ out_top, int out_ld,
-                                                     const float *__restrict__ dnorm_c,
-                                                     unsigned int *__restrict__ err_ratio_bits) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // P keys, then staging floats
+// the list is exact.
+//
+// rescore_rows_kernel: one WAVE per 64 survivors of a query, one lane per survivor, sequential fmaf chain over k
+// (the oracle's chain).  Rows are gathered 64 x 128 B at a time (whole lines, the next slab in flight in
+// registers while this one is consumed) through a 9 KiB per-wave LDS tile; waves are independent, so a CU holds
+// 16 of them and the gather runs near the random-row HBM rate.  The keys are re-scored in place.
+constexpr int RS_LD = 36;  // floats per staged row: 32 + 4 pad (16-byte aligned, conflict-light float4 reads)
+__global__ __launch_bounds__(256) void rescore_rows_kernel(const float *__restrict__ Q, const float *__restrict__ D,
+                                                          int dim, unsigned long long *__restrict__ buf, int S,
+                                                          int kp, int nq, unsigned int id_base,
+                                                          const float *__restrict__ qnorm,
+                                                          const float *__restrict__ qinv,
+                                                          const double *__restrict__ qshift, float c1, float c2,
+                                                          const unsigned int *__restrict__ dmax_bits,
+                                                          const float *__restrict__ dnorm_c,
+                                                          unsigned int *__restrict__ err_ratio_bits) {
+  __shared__ __attribute__((aligned(16))) float tiles[4][64 * RS_LD];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpq = (kp + 63) / 64;
+  const long long gw = (long long)blockIdx.x * 4 + wave;
+  const int q = (int)(gw / wpq);
+  if (q >= nq) return;  // wave-uniform; no workgroup barrier in this kernel
+  const int c = (int)(gw - (long long)q * wpq) * 64 + lane;
+  unsigned long long *row = buf + (size_t)q * S;
+  const unsigned long long key = (c < kp) ? row[c] : 0ull;
+  const bool valid = key != 0ull;
+  const unsigned int my_id = valid ? key_id(key) - id_base : 0u;
+  float *sd = tiles[wave];
+  // staging duty: float4 number lane&7 of the rows (lane>>3) + 8i
+  const float *src[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) src[i] = D + (size_t)__shfl(my_id, (lane >> 3) + 8 * i) * dim + (lane & 7) * 4;
+  const float *qr = Q + (size_t)q * dim;
+  const int nslab = (dim + 31) / 32;
+  float4 v[8];
+  auto fetch = [&](int s) {
+    const bool in = s * 32 + (lane & 7) * 4 < dim;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = in ? *reinterpret_cast<const float4 *>(src[i] + s * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  fetch(0);
+  float acc = 0.f;
+  for (int s = 0; s < nslab; ++s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(sd + ((lane >> 3) + 8 * i) * RS_LD + (lane & 7) * 4) = v[i];
+    if (s + 1 < nslab) fetch(s + 1);
+    __builtin_amdgcn_wave_barrier();  // LDS is in order within a wave: the reads below see the stores above
+    const float *dr = sd + lane * RS_LD;
+#pragma unroll
+    for (int k4 = 0; k4 < 32; k4 += 4) {
+      const float4 x = *reinterpret_cast<const float4 *>(dr + k4);
+      const int kk = s * 32 + k4;  // dim % 4 == 0: a float4 of q is inside the row or entirely past it
+      const float4 qq = kk < dim ? *reinterpret_cast<const float4 *>(qr + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = fmaf(qq.x, x.x, acc);
+      acc = fmaf(qq.y, x.y, acc);
+      acc = fmaf(qq.z, x.z, acc);
+      acc = fmaf(qq.w, x.w, acc);
+    }
+    __builtin_amdgcn_wave_barrier();  // ... and the next slab's stores come after these reads
+  }
+  if (c < kp) row[c] = valid ? make_key(acc, key_id(key)) : 0ull;
+  if (err_ratio_bits) {  // observed |approx - exact| / its bound: must stay far below 1
+    float ratio = 0.f;
+    if (valid) {
+      const double den = (double)qnorm[q] * ((double)c1 * dnorm_c[my_id] + (double)c2 * __uint_as_float(dmax_bits[1]));
+      const double est = (double)key_score(key) * (double)qinv[q] + qshift[q];
+      if (den > 0.0) ratio = (float)(fabs(est - (double)acc) / den);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ratio = fmaxf(ratio, __shfl_xor(ratio, off));
+    if (lane == 0 && ratio > 0.f) atomicMax(err_ratio_bits, __float_as_uint(ratio));
+  }
+}
+
+// rescore_finish_kernel: per query, sort the kp re-scored keys, emit the exact top-k, run the proof.
+// tau[q] is the raw accumulator of the kp-th survivor (-inf: fewer than kp rows exist, nothing is outside).
+__global__ __launch_bounds__(256) void rescore_finish_kernel(const unsigned long long *__restrict__ buf, int S, int k,
+                                                            int kp, const float *__restrict__ tau,
+                                                            const float *__restrict__ qnorm,
+                                                            const float *__restrict__ qinv,
+                                                            const double *__restrict__ qshift, float c1, float c2,
+                                                            const unsigned int *__restrict__ dmax_bits,
+                                                            unsigned int *__restrict__ failed,
+                                                            unsigned long long *__restrict__ out_top, int out_ld) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
   const int q = blockIdx.x, t = threadIdx.x;
   int P = 64;
   while (P < kp) P <<= 1;
-  float *sd = reinterpret_cast<float *>(skeys + P);  // [256][36]
-  float *sq = sd + 256 * 36;                         // [32]
-  unsigned int *sid = reinterpret_cast<unsigned int *>(sq + 32);  // [256]
-  unsigned long long *row = buf + (size_t)q * S;
-  const unsigned long long last = row[kp - 1];
-  const float *qr = Q + (size_t)q * dim;
-  const int srow = t >> 3, spc = (t & 7) * 4;
-  const int nslab = (dim + 31) / 32;
-  for (int i = kp + t; i < P; i += 256) skeys[i] = 0ull;
-  for (int base = 0; base < kp; base += 256) {
-    const int c = base + t;
-    const unsigned long long key = (c < kp) ? row[c] : 0ull;
-    const bool valid = key != 0ull;
-    sid[t] = valid ? key_id(key) - id_base : 0u;
-    float acc = 0.f;
-    for (int s = 0; s < nslab; ++s) {
-      __syncthreads();
-      const int kk = s * 32 + spc;
-      const bool in = kk < dim;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rr = srow + 32 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) v = *reinterpret_cast<const float4 *>(D + (size_t)sid[rr] * dim + kk);
-        *reinterpret_cast<float4 *>(sd + rr * 36 + spc) = v;
-      }
-      if (t < 32) sq[t] = (s * 32 + t < dim) ? qr[s * 32 + t] : 0.f;
-      __syncthreads();
-      const float *dr = sd + t * 36;
-#pragma unroll
-      for (int k4 = 0; k4 < 32; k4 += 4) {
-        const float4 x = *reinterpret_cast<const float4 *>(dr + k4);
-        acc = fmaf(sq[k4], x.x, acc);
-        acc = fmaf(sq[k4 + 1], x.y, acc);
-        acc = fmaf(sq[k4 + 2], x.z, acc);
-        acc = fmaf(sq[k4 + 3], x.w, acc);
-      }
-    }
-    if (c < P) skeys[c] = valid ? make_key(acc, key_id(key)) : 0ull;
-    if (valid && err_ratio_bits) {  // observed |approx - exact| / its bound: must stay far below 1
-      const double den = (double)qnorm[q] * ((double)c1 * dnorm_c[sid[t]] + (double)c2 * __uint_as_float(dmax_bits[1]));
-      const double est = (double)key_score(key) * (double)qinv[q] + qshift[q];
-      if (den > 0.0) atomicMax(err_ratio_bits, __float_as_uint((float)(fabs(est - (double)acc) / den)));
-    }
-    __syncthreads();
-  }
+  const unsigned long long *row = buf + (size_t)q * S;
+  for (int i = t; i < P; i += 256) skeys[i] = (i < kp) ? row[i] : 0ull;
+  __syncthreads();
   bitonic_sort_desc<256>(skeys, P, t);
   for (int i = t; i < k; i += 256) out_top[(size_t)q * out_ld + i] = skeys[i];
   if (t == 0) {
     bool ok = true;
-    if (last != 0ull) {  // the survivor list is full: there are documents outside it
+    const float a_last = tau[q];
+    if (a_last > -INFINITY) {  // the survivor list is full: there are documents outside it
       const unsigned long long kth = skeys[k - 1];
       const double eps = (double)qnorm[q] * ((double)c1 * __uint_as_float(dmax_bits[0]) + (double)c2 * __uint_as_float(dmax_bits[1]));
-      ok = (kth != 0ull) && ((double)key_score(last) * (double)qinv[q] + qshift[q] + eps < (double)key_score(kth));
+      ok = (kth != 0ull) && ((double)a_last * (double)qinv[q] + qshift[q] + eps < (double)key_score(kth));
     }
     if (!ok) failed[q] = 1u;  // keeps an overflow flag set by compact_kernel during the approximate pass
   }
@@ -1089,15 +1121,15 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   // exact re-scoring + verification
   int P = 64;
   while (P < kp) P <<= 1;
-  const size_t rs_lds = (size_t)P * 8 + (256 * 36 + 32 + 256) * 4;
-  if (rs_lds > 65536)
-    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds));
   unsigned int *err_bits = reinterpret_cast<unsigned int *>(qnorm + nq);  // spare slot behind the norms (256-byte padded)
   MEVI_HIP_CHECK(hipMemsetAsync(err_bits, 0, 4, stream));
-  hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(256), rs_lds, stream, q, docs, (int)dim, st.buf, gp.S,
-                     (int)k, kp, (unsigned int)id_offset, qnorm, qinv, qshift, c1, c2, iv.bits, st.failed, top, (int)k,
-                     iv.norms_c, err_bits);
+  {
+    const long long waves = nq * (long long)((kp + 63) / 64);
+    hipLaunchKernelGGL(rescore_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, q, docs, (int)dim, st.buf,
+                       gp.S, kp, (int)nq, (unsigned int)id_offset, qnorm, qinv, qshift, c1, c2, iv.bits, iv.norms_c, err_bits);
+    hipLaunchKernelGGL(rescore_finish_kernel, dim3((unsigned)nq), dim3(256), (size_t)P * 8, stream, st.buf, gp.S, (int)k, kp,
+                       st.tau, qnorm, qinv, qshift, c1, c2, iv.bits, st.failed, top, (int)k);
+  }
   unsigned int err_host = 0;
   MEVI_HIP_CHECK(hipMemcpyAsync(&err_host, err_bits, 4, hipMemcpyDeviceToHost, stream));
   MEVI_HIP_CHECK(hipGetLastError());
