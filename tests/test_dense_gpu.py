@@ -146,6 +146,26 @@ def test_truncated_shard_lists_are_proven_or_redone(cuda):
     np.testing.assert_array_equal(ri.cpu().numpy(), full_i[redo])
 
 
+def test_centred_image_proves_queries_on_mean_shifted_embeddings(cuda):
+    """Dense-retriever embeddings share a large common component (cosines ~0.97 between any two rows).  The
+    error bound of the f16 pre-filter scales with ||d - mu||, not ||d||, so such a corpus is still proven
+    without falling back; the answer is the exact one either way."""
+    rng = np.random.default_rng(41)
+    nq, nd, dim, k = 64, 60000, 768, 100
+    common = np.full(dim, 0.2, dtype=np.float32)
+    d = (0.05 * rng.standard_normal((nd, dim), dtype=np.float32) + common).astype(np.float32)
+    q = (0.05 * rng.standard_normal((nq, dim), dtype=np.float32) + common).astype(np.float32)
+    cos = (d[:100] @ d[100:200].T) / (np.linalg.norm(d[:100], axis=1)[:, None] * np.linalg.norm(d[100:200], axis=1)[None])
+    assert cos.mean() > 0.9
+    s, i = _run_indexed(q, d, k, cuda)
+    st = _stats()
+    es, ei = odense.ip_topk_exact(q, d, k)
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
+    assert st.n_failed_queries == 0, st.n_failed_queries
+    assert st.max_err_ratio <= 0.25
+
+
 def test_adversarial_row_order_takes_guaranteed_path(cuda):
     # rows sorted by ascending score for every query: each chunk floods the
     # candidate list -> overflow -> flagged queries are recomputed exactly.

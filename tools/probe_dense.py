@@ -8,6 +8,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mevi_amd import dense, hip  # noqa: E402
 INDEXED = os.environ.get("INDEXED", "1") == "1"
+MEAN = float(os.environ.get("MEAN", "0.02"))  # common component of every row (0.2: cosines ~0.94, dense-retriever like)
 if os.environ.get("MEVI_PROBE_LIB"):  # A/B timing of another build of the library on the same device
     hip.LIB = os.path.abspath(os.environ["MEVI_PROBE_LIB"])
 
@@ -18,9 +19,11 @@ dim = 768
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 q = torch.randn((nq, dim), device=dev, generator=g)
+if os.environ.get("MEAN"):
+    q = 0.05 * q + MEAN
 d = torch.empty((nd, dim), device=dev)
 for a in range(0, nd, 1 << 20):
-    d[a:a + (1 << 20)] = 0.05 * torch.randn((min(1 << 20, nd - a), dim), device=dev, generator=g) + 0.02
+    d[a:a + (1 << 20)] = 0.05 * torch.randn((min(1 << 20, nd - a), dim), device=dev, generator=g) + MEAN
 hip.lib().mevi_ip_topk_set_profiling(1)
 index = dense.DenseIndex(d) if INDEXED else None
 for it in range(3):
