@@ -183,6 +183,17 @@ def main():
         else:  # one f16 MFMA per product
             kernel, peak = "ip_filter_h1_kernel", PEAK_F16_MFMA_TFLOPS
             peak_note = "f16 MFMA dense peak"
+        # HBM-side bytes per filter launch: PMC (FETCH_SIZE x 2 on gfx950) of THIS command, recorded by
+        # tools/prof_traffic.sh + tools/traffic_summary.py; PMC passes cannot run inside the timed bench.
+        traffic, traffic_note = None, "PMC not collected for this configuration"
+        tfile = os.path.join(ROOT, "profiles", "r01_filter_h1_traffic.json")
+        if (not args.exact_f32_path and world == 1 and n_docs == N_DOCS and nq == N_QUERIES and os.path.exists(tfile)):
+            with open(tfile) as f:
+                tj = json.load(f)
+            traffic = tj["hbm_side_bytes_per_launch"]
+            traffic_note = ("bytes per launch, recorded PMC pass (profiles/r01_filter_h1_traffic.json): L2 memory-side "
+                            "requests incl. Infinity Cache hits; L2 hit rate %.2f; the corpus image itself is %.2f GB per "
+                            "launch" % (tj["l2_hit_rate"], n_docs * DIM * 2 / 1e9 / (launches / args.steps)))
         out = {
             "metric": "queries/sec @ MRR@10-match, MSMARCO dev, 1/2/4/8 MI355X",
             "value": nq * args.steps / elapsed,
@@ -213,7 +224,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / peak if achieved else None,
                 "queries_sent_to_exact_fallback": n_unproven,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "launches": launches,
                 "avg_launch_ms": filt_ms / launches if launches else None,
                 "algorithmic_flops_per_launch": filt_flops / launches if launches else None,
