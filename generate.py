@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""Query-embedding CLI -- same argv and output file as the reference's MEVI/generate.py:283-311
-(`--gen_query`): raw little-endian f32 [n_queries, dim].  One process per GPU (`--gpus "0,1,..."`),
-contiguous query ranges per rank (generate.py:74-82), per-rank files concatenated by rank 0.
-The T5-ANCE tower runs on the HIP kernels (mevi_amd.t5.TwinTower); tokenisation stays an HF call.
+"""Embedding CLI -- same argv and output file as the reference's MEVI/generate.py:283-311 (`--gen_query`):
+raw little-endian f32 [n_queries, dim].  One process per GPU (`--gpus "0,1,..."`), contiguous query ranges
+per rank (generate.py:74-82), per-rank files concatenated by rank 0.  The T5-ANCE tower runs on the HIP
+kernels (mevi_amd.t5.TwinTower); tokenisation stays an HF call.
+
+`gen_doc_embedding` mirrors MEVI/generate.py:116-187 (the passage side: pre-tokenised 128-token passages ->
+docemb.bin).  The reference reaches it from Python only; here it also has a flag, `--gen_doc --document_dir D
+--doc_embedding_path P` (an addition: SURVEY 8(f).1).
 """
 import argparse
 import os
@@ -23,6 +27,13 @@ def rank_range(n, rank, nrank):
     base, extra = divmod(n, nrank)
     start = base * rank + min(rank, extra)
     return start, start + base + (1 if rank < extra else 0)
+
+
+def doc_rank_range(n, rank, nrank):
+    """[start, end) of `rank` for documents: n // nrank each, the LAST rank takes the remainder (generate.py:141-147)."""
+    per = n // nrank
+    start = per * rank
+    return start, (n if rank + 1 == nrank else start + per)
 
 
 def load_document_encoder(model_path, ckpt_path, device):
@@ -78,6 +89,51 @@ def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path,
         dist.destroy_process_group()
 
 
+def gen_doc_embedding(rank, document_dir, model_path, ckpt_path, output_path, batch_size, dim, gpus, doc_length=128,
+                      encoder=None):
+    """all_document_tokens.bin / all_document_masks.bin (i64 [N, doc_length]) -> f32 [N, dim] at `output_path`
+    (MEVI/generate.py:116-187: per-rank part files `<output>_<rank>.bin`, merged by rank 0)."""
+    import torch
+    import torch.distributed as dist
+
+    nrank = len(gpus)
+    if nrank > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=nrank)
+    device = torch.device(f"cuda:{gpus[rank]}")
+    torch.cuda.set_device(device)
+    encoder = encoder or load_document_encoder(model_path, ckpt_path, device)
+    tokens = np.memmap(os.path.join(document_dir, "all_document_tokens.bin"), dtype=np.int64, mode="r").reshape(-1, doc_length)
+    masks = np.memmap(os.path.join(document_dir, "all_document_masks.bin"), dtype=np.int64, mode="r").reshape(-1, doc_length)
+    n = tokens.shape[0]
+    start, end = doc_rank_range(n, rank, nrank)
+    part_path = output_path[:-4] + f"_{rank}.bin"
+    part = np.memmap(part_path, dtype=np.float32, mode="w+", shape=(end - start, dim))
+    for s in range(start, end, batch_size):
+        e = min(s + batch_size, end)
+        psg = {"input_ids": torch.from_numpy(np.array(tokens[s:e])),
+               "attention_mask": torch.from_numpy(np.array(masks[s:e]))}
+        part[s - start:e - start] = encoder.encode_passage(psg).cpu().numpy()
+    part.flush()
+    del part
+    if nrank > 1:
+        dist.barrier()
+    if rank == 0:
+        allp = np.memmap(output_path, dtype=np.float32, mode="w+", shape=(n, dim))
+        at = 0
+        for r in range(nrank):
+            p_ = np.memmap(output_path[:-4] + f"_{r}.bin", dtype=np.float32, mode="r").reshape(-1, dim)
+            allp[at:at + p_.shape[0]] = p_
+            at += p_.shape[0]
+            del p_
+        allp.flush()
+        del allp
+        for r in range(nrank):
+            os.remove(output_path[:-4] + f"_{r}.bin")
+    if nrank > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
     s.bind(("127.0.0.1", 0))
@@ -98,10 +154,28 @@ if __name__ == "__main__":
     parser.add_argument("--gpus", type=str, default=None)
     parser.add_argument("--gen_query", action="store_true", default=False)
     parser.add_argument("--timing_infer_step", type=int, default=0)
+    parser.add_argument("--gen_doc", action="store_true", default=False)       # additions (see the module docstring)
+    parser.add_argument("--document_dir", type=str, default=None)
+    parser.add_argument("--doc_embedding_path", type=str, default=None)
+    parser.add_argument("--doc_length", type=int, default=128)
     args = parser.parse_args()
     gpus = [int(g) for g in args.gpus.split(",")] if args.gpus is not None else [0]
+    if args.gen_doc:
+        assert args.document_dir is not None and args.doc_embedding_path is not None, \
+            "Need to specify source path and target path!"
+        common = (args.document_dir, args.model_path, args.ckpt_path, args.doc_embedding_path, args.batch_size, args.dim,
+                  gpus, args.doc_length)
+        if len(gpus) > 1:
+            import torch.multiprocessing as mp
+
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(_free_port())
+            mp.spawn(gen_doc_embedding, nprocs=len(gpus), args=common)
+        else:
+            gen_doc_embedding(0, *common)
+        raise SystemExit(0)
     if not args.gen_query:
-        raise SystemExit("only --gen_query is built (document embedding generation is SURVEY 8(f) 'next')")
+        raise SystemExit("nothing to do: pass --gen_query or --gen_doc (--timing_infer_step profiling is not built)")
     assert args.query_file is not None and args.query_embedding_path is not None, \
         "Need to specify source path and target path!"
     common = (args.query_file, args.model_path, args.ckpt_path, args.tokenizer_path, args.query_embedding_path,

@@ -140,7 +140,7 @@ int mevi_add_layernorm_f32(const float *x, int64_t ldx, const float *y, int64_t 
 int mevi_gather_rows_f32(const float *table, int64_t ldt, const int64_t *idx, int64_t n, int64_t dim,
                          float *out, int64_t ldo, void *stream);
 int mevi_scale_f32(const float *x, float alpha, int64_t n, float *out, void *stream);
-/* softmax(scale*q.k^T + bias[h, q_pos0+t, j] + key mask + causal mask) . v for <= 64 keys
+/* softmax(scale*q.k^T + bias[h, q_pos0+t, j] + key mask + causal mask) . v for <= 256 keys
  * (T5Attention.forward, modeling_t5.py:374-410: no 1/sqrt(d) scaling, fp32 softmax; also
  * nn.MultiheadAttention of the adaptor with scale = head_dim^-0.5).
  *   q[b, t, h*dh + d] via (q_bs, q_ts); k/v[b / kv_div, j, h*dh + d]; out like q.

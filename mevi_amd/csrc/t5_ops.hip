@@ -4,7 +4,7 @@
 //   rmsnorm          T5LayerNorm                      modeling_t5.py:155-171
 //   add_layernorm    torch LayerNorm(x + y + c)       nn.TransformerDecoderLayer post-LN (modeling_t5.py:1252-1255)
 //   gather_rows      nn.Embedding / beam reorder      modeling_t5.py:718, generation_utils.py:927-934
-//   attention        T5Attention / nn.MultiheadAttention for <= 64 keys
+//   attention        T5Attention / nn.MultiheadAttention for <= 256 keys
 //                    modeling_t5.py:374-410 (no 1/sqrt(d) scaling, additive bias + mask, fp32 softmax)
 //   adaptive_logits  PAWA head, valid columns only    modeling_t5.py:1607, 1677-1689
 //   scale            hidden * d_model^-0.5            modeling_t5.py:1607
@@ -112,7 +112,28 @@ struct AttnArgs {
   float scale;                // multiplies q before the dot product (1 for T5)
 };
 
-// one wave per (batch, head, query token); lane j owns key j (tk <= 64)
+constexpr int ATT_KPL = 4;  // keys per lane: key j lives on lane j & 63, slot j >> 6 (tk <= 256)
+
+// softmax over the wave's keys (ATT_KPL per lane): s -> p in place
+__device__ __forceinline__ void attn_softmax(float (&s)[ATT_KPL], int lane, int tk) {
+  float m = s[0];
+#pragma unroll
+  for (int i = 1; i < ATT_KPL; ++i) m = fmaxf(m, s[i]);
+  m = wave_max(m);
+  float e[ATT_KPL], sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < ATT_KPL; ++i) {
+    e[i] = (64 * i + lane < tk) ? expf(s[i] - m) : 0.f;
+    sum += e[i];
+  }
+  // the reference sums the row left to right; a wave reduction is a different association of the same
+  // non-negative terms (covered by the 5e-5 tolerance of the T5 parity tests, as for tk <= 64)
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int i = 0; i < ATT_KPL; ++i) s[i] = e[i] / sum;
+}
+
+// one wave per (batch, head, query token); lane l owns keys l, l + 64, ... (tk <= 256)
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long total = (long long)a.nb * a.H * a.tq;
@@ -125,36 +146,44 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   const float *q = a.q + (size_t)b * a.q_bs + (size_t)t * a.q_ts + (size_t)h * a.dh;
   const int qpos = a.q_pos0 + t;
 
-  float s = -INFINITY;
-  if (lane < a.tk) {
-    const float *kr = a.k + (size_t)bk * a.k_bs + (size_t)lane * a.k_ts + (size_t)h * a.dh;
-    float acc = 0.f;
-    for (int d = 0; d < a.dh; d += 4) {
-      const float4 kv = *reinterpret_cast<const float4 *>(kr + d);
-      const float4 qv = *reinterpret_cast<const float4 *>(q + d);
-      acc = fmaf(qv.x * a.scale, kv.x, acc);
-      acc = fmaf(qv.y * a.scale, kv.y, acc);
-      acc = fmaf(qv.z * a.scale, kv.z, acc);
-      acc = fmaf(qv.w * a.scale, kv.w, acc);
+  float s[ATT_KPL];
+#pragma unroll
+  for (int i = 0; i < ATT_KPL; ++i) {
+    const int key = 64 * i + lane;
+    s[i] = -INFINITY;
+    if (key < a.tk) {
+      const float *kr = a.k + (size_t)bk * a.k_bs + (size_t)key * a.k_ts + (size_t)h * a.dh;
+      float acc = 0.f;
+      for (int d = 0; d < a.dh; d += 4) {
+        const float4 kv = *reinterpret_cast<const float4 *>(kr + d);
+        const float4 qv = *reinterpret_cast<const float4 *>(q + d);
+        acc = fmaf(qv.x * a.scale, kv.x, acc);
+        acc = fmaf(qv.y * a.scale, kv.y, acc);
+        acc = fmaf(qv.z * a.scale, kv.z, acc);
+        acc = fmaf(qv.w * a.scale, kv.w, acc);
+      }
+      float add = 0.f;
+      if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + key];
+      if (a.key_mask && a.key_mask[(size_t)bk * a.tk + key] == 0) add += -1e9f;
+      if (a.causal && key > qpos) add += -1e9f;
+      s[i] = acc + add;
     }
-    float add = 0.f;
-    if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + lane];
-    if (a.key_mask && a.key_mask[(size_t)bk * a.tk + lane] == 0) add += -1e9f;
-    if (a.causal && lane > qpos) add += -1e9f;
-    s = acc + add;
   }
-  const float m = wave_max(s);
-  const float e = (lane < a.tk) ? expf(s - m) : 0.f;
-  const float p = e / wave_sum(e);
+  attn_softmax(s, lane, a.tk);
 
   float *o = a.out + (size_t)b * a.o_bs + (size_t)t * a.o_ts + (size_t)h * a.dh;
   const float *vb = a.v + (size_t)bk * a.v_bs + (size_t)h * a.dh;
   // every lane takes part in the shuffles (a lane outside dh must still SOURCE p for its key)
   float acc0 = 0.f, acc1 = 0.f;  // output dims lane and lane + 64 (dh <= 128)
-  for (int j = 0; j < a.tk; ++j) {
-    const float pj = __shfl(p, j);
-    if (lane < a.dh) acc0 = fmaf(pj, vb[(size_t)j * a.v_ts + lane], acc0);
-    if (lane + 64 < a.dh) acc1 = fmaf(pj, vb[(size_t)j * a.v_ts + lane + 64], acc1);
+#pragma unroll
+  for (int i = 0; i < ATT_KPL; ++i) {
+    const int jend = a.tk - 64 * i < 64 ? a.tk - 64 * i : 64;
+    for (int j = 0; j < jend; ++j) {
+      const float pj = __shfl(s[i], j);
+      const size_t row = (size_t)(64 * i + j) * a.v_ts;
+      if (lane < a.dh) acc0 = fmaf(pj, vb[row + lane], acc0);
+      if (lane + 64 < a.dh) acc1 = fmaf(pj, vb[row + lane + 64], acc1);
+    }
   }
   if (lane < a.dh) o[lane] = acc0;
   if (lane + 64 < a.dh) o[lane + 64] = acc1;
@@ -184,26 +213,33 @@ __global__ __launch_bounds__(256) void attention_tile_kernel(AttnArgs a) {
   __syncthreads();
   for (int tq = wave; tq < a.tq; tq += 4) {
     const int qpos = a.q_pos0 + tq;
-    float s = -INFINITY;
-    if (lane < tk) {
-      float acc = 0.f;
-      const float *qr = sq + tq * dh;
-      const float *kr = sk + lane * ldk;
-      for (int d = 0; d < dh; ++d) acc = fmaf(qr[d], kr[d], acc);
-      float add = 0.f;
-      if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + lane];
-      if (a.key_mask && a.key_mask[(size_t)b * tk + lane] == 0) add += -1e9f;
-      if (a.causal && lane > qpos) add += -1e9f;
-      s = acc + add;
+    float s[ATT_KPL];
+    const float *qr = sq + tq * dh;
+#pragma unroll
+    for (int i = 0; i < ATT_KPL; ++i) {
+      const int key = 64 * i + lane;
+      s[i] = -INFINITY;
+      if (key < tk) {
+        float acc = 0.f;
+        const float *kr = sk + key * ldk;
+        for (int d = 0; d < dh; ++d) acc = fmaf(qr[d], kr[d], acc);
+        float add = 0.f;
+        if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + key];
+        if (a.key_mask && a.key_mask[(size_t)b * tk + key] == 0) add += -1e9f;
+        if (a.causal && key > qpos) add += -1e9f;
+        s[i] = acc + add;
+      }
     }
-    const float m = wave_max(s);
-    const float e = (lane < tk) ? expf(s - m) : 0.f;
-    const float p = e / wave_sum(e);
+    attn_softmax(s, lane, tk);
     float acc0 = 0.f, acc1 = 0.f;
-    for (int j = 0; j < tk; ++j) {
-      const float pj = __shfl(p, j);
-      if (lane < dh) acc0 = fmaf(pj, sv[j * dh + lane], acc0);
-      if (lane + 64 < dh) acc1 = fmaf(pj, sv[j * dh + lane + 64], acc1);
+#pragma unroll
+    for (int i = 0; i < ATT_KPL; ++i) {
+      const int jend = tk - 64 * i < 64 ? tk - 64 * i : 64;
+      for (int j = 0; j < jend; ++j) {
+        const float pj = __shfl(s[i], j);
+        if (lane < dh) acc0 = fmaf(pj, sv[(64 * i + j) * dh + lane], acc0);
+        if (lane + 64 < dh) acc1 = fmaf(pj, sv[(64 * i + j) * dh + lane + 64], acc1);
+      }
     }
     float *o = a.out + (size_t)b * a.o_bs + (size_t)tq * a.o_ts + (size_t)h * dh;
     if (lane < dh) o[lane] = acc0;
@@ -298,7 +334,8 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
                                   float scale, void *stream) {
   MEVI_REQUIRE(nb >= 0 && tq > 0 && tk > 0 && heads > 0 && dh > 0 && kv_div > 0, MEVI_ERR_INVALID_ARG,
                "attention: bad shape");
-  MEVI_REQUIRE(tk <= 64, MEVI_ERR_UNSUPPORTED, "attention: tk=%lld > 64 keys not supported", (long long)tk);
+  MEVI_REQUIRE(tk <= 64 * ATT_KPL, MEVI_ERR_UNSUPPORTED, "attention: tk=%lld > %d keys not supported", (long long)tk,
+               64 * ATT_KPL);
   MEVI_REQUIRE(dh <= 128, MEVI_ERR_UNSUPPORTED, "attention: head dim %lld > 128 not supported", (long long)dh);
   MEVI_REQUIRE(dh % 4 == 0 && q_bs % 4 == 0 && q_ts % 4 == 0 && k_bs % 4 == 0 && k_ts % 4 == 0,
                MEVI_ERR_INVALID_ARG, "attention: dh and q/k strides must be multiples of 4");
@@ -312,7 +349,10 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = (int)q_pos0;
   a.key_mask = reinterpret_cast<const long long *>(key_mask); a.causal = causal; a.scale = scale;
   const size_t tile_lds = (size_t)tk * (3 * dh + 1) * sizeof(float);
-  if (kv_div == 1 && tq == tk && tq >= 8 && tile_lds <= 65536) {  // self-attention over a whole sequence
+  if (kv_div == 1 && tq == tk && tq >= 8 && tile_lds <= 160 * 1024) {  // self-attention over a whole sequence
+    if (tile_lds > 65536)  // dynamic LDS beyond 64 KiB must be opted into (128 passage tokens x 64: 97 KiB)
+      MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_tile_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
     hipLaunchKernelGGL(attention_tile_kernel, dim3((unsigned)(nb * heads)), dim3(256), tile_lds, (hipStream_t)stream, a);
   } else {
     hipLaunchKernelGGL(attention_kernel, dim3(blocks4(nb * heads * tq)), dim3(256), 0, (hipStream_t)stream, a);

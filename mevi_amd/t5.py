@@ -84,7 +84,7 @@ class EncoderStack:
         return self._bias[S]
 
     def forward(self, embeddings, input_ids, attention_mask):
-        """input_ids/attention_mask i64[B, S] (S <= 64) -> last hidden state f32[B, S, d_model]."""
+        """input_ids/attention_mask i64[B, S] (S <= 256) -> last hidden state f32[B, S, d_model]."""
         d = self.d
         B, S = input_ids.shape
         x = ops.gather_rows(embeddings, input_ids.reshape(-1))
@@ -165,7 +165,7 @@ class DecoderStack:
 
 
 class TwinTower:
-    """The query tower of the dense arm: T5Model encoder + one decoder step on token 0,
+    """The (tied) tower of the dense arm: T5Model encoder + one decoder step on token 0,
     reps = last_hidden_state[:, 0, :], normalize=False (DocumentEncoder.encode, document_encoder.py:104-120).
 
     `encode_query(qry)` takes the reference's {'input_ids', 'attention_mask'} mapping."""
@@ -191,3 +191,6 @@ class TwinTower:
         return torch.cat(outs) if outs else torch.empty((0, self.d.d_model), device=self.dev)
 
     encode = encode_query
+    # tied towers (T5-ANCE, DocumentEncoder.build(tied=True)): lm_p is lm_q, a passage is a 128-token "query"
+    # (document_encoder.py:122-123)
+    encode_passage = encode_query

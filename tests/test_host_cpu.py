@@ -41,7 +41,7 @@ def test_main_accepts_every_flag_of_marco_eval_nci_rq_sh():
 def test_cli_argument_surfaces_match_reference():
     for script, flags in {
         "faiss_search.py": ["--query_path", "--doc_path", "--output_path", "--raw_query_path", "--dim", "--topk", "--param"],
-        "generate.py": ["--query_file", "--model_path", "--tokenizer_path", "--query_embedding_path", "--ckpt_path",
+        "generate.py": ["--gen_doc", "--document_dir", "--doc_embedding_path", "--query_file", "--model_path", "--tokenizer_path", "--query_embedding_path", "--ckpt_path",
                         "--batch_size", "--dim", "--gpus", "--gen_query", "--timing_infer_step"],
         "evaluate.py": ["--dir_path", "--gt_file", "--ance_file", "--recall_num", "--ofile"],
         "ensemble_marco.py": ["--dir_path", "--gt_file", "--ance_file", "--fine_file", "--coarse_file", "--mapping_file",
@@ -65,6 +65,9 @@ def test_rank_partition_rules():
         assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
         sizes = [b - a for a, b in r]
         assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    # documents (generate.py:141-147): n // nrank each, the last rank takes the remainder
+    assert [generate.doc_rank_range(10, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 10)]
+    assert generate.doc_rank_range(8841823, 7, 8) == (7 * 1105227, 8841823)
     # dense arm: ceil(N / W) rows per rank
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert shard_range(8841823, 7, 8) == (7 * 1105228, 8841823)

@@ -79,6 +79,10 @@ def test_rmsnorm_layernorm_gather_scale(cuda):
     (8, 1, 3, 8, 96, 1, True, 96 ** -0.5),  # adaptor nn.MultiheadAttention, head dim 96
     (8, 32, 32, 4, 8, 1, False, 1.0),       # tiny heads (fixture models): fewer output dims than keys
     (6, 1, 6, 8, 4, 1, True, 0.5),
+    (3, 128, 128, 12, 64, 1, False, 1.0),   # passage encoder self-attention (two keys per lane, 97 KiB LDS tile)
+    (5, 1, 128, 12, 64, 1, False, 1.0),     # decoder cross-attention over a 128-token passage
+    (2, 7, 200, 4, 32, 1, False, 1.0),      # four keys per lane, ragged tail
+    (2, 130, 130, 2, 128, 1, True, 1.0),    # causal, tile kernel refused (LDS) -> wave-per-query kernel
 ])
 def test_attention(cuda, nb, tq, tk, H, dh, kv_div, causal, scale):
     rng = np.random.default_rng(nb * tk)

@@ -37,6 +37,40 @@ def test_twin_tower_matches_reference_golden(cuda):
     assert np.abs(reps.cpu().numpy() - g["reps"]).max() <= 5e-5
 
 
+def test_passage_tower_matches_reference_golden(cuda):
+    """The tied tower on 128-token passages (encode_passage, document_encoder.py:122-123) vs the reference's
+    own T5Model outputs."""
+    g = np.load(os.path.join(GOLD, "g2p_t5_passage.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    tower = t5.TwinTower(nci.load_npz_weights(g), device=cuda, **cfg)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    enc = tower.encoder.forward(tower.shared, ids.to(cuda), mask.to(cuda))
+    assert np.abs(enc.cpu().numpy() - g["enc_last"]).max() <= 5e-5
+    reps = tower.encode_passage({"input_ids": ids, "attention_mask": mask})
+    assert np.abs(reps.cpu().numpy() - g["reps"]).max() <= 5e-5
+
+
+def test_gen_doc_embedding_writes_the_reference_file_format(cuda, tmp_path):
+    """generate.gen_doc_embedding: all_document_tokens.bin / all_document_masks.bin -> raw f32 [N, dim], batches
+    that do not divide N, same values as one encode_passage call."""
+    import generate
+
+    g = np.load(os.path.join(GOLD, "g2p_t5_passage.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    tower = t5.TwinTower(nci.load_npz_weights(g), device=cuda, **cfg)
+    ids = np.concatenate([g["input_ids"], g["input_ids"][::-1]])[:11]
+    mask = np.concatenate([g["attention_mask"], g["attention_mask"][::-1]])[:11]
+    ids.astype(np.int64).tofile(tmp_path / "all_document_tokens.bin")
+    mask.astype(np.int64).tofile(tmp_path / "all_document_masks.bin")
+    out = str(tmp_path / "docemb.bin")
+    generate.gen_doc_embedding(0, str(tmp_path), None, None, out, 4, cfg["d_model"], [0], 128, encoder=tower)
+    got = np.fromfile(out, dtype=np.float32).reshape(-1, cfg["d_model"])
+    want = tower.encode_passage({"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}).cpu().numpy()
+    assert got.shape == (11, cfg["d_model"]) and np.array_equal(got, want)
+    assert np.abs(got[:6] - g["reps"]).max() <= 5e-5
+    assert sorted(os.listdir(tmp_path)) == ["all_document_masks.bin", "all_document_tokens.bin", "docemb.bin"]
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1_nci_*.npz"))))
 def test_nci_generate_matches_reference_golden(cuda, path):
     g = np.load(path)

@@ -34,6 +34,19 @@ def test_tower_matches_reference_t5model():
     assert np.abs(reps.numpy() - g["reps"]).max() <= 2e-5
 
 
+def test_tower_matches_reference_t5model_at_passage_shape():
+    """128-token passages (gen_doc_embedding, generate.py:116-187): ragged lengths incl. a full window and a
+    3-token one."""
+    g = np.load(os.path.join(GOLD, "g2p_t5_passage.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    W = ot5.load_weights(g)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    enc = ot5.encoder(W, cfg, ids, mask)
+    assert np.abs(enc.numpy() - g["enc_last"]).max() <= 2e-5
+    reps = ot5.tower_encode(W, cfg, ids, mask)
+    assert np.abs(reps.numpy() - g["reps"]).max() <= 2e-5
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1_nci_*.npz"))))
 def test_nci_generate_matches_reference(path):
     g = np.load(path)

@@ -8,6 +8,10 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+from mevi_amd import hip as _hip
+if _os.environ.get("MEVI_PROBE_LIB"):  # A/B timing of another build of the library on the same device
+    _hip.LIB = _os.path.abspath(_os.environ["MEVI_PROBE_LIB"])
 from mevi_amd import fine, nci, rq, t5  # noqa: E402
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
@@ -88,6 +92,22 @@ def timed(fn, reps=2):
 
 dt, reps_ = timed(lambda: tower.encode_query({"input_ids": ids, "attention_mask": mask}))
 print(f"tower  : {nq} queries in {dt*1e3:.1f} ms  -> {nq/dt:.0f} q/s   ({6.51e9*nq/dt/1e12:.1f} TFLOP/s algorithmic)", flush=True)
+
+# passage side of the same tower (gen_doc_embedding): 128-token windows, lengths ~ clip(N(70, 30), 8, 128)
+npsg = 4096
+pids = np.zeros((npsg, 128), np.int64)
+pmask = np.zeros((npsg, 128), np.int64)
+for i in range(npsg):
+    L = int(np.clip(rng.normal(70, 30), 8, 128))
+    pids[i, :L - 1] = rng.integers(3, 32100, size=L - 1)
+    pids[i, L - 1] = 1
+    pmask[i, :L] = 1
+pids, pmask = torch.from_numpy(pids).to(dev), torch.from_numpy(pmask).to(dev)
+dt, _ = timed(lambda: tower.encode_passage({"input_ids": pids, "attention_mask": pmask}))
+# encoder 12 layers x 128 tokens: 2*(4*768*768 + 2*768*3072) MACs per token and layer + attention 2*2*128*768
+enc_flop = 12 * 128 * (2 * (4 * 768 * 768 + 2 * 768 * 3072) + 4 * 128 * 768)
+print(f"passage: {npsg} passages x 128 tokens in {dt*1e3:.1f} ms -> {npsg/dt:.0f} passages/s   "
+      f"({enc_flop*npsg/dt/1e12:.1f} TFLOP/s algorithmic, encoder only)", flush=True)
 
 
 def gen_all():

@@ -376,6 +376,44 @@ def g2_t5_tower():
     print("g2 reps", tuple(out.last_hidden_state.shape))
 
 
+def g2p_t5_passage():
+    """The same T5Model forward at the PASSAGE shape of gen_doc_embedding (generate.py:116-187): 128-token windows,
+    ragged lengths (one full window, one near-empty), reps = last_hidden_state[:, 0, :]."""
+    ref_import.setup()
+    import torch
+    from transformers import T5Config, T5Model
+
+    torch.manual_seed(7)
+    cfg = T5Config(vocab_size=512, d_model=32, d_ff=64, num_heads=4, d_kv=8, num_layers=2, num_decoder_layers=2,
+                   dropout_rate=0.1)
+    model = T5Model(cfg)
+    model.eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("layer_norm.weight"):
+                p_.copy_(1.0 + 0.2 * torch.randn_like(p_))
+            if "relative_attention_bias" in n_:
+                p_.copy_(torch.randn_like(p_))
+    rng = np.random.default_rng(78)
+    n, S = 6, 128
+    ids = np.zeros((n, S), np.int64)
+    mask = np.zeros((n, S), np.int64)
+    for i, L in enumerate([128, 3, 65, 64, 100, 37]):
+        ids[i, :L - 1] = rng.integers(3, cfg.vocab_size, size=L - 1)
+        ids[i, L - 1] = 1
+        mask[i, :L] = 1
+    with torch.no_grad():
+        out = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                    decoder_input_ids=torch.zeros((n, 1), dtype=torch.long), return_dict=True)
+    np.savez(os.path.join(GOLD, "g2p_t5_passage.npz"), input_ids=ids, attention_mask=mask,
+             reps=out.last_hidden_state[:, 0, :].numpy(), enc_last=out.encoder_last_hidden_state.numpy(),
+             **{"w." + k_: v_.detach().numpy() for k_, v_ in model.state_dict().items()},
+             cfg=np.array(json.dumps(dict(d_model=32, d_ff=64, num_heads=4, d_kv=8, num_layers=2,
+                                          num_decoder_layers=2, vocab_size=512, layer_norm_epsilon=cfg.layer_norm_epsilon,
+                                          relative_attention_num_buckets=cfg.relative_attention_num_buckets))))
+    print("g2p reps", tuple(out.last_hidden_state.shape))
+
+
 def g3_relative_buckets():
     """T5Attention._relative_position_bucket tables (modeling_t5.py:241-304)."""
     ref_import.setup()
@@ -392,7 +430,7 @@ def g3_relative_buckets():
     print("g3 ok")
 
 
-ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower,
+ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower, g2p=g2p_t5_passage,
            g3=g3_relative_buckets)
 
 if __name__ == "__main__":
