@@ -247,6 +247,123 @@ __global__ __launch_bounds__(256) void attention_tile_kernel(AttnArgs a) {
   }
 }
 
+// Whole-sequence self-attention on the f32 matrix cores, for 64 < tk = tq <= 128 and 64-wide heads (the
+// 128-token passages of gen_doc_embedding): one (batch, head) per workgroup, wave w owns query rows
+// 32w .. 32w+31.  Scores = Q.K^T and context = P.V run as v_mfma_f32_32x32x2_f32 chains (exact f32 products,
+// accumulated in k order: the same fmaf chain over d, then over the keys, as the scalar kernels above -- which
+// spent 44 % of the passage tower's time at 2.8 TFLOP/s).  The softmax works on the wave's own 32 rows in
+// LDS: two lanes per row, 64 keys each.  LDS: Q, K [128][65] and V [128][64] staged once (odd row stride:
+// conflict-free operand reads), P [128][129] re-uses the Q|K region once every wave holds its scores.
+constexpr int AM_S = 128, AM_D = 64, AM_LQ = AM_D + 1, AM_LP = AM_S + 1;
+constexpr size_t AM_LDS = (size_t)(2 * AM_S * AM_LQ + AM_S * AM_D) * sizeof(float);
+static_assert((size_t)AM_S * AM_LP <= (size_t)2 * AM_S * AM_LQ, "P must fit over Q|K");
+typedef float am_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *sq = sm;                     // [128][65]
+  float *sk = sq + AM_S * AM_LQ;      // [128][65]
+  float *sv = sk + AM_S * AM_LQ;      // [128][64]
+  float *sp = sm;                     // [128][129], after the scores are in registers
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int lrow = lane & 31, half = lane >> 5;
+  const int tk = a.tk;  // == tq
+  const float *qg = a.q + (size_t)b * a.q_bs + (size_t)h * AM_D;
+  const float *kg = a.k + (size_t)b * a.k_bs + (size_t)h * AM_D;
+  const float *vg = a.v + (size_t)b * a.v_bs + (size_t)h * AM_D;
+  for (int i = t; i < AM_S * (AM_D / 4); i += 256) {  // rows past tk are zero
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
+    if (r < tk) {
+      q4 = *reinterpret_cast<const float4 *>(qg + (size_t)r * a.q_ts + c4);
+      k4 = *reinterpret_cast<const float4 *>(kg + (size_t)r * a.k_ts + c4);
+      v4 = *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + c4);
+    }
+    float *dq = sq + r * AM_LQ + c4, *dk = sk + r * AM_LQ + c4;
+    dq[0] = q4.x * a.scale; dq[1] = q4.y * a.scale; dq[2] = q4.z * a.scale; dq[3] = q4.w * a.scale;
+    dk[0] = k4.x; dk[1] = k4.y; dk[2] = k4.z; dk[3] = k4.w;
+    *reinterpret_cast<float4 *>(sv + r * AM_D + c4) = v4;
+  }
+  __syncthreads();
+  const bool active = 32 * w < a.tq;  // wave-uniform
+  am_f32x16 sc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[n][r] = 0.f;
+  if (active) {
+    const float *qa = sq + (32 * w + lrow) * AM_LQ + half;
+    const float *kb = sk + lrow * AM_LQ + half;
+#pragma unroll 4
+    for (int j = 0; j < AM_D / 2; ++j) {
+      const float av = qa[2 * j];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) sc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, kb[32 * n * AM_LQ + 2 * j], sc[n], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done with Q and K: P may overwrite them
+  if (!active) return;  // no workgroup barrier below
+  // scores + bias + masks -> P rows of this wave (C/D map: col = lane&31 = key, row = (r&3) + 8*(r>>2) + 4*half)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int key = 32 * n + lrow;
+    if (key < tk) {
+      const float madd = (a.key_mask && a.key_mask[(size_t)b * tk + key] == 0) ? -1e9f : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (qi < a.tq) {
+          const int qpos = a.q_pos0 + qi;
+          float add = madd;
+          if (a.bias) add += a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + key];
+          if (a.causal && key > qpos) add += -1e9f;
+          sp[qi * AM_LP + key] = sc[n][r] + add;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // LDS is in order within a wave; the rows are this wave's own
+  {  // softmax: lane (row = 32w + lrow, keys [64*half, 64*half + 64))
+    float *pr = sp + (32 * w + lrow) * AM_LP + 64 * half;
+    const int nk = tk - 64 * half < 0 ? 0 : (tk - 64 * half > 64 ? 64 : tk - 64 * half);
+    float m = -INFINITY;
+    for (int j = 0; j < nk; ++j) m = fmaxf(m, pr[j]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+    for (int j = 0; j < nk; ++j) {
+      const float e = expf(pr[j] - m);
+      pr[j] = e;
+      sum += e;
+    }
+    sum += __shfl_xor(sum, 32);
+    for (int j = 0; j < 64; ++j) pr[j] = j < nk ? pr[j] / sum : 0.f;  // padded keys: p = 0 (their V rows are 0 too)
+  }
+  __builtin_amdgcn_wave_barrier();
+  am_f32x16 o[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+  {
+    const float *pa = sp + (32 * w + lrow) * AM_LP + half;
+    const float *vb = sv + half * AM_D + lrow;
+    const int nsteps = (tk + 1) / 2;
+    for (int j = 0; j < nsteps; ++j) {
+      const float av = pa[2 * j];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, vb[2 * j * AM_D + 32 * n], o[n], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (qi < a.tq) a.out[(size_t)b * a.o_bs + (size_t)qi * a.o_ts + (size_t)h * AM_D + 32 * n + lrow] = o[n][r];
+    }
+}
+
 // logits[row, c] = sum_d s[row, d] * (T[row, c*dim + d] + E[c, d]); one wave per (row, c)
 __global__ __launch_bounds__(256) void adaptive_logits_kernel(const float *__restrict__ s, long long lds_,
                                                              const float *__restrict__ T, long long ldt,
@@ -349,7 +466,11 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = (int)q_pos0;
   a.key_mask = reinterpret_cast<const long long *>(key_mask); a.causal = causal; a.scale = scale;
   const size_t tile_lds = (size_t)tk * (3 * dh + 1) * sizeof(float);
-  if (kv_div == 1 && tq == tk && tq >= 8 && tile_lds <= 160 * 1024) {  // self-attention over a whole sequence
+  if (kv_div == 1 && tq == tk && tk > 64 && tk <= AM_S && dh == AM_D) {  // passages: f32 matrix cores
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(nb * heads)), dim3(256), AM_LDS, (hipStream_t)stream, a);
+  } else if (kv_div == 1 && tq == tk && tq >= 8 && tile_lds <= 160 * 1024) {  // self-attention over a whole sequence
     if (tile_lds > 65536)  // dynamic LDS beyond 64 KiB must be opted into (128 passage tokens x 64: 97 KiB)
       MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_tile_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));

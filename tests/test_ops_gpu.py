@@ -81,6 +81,9 @@ def test_rmsnorm_layernorm_gather_scale(cuda):
     (6, 1, 6, 8, 4, 1, True, 0.5),
     (3, 128, 128, 12, 64, 1, False, 1.0),   # passage encoder self-attention (two keys per lane, 97 KiB LDS tile)
     (5, 1, 128, 12, 64, 1, False, 1.0),     # decoder cross-attention over a 128-token passage
+    (2, 100, 100, 12, 64, 1, False, 1.0),   # matrix-core kernel, ragged sequence (padded keys and query rows)
+    (2, 128, 128, 4, 64, 1, True, 0.5),     # matrix-core kernel, causal + scale
+    (1, 65, 65, 3, 64, 1, False, 1.0),
     (2, 7, 200, 4, 32, 1, False, 1.0),      # four keys per lane, ragged tail
     (2, 130, 130, 2, 128, 1, True, 1.0),    # causal, tile kernel refused (LDS) -> wave-per-query kernel
 ])
