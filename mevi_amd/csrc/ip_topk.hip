@@ -1144,9 +1144,13 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
     g_stats.err_bound = 1.0;  // the ratio is observed error / proven bound
   }
   // approx-state overflow (adversarial order) is flagged by compact_kernel in the same array (bitwise or: both set 1)
+  // Safety net for the proof itself: the bound must dominate every error actually observed on the re-scored
+  // survivors (typically by 10-30x).  If an observation ever comes within a factor two of it, the premise of the
+  // proofs is in doubt and every query takes the exact path.
+  const bool bound_suspect = g_stats.max_err_ratio > 0.5;
   std::vector<int> idx;
   for (int64_t i = 0; i < nq; ++i)
-    if (failed[(size_t)i]) idx.push_back((int)i);
+    if (failed[(size_t)i] || bound_suspect) idx.push_back((int)i);
   if (!idx.empty()) {  // unproven or overflowed queries: exact f32 search of just those, scattered into `top`
     const int64_t nf = (int64_t)idx.size();
     g_stats.n_failed_queries = nf;
