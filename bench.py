@@ -71,7 +71,7 @@ def gen_queries(nq, device, n_docs):
     return (blk0[gid] + 0.005 * torch.randn((nq, DIM), device=device, generator=g)).contiguous()
 
 
-def cpu_baseline(n_docs, nq_full, target_s=30.0):
+def cpu_baseline(n_docs, nq_full, target_s=60.0):
     """faiss-Flat-style CPU evaluation (BLAS sgemm blocks + per-query heaps = oracle.dense.ip_topk_blas)
     on a bounded sample, scaled linearly in rows to the full corpus."""
     from oracle import dense as odense
