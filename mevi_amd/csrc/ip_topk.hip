@@ -60,6 +60,36 @@ static inline TopkGeom make_geom(int k) {
 }
 
 // ---------------------------------------------------------------------------
+// Per-wave stash of candidates (LDS) for the persistent f16 filter.  In the large chunks a wave tile holds a
+// couple of candidates at most, yet handing out their slots costs a returning atomic -- a memory round trip
+// with the matrix pipes idle -- on nearly every tile.  Sparse tiles therefore only APPEND (key, query) to the
+// stash; it is flushed 64 entries at a time (one atomic round trip per 64 candidates instead of per tile),
+// when it fills up and at the end of the kernel.
+constexpr int STASH_N = 256;        // entries per wave
+constexpr int STASH_TILE_MAX = 64;  // tiles with more candidates than this take the direct path
+constexpr size_t STASH_BYTES_PER_WAVE = (size_t)STASH_N * 12;
+struct Stash {
+  unsigned long long *keys;  // [STASH_N]
+  unsigned int *qs;          // [STASH_N]
+  int n;                     // wave-uniform
+};
+__device__ __forceinline__ void stash_flush(Stash &st, unsigned long long *__restrict__ buf,
+                                            unsigned int *__restrict__ count, int S, int k, int cap) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_wave_barrier();
+  for (int base = 0; base < st.n; base += 64) {
+    const int e = base + lane;
+    if (e < st.n) {
+      const unsigned int q = st.qs[e];
+      const unsigned long long key = st.keys[e];
+      const unsigned int slot = atomicAdd(&count[q], 1u);
+      if (slot < (unsigned int)cap) buf[(size_t)q * S + k + slot] = key;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  st.n = 0;
+}
+
 // Threshold-filter epilogue of one wave tile (64 corpus rows x 32*NI queries, acc[2][NI]).
 // C/D map of the 32x32 MFMA: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*half (doc).
 // Every score above the query's current threshold tq[ni] (= tau of column q0 + 32*ni + lane&31, +inf past
@@ -74,7 +104,7 @@ template <int NI>
 __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq)[NI], int q0, long long d0,
                                           long long doc_end, unsigned long long *__restrict__ buf,
                                           unsigned int *__restrict__ count, int S, int k, int cap,
-                                          unsigned int id_base) {
+                                          unsigned int id_base, Stash *stash = nullptr) {
   const int lane = threadIdx.x & 63;
   const int lrow = lane & 31, half = lane >> 5;
   if (d0 + 64 > doc_end) {  // ragged last tile (wave-uniform): rows past the shard never pass
@@ -116,6 +146,47 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq
       }
     }
   }
+  if (qmask == 0u) return;  // nothing passes anywhere in the wave tile
+  // key = ord(score) << 32 | ~id;  ~(id0 + c) = ~id0 - c
+  const unsigned int nid0 = 0xFFFFFFFFu - (id_base + (unsigned int)(d0 + 4 * half));
+  if (stash) {
+    unsigned int tot = 0u;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) tot += n[ni];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if (tot <= (unsigned int)STASH_TILE_MAX) {  // sparse tile (wave-uniform): append, no atomics, no global stores
+      if (stash->n + (int)tot > STASH_N) stash_flush(*stash, buf, count, S, k, cap);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          if (((qmask >> (4 * (mi * NI + ni))) & 15u) == 0u) continue;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (((qmask >> (4 * (mi * NI + ni) + i)) & 1u) == 0u) continue;
+#pragma unroll
+            for (int r = 4 * i; r < 4 * i + 4; ++r) {
+              const float v = acc[mi][ni][r];
+              const bool pass = v > tq[ni];
+              const unsigned long long mask = __ballot(pass);
+              if (mask != 0ull) {
+                if (pass) {
+                  const int pos = stash->n + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+                  stash->keys[pos] = ((unsigned long long)f32_to_ord(v) << 32) |
+                                     (unsigned long long)(nid0 - (unsigned int)(32 * mi + (r & 3) + 8 * (r >> 2)));
+                  stash->qs[pos] = (unsigned int)(q0 + 32 * ni + lrow);
+                }
+                stash->n += __popcll(mask);
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const unsigned int other = __shfl_xor(n[ni], 32);
@@ -123,8 +194,6 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq
     if (half == 0 && n[ni] + other != 0u) base[ni] = atomicAdd(&count[q0 + 32 * ni + lrow], n[ni] + other);
     n[ni] = other;  // kept for the upper half's offset
   }
-  // key = ord(score) << 32 | ~id;  ~(id0 + c) = ~id0 - c
-  const unsigned int nid0 = 0xFFFFFFFFu - (id_base + (unsigned int)(d0 + 4 * half));
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const unsigned int b = __shfl(base[ni], lrow);
@@ -627,6 +696,13 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
     return true;
   };
   float tq[4];
+  Stash stash;  // behind the unit buffers of the tile stream
+  {
+    char *sb = reinterpret_cast<char *>(lds) + h1_lds_bytes() + (size_t)w8 * STASH_BYTES_PER_WAVE;
+    stash.keys = reinterpret_cast<unsigned long long *>(sb);
+    stash.qs = reinterpret_cast<unsigned int *>(sb + (size_t)STASH_N * 8);
+    stash.n = 0;
+  }
   auto begin = [&]() {  // start of the tile at the head of the FIFO: fetch its thresholds under the main loop
     load_tq<4>(tq, tau, head_q * H1_QT + 128 * wn, nq);
   };
@@ -635,9 +711,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
     head_d = tail_d, head_q = tail_q;
     --n_pend;
     const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
-    emit_tile<4>(acc, tq, qtile * H1_QT + 128 * wn, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base);
+    emit_tile<4>(acc, tq, qtile * H1_QT + 128 * wn, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base, &stash);
   };
   h1_tile_stream(row_bytes, dimp / 32, lds, next, begin, emit);
+  stash_flush(stash, buf, count, S, k, cap);
 }
 
 // Exact re-scoring of the kp approximate survivors of every query, exact top-k, and the proof that nothing
@@ -832,7 +909,7 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   double growth = g_growth > 0.0 ? g_growth : (double)g.cap / (3.0 * g.k);  // expected survivors per chunk ~ cap/3
   if (growth < 1.0) growth = 1.0;
   const int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
-  const size_t pp_lds = h1 ? h1_lds_bytes() : pp_lds_bytes<2>();
+  const size_t pp_lds = h1 ? h1_lds_bytes() + 8 * STASH_BYTES_PER_WAVE : pp_lds_bytes<2>();
   const bool ktail = (dim % BK) != 0;
   const void *fn = nullptr;
 #define MEVI_PICK(NI_, T_) fn = reinterpret_cast<const void *>(ip_filter_kernel<NI_, T_>)
