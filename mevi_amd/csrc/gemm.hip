@@ -11,12 +11,13 @@
 namespace mevi {
 namespace {
 
-template <bool KTAIL>
+// NI = 2: 256 x 128 output tiles; NI = 1: 256 x 64 tiles for grids that would leave CUs idle (a decode-step
+// GEMM of 5120 x 768 is 120 tiles of the first kind on 256 CUs).
+template <int NI, bool KTAIL>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_kernel(
     const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
     float *__restrict__ C, long long ldc, int M, int N, int K, const float *__restrict__ bias,
     const float *__restrict__ residual, long long ldr, int act, int n_ntiles, int n_mpairs) {
-  constexpr int NI = 2;
   constexpr int QT = 64 * NI;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -96,12 +97,26 @@ extern "C" int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int
                "gemm_nt: a/w must be 16-byte aligned");
   MEVI_REQUIRE(act == 0 || act == 1, MEVI_ERR_INVALID_ARG, "gemm_nt: act must be 0 (none) or 1 (relu)");
   MEVI_REQUIRE(m < (1LL << 31) && n < (1LL << 31) && k < (1LL << 24), MEVI_ERR_UNSUPPORTED, "gemm_nt: too large");
-  const int64_t n_mpairs = (m + 2 * BM - 1) / (2 * BM), n_ntiles = (n + 127) / 128;
+  const int64_t n_mpairs = (m + 2 * BM - 1) / (2 * BM);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  // A 256x64 tile takes half the time of a 256x128 one (measured), so on small grids pick the width whose last,
+  // partly filled round of workgroups wastes less: wide = 2 * ceil(T / CUs) half-rounds, narrow = ceil(2T / CUs).
+  const int64_t t_wide = n_mpairs * ((n + 127) / 128);
+  const bool narrow = n > 64 && t_wide < 8 * (int64_t)n_cu &&
+                      (2 * t_wide + n_cu - 1) / n_cu < 2 * ((t_wide + n_cu - 1) / n_cu);
+  const int64_t n_ntiles = narrow ? (n + 63) / 64 : (n + 127) / 128;
   MEVI_REQUIRE(n_mpairs * n_ntiles <= 0x7fffffffLL, MEVI_ERR_UNSUPPORTED, "gemm_nt: grid too large");
-  const size_t lds_bytes = pp_lds_bytes<2>();
+  const size_t lds_bytes = narrow ? pp_lds_bytes<1>() : pp_lds_bytes<2>();
   const bool ktail = (k % BK) != 0;
-  const void *fn = ktail ? reinterpret_cast<const void *>(gemm_nt_kernel<true>)
-                         : reinterpret_cast<const void *>(gemm_nt_kernel<false>);
+  const void *fn = narrow ? (ktail ? reinterpret_cast<const void *>(gemm_nt_kernel<1, true>)
+                                   : reinterpret_cast<const void *>(gemm_nt_kernel<1, false>))
+                          : (ktail ? reinterpret_cast<const void *>(gemm_nt_kernel<2, true>)
+                                   : reinterpret_cast<const void *>(gemm_nt_kernel<2, false>));
   MEVI_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   long long lda_ = lda, ldw_ = ldw, ldc_ = ldc, ldr_ = ldr;
   int m_ = (int)m, n_ = (int)n, k_ = (int)k, nt = (int)n_ntiles, mp = (int)n_mpairs;
