@@ -154,7 +154,7 @@ class EvalRun:
             self.coarse_log.add((text, d, gt_codes, scores[i].tolist()))
             cr = tuple(d.index(g) if g in d else None for g in gt_codes)
             docs, sc = ranked[i]
-            self.fine_log.add((text, docs, doc_ids[i]))
+            self.fine_log.add((text, docs.tolist(), doc_ids[i]))
             if self.hn_log is not None:
                 n = a.save_hard_neg
                 self.hn_log.add((text, mfine.f32_repr(gt_s[i]), ",".join(map(str, docs[:n])), mfine.f32_repr(sc[:n])))

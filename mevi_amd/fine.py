@@ -31,6 +31,7 @@ class FineStage:
         self.emb = doc_embeddings
         self.index = cluster_index
         self.dev = doc_embeddings.device
+        self._dev_index = None
 
     def candidates(self, beam_codes):
         """beam_codes i64[B, R, M] -> (cand_doc_ids i64[total], cand_query i64[total], seg i64[B+1], ndoc i64[B])
@@ -53,14 +54,46 @@ class FineStage:
         seg = np.concatenate([[0], np.cumsum(ndoc)]).astype(np.int64)
         return cand, cand_q, seg, ndoc
 
+    def candidates_device(self, beam_codes):
+        """candidates() with the expansion done on the GPU (the CSR arrays are uploaded once): the candidate list of
+        a batch is tens of millions of ids -- building it with numpy and shipping two i64 arrays over PCIe
+        dominated the fine stage.  Returns (cand i64[total] CUDA, cand_q i64[total] CUDA, seg, ndoc) with seg / ndoc
+        as host arrays."""
+        idx = self.index
+        if self._dev_index is None:
+            self._dev_index = tuple(torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(self.dev)
+                                    for a in (idx.keys, idx.offsets, idx.doc_ids))
+        keys_t, offs_t, docs_t = self._dev_index
+        codes = torch.as_tensor(np.asarray(beam_codes, dtype=np.int64), device=self.dev)
+        B, R, M = codes.shape
+        w = torch.tensor([idx.K ** (M - 1 - j) for j in range(M)], dtype=torch.int64, device=self.dev)
+        keys = (codes * w).sum(-1).reshape(-1)
+        n = keys_t.numel()
+        if n == 0:
+            return (torch.zeros(0, dtype=torch.int64, device=self.dev),) * 2 + (np.zeros(B + 1, np.int64), np.zeros(B, np.int64))
+        pos = torch.searchsorted(keys_t, keys)
+        pos_c = pos.clamp(max=n - 1)
+        found = (pos < n) & (keys_t[pos_c] == keys)
+        zero = torch.zeros_like(keys)
+        start = torch.where(found, offs_t[pos_c], zero)
+        size = torch.where(found, offs_t[pos_c + 1] - offs_t[pos_c], zero)
+        first = torch.cumsum(size, 0) - size
+        total = int(size.sum().item())
+        flat = torch.arange(total, dtype=torch.int64, device=self.dev) + torch.repeat_interleave(start - first, size)
+        cand = docs_t[flat]
+        cand_q = torch.repeat_interleave(torch.arange(B, dtype=torch.int64, device=self.dev).repeat_interleave(R), size)
+        ndoc = size.view(B, R).sum(1).cpu().numpy()
+        seg = np.concatenate([[0], np.cumsum(ndoc)]).astype(np.int64)
+        return cand, cand_q, seg, ndoc
+
     def rerank(self, query_emb, beam_codes):
-        """query_emb f32[B, dim] (CUDA).  Returns per query: (doc ids list[int], scores f32 ndarray), and ndoc."""
-        cand, cand_q, seg, ndoc = self.candidates(beam_codes)
+        """query_emb f32[B, dim] (CUDA).  Returns per query: (doc ids i64 ndarray, scores f32 ndarray) -- views of
+        one host copy of the sorted batch --, and ndoc."""
+        cand_t, cand_q, seg, ndoc = self.candidates_device(beam_codes)
         B = len(ndoc)
-        if len(cand) == 0:
-            return [([], np.zeros(0, np.float32)) for _ in range(B)], ndoc
-        cand_t = torch.from_numpy(cand).to(self.dev)
-        sc = ops.pair_dot(query_emb, torch.from_numpy(cand_q).to(self.dev), self.emb, cand_t)
+        if cand_t.numel() == 0:
+            return [(np.zeros(0, np.int64), np.zeros(0, np.float32)) for _ in range(B)], ndoc
+        sc = ops.pair_dot(query_emb, cand_q, self.emb, cand_t)
         longest = int(ndoc.max())
         if longest <= MAX_SEGMENT:
             s_sorted, i_sorted = ops.segment_sort_desc(sc, cand_t, torch.from_numpy(seg), longest)
@@ -73,7 +106,7 @@ class FineStage:
             o = o[torch.argsort(segid[o], stable=True)]
             s_sorted, i_sorted = sc[o], cand_t[o]
         s_sorted, i_sorted = s_sorted.cpu().numpy(), i_sorted.cpu().numpy()
-        out = [(i_sorted[a:b].tolist(), s_sorted[a:b]) for a, b in zip(seg[:-1], seg[1:])]
+        out = [(i_sorted[a:b], s_sorted[a:b]) for a, b in zip(seg[:-1], seg[1:])]
         return out, ndoc
 
     def gt_scores(self, query_emb, gt_doc_ids):
@@ -94,7 +127,10 @@ def coarse_ranks(beam_codes, gt_codes):
 
 
 def fine_ranks(sorted_docs, gt_doc_ids):
-    pos = {}
-    for i, p in enumerate(sorted_docs):
-        pos.setdefault(p, i)
-    return tuple(pos.get(g) for g in gt_doc_ids)
+    """first position of every gt doc in the ranked list, None when absent (main_models.py:4016-4019)."""
+    docs = np.asarray(sorted_docs, dtype=np.int64)
+    out = []
+    for g in gt_doc_ids:
+        hit = np.flatnonzero(docs == int(g))
+        out.append(int(hit[0]) if hit.size else None)
+    return tuple(out)

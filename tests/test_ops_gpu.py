@@ -202,7 +202,7 @@ def test_fine_stage_matches_reference_procedure(cuda):
             seen.add(key)
         assert ndoc[b] == len(docs)
         order = np.lexsort((np.array(docs, dtype=np.int64), -np.array(sc, dtype=np.float32))) if docs else []
-        assert out[b][0] == [docs[i] for i in order]
+        assert out[b][0].tolist() == [docs[i] for i in order]
         assert np.array_equal(out[b][1].view(np.uint32), np.array([sc[i] for i in order], np.float32).view(np.uint32))
     gts = [[int(x) for x in rng.integers(0, N, size=1 + b % 2)] for b in range(B)]
     gs = fs.gt_scores(torch.from_numpy(q).to(cuda), gts)
