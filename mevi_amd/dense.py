@@ -179,12 +179,17 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
     world = dist.get_world_size(group)
 
     def exchange(q, kk):
+        # one collective per round: (score bits << 32 | id as u32) in an i64 per entry -- 8 bytes instead of the 12
+        # of separate f32 + i64 tensors, and half the launches.  Ids fit 32 bits (the C ABI enforces it); the
+        # padding id -1 travels as 0xFFFFFFFF.
         s, i = local(q, kk)
         n = s.shape[0]
-        all_s = torch.empty((world * n, kk), dtype=s.dtype, device=s.device)   # rank-major concatenation
-        all_i = torch.empty((world * n, kk), dtype=i.dtype, device=i.device)
-        dist.all_gather_into_tensor(all_s, s.contiguous(), group=group)
-        dist.all_gather_into_tensor(all_i, i.contiguous(), group=group)
+        packed = (s.contiguous().view(torch.int32).to(torch.int64) << 32) | (i & 0xFFFFFFFF)
+        gathered = torch.empty((world * n, kk), dtype=torch.int64, device=s.device)   # rank-major concatenation
+        dist.all_gather_into_tensor(gathered, packed.contiguous(), group=group)
+        all_s = (gathered >> 32).to(torch.int32).view(torch.float32)
+        all_i = gathered & 0xFFFFFFFF
+        all_i = torch.where(all_i == 0xFFFFFFFF, torch.full_like(all_i, -1), all_i)
         return all_s.view(world, n, kk), all_i.view(world, n, kk)
 
     kl = truncated_list_len(k, world)
