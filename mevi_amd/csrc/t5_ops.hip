@@ -247,6 +247,79 @@ __global__ __launch_bounds__(256) void attention_tile_kernel(AttnArgs a) {
   }
 }
 
+// Decode-step cross-attention where kv_div rows (the beams of one query) share K and V: one workgroup per
+// (query, head) stages K [tk][dh + 4], V [tk][dh] and the group's q rows in LDS ONCE and its waves take the
+// beams in turn.  The wave-per-row kernel re-read the shared K|V from L2 for every beam (10x the traffic).
+// Same arithmetic as attention_kernel, lane for lane.
+__global__ __launch_bounds__(256) void attention_group_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int bk = blockIdx.x / a.H, h = blockIdx.x % a.H;  // query group, head
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int dh = a.dh, tk = a.tk, ldk = dh + 4;  // 16-byte aligned rows; 4r mod 64 banks: float4 reads conflict free
+  float *sk = sm;                      // [tk][dh + 4]
+  float *sv = sk + tk * ldk;           // [tk][dh]
+  float *sq = sv + tk * dh;            // [kv_div][dh], pre-scaled
+  const float *kg = a.k + (size_t)bk * a.k_bs + (size_t)h * dh;
+  const float *vg = a.v + (size_t)bk * a.v_bs + (size_t)h * dh;
+  const int dq = dh / 4;
+  for (int i = t; i < tk * dq; i += 256) {
+    const int r = i / dq, c4 = (i - r * dq) * 4;
+    *reinterpret_cast<float4 *>(sk + r * ldk + c4) = *reinterpret_cast<const float4 *>(kg + (size_t)r * a.k_ts + c4);
+    *reinterpret_cast<float4 *>(sv + r * dh + c4) = *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + c4);
+  }
+  for (int i = t; i < a.kv_div * dq; i += 256) {
+    const int r = i / dq, c4 = (i - r * dq) * 4;
+    const int b = bk * a.kv_div + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < a.nb) v = *reinterpret_cast<const float4 *>(a.q + (size_t)b * a.q_bs + (size_t)h * dh + c4);
+    *reinterpret_cast<float4 *>(sq + r * dh + c4) = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
+  }
+  __syncthreads();
+  const int qpos = a.q_pos0;  // tq == 1
+  for (int r = wave; r < a.kv_div; r += 4) {
+    const int b = bk * a.kv_div + r;
+    if (b >= a.nb) break;
+    const float *q = sq + r * dh;
+    float s[ATT_KPL];
+#pragma unroll
+    for (int i = 0; i < ATT_KPL; ++i) {
+      const int key = 64 * i + lane;
+      s[i] = -INFINITY;
+      if (key < tk) {
+        const float *kr = sk + key * ldk;
+        float acc = 0.f;
+        for (int d = 0; d < dh; d += 4) {
+          const float4 kv = *reinterpret_cast<const float4 *>(kr + d);
+          const float4 qv = *reinterpret_cast<const float4 *>(q + d);
+          acc = fmaf(qv.x, kv.x, acc);
+          acc = fmaf(qv.y, kv.y, acc);
+          acc = fmaf(qv.z, kv.z, acc);
+          acc = fmaf(qv.w, kv.w, acc);
+        }
+        float add = 0.f;
+        if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + key];
+        if (a.key_mask && a.key_mask[(size_t)bk * tk + key] == 0) add += -1e9f;
+        if (a.causal && key > qpos) add += -1e9f;
+        s[i] = acc + add;
+      }
+    }
+    attn_softmax(s, lane, tk);
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < ATT_KPL; ++i) {
+      const int jend = tk - 64 * i < 64 ? tk - 64 * i : 64;
+      for (int j = 0; j < jend; ++j) {
+        const float pj = __shfl(s[i], j);
+        if (lane < dh) acc0 = fmaf(pj, sv[(64 * i + j) * dh + lane], acc0);
+        if (lane + 64 < dh) acc1 = fmaf(pj, sv[(64 * i + j) * dh + lane + 64], acc1);
+      }
+    }
+    float *o = a.out + (size_t)b * a.o_bs + (size_t)h * dh;
+    if (lane < dh) o[lane] = acc0;
+    if (lane + 64 < dh) o[lane + 64] = acc1;
+  }
+}
+
 // Whole-sequence self-attention on the f32 matrix cores, for 64 < tk = tq <= 128 and 64-wide heads (the
 // 128-token passages of gen_doc_embedding): one (batch, head) per workgroup, wave w owns query rows
 // 32w .. 32w+31.  Scores = Q.K^T and context = P.V run as v_mfma_f32_32x32x2_f32 chains (exact f32 products,
@@ -470,6 +543,11 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
     MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
     hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(nb * heads)), dim3(256), AM_LDS, (hipStream_t)stream, a);
+  } else if (kv_div > 1 && tq == 1 && nb % kv_div == 0 && v_bs % 4 == 0 && v_ts % 4 == 0 &&
+             ((size_t)tk * (2 * dh + 4) + (size_t)kv_div * dh) * sizeof(float) <= 65536) {
+    // the beams of a query share K|V: stage them once per (query, head)
+    hipLaunchKernelGGL(attention_group_kernel, dim3((unsigned)((nb / kv_div) * heads)), dim3(256),
+                       ((size_t)tk * (2 * dh + 4) + (size_t)kv_div * dh) * sizeof(float), (hipStream_t)stream, a);
   } else if (kv_div == 1 && tq == tk && tq >= 8 && tile_lds <= 160 * 1024) {  // self-attention over a whole sequence
     if (tile_lds > 65536)  // dynamic LDS beyond 64 KiB must be opted into (128 passage tokens x 64: 97 KiB)
       MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_tile_kernel),
