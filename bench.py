@@ -205,7 +205,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if args.exact_f32_path else "f32 results (f16 MFMA pre-filter, exact f32 re-score + proof)",
+            "dtype": "f32" if args.exact_f32_path else "f16+f32",
+            "dtype_note": "f32 MFMA chains only" if args.exact_f32_path else
+            "f16 MFMA pre-filter (selection only) + exact f32 fmaf-chain re-score with a per-query completeness proof: "
+            "results are the f32 results, bit for bit",
             "data": "synthetic",
             "config": {
                 "workload": "C2 dense arm (faiss_search.py Flat): %d x %d f32 queries x %d x %d f32 docs, "
