@@ -166,6 +166,27 @@ def test_centred_image_proves_queries_on_mean_shifted_embeddings(cuda):
     assert st.max_err_ratio <= 0.25
 
 
+def test_heavy_tailed_magnitudes_keep_the_f16_bound_honest(cuda):
+    """Rows whose elements span 2^-30 .. 2^10 (log-normal magnitudes, many below the f16 normal range after
+    scaling, exact zeros, one dominant column): the observed f16 error must stay below the proven bound and the
+    answer must be the exact one, proven or not."""
+    rng = np.random.default_rng(53)
+    nq, nd, dim, k = 48, 30000, 256, 50
+    mag_d = np.exp(rng.normal(0.0, 4.0, size=(nd, dim))).astype(np.float32)
+    d = (mag_d * rng.choice([-1.0, 1.0], size=(nd, dim))).astype(np.float32)
+    d[:, 7] *= 64.0
+    d[rng.random((nd, dim)) < 0.05] = 0.0
+    mag_q = np.exp(rng.normal(0.0, 3.0, size=(nq, dim))).astype(np.float32)
+    q = (mag_q * rng.choice([-1.0, 1.0], size=(nq, dim))).astype(np.float32)
+    q[3] *= 1e-6                                   # one query far below the others (per-query scaling)
+    s, i = _run_indexed(q, d, k, cuda)
+    st = _stats()
+    es, ei = odense.ip_topk_exact(q, d, k)
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
+    assert 0 < st.max_err_ratio <= 0.5, st.max_err_ratio
+
+
 def test_adversarial_row_order_takes_guaranteed_path(cuda):
     # rows sorted by ascending score for every query: each chunk floods the
     # candidate list -> overflow -> flagged queries are recomputed exactly.
