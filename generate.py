@@ -134,6 +134,33 @@ def gen_doc_embedding(rank, document_dir, model_path, ckpt_path, output_path, ba
         dist.destroy_process_group()
 
 
+def profile_generate_query(query_file, model_path, ckpt_path, tokenizer_path, step_num, query_length=32, tokenizer=None,
+                           encoder=None, out_path="timer.pkl"):
+    """Per-query latency of tokenise + encode at batch size 1, pickled as a list of seconds to `timer.pkl`
+    (MEVI/generate.py:245-281, `--timing_infer_step N`)."""
+    import pickle
+    from time import time
+
+    import torch
+
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(device)
+    encoder = encoder or load_document_encoder(model_path, ckpt_path, device)
+    tokenizer = tokenizer or get_tokenizer(tokenizer_path)
+    df = pd.read_csv(query_file, names=["query", "oldid"], encoding="utf-8", header=None, sep="\t")["query"]
+    timer = []
+    for start in range(0, step_num):
+        batch = list(df[start:min(start + 1, step_num)])
+        t0 = time()
+        tok = tokenizer.batch_encode_plus(batch, max_length=query_length, padding="max_length", truncation=True,
+                                          return_tensors="pt")
+        encoder.encode_query(tok).cpu().numpy()
+        timer.append(time() - t0)
+    with open(out_path, "wb") as fw:
+        pickle.dump(timer, fw)
+    return timer
+
+
 def _free_port():
     s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
     s.bind(("127.0.0.1", 0))
@@ -175,7 +202,10 @@ if __name__ == "__main__":
             gen_doc_embedding(0, *common)
         raise SystemExit(0)
     if not args.gen_query:
-        raise SystemExit("nothing to do: pass --gen_query or --gen_doc (--timing_infer_step profiling is not built)")
+        if args.timing_infer_step > 0:
+            profile_generate_query(args.query_file, args.model_path, args.ckpt_path, args.tokenizer_path,
+                                   args.timing_infer_step)
+        raise SystemExit(0)
     assert args.query_file is not None and args.query_embedding_path is not None, \
         "Need to specify source path and target path!"
     common = (args.query_file, args.model_path, args.ckpt_path, args.tokenizer_path, args.query_embedding_path,
