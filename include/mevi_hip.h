@@ -70,8 +70,9 @@ int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, int64_t nd,
  * fmaf chain, and PROVES per query that no other row can enter the top-k:
  *   |approx + q.mu - exact| <= ||q|| * (c1 * max||d - mu|| + c2 * max||d||),
  *   c1 = 2^-10 + 2^-22 + 4 dim 2^-24 (f16 roundings + accumulation), c2 = dim 2^-24 (the exact chain);
- * unproven queries are re-run through the exact f32 path.  `docs` (f32) is still needed for the exact
- * re-scoring.
+ * unproven queries are retried once with twice as many survivors (when they are at most a quarter of the
+ * batch), what is still unproven is re-run through the exact f32 path.  `docs` (f32) is still needed for the
+ * exact re-scoring.
  *   index buffer: mevi_ip_index_bytes(nd, dim) bytes, 256-byte aligned, filled by mevi_ip_index_build_f32.
  *   dim % 4 == 0.  Synchronising like mevi_ip_topk_f32. */
 size_t mevi_ip_index_bytes(int64_t nd, int64_t dim);
@@ -205,6 +206,7 @@ typedef struct mevi_ip_topk_stats {
   double filter_flops;       /* algorithmic flops of those filter launches: 2 * nq * rows * dim */
   double max_err_ratio;      /* indexed search: largest observed |f16 approx - exact| / proven bound among survivors */
   double err_bound;          /* indexed search: 1.0 (max_err_ratio is relative to the bound the proof uses) */
+  int64_t n_second_pass_queries; /* indexed search: unproven queries retried with a 2x wider survivor list */
 } mevi_ip_topk_stats;
 void mevi_ip_topk_set_growth(double growth);
 void mevi_ip_topk_set_profiling(int enable); /* record HIP events around every filter/compact launch */

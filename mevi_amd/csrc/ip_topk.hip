@@ -856,7 +856,7 @@ static SearchState carve_state(char *&p, int64_t nq, const TopkGeom &g) {
 
 thread_local double g_growth = 0.0;
 thread_local int g_profile = 0;
-thread_local mevi_ip_topk_stats g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0};
+thread_local mevi_ip_topk_stats g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
 thread_local std::vector<hipEvent_t> g_events;  // triples: before filter, after filter, after compact
 thread_local std::vector<long long> g_chunk_rows;  // rows of the launch each triple brackets (profiling on)
 
@@ -1006,7 +1006,7 @@ extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, i
                                 int64_t k, int64_t id_offset, float *out_score, int64_t *out_id,
                                 void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
   for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
   g_events.clear();
   MEVI_REQUIRE(nq >= 0 && nd >= 0 && dim > 0 && k > 0, MEVI_ERR_INVALID_ARG,
@@ -1140,13 +1140,32 @@ extern "C" int mevi_ip_index_build_f32(const float *docs, int64_t nd, int64_t di
   return MEVI_OK;
 }
 
+namespace {
+// Second f16 pass for the queries the first one could not prove: twice the survivors (0: not available for
+// this k -- the sort + proof kernel holds at most 8192 keys in LDS), for at most a quarter of the batch.
+inline int h1_kprime2(int k) {
+  const int kp2 = 2 * h1_kprime(k);
+  return kp2 <= 8192 ? kp2 : 0;
+}
+inline int64_t h1_second_pass_max(int64_t nq) { return (nq + 3) / 4; }
+inline size_t h1_second_pass_bytes(int64_t nq, int64_t dim, int64_t k) {
+  const int kp2 = h1_kprime2((int)k);
+  if (kp2 == 0) return 0;
+  const int64_t n2 = h1_second_pass_max(nq);
+  // state + exact lists + f32 and f16 query rows + norm / scale / shift + row indices
+  return state_bytes(n2, make_geom(kp2)) + align_up((size_t)n2 * k * 8, 256) + align_up((size_t)n2 * dim * 4, 256) +
+         align_up((size_t)n2 * pad_k(dim) * 2, 256) + 2 * align_up((size_t)(n2 + 1) * 4, 256) +
+         align_up((size_t)n2 * 8, 256) + align_up((size_t)n2 * 4, 256);
+}
+}  // namespace
+
 extern "C" size_t mevi_ip_topk_indexed_workspace_bytes(int64_t nq, int64_t dim, int64_t k) {
   if (nq <= 0 || k <= 0 || k > 4096 || dim <= 0) return 0;
   const TopkGeom gp = make_geom(h1_kprime((int)k));
-  // approx state (K' geometry) + exact top lists + f16 queries + per-query norm / scale / shift, then the
-  // exact-path workspace for the fallback
+  // approx state (K' geometry) + exact top lists + f16 queries + per-query norm / scale / shift, the second
+  // pass, then the exact-path workspace for the fallback
   return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)nq * pad_k(dim) * 2, 256) +
-         2 * align_up((size_t)(nq + 1) * 4, 256) + align_up((size_t)nq * 8, 256) +
+         2 * align_up((size_t)(nq + 1) * 4, 256) + align_up((size_t)nq * 8, 256) + h1_second_pass_bytes(nq, dim, k) +
          mevi_ip_topk_workspace_bytes(nq, dim, k) + 256;
 }
 
@@ -1154,7 +1173,7 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
                                         int64_t dim, int64_t k, int64_t id_offset, float *out_score,
                                         int64_t *out_id, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
   for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
   g_events.clear();
   MEVI_REQUIRE(nq >= 0 && nd >= 0 && dim > 0 && k > 0, MEVI_ERR_INVALID_ARG, "ip_topk_indexed: bad shape");
@@ -1185,6 +1204,8 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   p += align_up((size_t)(nq + 1) * 4, 256);
   double *qshift = reinterpret_cast<double *>(p);  // [nq] q.mu
   p += align_up((size_t)nq * 8, 256);
+  char *second_ws = p;
+  p += h1_second_pass_bytes(nq, dim, k);
   void *exact_ws = p;
   const size_t exact_ws_bytes = mevi_ip_topk_workspace_bytes(nq, dim, k);
   const float c1 = h1_c1(dimp), c2 = h1_c2(dim);
@@ -1228,6 +1249,56 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   std::vector<int> idx;
   for (int64_t i = 0; i < nq; ++i)
     if (failed[(size_t)i] || bound_suspect) idx.push_back((int)i);
+  const int kp2 = h1_kprime2((int)k);
+  if (!idx.empty() && !bound_suspect && kp2 != 0 && (int64_t)idx.size() <= h1_second_pass_max(nq)) {
+    // Second chance before the 7x slower exact path: the same f16 search for the unproven queries only, with twice
+    // the survivors -- what a cluster of near-identical scores around the k-th needs (duplicated passages).
+    const int64_t n2 = (int64_t)idx.size();
+    g_stats.n_second_pass_queries = n2;
+    const TopkGeom g2 = make_geom(kp2);
+    char *w = second_ws;
+    SearchState s2 = carve_state(w, h1_second_pass_max(nq), g2);
+    unsigned long long *top2 = reinterpret_cast<unsigned long long *>(w);
+    w += align_up((size_t)h1_second_pass_max(nq) * k * 8, 256);
+    float *q2 = reinterpret_cast<float *>(w);
+    w += align_up((size_t)h1_second_pass_max(nq) * dim * 4, 256);
+    float *qimage2 = reinterpret_cast<float *>(w);
+    w += align_up((size_t)h1_second_pass_max(nq) * dimp * 2, 256);
+    float *qnorm2 = reinterpret_cast<float *>(w);
+    w += align_up((size_t)(h1_second_pass_max(nq) + 1) * 4, 256);
+    float *qinv2 = reinterpret_cast<float *>(w);
+    w += align_up((size_t)(h1_second_pass_max(nq) + 1) * 4, 256);
+    double *qshift2 = reinterpret_cast<double *>(w);
+    w += align_up((size_t)h1_second_pass_max(nq) * 8, 256);
+    int *idx2 = reinterpret_cast<int *>(w);
+    MEVI_HIP_CHECK(hipMemcpyAsync(idx2, idx.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n2), dim3(256), 0, stream, q, idx2, (int)n2, (int)dim, q2);
+    hipLaunchKernelGGL(split_queries_f16_kernel, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, stream, q2, (long long)n2,
+                       (int)dim, (int)dimp, iv.mu, iv.scal, reinterpret_cast<_Float16 *>(qimage2), qnorm2, qinv2, qshift2);
+    const double keep_flops = g_stats.filter_flops;
+    const int64_t l2 = run_pass(qimage2, n2, iv.image, nd, (int)dimp, g2, (uint32_t)id_offset, s2, false, stream, true);
+    g_stats.filter_flops = keep_flops;
+    if (l2 < 0) return MEVI_ERR_HIP;
+    int P2 = 64;
+    while (P2 < kp2) P2 <<= 1;
+    const long long waves2 = n2 * (long long)((kp2 + 63) / 64);
+    hipLaunchKernelGGL(rescore_rows_kernel, dim3((unsigned)((waves2 + 3) / 4)), dim3(256), 0, stream, q2, docs, (int)dim, s2.buf,
+                       g2.S, kp2, (int)n2, (unsigned int)id_offset, qnorm2, qinv2, qshift2, c1, c2, iv.bits, iv.norms_c,
+                       (unsigned int *)nullptr);
+    hipLaunchKernelGGL(rescore_finish_kernel, dim3((unsigned)n2), dim3(256), (size_t)P2 * 8, stream, s2.buf, g2.S, (int)k, kp2,
+                       s2.tau, qnorm2, qinv2, qshift2, c1, c2, iv.bits, s2.failed, top2, (int)k);
+    // proven rows go to their place in `top` (unproven ones are overwritten by the exact path below)
+    hipLaunchKernelGGL(scatter_top_kernel, dim3((unsigned)n2), dim3(256), 0, stream, top2, idx2, (int)n2, (int)k, (int)k, top,
+                       (int)k);
+    std::vector<unsigned int> failed2((size_t)n2);
+    MEVI_HIP_CHECK(hipMemcpyAsync(failed2.data(), s2.failed, (size_t)n2 * 4, hipMemcpyDeviceToHost, stream));
+    MEVI_HIP_CHECK(hipStreamSynchronize(stream));
+    profile_collect();
+    std::vector<int> still;
+    for (int64_t i = 0; i < n2; ++i)
+      if (failed2[(size_t)i]) still.push_back(idx[(size_t)i]);
+    idx.swap(still);
+  }
   if (!idx.empty()) {  // unproven or overflowed queries: exact f32 search of just those, scattered into `top`
     const int64_t nf = (int64_t)idx.size();
     g_stats.n_failed_queries = nf;

@@ -21,7 +21,7 @@ class MeviHipError(RuntimeError):
 class IpTopkStats(ctypes.Structure):
     _fields_ = [("n_chunks", c_int64), ("n_failed_queries", c_int64), ("n_fallback_chunks", c_int64),
                 ("filter_ms", c_double), ("compact_ms", c_double), ("filter_flops", c_double),
-                ("max_err_ratio", c_double), ("err_bound", c_double)]
+                ("max_err_ratio", c_double), ("err_bound", c_double), ("n_second_pass_queries", c_int64)]
 
 
 _SIGNATURES = {

@@ -258,6 +258,23 @@ def test_indexed_prefilter_proves_most_queries_and_falls_back_for_the_rest(cuda)
     assert _stats().n_failed_queries >= 1
 
 
+def test_second_pass_proves_a_cluster_of_duplicates(cuda):
+    """250 near-identical rows on top of a query's list: the 192 survivors of the first pass cannot separate
+    them from the rest, the second pass (384 survivors) holds them all and proves the list -- no exact-path run."""
+    rng = np.random.default_rng(61)
+    base = rng.standard_normal((1, 64), dtype=np.float32)
+    d = np.concatenate([base + 1e-6 * rng.standard_normal((250, 64)).astype(np.float32),
+                        rng.standard_normal((8000, 64), dtype=np.float32)])
+    d = d[rng.permutation(len(d))]
+    q = np.concatenate([base * 2, rng.standard_normal((7, 64), dtype=np.float32)])
+    s, i = _run_indexed(q, d, 50, cuda)
+    st = _stats()
+    es, ei = odense.ip_topk_exact(q, d, 50)
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
+    assert st.n_second_pass_queries >= 1 and st.n_failed_queries == 0, (st.n_second_pass_queries, st.n_failed_queries)
+
+
 def test_rejects_bad_arguments(cuda):
     q = torch.zeros((4, 6), device=cuda)
     d = torch.zeros((9, 6), device=cuda)
