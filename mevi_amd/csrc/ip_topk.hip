@@ -3,26 +3,25 @@
 // Replaces faiss IndexFlat(IP).add/search at MEVI/faiss_search.py:13-21 and the
 // in-cluster matmul+sort at MEVI/main_models.py:3967-3968,4012.
 //
-// Structure (see DESIGN.md "Dense arm"):
-//   * ip_filter_kernel  -- f32 MFMA (v_mfma_f32_32x32x2_f32) tile GEMM
-//     docs[128] x queries[128] per workgroup, K streamed through LDS in 32-wide
-//     slabs (register-staged double buffer).  The score matrix is never
-//     written: the epilogue compares every accumulator with the query's running
-//     threshold tau[q] (its current k-th best score) and appends the few
-//     survivors to a per-query candidate list with one atomic each.
-//   * compact_kernel    -- per query: radix-selects the k largest of current top-k
-//     + new candidates in LDS (64-bit score|id keys), keeps the best k, raises
-//     tau[q].
-//   The corpus is walked in geometrically growing chunks (each chunk doubles
-//   the number of rows seen) so the expected number of survivors per chunk is
-//   ~k per query; a query whose candidate list overflows (adversarial row
-//   order) is flagged and recomputed by the guaranteed path (chunk <= capacity).
-//   * finalize_kernel   -- keys -> (f32 score, i64 id) with faiss-style padding.
+// Structure:
+//   * ip_filter_kernel     -- exact path: f32 MFMA (v_mfma_f32_32x32x2_f32) tile GEMM, 2 x 128 docs x 128 queries
+//     per workgroup (mfma_pp.h).  The score matrix is never written: the epilogue (emit_tile) compares every
+//     accumulator with the query's running threshold tau[q] (its current k-th best score) and appends the
+//     survivors to the query's candidate slots (count pass, one slot-allocating atomic per column, plain stores).
+//   * ip_filter_h1_kernel  -- indexed path: the same filter on APPROXIMATE scores, one f16 MFMA per product on
+//     centred, scaled f16 images (mfma_pp_f16.h); persistent workgroups, per-wave candidate stash.
+//   * compact_kernel       -- per query: radix-selects the k largest of (current list + new candidates) in LDS
+//     (64-bit score|id keys) and raises tau[q]; the lists are sorted once (sort_lists_kernel / after re-scoring).
+//   * rescore_rows_kernel, rescore_finish_kernel -- exact f32 chains of the survivors, exact top-k and the
+//     per-query proof that nothing outside the survivors can belong to it; unproven queries get a second, wider
+//     f16 pass and then the exact path.
+//   The corpus is walked in geometrically growing chunks so the expected number of candidates per chunk is a small
+//   multiple of k per query; a query whose candidate slots overflow (adversarial row order) is flagged and
+//   recomputed by the guaranteed path (chunk <= capacity).
+//   * finalize_kernel      -- keys -> (f32 score, i64 id) with faiss-style padding; merge_kernel -- shard lists.
 //
-// Numerics: each score is the f32 fmaf chain over k = 0..dim-1 in order (the
-// LDS image de-interleaves even/odd k so that MFMA lane half 0 supplies even k
-// and half 1 odd k); oracle/mevi_oracle.c computes the same chain on the CPU,
-// so parity is bit-exact.
+// Numerics: every returned score is the f32 fmaf chain over k = 0..dim-1 in order (MFMA lane half h supplies
+// k = 2j + h); oracle/mevi_oracle.c computes the same chain on the CPU, so parity is bit-exact on both paths.
 
 #include "mfma_pp_f16.h"
 
