@@ -194,6 +194,18 @@ int mevi_rq_neg_dist_f32(const float *x, int64_t n, int64_t dim, const float *ce
 int mevi_gather_sub_f32(const float *x, const int64_t *src, const float *centroids, const int32_t *code,
                         int64_t n, int64_t dim, float *out, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Centroid update of k-means / RQ codebook training (the offline index build the reference does with
+ * scikit-learn, MEVI/pq.py:550-598; assignment = mevi_rq_encode_f32 with a one-level codebook):
+ *   centroids[k] = mean of the rows x[i] with codes[i * code_stride] == k  (an empty cluster keeps
+ *   old_centroids[k], or 0 when old_centroids is null), counts[k] = their number, *sum_sq = sum ||x_i||^2.
+ * Deterministic (fixed-order two-stage reduction, f64 second stage).  Stream-ordered.
+ *   x f32 [n, dim], codes i32, centroids f32 [K, dim], counts i32 [K], sum_sq f64 [1] (may be null). */
+size_t mevi_cluster_means_workspace_bytes(int64_t n, int64_t dim, int64_t K);
+int mevi_cluster_means_f32(const float *x, int64_t n, int64_t dim, const int32_t *codes, int64_t code_stride,
+                           int64_t K, const float *old_centroids, float *centroids, int32_t *counts, double *sum_sq,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* Test / tuning hooks for the dense arm (not part of the drop-in surface):
  * force the chunk growth factor (0 = default) and read back statistics of the
  * last mevi_ip_topk_f32 call on this thread. */

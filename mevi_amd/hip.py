@@ -58,6 +58,9 @@ _SIGNATURES = {
     "mevi_segment_sort_desc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mevi_rq_neg_dist_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "mevi_gather_sub_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "mevi_cluster_means_workspace_bytes": (ctypes.c_size_t, [c_int64, c_int64, c_int64]),
+    "mevi_cluster_means_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "mevi_ip_topk_set_growth": (None, [c_double]),
     "mevi_ip_topk_set_profiling": (None, [c_int]),
     "mevi_ip_topk_get_stats": (None, [ctypes.POINTER(IpTopkStats)]),

@@ -36,6 +36,109 @@ def rq_encode(x, codebook):
     return codes
 
 
+def cluster_means(x, labels, K, old=None):
+    """Per-cluster means of x f32[n, dim] under labels i32[n] (or [n, 1]): (centroids f32[K, dim], counts i32[K],
+    sum of squared row norms as a float).  Deterministic; an empty cluster keeps `old[k]` (0 without `old`)."""
+    hip.require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and labels.dtype == torch.int32 and x.is_contiguous()
+    n, dim = x.shape
+    labels = labels.contiguous().view(-1)
+    cent = torch.empty((K, dim), dtype=torch.float32, device=x.device)
+    counts = torch.empty(K, dtype=torch.int32, device=x.device)
+    sumsq = torch.zeros(1, dtype=torch.float64, device=x.device)
+    L = hip.lib()
+    nbytes = L.mevi_cluster_means_workspace_bytes(n, dim, K)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        st = L.mevi_cluster_means_f32(hip.ptr(x), n, dim, hip.ptr(labels), 1, K,
+                                      hip.ptr(old.contiguous()) if old is not None else None, hip.ptr(cent),
+                                      hip.ptr(counts), hip.ptr(sumsq), hip.ptr(ws), nbytes, hip.stream_ptr())
+    hip.check(st, "mevi_cluster_means_f32")
+    return cent, counts, float(sumsq.item())
+
+
+def _kmeans_pp(xs, K, gen):
+    """k-means++ seeding with 2 + log(K) greedy trials per centre (the scheme scikit-learn's `init='k-means++'` uses),
+    on a sample that fits a [trials, m] distance matrix; torch ops on the device (seeding is a few thousand rows)."""
+    m = xs.shape[0]
+    trials = 2 + int(np.log(K))
+    centers = torch.empty((K, xs.shape[1]), dtype=torch.float32, device=xs.device)
+    first = int(torch.randint(m, (1,), generator=gen, device=xs.device).item())
+    centers[0] = xs[first]
+    d2 = ((xs - centers[0]) ** 2).sum(1)
+    for c in range(1, K):
+        probs = (d2 / d2.sum().clamp_min(1e-30)).clamp_min(0)
+        cand = torch.multinomial(probs, trials, replacement=True, generator=gen)
+        dc = torch.cdist(xs[cand], xs) ** 2                    # [trials, m]
+        pot = torch.minimum(dc, d2[None]).sum(1)
+        best = int(torch.argmin(pot).item())
+        centers[c] = xs[cand[best]]
+        d2 = torch.minimum(d2, dc[best])
+    return centers
+
+
+def kmeans(x, K, seed=0, max_iter=100, n_init=10, sample=32768, tol=1e-7):
+    """Lloyd's k-means on the GPU: assignment = mevi_rq_encode_f32 against a one-level codebook (lowest index on ties,
+    as everywhere), update = mevi_cluster_means_f32.  `n_init` k-means++ seedings are tried on a sample, the one with
+    the lowest sample inertia after a few iterations starts the full run.  Returns (centres f32[K, dim],
+    labels i32[n], inertia).  Deterministic for a given seed.
+
+    Stands in for the scikit-learn (Mini-batch) KMeans the reference trains its codebooks with (MEVI/pq.py:550-567):
+    a randomised algorithm, so parity is statistical -- tests hold the final quantisation error against
+    scikit-learn's on the same data."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    x = x.contiguous()
+    n = x.shape[0]
+    gen = torch.Generator(device=x.device).manual_seed(int(seed))
+    xs = x[torch.randperm(n, generator=gen, device=x.device)[:min(n, sample)]].contiguous()
+
+    def lloyd(data, centers, iters):
+        inertia = float("inf")
+        labels = None
+        for _ in range(iters):
+            labels = rq_encode(data, centers[None].contiguous()).view(-1)
+            new, counts, sumsq = cluster_means(data, labels, K, old=centers)
+            # inertia of the NEW centres w.r.t. this assignment: sum ||x||^2 - sum_k n_k ||m_k||^2
+            new_inertia = sumsq - float((counts.double() * (new.double() ** 2).sum(1)).sum().item())
+            shift = float(((new - centers) ** 2).sum().item())
+            centers = new
+            if shift <= tol * max(float((centers ** 2).sum().item()), 1e-30) or abs(inertia - new_inertia) <= tol * abs(new_inertia):
+                inertia = new_inertia
+                break
+            inertia = new_inertia
+        return centers, labels, inertia
+
+    best = None
+    for _ in range(max(1, n_init)):
+        c0 = _kmeans_pp(xs, K, gen)
+        c1, _, inert = lloyd(xs, c0, 10)
+        if best is None or inert < best[1]:
+            best = (c1, inert)
+    centers, labels, inertia = lloyd(x, best[0], max_iter)
+    labels = rq_encode(x, centers[None].contiguous()).view(-1)   # labels of the returned centres
+    return centers, labels, inertia
+
+
+def train_rq_codebook(x, M, K, seed=0, **kw):
+    """Residual quantisation codebook as the reference trains it (MEVI/pq.py:577-592): level i is k-means on the
+    residual left by levels < i.  Returns (codebook f32[M, K, dim], codes i32[n, M]); `x` is not modified."""
+    res = x.contiguous().clone()
+    n, dim = res.shape
+    src = torch.arange(n, dtype=torch.int64, device=x.device)
+    book, codes = [], []
+    L = hip.lib()
+    for level in range(M):
+        centers, labels, _ = kmeans(res, K, seed=seed + level, **kw)
+        book.append(centers)
+        codes.append(labels)
+        if level != M - 1:
+            with torch.cuda.device(x.device):   # res -= centers[labels], row by row in place
+                st = L.mevi_gather_sub_f32(hip.ptr(res), hip.ptr(src), hip.ptr(centers), hip.ptr(labels), n, dim,
+                                           hip.ptr(res), hip.stream_ptr())
+            hip.check(st, "mevi_gather_sub_f32")
+    return torch.stack(book), torch.stack(codes, 1).contiguous()
+
+
 class ClusterIndex:
     """CSR form of the reference's `pq_doc_cluster: dict[tuple -> list[int]]` and
     `pq_mapping: dict[int -> tuple]` (MEVI/main_models.py:3200-3220).
@@ -129,12 +232,29 @@ class ProductQuantization:
         import torch.distributed as dist
 
         if rank == 0:
-            if index_file is None or not os.path.isfile(index_file):
-                raise FileNotFoundError(f"RQ codebook {index_file}: training a codebook is out of scope")
-            print("Intializing codebook with torch file...")
-            self.load_codebook(torch.load(index_file, map_location="cpu"))
+            if index_file is not None and os.path.isfile(index_file):
+                print("Intializing codebook with torch file...")
+                self.load_codebook(torch.load(index_file, map_location="cpu"))
+            elif doc_emb is not None:  # pq.py:402-419: no file -> train on the embeddings, then save next to it
+                self.unsupervised_update_codebook_manually(doc_emb, seed, self.pq_init_method)
+                if index_file is not None:
+                    torch.save(self.codebook.detach().cpu(), index_file)
+            else:
+                raise FileNotFoundError(f"RQ codebook {index_file} not found and no embeddings to train one on")
         if dist.is_available() and dist.is_initialized():
             dist.broadcast(self.codebook, 0)
+
+    def unsupervised_update_codebook_manually(self, doc_emb, seed, kmeans_method="kmeans"):
+        """Train the residual codebook on `doc_emb` (MEVI/pq.py:550-598, the scikit-learn path): level i = k-means
+        (k = 2**bits) on the residual of levels < i.  Runs on the GPU (`train_rq_codebook`); sets `last_preds`
+        (i64 ndarray [n, M]) like the reference."""
+        assert kmeans_method == "kmeans", kmeans_method
+        print("Updating codebook using KMeans...")
+        x = doc_emb if torch.is_tensor(doc_emb) else torch.from_numpy(np.ascontiguousarray(doc_emb, dtype=np.float32))
+        x = x.to(self.device, torch.float32)
+        book, codes = train_rq_codebook(x, self.subvector_num, self.subvector_cents, seed=int(seed))
+        self.codebook.copy_(book)
+        self.last_preds = codes.cpu().numpy().astype(np.int64)
 
     def forward(self, vecs, return_loss=False):
         """index i32[n, M]; the reference's (proba, index, loss) triple minus the training outputs."""
