@@ -37,11 +37,16 @@ def doc_rank_range(n, rank, nrank):
 
 
 def load_document_encoder(model_path, ckpt_path, device):
+    """T5-ANCE (tied T5 towers) or a BERT-family tower (coCondenser directory / AR2 `.pkl`), chosen like the
+    reference's get_document_encoder + AutoModel (generate.py:31-44)."""
     import torch
 
-    from mevi_amd.evalrun import load_tower_weights
+    from mevi_amd.evalrun import load_bert_tower, load_tower_weights, tower_model_type
     from mevi_amd.t5 import TwinTower
 
+    if tower_model_type(model_path) == "bert":
+        assert ckpt_path is None, "--ckpt_path (fine-tuned T5 tower inside a training checkpoint) does not apply to BERT towers"
+        return load_bert_tower(model_path, device)
     weights, dims = load_tower_weights(model_path)
     if ckpt_path is not None:  # fine-tuned tower inside a training checkpoint (generate.py:200-211)
         sd = torch.load(ckpt_path, map_location="cpu")

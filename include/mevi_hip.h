@@ -116,7 +116,7 @@ int mevi_rq_encode_f32(const float *x, int64_t n, int64_t dim, const float *code
  * the adaptor's nn.TransformerDecoderLayer projections and adaptor_linear
  * (modeling_t5.py:1252-1255, 1677-1682).  W is the [out, in] weight of nn.Linear.
  *   lda/ldw/ldc/ldr: row strides in floats; bias, residual may be NULL;
- *   act: 0 = identity, 1 = ReLU (applied before the residual add).
+ *   act: 0 = identity, 1 = ReLU, 2 = erf GELU (BERT towers, modeling_bert.py intermediate) -- applied before the residual add.
  *   Each output is the sequential f32 fmaf chain over k.
  *   Requirements: K, lda, ldw multiples of 4; A, W 16-byte aligned.
  * Fully stream-ordered; no workspace.

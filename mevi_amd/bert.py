@@ -1,0 +1,93 @@
+"""BERT-family towers of the dense arm (coCondenser / AR2 / ERNIE-2.0: `DocumentEncoder` with mtype 'bert',
+MEVI/document_encoder.py:43-44,104-123; model = the vendored `transformers.modeling_bert.BertModel`):
+reps = last_hidden_state[:, 0, :] of a post-LN encoder with absolute position embeddings, erf-GELU and biased
+linear layers.  Everything runs on the HIP kernels (GEMM with bias / GELU / residual epilogues, add+LayerNorm,
+attention with the 1/sqrt(d) scale and the key mask)."""
+import torch
+
+from . import ops
+
+
+def _dev(w, name, device):
+    import numpy as np
+
+    t = w[name]
+    t = torch.from_numpy(np.ascontiguousarray(t)) if not torch.is_tensor(t) else t
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class BertEncoder:
+    """BertModel (embeddings + encoder, no pooler).  Weights: the reference's state_dict names (optionally under
+    `prefix`, e.g. 'bert.')."""
+
+    def __init__(self, w, num_layers, num_heads, eps=1e-12, device=None, prefix=""):
+        self.dev = torch.device(device if device is not None else "cuda")
+        self.H, self.eps = num_heads, eps
+        g = lambda n: _dev(w, prefix + n, self.dev)  # noqa: E731
+        self.word = g("embeddings.word_embeddings.weight")
+        self.pos = g("embeddings.position_embeddings.weight")
+        self.type0 = g("embeddings.token_type_embeddings.weight")[0].contiguous()
+        task = prefix + "embeddings.task_type_embeddings.weight"       # ERNIE with use_task_id: task id 0
+        if task in w:
+            self.type0 = (self.type0 + _dev(w, task, self.dev)[0]).contiguous()
+        self.emb_ln = (g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"))
+        self.layers = []
+        for l in range(num_layers):
+            p = f"encoder.layer.{l}."
+            self.layers.append(dict(
+                wqkv=torch.cat([g(p + f"attention.self.{n}.weight") for n in ("query", "key", "value")]).contiguous(),
+                bqkv=torch.cat([g(p + f"attention.self.{n}.bias") for n in ("query", "key", "value")]).contiguous(),
+                wo=g(p + "attention.output.dense.weight"), bo=g(p + "attention.output.dense.bias"),
+                ln1=(g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias")),
+                wi=g(p + "intermediate.dense.weight"), bi=g(p + "intermediate.dense.bias"),
+                wo2=g(p + "output.dense.weight"), bo2=g(p + "output.dense.bias"),
+                ln2=(g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"))))
+        self.d = self.word.shape[1]
+        self.dh = self.d // num_heads
+
+    def forward(self, input_ids, attention_mask):
+        """input_ids / attention_mask i64[B, S] (S <= 256, token types all 0) -> last hidden state f32[B, S, d]."""
+        B, S = input_ids.shape
+        d = self.d
+        x = ops.gather_rows(self.word, input_ids.reshape(-1))
+        pos = self.pos[:S].repeat(B, 1)
+        x = ops.add_layernorm(x, pos, self.emb_ln[0], self.emb_ln[1], eps=self.eps, cvec=self.type0)
+        scale = float(self.dh) ** -0.5
+        for L in self.layers:
+            qkv = ops.linear(x, L["wqkv"], bias=L["bqkv"]).view(B, S, 3 * d)
+            ctx = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], self.H, key_mask=attention_mask,
+                                scale=scale)
+            a = ops.linear(ctx.view(B * S, d), L["wo"], bias=L["bo"])
+            x = ops.add_layernorm(a, x, L["ln1"][0], L["ln1"][1], eps=self.eps)
+            h = ops.linear(x, L["wi"], bias=L["bi"], gelu=True)
+            o = ops.linear(h, L["wo2"], bias=L["bo2"])
+            x = ops.add_layernorm(o, x, L["ln2"][0], L["ln2"][1], eps=self.eps)
+        return x.view(B, S, d)
+
+
+class BertTower:
+    """`DocumentEncoder` of mtype 'bert': reps = last_hidden_state[:, 0, :] (normalize=False).  `weights_p` gives the
+    passage model its own weights (AR2: ctx_model / question_model); tied otherwise."""
+
+    def __init__(self, weights_q, num_layers, num_heads, weights_p=None, eps=1e-12, device=None, batch_size=512, prefix=""):
+        self.dev = torch.device(device if device is not None else "cuda")
+        self.lm_q = BertEncoder(weights_q, num_layers, num_heads, eps, self.dev, prefix)
+        self.lm_p = self.lm_q if weights_p is None else BertEncoder(weights_p, num_layers, num_heads, eps, self.dev, prefix)
+        self.batch_size = batch_size
+
+    def _encode(self, model, items):
+        ids = items["input_ids"].to(self.dev, torch.int64)
+        mask = items["attention_mask"].to(self.dev, torch.int64)
+        outs = []
+        for a in range(0, ids.shape[0], self.batch_size):
+            i, m = ids[a:a + self.batch_size].contiguous(), mask[a:a + self.batch_size].contiguous()
+            outs.append(model.forward(i, m)[:, 0, :].contiguous())
+        return torch.cat(outs) if outs else torch.empty((0, model.d), device=self.dev)
+
+    def encode_query(self, qry):
+        return self._encode(self.lm_q, qry)
+
+    def encode_passage(self, psg):
+        return self._encode(self.lm_p, psg)
+
+    encode = encode_query

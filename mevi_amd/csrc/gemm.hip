@@ -1,4 +1,5 @@
-// C[M, N] = act(A[M, K] . W[N, K]^T + bias[N]) + residual[M, N]   (all f32, row-major, K contiguous)
+// C[M, N] = act(A[M, K] . W[N, K]^T + bias[N]) + residual[M, N]   (all f32, row-major, K contiguous;
+// act: none / relu / erf-gelu)
 //
 // The linear layers of the T5 stacks: q/k/v/o projections and wi/wo of every block
 // (MEVI/transformers/modeling_t5.py:181-186, 217-220, 350-358, 412), the adaptor's packed
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_kernel(
           float v = acc[mi][ni][r];
           if (bias) v += b;
           if (act == 1) v = fmaxf(v, 0.f);
+          else if (act == 2) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752f));  // erf GELU (BERT 'gelu')
           if (residual) v += residual[(size_t)m * ldr + n];
           C[(size_t)m * ldc + n] = v;
         }
@@ -95,7 +97,7 @@ extern "C" int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int
                (long long)lda, (long long)ldw);
   MEVI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0, MEVI_ERR_INVALID_ARG,
                "gemm_nt: a/w must be 16-byte aligned");
-  MEVI_REQUIRE(act == 0 || act == 1, MEVI_ERR_INVALID_ARG, "gemm_nt: act must be 0 (none) or 1 (relu)");
+  MEVI_REQUIRE(act >= 0 && act <= 2, MEVI_ERR_INVALID_ARG, "gemm_nt: act must be 0 (none), 1 (relu) or 2 (erf gelu)");
   MEVI_REQUIRE(m < (1LL << 31) && n < (1LL << 31) && k < (1LL << 24), MEVI_ERR_UNSUPPORTED, "gemm_nt: too large");
   const int64_t n_mpairs = (m + 2 * BM - 1) / (2 * BM);
   static int n_cu = 0;

@@ -57,6 +57,47 @@ def load_tower_weights(model_dir):
     return sd, dims
 
 
+def load_bert_tower(model_path, device, batch_size=512):
+    """BERT-family tower as `generate.get_document_encoder` + `DocumentEncoder.build` load it (MEVI/generate.py:31-44,
+    document_encoder.py:141-188): an HF directory (config.json + pytorch_model.bin, tied towers), or an AR2 checkpoint
+    `ar2g_{nq,marco}_finetune.pkl` ({'model_dict': {'ctx_model.*', 'question_model.*'}}) with its config directory
+    next to it (`ernie-2.0-base-en` / `co-condenser-marco-retriever`)."""
+    import json
+
+    from .bert import BertTower
+
+    def strip(sd):  # AutoModel state dicts may carry the task-model prefix
+        for pre in ("bert.", "ernie."):
+            if any(k.startswith(pre + "embeddings.") for k in sd):
+                return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        return sd
+
+    wp = None
+    if model_path.endswith(".pkl"):
+        cfg_dir = os.path.join(os.path.split(model_path)[0],
+                               "ernie-2.0-base-en" if model_path.endswith("ar2g_nq_finetune.pkl")
+                               else "co-condenser-marco-retriever")
+        params = torch.load(model_path, map_location="cpu")["model_dict"]
+        wq = strip({k[len("question_model."):]: v for k, v in params.items() if k.startswith("question_model.")})
+        wp = strip({k[len("ctx_model."):]: v for k, v in params.items() if k.startswith("ctx_model.")})
+    else:
+        cfg_dir = model_path
+        wq = strip(torch.load(os.path.join(model_path, "pytorch_model.bin"), map_location="cpu"))
+    cfg = json.load(open(os.path.join(cfg_dir, "config.json")))
+    return BertTower(wq, cfg["num_hidden_layers"], cfg["num_attention_heads"], weights_p=wp,
+                     eps=cfg.get("layer_norm_eps", 1e-12), device=device, batch_size=batch_size)
+
+
+def tower_model_type(model_path):
+    """'t5' or 'bert' (BERT / ERNIE), from the config.json the reference's AutoConfig would read."""
+    import json
+
+    if model_path.endswith(".pkl"):
+        return "bert"
+    mt = json.load(open(os.path.join(model_path, "config.json"))).get("model_type", "t5")
+    return "bert" if mt in ("bert", "ernie") else "t5"
+
+
 def load_queries(data_dir, n_test=-1, fname="dev_mevi_dedup.tsv"):
     """dev_mevi_dedup.tsv: `query \\t id,id,...` (main_utils.load_data_infer, MEVI/main_utils.py:271-278)."""
     df = pd.read_csv(os.path.join(data_dir, fname), names=["query", "oldid"], encoding="utf-8", header=None,

@@ -17,8 +17,10 @@ def _rows2d(t):
     return t, t.shape[0], t.shape[1], t.stride(0)
 
 
-def linear(x, weight, bias=None, residual=None, relu=False, out=None):
-    """out = act(x @ weight.T + bias) + residual   (x [M,K], weight [N,K] = nn.Linear layout)."""
+def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False):
+    """out = act(x @ weight.T + bias) + residual   (x [M,K], weight [N,K] = nn.Linear layout; act = relu, erf-gelu
+    or none)."""
+    assert not (relu and gelu)
     x, M, K, lda = _rows2d(_f32(x))
     w, N, K2, ldw = _rows2d(_f32(weight))
     assert K == K2, (x.shape, weight.shape)
@@ -31,7 +33,7 @@ def linear(x, weight, bias=None, residual=None, relu=False, out=None):
         ldr = residual.stride(0)
     st = hip.lib().mevi_gemm_nt_f32(hip.ptr(x), lda, hip.ptr(w), ldw, hip.ptr(out), out.stride(0), M, N, K,
                                     hip.ptr(bias) if bias is not None else None,
-                                    hip.ptr(residual) if residual is not None else None, ldr, 1 if relu else 0,
+                                    hip.ptr(residual) if residual is not None else None, ldr, 1 if relu else (2 if gelu else 0),
                                     hip.stream_ptr())
     hip.check(st, "mevi_gemm_nt_f32")
     return out

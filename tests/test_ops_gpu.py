@@ -45,6 +45,8 @@ def test_linear_epilogues_and_strides(cuda):
     ref = F.relu(a @ w.T + b) + r
     out = ops.linear(a.to(cuda), w.to(cuda), bias=b.to(cuda), residual=r.to(cuda), relu=True)
     assert (out.cpu() - ref).abs().max() <= 1e-4
+    gel = ops.linear(a.to(cuda), w.to(cuda), bias=b.to(cuda), gelu=True)
+    assert (gel.cpu() - F.gelu(a @ w.T + b)).abs().max() <= 1e-4
     # strided views: A is a column slice, output goes into a slice of a wider buffer
     big = torch.zeros((200, 400), device=cuda)
     wide = torch.from_numpy(rng.standard_normal((200, 192)).astype(np.float32)).to(cuda)

@@ -66,3 +66,17 @@ def test_nci_generate_matches_reference(path):
         assert np.abs(mine - ref).max() <= 2e-4 * max(1.0, np.abs(ref[ref > -1e8]).max())
     codes = ot5.decode_token(dec, cfg["K"])
     assert codes.min() >= 0 and codes.max() < cfg["K"] and codes.shape[1] == cfg["M"]
+
+
+def test_bert_tower_oracle_matches_reference_bertmodel():
+    """oracle/bert.py against the vendored BertModel's own outputs (mtype 'bert' towers: coCondenser / AR2)."""
+    from oracle import bert as obert
+
+    g = np.load(os.path.join(GOLD, "g8_bert_tower.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    W = obert.load_weights(g)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    hid = obert.encoder(W, cfg, ids, mask)
+    valid = g["attention_mask"].astype(bool)
+    assert np.abs(hid.numpy() - g["hidden"])[valid].max() <= 2e-5      # padded positions are not defined outputs
+    assert np.abs(obert.tower_encode(W, cfg, ids, mask).numpy() - g["reps"]).max() <= 2e-5

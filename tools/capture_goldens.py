@@ -414,6 +414,47 @@ def g2p_t5_passage():
     print("g2p reps", tuple(out.last_hidden_state.shape))
 
 
+def g8_bert_tower():
+    """BertModel forward as DocumentEncoder.encode does it for mtype 'bert' (document_encoder.py:104-120):
+    reps = last_hidden_state[:, 0, :]; 40-token windows with ragged lengths, token types all 0."""
+    ref_import.setup()
+    import torch
+    from transformers import BertConfig, BertModel
+
+    torch.manual_seed(9)
+    cfg = BertConfig(vocab_size=400, hidden_size=48, num_hidden_layers=2, num_attention_heads=4, intermediate_size=96,
+                     max_position_embeddings=64, type_vocab_size=2)
+    model = BertModel(cfg)
+    model.eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("LayerNorm.weight"):
+                p_.copy_(1.0 + 0.2 * torch.randn_like(p_))
+            elif n_.endswith("bias"):
+                p_.copy_(0.1 * torch.randn_like(p_))
+            elif "embeddings" not in n_:
+                p_.copy_(0.15 * torch.randn_like(p_))
+    rng = np.random.default_rng(80)
+    n, S = 7, 40
+    ids = np.zeros((n, S), np.int64)
+    mask = np.zeros((n, S), np.int64)
+    for i, L in enumerate([40, 3, 17, 33, 8, 25, 40]):
+        ids[i, 0] = 101
+        ids[i, 1:L - 1] = rng.integers(5, cfg.vocab_size, size=L - 2)
+        ids[i, L - 1] = 102
+        mask[i, :L] = 1
+    with torch.no_grad():
+        out = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                    token_type_ids=torch.zeros((n, S), dtype=torch.long), return_dict=True)
+    sd = {k_: v_ for k_, v_ in model.state_dict().items() if "position_ids" not in k_ and not k_.startswith("pooler")}
+    np.savez(os.path.join(GOLD, "g8_bert_tower.npz"), input_ids=ids, attention_mask=mask,
+             hidden=out.last_hidden_state.numpy(), reps=out.last_hidden_state[:, 0, :].numpy(),
+             **{"w." + k_: v_.detach().numpy() for k_, v_ in sd.items()},
+             cfg=np.array(json.dumps(dict(num_hidden_layers=2, num_attention_heads=4, layer_norm_eps=cfg.layer_norm_eps,
+                                          hidden_act=cfg.hidden_act))))
+    print("g8 reps", tuple(out.last_hidden_state.shape), cfg.hidden_act)
+
+
 def g3_relative_buckets():
     """T5Attention._relative_position_bucket tables (modeling_t5.py:241-304)."""
     ref_import.setup()
@@ -430,7 +471,7 @@ def g3_relative_buckets():
     print("g3 ok")
 
 
-ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower, g2p=g2p_t5_passage,
+ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower, g2p=g2p_t5_passage, g8=g8_bert_tower,
            g3=g3_relative_buckets)
 
 if __name__ == "__main__":
