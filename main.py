@@ -2,7 +2,7 @@
 """`python main.py --mode eval ...` -- the argv surface of the reference's MEVI/main.py for the eval
 path that marco_eval_nci_rq.sh drives (MEVI/main.py:356-794, 267-337).  Every flag of that script is
 accepted; the ones that configure training are parsed and ignored.  Only --mode eval with
---codebook 1 --pq_type rq --document_encoder ance --query_encoder twin --recall_level both is built
+--codebook 1 --pq_type rq --document_encoder ance|cocondenser|ar2 --query_encoder twin --recall_level both is built
 (the configuration of every shipped eval script); anything else raises.
 
 One process per GPU: `--n_gpu N` spawns N ranks itself like the reference (queries split by rank,
@@ -82,8 +82,9 @@ def parsers_parser(argv=None):
 def check_supported(a):
     if a.mode != "eval":
         raise SystemExit("mevi_amd builds the inference hot path only: use --mode eval (training is out of scope)")
-    need = dict(codebook=1, pq_type="rq", document_encoder="ance", query_encoder="twin", recall_level="both",
-                doc_multiclus=1, eval_all_documents=0)
+    if a.document_encoder not in ("ance", "cocondenser", "ar2"):
+        raise SystemExit(f"main.py --mode eval: --document_encoder {a.document_encoder!r} is not built")
+    need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both", doc_multiclus=1, eval_all_documents=0)
     for k, v in need.items():
         if getattr(a, k) != v:
             raise SystemExit(f"main.py --mode eval: --{k} {getattr(a, k)!r} is not built (only {v!r}, as in marco_eval_nci_rq.sh)")

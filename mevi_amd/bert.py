@@ -74,6 +74,7 @@ class BertTower:
         self.lm_q = BertEncoder(weights_q, num_layers, num_heads, eps, self.dev, prefix)
         self.lm_p = self.lm_q if weights_p is None else BertEncoder(weights_p, num_layers, num_heads, eps, self.dev, prefix)
         self.batch_size = batch_size
+        self.dim = self.lm_q.d         # width of the embeddings this tower emits
 
     def _encode(self, model, items):
         ids = items["input_ids"].to(self.dev, torch.int64)

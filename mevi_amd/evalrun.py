@@ -118,7 +118,7 @@ def rank_slice(n, rank, nrank):
 
 
 class EvalRun:
-    def __init__(self, args, tokenizer=None, rank=0, nrank=1, barrier=None, device=None):
+    def __init__(self, args, tokenizer=None, rank=0, nrank=1, barrier=None, device=None, tower_tokenizer=None):
         self.args, self.rank, self.nrank = args, rank, nrank
         self.barrier = barrier or (lambda: None)
         hip.require_gpu()
@@ -130,15 +130,36 @@ class EvalRun:
         d_model = self.cfg.d_model
         self.nci = NCIModel(nci_w, cfg=self.cfg, device=self.dev)
         del nci_w
-        tower_dir = os.path.join(a.ckpt_dir, "t5-ance")
-        tw, tdims = load_tower_weights(tower_dir)
-        self.tower = TwinTower(tw, dims=tdims, device=self.dev)
+        # the tower and its tokenizer (init_document_encoder, MEVI/main_models.py:1643-1681)
+        enc = getattr(a, "document_encoder", None) or "ance"
+        tower_dir = os.path.join(a.ckpt_dir, "t5-ance")       # NCI shares the T5-ANCE vocabulary in every configuration
+        if enc == "ance":
+            tw, tdims = load_tower_weights(tower_dir)
+            self.tower = TwinTower(tw, dims=tdims, device=self.dev)
+        elif enc == "cocondenser":
+            self.tower = load_bert_tower(os.path.join(a.ckpt_dir, "co-condenser-marco-retriever"), self.dev)
+        elif enc == "ar2":
+            name = "ar2g_marco_finetune.pkl" if getattr(a, "dataset", "marco") == "marco" else "ar2g_nq_finetune.pkl"
+            self.tower = load_bert_tower(os.path.join(a.ckpt_dir, name), self.dev)
+        else:
+            raise NotImplementedError(enc)
         if tokenizer is None:
             from transformers import AutoTokenizer  # host-side tokenisation stays an HF call (boundary)
 
             tokenizer = AutoTokenizer.from_pretrained(tower_dir)
         self.tokenizer = tokenizer
+        # BERT-family towers read the query through their own tokenizer (`qenc_source_ids`, main_models.py:853-856):
+        # bert-base-uncased, special tokens only for 'ar2' (main_models.py:359-360)
+        self.tower_tokenizer = tower_tokenizer
+        self.tower_special_tokens = enc in ("ance", "ar2")
+        if enc != "ance" and tower_tokenizer is None:
+            from transformers import AutoTokenizer
+
+            local = os.path.join(a.ckpt_dir, "bert-base-uncased")
+            self.tower_tokenizer = AutoTokenizer.from_pretrained(local if os.path.isdir(local) else "bert-base-uncased",
+                                                                 do_lower_case=True)
         # corpus embeddings resident in HBM (the reference keeps a CPU memmap and copies per cluster)
+        d_model = self.tower.dim     # the corpus embeddings and the RQ codebook live in the tower's output space
         n_docs = os.path.getsize(a.embedding_path) // (4 * d_model)
         emb = np.memmap(a.embedding_path, dtype=np.float32, mode="r", shape=(n_docs, d_model))
         self.emb = torch.empty((n_docs, d_model), dtype=torch.float32, device=self.dev)
@@ -185,7 +206,12 @@ class EvalRun:
         B = len(texts)
         codes = decode_token(decoded, self.K).view(B, R, self.M).cpu().numpy()
         scores = np.array(scores).reshape(B, R)
-        qemb = self.tower.encode_query({"input_ids": ids, "attention_mask": mask})
+        if self.tower_tokenizer is None:      # T5-ANCE: the tower reads the NCI input ids (main_models.py:3797-3799)
+            qemb = self.tower.encode_query({"input_ids": ids, "attention_mask": mask})
+        else:
+            tok = self.tower_tokenizer.batch_encode_plus(list(texts), max_length=32, truncation=True, padding="max_length",
+                                                         add_special_tokens=self.tower_special_tokens, return_tensors="pt")
+            qemb = self.tower.encode_query({"input_ids": tok["input_ids"], "attention_mask": tok["attention_mask"]})
         ranked, ndoc = self.fine.rerank(qemb, codes)
         gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None else None
         results = []

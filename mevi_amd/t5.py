@@ -177,6 +177,7 @@ class TwinTower:
         self.encoder = EncoderStack(weights, self.d, self.dev)
         self.decoder = DecoderStack(weights, self.d, self.dev, max_len=1)
         self.batch_size = batch_size
+        self.dim = self.d.d_model      # width of the embeddings this tower emits
 
     def encode_query(self, qry):
         ids = qry["input_ids"].to(self.dev, torch.int64)

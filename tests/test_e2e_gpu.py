@@ -170,3 +170,67 @@ def test_dense_cli_and_ensemble_chain(cuda, mini, tmp_path):
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-1500:]
     assert "ANCE Pred" in r.stdout and "Fine Pred" in r.stdout and "score + 0.6 / (0.03 * crank + 1)" in r.stdout
+
+
+def test_eval_driver_with_a_bert_tower(cuda, mini, tmp_path):
+    """--document_encoder cocondenser: the fine stage scores with a BERT-family tower that reads the query through its
+    own tokenizer (no special tokens for 'cocondenser'), in the tower's embedding space (48-d here, NCI is 32-d)."""
+    from mevi_amd.evalrun import EvalRun, load_queries
+    from oracle import bert as obert
+
+    g = np.load(os.path.join(GOLD, "g8_bert_tower.npz"))
+    bcfg = json.loads(str(g["cfg"]))
+    BW = obert.load_weights(g)
+    d = tmp_path
+    a0 = mini["args"]
+    ck = d / "ckpts"
+    os.makedirs(ck / "co-condenser-marco-retriever")
+    os.symlink(os.path.join(a0.ckpt_dir, "t5-ance"), ck / "t5-ance")
+    torch.save(BW, ck / "co-condenser-marco-retriever" / "pytorch_model.bin")
+    json.dump(dict(model_type="bert", **bcfg), open(ck / "co-condenser-marco-retriever" / "config.json", "w"))
+    rng = np.random.default_rng(5)
+    dim, M, K, N = 48, 4, 32, mini["N"]          # at least as many docs as the gt ids of the query file refer to
+    C = (rng.standard_normal((M, K, dim)) * (1.0 / np.arange(1, M + 1))[:, None, None]).astype(np.float32)
+    tok = FakeTokenizer(512)
+    enc = tok.batch_encode_plus(mini["queries"])
+    dec, _, _ = ot5.nci_generate(mini["W"], mini["cfg"], enc["input_ids"], enc["attention_mask"], 10)
+    beam_codes = ot5.decode_token(dec, K).numpy()
+    paths = np.concatenate([np.repeat(beam_codes[::3], 4, axis=0), rng.integers(0, K, size=(N, M))])
+    emb = sum(C[j][paths[:, j]] for j in range(M)).astype(np.float32) + 0.01 * rng.standard_normal((len(paths), dim)).astype(np.float32)
+    os.makedirs(d / "ance")
+    emb.tofile(d / "ance" / "docemb.bin")
+    torch.save(torch.nn.Parameter(torch.from_numpy(C)), d / "ance" / "rqcodebook4_5.pt")
+    args = Namespace(**{**vars(a0), **dict(ckpt_dir=str(ck), embedding_path=str(d / "ance" / "docemb.bin"),
+                                           pq_path=str(d / "ance" / "rqcodebook4_5.pt"),
+                                           pq_cluster_path=str(d / "ance" / "rqclus4_5.pkl"),
+                                           custom_save_path=str(d / "ance" / "res.tsv"), save_hard_neg=len(paths),
+                                           metric_path=str(d / "logs" / "m.txt"), document_encoder="cocondenser",
+                                           dataset="marco")})
+
+    class BertFake(FakeTokenizer):
+        def batch_encode_plus(self, texts, max_length=32, padding="max_length", truncation=True, return_tensors="pt",
+                              add_special_tokens=True):
+            assert add_special_tokens is False            # 'cocondenser' (main_models.py:359-360)
+            return super().batch_encode_plus(texts, max_length=max_length)
+
+    btok = BertFake(400)
+    run = EvalRun(args, tokenizer=tok, device=cuda, tower_tokenizer=btok)
+    run.run(load_queries(args.data_dir))
+    prefix = args.custom_save_path[:-4]
+    hn = [l.rstrip("\n").split("\t") for l in open(f"{prefix}_hn{args.save_hard_neg}.tsv")]
+    fine = [l.rstrip("\n").split("\t") for l in open(prefix + "_fine.tsv")]
+    benc = FakeTokenizer(400).batch_encode_plus(mini["queries"])
+    qemb = obert.tower_encode(BW, bcfg, benc["input_ids"], benc["attention_mask"]).numpy()
+    cluster, _ = orq.cluster_dict(orq.rq_encode(emb, C))
+    codes = beam_codes.reshape(len(mini["queries"]), 10, 4)
+    checked = 0
+    for i in range(len(mini["queries"])):
+        docs = [x for c in codes[i].tolist() for x in cluster.get(tuple(c), [])]
+        got_docs = eval(fine[i][1])
+        assert sorted(got_docs) == sorted(docs)
+        if docs:
+            ref = np.sort(emb[docs] @ qemb[i])[::-1]
+            got_s = np.array([float(x) for x in hn[i][3].split(",")])
+            assert np.abs(got_s - ref).max() <= 3e-4
+            checked += 1
+    assert checked >= 5

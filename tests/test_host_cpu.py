@@ -34,8 +34,11 @@ def test_main_accepts_every_flag_of_marco_eval_nci_rq_sh():
     assert main.parsers_parser(["--mode", "eval", "--data_dir", "x", "--n_gpu", "[2,5]"]).n_gpu == [2, 5]
     with pytest.raises(SystemExit):
         main.check_supported(main.parsers_parser(["--mode", "train", "--data_dir", "x"]))
-    with pytest.raises(SystemExit):   # NQ / AR2 towers are out of scope
-        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--document_encoder", "ar2"]))
+    main.check_supported(main.parsers_parser(EVAL_ARGV + ["--document_encoder", "ar2"]))   # BERT-family towers are built
+    with pytest.raises(SystemExit):
+        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--document_encoder", "dpr"]))
+    with pytest.raises(SystemExit):   # ablation modes are not
+        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--eval_all_documents", "1"]))
 
 
 def test_cli_argument_surfaces_match_reference():
