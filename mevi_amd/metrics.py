@@ -146,3 +146,93 @@ def ensemble_main(dir_path, gt_file, ance_file, fine_file, coarse_file, mapping_
                 title = f"score + {a} / ({b} * crank + 1); punishment (1 - {g} * {a})"
                 results[title] = evaluate_ranked(title, cutoffs, gts, ranked, ofile)
     return results
+
+
+# ---- Natural Questions (answer-based hits): ensemble_nqdpr.py -------------------------------------------------
+def parse_indexed(path, template, index_of=None):
+    """(pred, score, cluster) dicts keyed by LINE INDEX (the dense file's order), as ensemble_nqdpr.py:81-113 does:
+    `index_of` maps the query text of the other files to its line in the dense file (None: the file's own lines)."""
+    qi = template["query"]
+    cols = [template.get(k) for k in ("pred", "score", "cluster")]
+    out = ({}, {}, {})
+    with open(path, "r") as f:
+        for i, line in enumerate(f):
+            items = line.rstrip("\n").split("\t")
+            key = i if index_of is None else index_of[items[qi]]
+            for c, d in zip(cols, out):
+                if c is not None:
+                    d[key] = mio.parse_list(items[c])
+    return out
+
+
+def nq_first_hit(qind, preds, offsets, array):
+    """Rank of the first doc that answers question `qind`: test_inverse_{offsets,array}.bin list, per doc, the
+    questions it answers (ensemble_nqdpr.py:27-31; a padded id -1 indexes an empty slice, as there)."""
+    for j, res in enumerate(preds):
+        if qind in array[offsets[res]:offsets[res + 1]]:
+            return j
+    return None
+
+
+def evaluate_nq(title, cutoffs, nq_eval, ranked, ofile=None):
+    offsets, array = nq_eval
+    mrr = {k: 0 for k in cutoffs}
+    hit = {k: 0 for k in cutoffs}
+    for qind, preds in ranked.items():
+        ind = nq_first_hit(qind, preds, offsets, array)
+        for k in cutoffs:
+            if ind is not None:
+                mrr[k] += 1 / (ind + 1) if ind < k else 0
+                hit[k] += ind < k
+    n = len(ranked)
+    lines = [f"MRR{k} {mrr[k] / n}" for k in cutoffs] + [f"HitRate{k} {hit[k] / n}" for k in cutoffs]
+    print(f"{title}")
+    print("\n".join(lines))
+    print()
+    if ofile is not None:
+        with open(ofile, "a") as f:
+            f.write(f"Scoring {title}\n" + "\n".join(lines) + "\n\n")
+    return {k: v / n for k, v in mrr.items()}, {k: v / n for k, v in hit.items()}
+
+
+def ensemble_nqdpr_main(dir_path, ance_file, fine_file=None, coarse_file=None, mapping_file=None, alphas="0.4",
+                        betas="0.03", gammas="0.02", recall_num="5,20,100", ofile=None, noensemble=False):
+    """MEVI/ensemble_nqdpr.py:166-252: the marco ensemble with NQ's answer-based hit test, queries keyed by their
+    line in the dense file."""
+    import numpy as np
+
+    if mapping_file is None or not os.path.exists(mapping_file):
+        raise AssertionError(f"mapping file {mapping_file} does not exist")
+    alphas, betas, gammas = ([float(x) for x in v.split(",")] for v in (alphas, betas, gammas))
+    cutoffs = [int(x) for x in recall_num.split(",")]
+    ance_path = resolve(ance_file, dir_path)
+    fine_path = resolve(fine_file, dir_path, must_exist=False)
+    have_fine = fine_path is not None and os.path.exists(fine_path)
+    nq_eval = (np.memmap(os.path.join(dir_path, "test_inverse_offsets.bin"), mode="r", dtype=np.int32),
+               np.memmap(os.path.join(dir_path, "test_inverse_array.bin"), mode="r", dtype=np.int32))
+    dense_p, dense_s, _ = parse_indexed(ance_path, RANKED_TEMPLATE)
+    index_of = {}
+    with open(ance_path, "r") as f:
+        for i, line in enumerate(f):
+            index_of[line.rstrip("\n").split("\t")[0]] = i
+    if have_fine:
+        fine_p, fine_s, _ = parse_indexed(fine_path, RANKED_TEMPLATE, index_of)
+    if ofile is not None:
+        open(ofile, "w").close()
+    results = {"ANCE Pred": evaluate_nq("ANCE Pred", cutoffs, nq_eval, dense_p, ofile)}
+    if have_fine:
+        results["Fine Pred"] = evaluate_nq("Fine Pred", cutoffs, nq_eval, fine_p, ofile)
+    if noensemble:
+        return results
+    _, _, clusters = parse_indexed(resolve(coarse_file, dir_path), COARSE_TEMPLATE, index_of)
+    with open(mapping_file, "rb") as f:
+        mapping = pickle.load(f)
+    cranks, n_clusters = cluster_ranks(dense_p, clusters, mapping)
+    for a in alphas:
+        for b in betas:
+            for g in gammas:
+                ranked = {q: ensemble_scores(dense_p[q], dense_s[q], cranks[q], fine_p[q] if have_fine else None,
+                                             fine_s[q] if have_fine else None, n_clusters, a, b, g) for q in dense_p}
+                title = f"score + {a} / ({b} * crank + 1); punishment (1 - {g} * {a})"
+                results[title] = evaluate_nq(title, cutoffs, nq_eval, ranked, ofile)
+    return results

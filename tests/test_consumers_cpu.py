@@ -38,6 +38,26 @@ def test_cli_output_matches_reference(name, g6_dir):
         assert open(os.path.join(g6_dir, out[0])).read() == exp["ofile"]
 
 
+G6N = os.path.join(GOLD, "g6_consumers_nq")
+
+
+@pytest.mark.parametrize("name", ["nq_default", "nq_grid_nofine", "nq_noensemble"])
+def test_nq_ensemble_cli_matches_reference(name, tmp_path):
+    """ensemble_nqdpr.py (answer-based hits through the inverse index files) vs the unmodified reference script."""
+    for f in os.listdir(G6N):
+        if f.endswith((".tsv", ".pkl", ".bin")):
+            shutil.copy(os.path.join(G6N, f), tmp_path)
+    d = str(tmp_path)
+    exp = json.load(open(os.path.join(G6N, "expected.json")))[name]
+    argv = [a.replace("{d}", d) for a in exp["argv"]]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, argv[0])] + argv[1:], capture_output=True, text=True, cwd=d,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == exp["stdout"]
+    if exp["ofile"] is not None:
+        assert open(os.path.join(d, "ens_out.txt")).read() == exp["ofile"]
+
+
 def test_stale_parse_cache_is_not_served(g6_dir):
     """The reference pickles the parsed TSV next to it and reuses it forever; we ignore a cache
     older than its TSV (documented deviation, SURVEY 'Bug-compatible ensemble')."""

@@ -198,6 +198,52 @@ def g6_consumers():
     print("g6", list(expected))
 
 
+def g6n_consumers_nq():
+    """stdout + ofile of the UNMODIFIED reference ensemble_nqdpr.py on synthetic NQ-style files: the marco TSVs of g6
+    plus the inverse answer index (test_inverse_offsets.bin / test_inverse_array.bin: per doc, the questions it answers)."""
+    out_dir = os.path.join(GOLD, "g6_consumers_nq")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    synth_consumer_files(out_dir, seed=2)
+    rng = np.random.default_rng(3)
+    ndoc, nq = 3000, 60
+    answers = [[] for _ in range(ndoc)]
+    for i, line in enumerate(open(os.path.join(out_dir, "gt.tsv"))):
+        for g in line.rstrip("\n").split("\t")[1].split(","):
+            answers[int(g)].append(i)
+    for d in rng.choice(ndoc, size=400, replace=False):          # other docs that happen to contain an answer
+        answers[int(d)].append(int(rng.integers(0, nq)))
+    offsets = np.zeros(ndoc + 1, np.int32)
+    offsets[1:] = np.cumsum([len(a) for a in answers])
+    np.concatenate([np.array(a, np.int32) for a in answers if a]).astype(np.int32).tofile(os.path.join(out_dir, "test_inverse_array.bin"))
+    offsets.tofile(os.path.join(out_dir, "test_inverse_offsets.bin"))
+    os.remove(os.path.join(out_dir, "gt.tsv"))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    runs = {
+        "nq_default": ["ensemble_nqdpr.py", "--dir_path", "{d}", "--mapping_file", "{d}/rqmapping.pkl", "--ance_file", "dense.tsv",
+                       "--coarse_file", "nci_coarse.tsv", "--fine_file", "nci_hn.tsv", "--ofile", "{d}/ens_out.txt"],
+        "nq_grid_nofine": ["ensemble_nqdpr.py", "--dir_path", "{d}", "--mapping_file", "{d}/rqmapping.pkl", "--ance_file", "dense.tsv",
+                           "--coarse_file", "nci_coarse.tsv", "--alphas", "0.3,1.0", "--betas", "0.03,0.5", "--gammas", "0.02,0.5",
+                           "--recall_num", "1,10,40"],
+        "nq_noensemble": ["ensemble_nqdpr.py", "--dir_path", "{d}", "--mapping_file", "{d}/rqmapping.pkl", "--ance_file", "dense.tsv",
+                          "--fine_file", "nci_hn.tsv", "--noensemble"],
+    }
+    expected = {}
+    for name, argv in runs.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            for f in os.listdir(out_dir):
+                if f.endswith((".tsv", ".pkl", ".bin")):
+                    shutil.copy(os.path.join(out_dir, f), tmp)
+            cmd = [sys.executable] + [a.replace("{d}", tmp) for a in argv]
+            cmd[1] = os.path.join(REF, cmd[1])
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=tmp)
+            assert r.returncode == 0, r.stderr[-2000:]
+            ofile = open(os.path.join(tmp, "ens_out.txt")).read() if os.path.exists(os.path.join(tmp, "ens_out.txt")) else None
+            expected[name] = dict(argv=argv, stdout=r.stdout, ofile=ofile)
+    json.dump(expected, open(os.path.join(out_dir, "expected.json"), "w"), indent=1)
+    print("g6n", list(expected))
+
+
 # --------------------------------------------------------------------------- G7
 def g7_writers():
     """Exact bytes of faiss_search.to_file (faiss_search.py:71-77) and LogTxtFile lines
@@ -471,7 +517,7 @@ def g3_relative_buckets():
     print("g3 ok")
 
 
-ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower, g2p=g2p_t5_passage, g8=g8_bert_tower,
+ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g6n=g6n_consumers_nq, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower, g2p=g2p_t5_passage, g8=g8_bert_tower,
            g3=g3_relative_buckets)
 
 if __name__ == "__main__":
