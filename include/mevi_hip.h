@@ -140,6 +140,12 @@ int mevi_add_layernorm_f32(const float *x, int64_t ldx, const float *y, int64_t 
 /* out[i] = table[idx[i]]: nn.Embedding (modeling_t5.py:718) and beam reorder (generation_utils.py:927-934) */
 int mevi_gather_rows_f32(const float *table, int64_t ldt, const int64_t *idx, int64_t n, int64_t dim,
                          float *out, int64_t ldo, void *stream);
+/* out[idx[r], :] = src[r, :] for r < n (rows must be distinct): the inverse of mevi_gather_rows_f32.  Used to run the
+ * linear layers of the T5 / BERT encoders on the REAL tokens of a batch only (the reference pads every query to 32 and
+ * every passage to 128 tokens, modeling_t5.py:969-1069 runs them all) and to put the rows back into the padded
+ * layout the attention kernels read. */
+int mevi_scatter_rows_f32(const float *src, int64_t lds, const int64_t *idx, int64_t n, int64_t dim, float *out,
+                          int64_t ldo, void *stream);
 int mevi_scale_f32(const float *x, float alpha, int64_t n, float *out, void *stream);
 /* softmax(scale*q.k^T + bias[h, q_pos0+t, j] + key mask + causal mask) . v for <= 256 keys
  * (T5Attention.forward, modeling_t5.py:374-410: no 1/sqrt(d) scaling, fp32 softmax; also

@@ -43,26 +43,48 @@ class BertEncoder:
                 wo2=g(p + "output.dense.weight"), bo2=g(p + "output.dense.bias"),
                 ln2=(g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"))))
         self.d = self.word.shape[1]
+        self.pack = True   # padding-free per-token operators (see forward)
         self.dh = self.d // num_heads
 
-    def forward(self, input_ids, attention_mask):
-        """input_ids / attention_mask i64[B, S] (S <= 256, token types all 0) -> last hidden state f32[B, S, d]."""
+    def forward(self, input_ids, attention_mask, pack=None):
+        """input_ids / attention_mask i64[B, S] (S <= 256, token types all 0) -> last hidden state f32[B, S, d].
+
+        pack (default: self.pack): per-token operators run on the real tokens only, the padded layout is used for
+        attention alone (as mevi_amd.t5.EncoderStack.forward); padded positions of the result are 0."""
         B, S = input_ids.shape
         d = self.d
-        x = ops.gather_rows(self.word, input_ids.reshape(-1))
-        pos = self.pos[:S].repeat(B, 1)
-        x = ops.add_layernorm(x, pos, self.emb_ln[0], self.emb_ln[1], eps=self.eps, cvec=self.type0)
+        pack = self.pack if pack is None else pack
+        idx = None
+        if pack:
+            idx = torch.nonzero(attention_mask.reshape(-1) != 0).view(-1)
+            if idx.numel() == 0 or idx.numel() > 0.9 * B * S:
+                idx = None
         scale = float(self.dh) ** -0.5
+        if idx is None:
+            tok, pos = input_ids.reshape(-1), self.pos[:S].repeat(B, 1)
+        else:
+            tok, pos = input_ids.reshape(-1)[idx], ops.gather_rows(self.pos, idx % S)
+        x = ops.gather_rows(self.word, tok)
+        x = ops.add_layernorm(x, pos, self.emb_ln[0], self.emb_ln[1], eps=self.eps, cvec=self.type0)
+        qkv = None if idx is None else torch.zeros((B * S, 3 * d), dtype=torch.float32, device=x.device)
         for L in self.layers:
-            qkv = ops.linear(x, L["wqkv"], bias=L["bqkv"]).view(B, S, 3 * d)
-            ctx = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], self.H, key_mask=attention_mask,
-                                scale=scale)
-            a = ops.linear(ctx.view(B * S, d), L["wo"], bias=L["bo"])
+            if idx is None:
+                q3 = ops.linear(x, L["wqkv"], bias=L["bqkv"]).view(B, S, 3 * d)
+            else:
+                q3 = ops.scatter_rows(ops.linear(x, L["wqkv"], bias=L["bqkv"]), idx, qkv).view(B, S, 3 * d)
+            ctx = ops.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], self.H, key_mask=attention_mask,
+                                scale=scale).view(B * S, d)
+            if idx is not None:
+                ctx = ops.gather_rows(ctx, idx)
+            a = ops.linear(ctx, L["wo"], bias=L["bo"])
             x = ops.add_layernorm(a, x, L["ln1"][0], L["ln1"][1], eps=self.eps)
             h = ops.linear(x, L["wi"], bias=L["bi"], gelu=True)
             o = ops.linear(h, L["wo2"], bias=L["bo2"])
             x = ops.add_layernorm(o, x, L["ln2"][0], L["ln2"][1], eps=self.eps)
-        return x.view(B, S, d)
+        if idx is None:
+            return x.view(B, S, d)
+        out = torch.zeros((B * S, d), dtype=torch.float32, device=x.device)
+        return ops.scatter_rows(x, idx, out).view(B, S, d)
 
 
 class BertTower:

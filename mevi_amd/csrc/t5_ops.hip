@@ -93,6 +93,18 @@ __global__ __launch_bounds__(256) void gather_rows_i64_kernel(const float *__res
   for (int i = lane; i < dim / 4; i += 64) d[i] = s[i];
 }
 
+// out[idx[r]] = src[r]: the inverse of gather_rows (padding-free token batches back into the padded layout)
+__global__ __launch_bounds__(256) void scatter_rows_i64_kernel(const float *__restrict__ src, long long lds_,
+                                                              const long long *__restrict__ idx, long long n,
+                                                              int dim, float *__restrict__ out, long long ldo) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float4 *s = reinterpret_cast<const float4 *>(src + r * lds_);
+  float4 *d = reinterpret_cast<float4 *>(out + idx[r] * ldo);
+  for (int i = lane; i < dim / 4; i += 64) d[i] = s[i];
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(const float *__restrict__ x, float alpha, long long n,
                                                    float *__restrict__ out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -568,6 +580,18 @@ extern "C" int mevi_gather_rows_f32(const float *table, int64_t ldt, const int64
   hipLaunchKernelGGL(gather_rows_i64_kernel, dim3(blocks4(n)), dim3(256), 0, (hipStream_t)stream, table,
                      (long long)ldt, reinterpret_cast<const long long *>(idx), (long long)n, (int)dim, out,
                      (long long)ldo);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_scatter_rows_f32(const float *src, int64_t lds_, const int64_t *idx, int64_t n, int64_t dim,
+                                     float *out, int64_t ldo, void *stream) {
+  MEVI_REQUIRE(n >= 0 && dim > 0 && dim % 4 == 0 && lds_ % 4 == 0 && ldo % 4 == 0, MEVI_ERR_INVALID_ARG,
+               "scatter_rows: dim/ld must be multiples of 4");
+  if (n == 0) return MEVI_OK;
+  MEVI_REQUIRE(src && idx && out, MEVI_ERR_INVALID_ARG, "scatter_rows: null pointer");
+  hipLaunchKernelGGL(scatter_rows_i64_kernel, dim3(blocks4(n)), dim3(256), 0, (hipStream_t)stream, src, (long long)lds_,
+                     reinterpret_cast<const long long *>(idx), (long long)n, (int)dim, out, (long long)ldo);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

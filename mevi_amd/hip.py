@@ -45,6 +45,7 @@ _SIGNATURES = {
     "mevi_add_layernorm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float,
                                        c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "mevi_gather_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mevi_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "mevi_scale_f32": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "mevi_attention_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                    c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,

@@ -144,7 +144,7 @@ class NCIModel:
         mask = attention_mask.to(self.dev, torch.int64).contiguous()
         B = ids.shape[0]
         enc = self.encoder.forward(self.shared, ids, mask)
-        xkv = self.decoder.cross_kv(enc)
+        xkv = self.decoder.cross_kv(enc, mask)
 
         nb = 1
         tokens = torch.zeros(B, dtype=torch.int64, device=self.dev)          # decoder_start_token_id = 0

@@ -76,6 +76,17 @@ def gather_rows(table, idx, out=None):
     return out
 
 
+def scatter_rows(src, idx, out):
+    """out[idx[r]] = src[r] (distinct rows); returns `out`."""
+    src, n, D, lds_ = _rows2d(_f32(src))
+    idx = idx.to(device=src.device, dtype=torch.int64).contiguous().view(-1)
+    assert idx.numel() == n and out.dim() == 2 and out.shape[1] == D and out.stride(1) == 1
+    st = hip.lib().mevi_scatter_rows_f32(hip.ptr(src), lds_, hip.ptr(idx), n, D, hip.ptr(out), out.stride(0),
+                                         hip.stream_ptr())
+    hip.check(st, "mevi_scatter_rows_f32")
+    return out
+
+
 def scale(x, alpha):
     x = _f32(x).contiguous()
     out = torch.empty_like(x)

@@ -31,8 +31,12 @@ def test_twin_tower_matches_reference_golden(cuda):
     cfg = json.loads(str(g["cfg"]))
     tower = t5.TwinTower(nci.load_npz_weights(g), device=cuda, **cfg)
     ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
-    enc = tower.encoder.forward(tower.shared, ids.to(cuda), mask.to(cuda))
+    enc = tower.encoder.forward(tower.shared, ids.to(cuda), mask.to(cuda), pack=False)     # reference layout, all positions
     assert np.abs(enc.cpu().numpy() - g["enc_last"]).max() <= 5e-5
+    packed = tower.encoder.forward(tower.shared, ids.to(cuda), mask.to(cuda), pack=True)  # real tokens only
+    valid = g["attention_mask"].astype(bool)
+    assert np.array_equal(packed.cpu().numpy()[valid], enc.cpu().numpy()[valid])           # bit-identical where it matters
+    assert np.abs(packed.cpu().numpy()[~valid]).max() == 0 if (~valid).any() else True
     reps = tower.encode_query({"input_ids": ids, "attention_mask": mask})
     assert np.abs(reps.cpu().numpy() - g["reps"]).max() <= 5e-5
 
@@ -44,8 +48,11 @@ def test_passage_tower_matches_reference_golden(cuda):
     cfg = json.loads(str(g["cfg"]))
     tower = t5.TwinTower(nci.load_npz_weights(g), device=cuda, **cfg)
     ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
-    enc = tower.encoder.forward(tower.shared, ids.to(cuda), mask.to(cuda))
+    enc = tower.encoder.forward(tower.shared, ids.to(cuda), mask.to(cuda), pack=False)
     assert np.abs(enc.cpu().numpy() - g["enc_last"]).max() <= 5e-5
+    packed = tower.encoder.forward(tower.shared, ids.to(cuda), mask.to(cuda), pack=True)
+    valid = g["attention_mask"].astype(bool)
+    assert np.array_equal(packed.cpu().numpy()[valid], enc.cpu().numpy()[valid])
     reps = tower.encode_passage({"input_ids": ids, "attention_mask": mask})
     assert np.abs(reps.cpu().numpy() - g["reps"]).max() <= 5e-5
 
@@ -79,7 +86,8 @@ def test_nci_generate_matches_reference_golden(cuda, path):
     model = nci.NCIModel(nci.load_npz_weights(g), device=cuda, **cfg)
     ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
     dec, scores, enc, _ = model.generate(ids, mask, num_beams=beams, num_return_sequences=beams, max_length=cfg["M"] + 2)
-    assert np.abs(enc.cpu().numpy() - g["enc_hidden"]).max() <= 5e-5
+    valid = g["attention_mask"].astype(bool)       # padded positions are don't-care outputs (0 in the packed encoder)
+    assert np.abs(enc.cpu().numpy() - g["enc_hidden"])[valid].max() <= 5e-5
     assert np.array_equal(dec.cpu().numpy(), g["decoded"])
     assert np.abs(np.array(scores) - g["scores"]).max() <= 1e-5
     codes = nci.decode_token(dec, cfg["K"])
@@ -140,7 +148,8 @@ def test_base_shape_model_against_oracle(cuda):
     odec, osc, oenc = ot5.nci_generate(W, cfg, ids, mask, R)
     model = nci.NCIModel(W, device=cuda, **cfg)
     dec, sc, enc, _ = model.generate(ids, mask, num_beams=R)
-    assert (enc.cpu() - oenc).abs().max() <= 2e-4 * oenc.abs().max()
+    valid = mask.bool()                                            # padded positions: don't-care (0 when packed)
+    assert (enc.cpu() - oenc)[valid].abs().max() <= 2e-4 * oenc.abs().max()
     sc = np.array(sc)
     assert np.abs(sc - osc.numpy()).max() <= 2e-4
     # identical beams wherever the oracle's neighbouring scores are separated by more than the tolerance
@@ -164,9 +173,11 @@ def test_bert_tower_matches_reference_golden(cuda):
     W = nci.load_npz_weights(g)
     tower = bert.BertTower(W, cfg["num_hidden_layers"], cfg["num_attention_heads"], eps=cfg["layer_norm_eps"], device=cuda)
     ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
-    hid = tower.lm_q.forward(ids.to(cuda), mask.to(cuda)).cpu().numpy()
+    hid = tower.lm_q.forward(ids.to(cuda), mask.to(cuda), pack=False).cpu().numpy()
     valid = g["attention_mask"].astype(bool)
     assert np.abs(hid - g["hidden"])[valid].max() <= 5e-5
+    packed = tower.lm_q.forward(ids.to(cuda), mask.to(cuda), pack=True).cpu().numpy()       # real tokens only
+    assert np.array_equal(packed[valid], hid[valid]) and np.abs(packed[~valid]).max() == 0
     reps = tower.encode_query({"input_ids": ids, "attention_mask": mask}).cpu().numpy()
     assert np.abs(reps - g["reps"]).max() <= 5e-5
     assert np.array_equal(reps, tower.encode_passage({"input_ids": ids, "attention_mask": mask}).cpu().numpy())  # tied

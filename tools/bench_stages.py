@@ -91,7 +91,7 @@ def timed(fn, reps=2):
 
 
 dt, reps_ = timed(lambda: tower.encode_query({"input_ids": ids, "attention_mask": mask}))
-print(f"tower  : {nq} queries in {dt*1e3:.1f} ms  -> {nq/dt:.0f} q/s   ({6.51e9*nq/dt/1e12:.1f} TFLOP/s algorithmic)", flush=True)
+print(f"tower  : {nq} queries in {dt*1e3:.1f} ms  -> {nq/dt:.0f} q/s   ({6.51e9*nq/dt/1e12:.1f} TFLOP/s padded-equivalent)", flush=True)
 
 # passage side of the same tower (gen_doc_embedding): 128-token windows, lengths ~ clip(N(70, 30), 8, 128)
 npsg = 4096
@@ -107,7 +107,7 @@ dt, _ = timed(lambda: tower.encode_passage({"input_ids": pids, "attention_mask":
 # encoder 12 layers x 128 tokens: 2*(4*768*768 + 2*768*3072) MACs per token and layer + attention 2*2*128*768
 enc_flop = 12 * 128 * (2 * (4 * 768 * 768 + 2 * 768 * 3072) + 4 * 128 * 768)
 print(f"passage: {npsg} passages x 128 tokens in {dt*1e3:.1f} ms -> {npsg/dt:.0f} passages/s   "
-      f"({enc_flop*npsg/dt/1e12:.1f} TFLOP/s algorithmic, encoder only)", flush=True)
+      f"({enc_flop*npsg/dt/1e12:.1f} TFLOP/s padded-equivalent, encoder only)", flush=True)
 
 
 def gen_all():
