@@ -49,4 +49,4 @@ for name, n, S, mean in (("queries", 2048, 32, 9), ("passages", 2048, 128, 70)):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
     flop = NL * S * (2 * (4 * d * d + 2 * d * ff) + 4 * S * d)
-    print(f"bert tower, {name}: {n} x {S} tokens in {dt*1e3:.1f} ms -> {n/dt:.0f} /s ({flop*n/dt/1e12:.1f} TFLOP/s algorithmic)", flush=True)
+    print(f"bert tower, {name}: {n} x {S} tokens in {dt*1e3:.1f} ms -> {n/dt:.0f} /s ({flop*n/dt/1e12:.1f} TFLOP/s padded-equivalent)", flush=True)

@@ -3,5 +3,5 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/stages
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/bench_stages.py 4096 2048 > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/bench_stages.py 2048 512 > $OUT/log.txt 2>&1
 tail -n 5 $OUT/log.txt
