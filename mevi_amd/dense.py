@@ -50,7 +50,7 @@ def ip_topk(query, docs, k, id_offset=0):
 
 class DenseIndex:
     """A corpus shard prepared for searching -- the analogue of faiss `index.add(doc)`
-    (MEVI/faiss_search.py:19): keeps the f32 rows and their (hi, lo) bfloat16 split image.
+    (MEVI/faiss_search.py:19): keeps the f32 rows and their centred, scaled f16 image (+ norms, mean, scales).
     `search` returns exactly what `ip_topk` returns (bit for bit), ~3x faster: candidates are
     selected with f16 MFMAs, re-scored with the exact f32 chain and proven complete per query."""
 

@@ -20,64 +20,12 @@ M = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 bits = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 K, R, d = 2 ** bits, 10, 768
 dev = torch.device("cuda:0")
-g = torch.Generator(device=dev).manual_seed(0)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth  # noqa: E402
 
-
-def rn(*shape, s=1.0):
-    return torch.randn(shape, device=dev, generator=g) * s
-
-
-def t5_weights(W, nl, ndl, prefix_dec="decoder"):
-    for st, n, dec in (("encoder", nl, False), (prefix_dec, ndl, True)):
-        for l in range(n):
-            p = f"{st}.block.{l}.layer"
-            W[f"{p}.0.SelfAttention.q.weight"] = rn(d, d, s=(d * 64) ** -0.5)
-            for nme in "kvo":
-                W[f"{p}.0.SelfAttention.{nme}.weight"] = rn(d, d, s=d ** -0.5)
-            W[f"{p}.0.layer_norm.weight"] = torch.ones(d, device=dev)
-            ff = 1
-            if dec:
-                W[f"{p}.1.EncDecAttention.q.weight"] = rn(d, d, s=(d * 64) ** -0.5)
-                for nme in "kvo":
-                    W[f"{p}.1.EncDecAttention.{nme}.weight"] = rn(d, d, s=d ** -0.5)
-                W[f"{p}.1.layer_norm.weight"] = torch.ones(d, device=dev)
-                ff = 2
-            W[f"{p}.{ff}.DenseReluDense.wi.weight"] = rn(3072, d, s=d ** -0.5)
-            W[f"{p}.{ff}.DenseReluDense.wo.weight"] = rn(d, 3072, s=3072 ** -0.5)
-            W[f"{p}.{ff}.layer_norm.weight"] = torch.ones(d, device=dev)
-        W[f"{st}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] = rn(32, 12, s=0.5)
-        W[f"{st}.final_layer_norm.weight"] = torch.ones(d, device=dev)
-
-
-V = K * (M + 2) + 2
-W = {"shared.weight": rn(32128, d), "decode_embeddings.weight": rn(V, d), "adaptor_embeddings": torch.rand((1, 1, d), device=dev),
-     "adaptor_linear.weight": rn(d * V, d, s=d ** -0.5 * 0.3)}
-W["lm_head.weight"] = W["decode_embeddings.weight"]
-t5_weights(W, 12, 6)
-for l in range(4):
-    p = f"adaptor.layers.{l}"
-    for a in ("self_attn", "multihead_attn"):
-        W[f"{p}.{a}.in_proj_weight"], W[f"{p}.{a}.in_proj_bias"] = rn(3 * d, d, s=d ** -0.5), rn(3 * d, s=0.02)
-        W[f"{p}.{a}.out_proj.weight"], W[f"{p}.{a}.out_proj.bias"] = rn(d, d, s=d ** -0.5), rn(d, s=0.02)
-    W[f"{p}.linear1.weight"], W[f"{p}.linear1.bias"] = rn(2048, d, s=d ** -0.5), rn(2048, s=0.02)
-    W[f"{p}.linear2.weight"], W[f"{p}.linear2.bias"] = rn(d, 2048, s=2048 ** -0.5), rn(d, s=0.02)
-    for n_ in (1, 2, 3):
-        W[f"{p}.norm{n_}.weight"], W[f"{p}.norm{n_}.bias"] = torch.ones(d, device=dev), torch.zeros(d, device=dev)
-model = nci.NCIModel(W, device=dev, M=M, K=K, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
-TW = {"shared.weight": W["shared.weight"]}
-t5_weights(TW, 12, 12)
-tower = t5.TwinTower(TW, device=dev, num_layers=12, num_decoder_layers=12, batch_size=batch)
-del W, TW
-
+model, tower, g, rn = synth.build(dev, M, K, batch)
 rng = np.random.default_rng(0)
-ids = np.zeros((nq, 32), np.int64)
-mask = np.zeros((nq, 32), np.int64)
-for i in range(nq):
-    L = int(np.clip(rng.poisson(9) + 2, 3, 32))
-    ids[i, :L - 1] = rng.integers(3, 32100, size=L - 1)
-    ids[i, L - 1] = 1
-    mask[i, :L] = 1
-ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+ids, mask = synth.query_ids(nq, dev, rng)
 
 
 def timed(fn, reps=2):
