@@ -232,7 +232,10 @@ class EvalRun:
         a = self.args
         idx = rank_slice(len(df), self.rank, self.nrank)
         cache = []
-        bs = max(1, a.eval_batch_size)
+        # --eval_batch_size is 2 in the reference's scripts (its infer() is per-sample Python); every output here is
+        # per query and independent of how queries are grouped (row-wise kernels, tested), so the GPU is fed
+        # device_batch_size queries at a time and the logs keep the sampler's order.
+        bs = max(1, a.eval_batch_size, getattr(a, "device_batch_size", None) or 1)
         for s in range(0, len(idx), bs):
             rows = df.iloc[idx[s:s + bs]]
             cache += self.infer(rows["query"].tolist(), rows["oldid"].tolist())

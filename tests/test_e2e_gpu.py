@@ -136,6 +136,25 @@ def test_eval_driver_matches_cpu_restatement(cuda, mini):
     assert os.path.exists(a.metric_path) and "ndocs@cluster10" in open(a.metric_path).read()
 
 
+def test_eval_outputs_do_not_depend_on_the_device_batch(cuda, mini, tmp_path):
+    """marco_eval_nci_rq.sh passes --eval_batch_size 2; the driver feeds the GPU --device_batch_size queries per pass.
+    Every log file must be byte-identical whatever the grouping (here 1, 4 and all 23 queries per pass)."""
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    blobs = []
+    for j, (ebs, dbs) in enumerate([(1, None), (4, None), (2, 512)]):
+        a = Namespace(**vars(mini["args"]))
+        a.eval_batch_size, a.device_batch_size = ebs, dbs
+        a.custom_save_path = str(tmp_path / f"r{j}" / "out.tsv")
+        a.metric_path = str(tmp_path / f"r{j}" / "m.txt")
+        os.makedirs(tmp_path / f"r{j}")
+        EvalRun(a, tokenizer=FakeTokenizer(512), device=cuda).run(load_queries(a.data_dir))
+        prefix = a.custom_save_path[:-4]
+        blobs.append([open(p, "rb").read() for p in (prefix + "_coarse.tsv", prefix + "_fine.tsv",
+                                                     f"{prefix}_hn{a.save_hard_neg}.tsv", a.metric_path)])
+    assert blobs[0] == blobs[1] == blobs[2] and all(len(b) > 0 for b in blobs[0])
+
+
 def test_dense_cli_and_ensemble_chain(cuda, mini, tmp_path):
     """faiss_search.py (C1-style plumbing on the GPU) -> evaluate.py -> ensemble_marco.py on the files above."""
     d, a = mini["dir"], mini["args"]
