@@ -16,6 +16,11 @@ import numpy as np
 import pandas as pd
 
 
+# padded tokens per device pass (= mevi_amd.t5.DEVICE_PASS_TOKENS); --batch_size only raises it: the embeddings do not
+# depend on how rows are grouped, the reference's 128 rows per pass would leave the GPU mostly idle
+DEVICE_PASS_TOKENS = 262144
+
+
 def get_tokenizer(model_path):
     from transformers import AutoTokenizer
 
@@ -72,6 +77,7 @@ def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path,
     start, end = rank_range(len(df), rank, nrank)
     cur_path = output_path[:-4] + f"_{rank}.bin" if nrank > 1 else output_path
     out = np.memmap(cur_path, dtype=np.float32, mode="w+", shape=(end - start, dim))
+    batch_size = max(batch_size, DEVICE_PASS_TOKENS // query_length)    # see DEVICE_PASS_TOKENS
     for s in range(start, end, batch_size):
         e = min(s + batch_size, end)
         tok = tokenizer.batch_encode_plus(list(df[s:e]), max_length=query_length, padding="max_length",
@@ -113,6 +119,7 @@ def gen_doc_embedding(rank, document_dir, model_path, ckpt_path, output_path, ba
     start, end = doc_rank_range(n, rank, nrank)
     part_path = output_path[:-4] + f"_{rank}.bin"
     part = np.memmap(part_path, dtype=np.float32, mode="w+", shape=(end - start, dim))
+    batch_size = max(batch_size, DEVICE_PASS_TOKENS // doc_length)
     for s in range(start, end, batch_size):
         e = min(s + batch_size, end)
         psg = {"input_ids": torch.from_numpy(np.array(tokens[s:e])),

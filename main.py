@@ -25,7 +25,7 @@ def parsers_parser(argv=None):
     p.add_argument("--query_type", type=str, default="gtq")
     p.add_argument("--eval_batch_size", type=int, default=2)
     p.add_argument("--encode_batch_size", type=int, default=None)
-    p.add_argument("--device_batch_size", type=int, default=512,
+    p.add_argument("--device_batch_size", type=int, default=2048,
                    help="(this build) queries per GPU pass; results do not depend on it. --eval_batch_size only raises it")
     p.add_argument("--document_encoder", type=str, default=None)
     p.add_argument("--query_encoder", type=str, default="twin")

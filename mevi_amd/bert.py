@@ -6,6 +6,7 @@ attention with the 1/sqrt(d) scale and the key mask)."""
 import torch
 
 from . import ops
+from .t5 import DEVICE_PASS_TOKENS
 
 
 def _dev(w, name, device):
@@ -91,7 +92,7 @@ class BertTower:
     """`DocumentEncoder` of mtype 'bert': reps = last_hidden_state[:, 0, :] (normalize=False).  `weights_p` gives the
     passage model its own weights (AR2: ctx_model / question_model); tied otherwise."""
 
-    def __init__(self, weights_q, num_layers, num_heads, weights_p=None, eps=1e-12, device=None, batch_size=512, prefix=""):
+    def __init__(self, weights_q, num_layers, num_heads, weights_p=None, eps=1e-12, device=None, batch_size=None, prefix=""):
         self.dev = torch.device(device if device is not None else "cuda")
         self.lm_q = BertEncoder(weights_q, num_layers, num_heads, eps, self.dev, prefix)
         self.lm_p = self.lm_q if weights_p is None else BertEncoder(weights_p, num_layers, num_heads, eps, self.dev, prefix)
@@ -102,8 +103,9 @@ class BertTower:
         ids = items["input_ids"].to(self.dev, torch.int64)
         mask = items["attention_mask"].to(self.dev, torch.int64)
         outs = []
-        for a in range(0, ids.shape[0], self.batch_size):
-            i, m = ids[a:a + self.batch_size].contiguous(), mask[a:a + self.batch_size].contiguous()
+        step = self.batch_size or max(1, DEVICE_PASS_TOKENS // max(1, ids.shape[1]))
+        for a in range(0, ids.shape[0], step):
+            i, m = ids[a:a + step].contiguous(), mask[a:a + step].contiguous()
             outs.append(model.forward(i, m)[:, 0, :].contiguous())
         return torch.cat(outs) if outs else torch.empty((0, model.d), device=self.dev)
 

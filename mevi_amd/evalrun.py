@@ -57,7 +57,7 @@ def load_tower_weights(model_dir):
     return sd, dims
 
 
-def load_bert_tower(model_path, device, batch_size=512):
+def load_bert_tower(model_path, device, batch_size=None):
     """BERT-family tower as `generate.get_document_encoder` + `DocumentEncoder.build` load it (MEVI/generate.py:31-44,
     document_encoder.py:141-188): an HF directory (config.json + pytorch_model.bin, tied towers), or an AR2 checkpoint
     `ar2g_{nq,marco}_finetune.pkl` ({'model_dict': {'ctx_model.*', 'question_model.*'}}) with its config directory

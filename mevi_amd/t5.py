@@ -207,27 +207,34 @@ class DecoderStack:
         return ops.rmsnorm(x, self.final_ln, d.eps)
 
 
+# Padded tokens per device pass of a tower (8192 queries x 32, 2048 passages x 128): results do not depend on the
+# grouping (row-wise operators, tested), larger passes fill the GEMM grids (t5-base tower: 19.5 k queries/s at 512 rows
+# per pass, 30.9 k at 2048, 35.4 k at 8192; passages 5.7 k/s at 512, 6.4 k/s at 2048).
+DEVICE_PASS_TOKENS = 262144
+
+
 class TwinTower:
     """The (tied) tower of the dense arm: T5Model encoder + one decoder step on token 0,
     reps = last_hidden_state[:, 0, :], normalize=False (DocumentEncoder.encode, document_encoder.py:104-120).
 
     `encode_query(qry)` takes the reference's {'input_ids', 'attention_mask'} mapping."""
 
-    def __init__(self, weights, dims=None, device=None, batch_size=512, **cfg):
+    def __init__(self, weights, dims=None, device=None, batch_size=None, **cfg):
         self.dev = torch.device(device if device is not None else "cuda")
         self.d = dims if dims is not None else T5Dims(**cfg)
         self.shared = _dev(weights, "shared.weight", self.dev)
         self.encoder = EncoderStack(weights, self.d, self.dev)
         self.decoder = DecoderStack(weights, self.d, self.dev, max_len=1)
-        self.batch_size = batch_size
+        self.batch_size = batch_size   # rows per device pass; None: DEVICE_PASS_TOKENS // sequence length
         self.dim = self.d.d_model      # width of the embeddings this tower emits
 
     def encode_query(self, qry):
         ids = qry["input_ids"].to(self.dev, torch.int64)
         mask = qry["attention_mask"].to(self.dev, torch.int64)
         outs = []
-        for a in range(0, ids.shape[0], self.batch_size):
-            i, m = ids[a:a + self.batch_size].contiguous(), mask[a:a + self.batch_size].contiguous()
+        step = self.batch_size or max(1, DEVICE_PASS_TOKENS // max(1, ids.shape[1]))
+        for a in range(0, ids.shape[0], step):
+            i, m = ids[a:a + step].contiguous(), mask[a:a + step].contiguous()
             enc = self.encoder.forward(self.shared, i, m)
             B = i.shape[0]
             x = ops.gather_rows(self.shared, torch.zeros(B, dtype=torch.int64, device=self.dev))

@@ -15,7 +15,8 @@ from mevi_amd import nci, t5
 from oracle import t5 as ot5
 
 pytestmark = pytest.mark.gpu
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def test_bucket_tables_match_reference():
@@ -208,3 +209,39 @@ def test_bert_towers_load_like_the_reference(cuda, tmp_path):
     q = enc2.encode_query({"input_ids": ids, "attention_mask": mask}).cpu().numpy()
     p_ = enc2.encode_passage({"input_ids": ids, "attention_mask": mask}).cpu().numpy()
     assert np.abs(q - g["reps"]).max() <= 5e-5 and np.abs(p_ - q).max() > 1e-4
+
+
+def test_results_do_not_depend_on_batch_grouping_or_stale_memory_at_base_shapes(cuda):
+    """t5-base-shaped NCI model and tower (synthetic weights, tools/synth.py): beams, scores and embeddings are
+    bit-identical whether the queries go through in one pass or in groups of 96 / 700 (GEMM tile shape, packed token
+    count and attention grids all change), and with the allocator's free blocks poisoned with NaN (no kernel reads
+    memory it did not write)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+
+    model, tower, _, _ = synth.build(cuda, 4, 32, 2048)
+    nq = 1500
+    ids, mask = synth.query_ids(nq, cuda, np.random.default_rng(7))
+
+    def gen(b):
+        parts = [model.generate(ids[a:a + b], mask[a:a + b], num_beams=10) for a in range(0, nq, b)]
+        return torch.cat([p[0] for p in parts]), np.concatenate([np.asarray(p[1]) for p in parts])
+
+    def emb(b):
+        tower.batch_size = b
+        return tower.encode_query({"input_ids": ids, "attention_mask": mask})
+
+    d0, s0 = gen(nq)
+    e0 = emb(2048)
+    assert np.isfinite(s0).all() and bool(torch.isfinite(e0).all())
+    for b in (96, 700):
+        d, s = gen(b)
+        assert torch.equal(d, d0) and np.array_equal(s, s0)
+        assert torch.equal(emb(b), e0)
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 28,), float("nan"), device=cuda) for _ in range(8)]
+    del junk
+    d, s = gen(700)
+    assert torch.equal(d, d0) and np.array_equal(s, s0) and torch.equal(emb(700), e0)

@@ -6,7 +6,7 @@
     ensemble_marco.py         alpha .6 beta .03 gamma .02                   -> MRR@10 (host, untimed: it is file parsing)
 
 queries/s = queries / (encode + search + beam + tower-again + fine), I/O excluded, inputs resident in HBM.
-python tools/bench_chain.py [nq] [n_docs]"""
+python tools/bench_chain.py [nq] [n_docs] [main.py --device_batch_size]"""
 import json
 import os
 import sys
@@ -24,9 +24,11 @@ from mevi_amd import dense, fine, metrics, nci, rq  # noqa: E402
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else bench.N_QUERIES
 N = int(sys.argv[2]) if len(sys.argv) > 2 else bench.N_DOCS
-M, K, R, k, batch, d = 4, 32, 10, bench.TOPK, 512, 768
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+M, K, R, k, d = 4, 32, 10, bench.TOPK, 768
 dev = torch.device("cuda:0")
 model, tower, g, rn = synth.build(dev, M, K, batch)
+tower.batch_size = None          # the product's default pass size (mevi_amd.t5.DEVICE_PASS_TOKENS)
 rng = np.random.default_rng(0)
 ids, mask = synth.query_ids(nq, dev, rng)
 
@@ -43,14 +45,23 @@ def encode():
     return tower.encode_query({"input_ids": ids, "attention_mask": mask})
 
 
-def beams():
-    dec, sc = [], []
+def main_py():
+    """main.py --mode eval: per device batch, beam search -> query tower -> fine stage (EvalRun.infer)."""
+    t = {"NCI beam search (main.py)": 0.0, "tower again (main.py fine stage)": 0.0, "fine stage: gather-dot + sort": 0.0}
+    codes, ranked, ndoc = [], [], []
     for a in range(0, nq, batch):
-        o = model.generate(ids[a:a + batch], mask[a:a + batch], num_beams=R)
-        dec.append(o[0])
-        sc += list(o[1])
-    codes = nci.decode_token(torch.cat(dec), K).view(nq, R, M)
-    return codes.cpu().numpy(), np.asarray(sc).reshape(nq, R)
+        i, m = ids[a:a + batch], mask[a:a + batch]
+        dt, o = sync_time(lambda: model.generate(i, m, num_beams=R))
+        t["NCI beam search (main.py)"] += dt
+        bc = nci.decode_token(o[0], K).view(-1, R, M).cpu().numpy()
+        dt, q2 = sync_time(lambda: tower.encode_query({"input_ids": i, "attention_mask": m}))
+        t["tower again (main.py fine stage)"] += dt
+        dt, (rk, nd) = sync_time(lambda: fs.rerank(q2, bc))
+        t["fine stage: gather-dot + sort"] += dt
+        codes.append(bc)
+        ranked += rk
+        ndoc.append(nd)
+    return t, np.concatenate(codes), ranked, np.concatenate(ndoc)
 
 
 # ---- untimed set-up: corpus of C2, one planted neighbour per query at a controlled margin, RQ clusters --------------
@@ -76,9 +87,8 @@ stages = {}
 for rep in range(2):
     stages["tower (generate.py)"], qemb = sync_time(encode)
     stages["dense top-1000 (faiss_search.py)"], (ds, di) = sync_time(lambda: dindex.search(qemb, k))
-    stages["NCI beam search (main.py)"], (bcodes, bscores) = sync_time(beams)
-    stages["tower again (main.py fine stage)"], qemb2 = sync_time(encode)
-    stages["fine stage: gather-dot + sort"], (ranked, ndoc) = sync_time(lambda: fs.rerank(qemb2, bcodes))
+    t, bcodes, ranked, ndoc = main_py()
+    stages.update(t)
 total = sum(stages.values())
 for n_, t in stages.items():
     print(f"{n_:36s} {t*1e3:8.1f} ms   {nq/t:9.0f} q/s", flush=True)
@@ -110,7 +120,11 @@ res = {"ANCE Pred": metrics.evaluate_ranked("ANCE Pred", [10, 50, 1000], gts, de
 ens = {q: metrics.ensemble_scores(dense_p[q], dense_s[q], cranks[q], fine_p[q], fine_s[q], n_clusters, 0.6, 0.03, 0.02)
        for q in gts}
 res["ensemble"] = metrics.evaluate_ranked("score + 0.6 / (0.03 * crank + 1); punishment (1 - 0.02 * 0.6)", [10, 50, 1000], gts, ens)
+import zlib  # noqa: E402
+print("checksums:", {n_: zlib.crc32(np.ascontiguousarray(a_).tobytes()) for n_, a_ in
+                     (("qemb", qemb.cpu().numpy()), ("codebook", codebook.cpu().numpy()), ("doc_codes", codes_h),
+                      ("beam_codes", bcodes), ("dense_ids", di_h), ("ndoc", ndoc))})
 line = {"workload": f"C4: {nq} queries, corpus {N} x {d}, beams {R}, RQ ({M},{K}), top-{k}",
-        "queries_per_s": round(nq / total, 1), "ms": {n_: round(t * 1e3, 2) for n_, t in stages.items()},
+        "device_batch": batch, "queries_per_s": round(nq / total, 1), "ms": {n_: round(t * 1e3, 2) for n_, t in stages.items()},
         "fine_candidates_per_query": float(ndoc.mean())}
 print(json.dumps(line))

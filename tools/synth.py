@@ -36,7 +36,7 @@ def build(dev, M, K, batch, seed=0):
             W[f"{st}.final_layer_norm.weight"] = torch.ones(d, device=dev)
 
     V = K * (M + 2) + 2
-    W = {"shared.weight": rn(32128, d), "decode_embeddings.weight": rn(V, d), "adaptor_embeddings": torch.rand((1, 1, d), device=dev),
+    W = {"shared.weight": rn(32128, d), "decode_embeddings.weight": rn(V, d), "adaptor_embeddings": torch.rand((1, 1, d), device=dev, generator=g),
          "adaptor_linear.weight": rn(d * V, d, s=d ** -0.5 * 0.3)}
     W["lm_head.weight"] = W["decode_embeddings.weight"]
     t5_weights(W, 12, 6)
