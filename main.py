@@ -3,6 +3,7 @@
 path that marco_eval_nci_rq.sh drives (MEVI/main.py:356-794, 267-337).  Every flag of that script is
 accepted; the ones that configure training are parsed and ignored.  Only --mode eval with
 --codebook 1 --pq_type rq --document_encoder ance|cocondenser|ar2 --query_encoder twin --recall_level both is built
+(+ the brute-force ablation --eval_all_documents 1 --recall_level fine --knn_topk_by_step 1)
 (the configuration of every shipped eval script); anything else raises.
 
 One process per GPU: `--n_gpu N` spawns N ranks itself like the reference (queries split by rank,
@@ -55,6 +56,7 @@ def parsers_parser(argv=None):
     p.add_argument("--test_set", type=str, default="dev")
     p.add_argument("--doc_multiclus", type=int, default=1)
     p.add_argument("--eval_all_documents", type=int, default=0)
+    p.add_argument("--knn_topk_by_step", type=int, default=0)
     p.add_argument("--timing_infer_step", type=int, default=0)
     args, rest = p.parse_known_args(argv)
     # training / ablation flags of marco_eval_nci_rq.sh: accepted, no effect on eval
@@ -86,7 +88,9 @@ def check_supported(a):
         raise SystemExit("mevi_amd builds the inference hot path only: use --mode eval (training is out of scope)")
     if a.document_encoder not in ("ance", "cocondenser", "ar2"):
         raise SystemExit(f"main.py --mode eval: --document_encoder {a.document_encoder!r} is not built")
-    need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both", doc_multiclus=1, eval_all_documents=0)
+    need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both", doc_multiclus=1)
+    if a.eval_all_documents:   # the brute-force ablation; same preconditions as the reference (MEVI/main.py:657-658)
+        need.update(recall_level="fine", knn_topk_by_step=1)
     for k, v in need.items():
         if getattr(a, k) != v:
             raise SystemExit(f"main.py --mode eval: --{k} {getattr(a, k)!r} is not built (only {v!r}, as in marco_eval_nci_rq.sh)")

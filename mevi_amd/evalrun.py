@@ -15,6 +15,7 @@ import numpy as np
 import pandas as pd
 import torch
 
+from . import dense as mdense
 from . import fine as mfine
 from . import hip
 from .io import RankLog
@@ -186,8 +187,12 @@ class EvalRun:
             self.barrier()
         print("Number of all pq document clusters:", len(self.index.keys))
         self.fine = mfine.FineStage(self.emb, self.index)
+        self._dense_index = None
         prefix = a.custom_save_path[:-4]
-        self.coarse_log = RankLog(f"{prefix}_coarse.tsv", rank, nrank, self.barrier)
+        # --eval_all_documents 1 (recall_level 'fine'): the brute-force ablation -- no beam search, the fine list is the
+        # exact top-max(recall_num) of q.d over the whole corpus (main_models.py:3570,3818-3876)
+        self.eval_all = bool(getattr(a, "eval_all_documents", 0))
+        self.coarse_log = None if self.eval_all else RankLog(f"{prefix}_coarse.tsv", rank, nrank, self.barrier)
         self.fine_log = RankLog(f"{prefix}_fine.tsv", rank, nrank, self.barrier)
         self.hn_log = RankLog(f"{prefix}_hn{a.save_hard_neg}.tsv", rank, nrank, self.barrier) if a.save_hard_neg else None
 
@@ -196,22 +201,62 @@ class EvalRun:
                                                return_tensors="pt")
         return out["input_ids"], out["attention_mask"]
 
+    def query_embedding(self, texts, ids, mask):
+        if self.tower_tokenizer is None:      # T5-ANCE: the tower reads the NCI input ids (main_models.py:3797-3799)
+            return self.tower.encode_query({"input_ids": ids, "attention_mask": mask})
+        tok = self.tower_tokenizer.batch_encode_plus(list(texts), max_length=32, truncation=True, padding="max_length",
+                                                     add_special_tokens=self.tower_special_tokens, return_tensors="pt")
+        return self.tower.encode_query({"input_ids": tok["input_ids"], "attention_mask": tok["attention_mask"]})
+
+    @torch.no_grad()
+    def infer_all_documents(self, texts, doc_ids, ids, mask):
+        """--eval_all_documents: [(text, N, fine ranks)].  The reference streams the corpus in --encode_batch_size
+        blocks through a running top-pool (main_models.py:3818-3876); the result is the exact top-pool of q.d, which
+        is what the dense arm's search returns (ties by ascending id here, unspecified `torch.topk` order there).
+        The hard-negative line keeps the reference's quirk (:3905-3908): its score column is NOT the sorted scores but
+        the last iteration's concatenation -- the running top-pool before the last block, then the last block's raw
+        scores in id order -- cut to save_hard_neg."""
+        a = self.args
+        N = self.emb.shape[0]
+        pool = max(a.recall_num)
+        qemb = self.query_embedding(texts, ids, mask)
+        if self._dense_index is None:
+            self._dense_index = mdense.DenseIndex(self.emb)
+        _, top_i = self._dense_index.search(qemb, min(N, pool))
+        top_i = top_i.cpu().numpy()
+        if self.hn_log is not None:
+            bs = max(1, a.encode_batch_size or 64)
+            last = ((N - 1) // bs) * bs
+            tail_s, tail_i = mdense.ip_topk(qemb, self.emb[last:], N - last, id_offset=last)
+            tail = torch.gather(tail_s, 1, torch.argsort(tail_i, dim=1))         # the last block's scores in id order
+            if last > 0:
+                head_s, _ = mdense.ip_topk(qemb, self.emb[:last], min(last, pool))
+                tail = torch.cat([head_s, tail], dim=1)
+            quirk = tail.cpu().numpy()
+            gt_s = self.fine.gt_scores(qemb, doc_ids)
+        results = []
+        for i, text in enumerate(texts):
+            docs = top_i[i]
+            self.fine_log.add((text, docs.tolist(), doc_ids[i]))
+            if self.hn_log is not None:
+                n = a.save_hard_neg
+                self.hn_log.add((text, mfine.f32_repr(gt_s[i]), ",".join(map(str, docs[:n])), mfine.f32_repr(quirk[i][:n])))
+            results.append((text, N, mfine.fine_ranks(docs, doc_ids[i])))
+        return results
+
     @torch.no_grad()
     def infer(self, texts, doc_ids):
         """One batch: returns [(text, ndoc, coarse ranks, fine ranks)] like infer() with recall_level='both'."""
         a, R = self.args, self.R
         ids, mask = self.tokenize(texts)
+        if self.eval_all:
+            return self.infer_all_documents(texts, doc_ids, ids, mask)
         decoded, scores, _, _ = self.nci.generate(ids, mask, num_beams=R, num_return_sequences=R,
                                                   length_penalty=a.length_penalty, max_length=self.M + 2)
         B = len(texts)
         codes = decode_token(decoded, self.K).view(B, R, self.M).cpu().numpy()
         scores = np.array(scores).reshape(B, R)
-        if self.tower_tokenizer is None:      # T5-ANCE: the tower reads the NCI input ids (main_models.py:3797-3799)
-            qemb = self.tower.encode_query({"input_ids": ids, "attention_mask": mask})
-        else:
-            tok = self.tower_tokenizer.batch_encode_plus(list(texts), max_length=32, truncation=True, padding="max_length",
-                                                         add_special_tokens=self.tower_special_tokens, return_tensors="pt")
-            qemb = self.tower.encode_query({"input_ids": tok["input_ids"], "attention_mask": tok["attention_mask"]})
+        qemb = self.query_embedding(texts, ids, mask)
         ranked, ndoc = self.fine.rerank(qemb, codes)
         gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None else None
         results = []
@@ -244,7 +289,8 @@ class EvalRun:
     # ---- handle_infer_results / validation_epoch_end ----------------------------------------
     def finish(self, cache):
         a = self.args
-        self.coarse_log.merge()
+        if self.coarse_log is not None:
+            self.coarse_log.merge()
         self.fine_log.merge()
         part = f"/tmp/{os.path.basename(a.custom_save_path)}.results_{self.rank}"
         with open(part, "wb") as f:
@@ -260,7 +306,7 @@ class EvalRun:
                 with open(p, "rb") as f:
                     allres += pickle.load(f)
                 os.remove(p)
-            out = summarize(allres, a.recall_num, self.R)
+            out = summarize(allres, a.recall_num, self.R, both=not self.eval_all)
             write_metrics(out, a.metric_path, self.R, len(self.index.keys))
         self.barrier()
         return out
@@ -278,25 +324,41 @@ def _acc(v, tables):
     return found, best
 
 
-def summarize(results, recall_num, R):
-    """recall / mrr / hitrate at recall_num for the fine list, cluster_* at the cut-offs <= R, mean ndoc."""
-    queries = {q: (length, findex, cindex) for (q, length, cindex, findex) in results}
+def summarize(results, recall_num, R, both=True):
+    """recall / mrr / hitrate at recall_num for the fine list and mean ndoc; with recall_level 'both' cluster_* at the
+    cut-offs <= R, with 'fine' the extra key f'cluster{R}' = found-at-all figures (handle_infer_results,
+    main_models.py:4100-4201)."""
+    if both:
+        queries = {q: (length, findex, cindex) for (q, length, cindex, findex) in results}
+    else:
+        queries = {q: (length, findex, None) for (q, length, findex) in results}
     fine = tuple({k: 0 for k in recall_num} for _ in range(3))
     ccut = sorted(k for k in recall_num if k <= R)
     if not ccut or ccut[-1] != R:
         ccut.append(R)
     coarse = tuple({k: 0 for k in ccut} for _ in range(3))
     nsamples = 0
+    at_all = [0, 0, 0]
     for q, (length, findex, cindex) in queries.items():
-        _acc(findex, fine)
-        _acc(cindex, coarse)
+        found, best = _acc(findex, fine)
+        if both:
+            _acc(cindex, coarse)
+        else:
+            at_all[0] += len(found) / len(findex)
+            at_all[1] += 1 / (best + 1) if best is not None else 0
+            at_all[2] += len(found) > 0
         nsamples += length
     n = len(queries)
+    if not both:
+        for t, v in zip(fine, at_all):
+            t[f"cluster{R}"] = v
     for t in fine + coarse:
         for k in t:
             t[k] /= n
-    return dict(recall=fine[0], mrr=fine[1], hitrate=fine[2], cluster_recall=coarse[0], cluster_mrr=coarse[1],
-                cluster_hitrate=coarse[2], ndoc=nsamples / n, nqueries=n)
+    out = dict(recall=fine[0], mrr=fine[1], hitrate=fine[2], ndoc=nsamples / n, nqueries=n)
+    if both:
+        out.update(cluster_recall=coarse[0], cluster_mrr=coarse[1], cluster_hitrate=coarse[2])
+    return out
 
 
 def write_metrics(out, metric_path, R, npqclus):
@@ -304,7 +366,8 @@ def write_metrics(out, metric_path, R, npqclus):
     for name in ("recall", "mrr", "hitrate"):
         lines += [f"{name}{k} {v}" for k, v in out[name].items()]
     for name in ("cluster_recall", "cluster_hitrate"):
-        lines += [f"{name}{k} {v}" for k, v in out[name].items()]
+        if name in out:
+            lines += [f"{name}{k} {v}" for k, v in out[name].items()]
     lines.append(f"ndocs@cluster{R}: {out['ndoc']}")
     print(f"npqclus: {npqclus}")
     print("\n".join(lines))

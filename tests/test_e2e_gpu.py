@@ -155,6 +155,50 @@ def test_eval_outputs_do_not_depend_on_the_device_batch(cuda, mini, tmp_path):
     assert blobs[0] == blobs[1] == blobs[2] and all(len(b) > 0 for b in blobs[0])
 
 
+def test_eval_all_documents_mode(cuda, mini, tmp_path):
+    """--eval_all_documents 1 (recall_level fine): no beam search, fine list = running top-pool over the corpus streamed
+    in --encode_batch_size blocks (main_models.py:3818-3876), restated on the CPU with the oracle tower; the
+    hard-negative score column is the reference's last-iteration concatenation (:3905-3908)."""
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    a = Namespace(**vars(mini["args"]))
+    a.eval_all_documents, a.recall_level, a.encode_batch_size, a.recall_num, a.save_hard_neg = 1, "fine", 64, [1, 5, 10, 20, 50, 100], 150
+    a.custom_save_path, a.metric_path = str(tmp_path / "all.tsv"), str(tmp_path / "m.txt")
+    tok = FakeTokenizer(512)
+    out = EvalRun(a, tokenizer=tok, device=cuda).run(load_queries(a.data_dir))
+    prefix = a.custom_save_path[:-4]
+    assert not os.path.exists(prefix + "_coarse.tsv")
+    fine = [l.rstrip("\n").split("\t") for l in open(prefix + "_fine.tsv")]
+    hn = [l.rstrip("\n").split("\t") for l in open(f"{prefix}_hn150.tsv")]
+    enc = tok.batch_encode_plus(mini["queries"])
+    qemb = ot5.tower_encode(mini["TW"], mini["tcfg"], enc["input_ids"], enc["attention_mask"])
+    emb = torch.from_numpy(mini["emb"])
+    N, pool = len(emb), 100
+    stack = torch.empty((len(qemb), 0))
+    docs = torch.empty((len(qemb), 0), dtype=torch.int64)
+    for st in range(0, N, 64):                       # the reference's loop, literally
+        new = qemb @ emb[st:st + 64].T
+        sc = torch.cat([stack, new], -1)
+        dd = torch.cat([docs, torch.arange(st, min(st + 64, N)).unsqueeze(0).expand(len(qemb), -1)], -1)
+        stack, idx = torch.topk(sc, k=min(sc.shape[-1], pool), dim=-1)
+        docs = dd.gather(-1, idx)
+    ranks = []
+    for i, q in enumerate(mini["queries"]):
+        assert fine[i][0] == hn[i][0] == q and eval(fine[i][2]) == mini["gts"][i]
+        got = eval(fine[i][1])
+        ref_s = stack[i].numpy()
+        firm = np.concatenate([[True], np.abs(np.diff(ref_s)) > 1e-4]) & np.concatenate([np.abs(np.diff(ref_s)) > 1e-4, [True]])
+        assert len(got) == pool and all(got[j] == int(docs[i, j]) for j in np.nonzero(firm)[0])
+        assert [int(x) for x in hn[i][2].split(",")] == got                 # pool (100) < save_hard_neg (150)
+        got_sc = np.array([float(x) for x in hn[i][3].split(",")])
+        want = sc[i, :150].numpy()      # 100 running-top scores + the (N % 64)-row last block, cut to 150
+        assert len(got_sc) == len(want) == min(150, pool + (N - 1) % 64 + 1) and np.abs(got_sc - want).max() <= 2e-4
+        ranks.append([got.index(g) if g in got else None for g in mini["gts"][i]])
+    assert out["ndoc"] == N and "cluster_recall" not in out
+    hit10 = np.mean([min([r for r in rk if r is not None], default=10 ** 9) < 10 for rk in ranks])
+    assert abs(out["hitrate"][10] - hit10) < 1e-12 and "recallcluster10" in open(a.metric_path).read()
+
+
 def test_dense_cli_and_ensemble_chain(cuda, mini, tmp_path):
     """faiss_search.py (C1-style plumbing on the GPU) -> evaluate.py -> ensemble_marco.py on the files above."""
     d, a = mini["dir"], mini["args"]

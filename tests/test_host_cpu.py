@@ -37,8 +37,12 @@ def test_main_accepts_every_flag_of_marco_eval_nci_rq_sh():
     main.check_supported(main.parsers_parser(EVAL_ARGV + ["--document_encoder", "ar2"]))   # BERT-family towers are built
     with pytest.raises(SystemExit):
         main.check_supported(main.parsers_parser(EVAL_ARGV + ["--document_encoder", "dpr"]))
-    with pytest.raises(SystemExit):   # ablation modes are not
+    with pytest.raises(SystemExit):   # the brute-force ablation needs recall_level fine + knn_topk_by_step 1 (MEVI/main.py:657-658)
         main.check_supported(main.parsers_parser(EVAL_ARGV + ["--eval_all_documents", "1"]))
+    main.check_supported(main.parsers_parser(EVAL_ARGV + ["--eval_all_documents", "1", "--recall_level", "fine",
+                                                          "--knn_topk_by_step", "1"]))
+    with pytest.raises(SystemExit):   # other ablation modes are not built
+        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--doc_multiclus", "3"]))
 
 
 def test_cli_argument_surfaces_match_reference():
@@ -109,6 +113,11 @@ def test_metric_aggregation_matches_consumer_semantics():
     assert out["recall"][5] == (0.5 + 0 + 1) / 3 and out["mrr"][5] == (1 / 4 + 0 + 1) / 3 and out["recall"][1] == 1 / 3
     assert out["cluster_recall"][10] == (0.5 + 0 + 1) / 3 and out["cluster_recall"][5] == 0.5 / 3
     assert list(out["cluster_recall"]) == [1, 5, 10]
+    # recall_level 'fine' (--eval_all_documents): 3-tuples, the extra 'cluster<R>' key = found-at-all figures
+    fine = summarize([("q1", 50, (3, None)), ("q2", 50, (None,)), ("q3", 50, (0,))], [1, 5], 10, both=False)
+    assert "cluster_recall" not in fine and fine["ndoc"] == 50
+    assert fine["recall"] == {1: 1 / 3, 5: (0.5 + 0 + 1) / 3, "cluster10": (0.5 + 0 + 1) / 3}
+    assert fine["mrr"]["cluster10"] == (1 / 4 + 0 + 1) / 3 and fine["hitrate"]["cluster10"] == 2 / 3
 
 
 def _gloo_worker(rank, world, port, q, d, k, ret):
