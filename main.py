@@ -88,6 +88,8 @@ def check_supported(a):
         raise SystemExit("mevi_amd builds the inference hot path only: use --mode eval (training is out of scope)")
     if a.document_encoder not in ("ance", "cocondenser", "ar2"):
         raise SystemExit(f"main.py --mode eval: --document_encoder {a.document_encoder!r} is not built")
+    if a.dataset not in ("marco", "nq_dpr"):
+        raise SystemExit(f"main.py --mode eval: --dataset {a.dataset!r} is not built (marco, nq_dpr)")
     need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both", doc_multiclus=1)
     if a.eval_all_documents:   # the brute-force ablation; same preconditions as the reference (MEVI/main.py:657-658)
         need.update(recall_level="fine", knn_topk_by_step=1)
@@ -113,7 +115,7 @@ def partial_inference(rank, args):
     import torch
     import torch.distributed as dist
 
-    from mevi_amd.evalrun import EvalRun, default_metric_path, load_queries
+    from mevi_amd.evalrun import EvalRun, default_metric_path, load_nq_queries, load_queries
 
     nrank = int(os.environ.get("WORLD_SIZE", len(args.n_gpu)))
     if "RANK" in os.environ:
@@ -128,7 +130,7 @@ def partial_inference(rank, args):
         args.time_str = time.strftime("%Y%m%d%H%M%S")
     args.metric_path = default_metric_path(args)
     run = EvalRun(args, rank=rank, nrank=nrank, barrier=barrier, device=torch.device("cuda", gpu))
-    df = load_queries(args.data_dir, args.n_test)
+    df = (load_nq_queries if args.dataset == "nq_dpr" else load_queries)(args.data_dir, args.n_test)
     print("Inference start...")
     run.run(df)
     if nrank > 1:

@@ -109,6 +109,39 @@ def load_queries(data_dir, n_test=-1, fname="dev_mevi_dedup.tsv"):
     return df
 
 
+def load_nq_queries(data_dir, n_test=-1, fname="nq-test.qa.csv"):
+    """--dataset nq_dpr: `question \t answers` (main_utils.py:279-287).  The 'oldid' column carries the row index -- the
+    `query_indices` a sample is judged by (main_models.py:857-858)."""
+    df = pd.read_csv(os.path.join(data_dir, fname), names=["query", "answers"], encoding="utf-8", header=None, sep="\t")
+    assert not df.isnull().values.any()
+    df["oldid"] = np.arange(len(df))
+    if n_test is not None and n_test >= 0:
+        df = df[:n_test]
+    return df
+
+
+class NqAnswers:
+    """test_inverse_offsets.bin / test_inverse_array.bin (i32): per document, the test questions it answers
+    (main_models.py:4267-4272).  A hit test `qind in array[offsets[d]:offsets[d+1]]` per ranked document is what the
+    reference loops over (:3744-3750, :4064-4069); here the lists are inverted once (question -> sorted doc ids) and a
+    ranked list is tested with one `np.isin`."""
+
+    def __init__(self, data_dir):
+        offsets = np.asarray(np.memmap(os.path.join(data_dir, "test_inverse_offsets.bin"), mode="r", dtype=np.int32), np.int64)
+        array = np.asarray(np.memmap(os.path.join(data_dir, "test_inverse_array.bin"), mode="r", dtype=np.int32))
+        doc = np.repeat(np.arange(len(offsets) - 1, dtype=np.int64), np.diff(offsets))
+        order = np.argsort(array[:offsets[-1]], kind="stable")
+        self.question, self.doc = array[:offsets[-1]][order], doc[order]
+
+    def docs_answering(self, qind):
+        lo, hi = np.searchsorted(self.question, [qind, qind + 1])
+        return self.doc[lo:hi]
+
+    def first_hit(self, qind, ranked_docs):
+        hit = np.flatnonzero(np.isin(np.asarray(ranked_docs, dtype=np.int64), self.docs_answering(qind)))
+        return int(hit[0]) if len(hit) else None
+
+
 def rank_slice(n, rank, nrank):
     """Indices DistributedSampler(shuffle=False) gives `rank`: every nrank-th item of the list padded to
     a multiple of nrank by repeating its head (MEVI/main.py:318-322); duplicates are de-duplicated by the
@@ -188,6 +221,8 @@ class EvalRun:
         print("Number of all pq document clusters:", len(self.index.keys))
         self.fine = mfine.FineStage(self.emb, self.index)
         self._dense_index = None
+        # --dataset nq_dpr: samples carry their question index instead of gt doc ids; hits are answer-based
+        self.nq = NqAnswers(a.data_dir) if getattr(a, "dataset", "marco") == "nq_dpr" else None
         prefix = a.custom_save_path[:-4]
         # --eval_all_documents 1 (recall_level 'fine'): the brute-force ablation -- no beam search, the fine list is the
         # exact top-max(recall_num) of q.d over the whole corpus (main_models.py:3570,3818-3876)
@@ -233,15 +268,17 @@ class EvalRun:
                 head_s, _ = mdense.ip_topk(qemb, self.emb[:last], min(last, pool))
                 tail = torch.cat([head_s, tail], dim=1)
             quirk = tail.cpu().numpy()
-            gt_s = self.fine.gt_scores(qemb, doc_ids)
+            gt_s = self.fine.gt_scores(qemb, doc_ids) if self.nq is None else None
         results = []
         for i, text in enumerate(texts):
             docs = top_i[i]
-            self.fine_log.add((text, docs.tolist(), doc_ids[i]))
+            self.fine_log.add((text, docs.tolist(), doc_ids[i]) if self.nq is None else (text, docs.tolist()))
             if self.hn_log is not None:
                 n = a.save_hard_neg
-                self.hn_log.add((text, mfine.f32_repr(gt_s[i]), ",".join(map(str, docs[:n])), mfine.f32_repr(quirk[i][:n])))
-            results.append((text, N, mfine.fine_ranks(docs, doc_ids[i])))
+                self.hn_log.add((text, mfine.f32_repr(gt_s[i]) if self.nq is None else "", ",".join(map(str, docs[:n])),
+                                 mfine.f32_repr(quirk[i][:n])))
+            ranks = mfine.fine_ranks(docs, doc_ids[i]) if self.nq is None else [self.nq.first_hit(doc_ids[i], docs)]
+            results.append((text, N, ranks))
         return results
 
     @torch.no_grad()
@@ -258,19 +295,29 @@ class EvalRun:
         scores = np.array(scores).reshape(B, R)
         qemb = self.query_embedding(texts, ids, mask)
         ranked, ndoc = self.fine.rerank(qemb, codes)
-        gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None else None
+        nq = self.nq
+        gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None and nq is None else None
         results = []
         for i, text in enumerate(texts):
             d = codes[i].tolist()
-            gt_codes = [list(self.mapping[g]) for g in doc_ids[i]]
-            self.coarse_log.add((text, d, gt_codes, scores[i].tolist()))
-            cr = tuple(d.index(g) if g in d else None for g in gt_codes)
             docs, sc = ranked[i]
-            self.fine_log.add((text, docs.tolist(), doc_ids[i]))
+            if nq is None:
+                gt_codes = [list(self.mapping[g]) for g in doc_ids[i]]
+                self.coarse_log.add((text, d, gt_codes, scores[i].tolist()))
+                cr = tuple(d.index(g) if g in d else None for g in gt_codes)
+                self.fine_log.add((text, docs.tolist(), doc_ids[i]))
+                fr = mfine.fine_ranks(docs, doc_ids[i])
+            else:      # main_models.py:3738-3757, 4060-4077: first beam cluster / first ranked doc answering the question
+                self.coarse_log.add((text, d, scores[i].tolist()))
+                answering = nq.docs_answering(doc_ids[i])
+                cr = [next((j for j, c in enumerate(d) if np.isin(self.index.lookup(c), answering).any()), None)]
+                self.fine_log.add((text, docs.tolist()))
+                fr = [nq.first_hit(doc_ids[i], docs)]
             if self.hn_log is not None:
                 n = a.save_hard_neg
-                self.hn_log.add((text, mfine.f32_repr(gt_s[i]), ",".join(map(str, docs[:n])), mfine.f32_repr(sc[:n])))
-            results.append((text, int(ndoc[i]), cr, mfine.fine_ranks(docs, doc_ids[i])))
+                self.hn_log.add((text, mfine.f32_repr(gt_s[i]) if nq is None else "", ",".join(map(str, docs[:n])),
+                                 mfine.f32_repr(sc[:n])))
+            results.append((text, int(ndoc[i]), cr, fr))
         return results
 
     def run(self, df):

@@ -199,6 +199,61 @@ def test_eval_all_documents_mode(cuda, mini, tmp_path):
     assert abs(out["hitrate"][10] - hit10) < 1e-12 and "recallcluster10" in open(a.metric_path).read()
 
 
+def test_eval_driver_on_the_nq_dataset_path(cuda, mini, tmp_path):
+    """--dataset nq_dpr: questions from nq-test.qa.csv, hits judged through test_inverse_{offsets,array}.bin; the log
+    lines lose their gt columns (main_models.py:3738-3757,4060-4077).  Same model and corpus as the marco run, so
+    beams and fine lists must be the ones that run logged, and the ranks must equal the reference's hit loops."""
+    from mevi_amd.evalrun import EvalRun, load_nq_queries, summarize
+    from mevi_amd.metrics import nq_first_hit
+
+    a0 = mini["args"]
+    prefix0 = a0.custom_save_path[:-4]
+    if not os.path.exists(prefix0 + "_coarse.tsv"):
+        pytest.skip("eval driver test did not run")
+    rng = np.random.default_rng(9)
+    nqst, N = len(mini["queries"]), mini["N"]
+    fine0 = [eval(l.rstrip("\n").split("\t")[1]) for l in open(prefix0 + "_fine.tsv")]
+    lists = [[] for _ in range(N)]
+    for qi in range(nqst):          # answers: a doc deep in the fine list for most questions, random docs otherwise
+        if fine0[qi] and qi % 4:
+            lists[fine0[qi][min(len(fine0[qi]) - 1, int(rng.integers(0, 12)))]].append(qi)
+        for dd in rng.choice(N, size=2, replace=False):
+            lists[int(dd)].append(qi)
+    data = tmp_path / "nq"
+    os.makedirs(data)
+    np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int32).tofile(data / "test_inverse_offsets.bin")
+    np.array([q for l in lists for q in sorted(set(l))], dtype=np.int32).tofile(data / "test_inverse_array.bin")
+    lists = [sorted(set(l)) for l in lists]
+    with open(data / "nq-test.qa.csv", "w") as f:
+        for q in mini["queries"]:
+            f.write(f"{q}\t['x']\n")
+    a = Namespace(**vars(a0))
+    a.dataset, a.data_dir, a.save_hard_neg = "nq_dpr", str(data), 50
+    a.custom_save_path, a.metric_path = str(tmp_path / "nqres.tsv"), str(tmp_path / "nq_m.txt")
+    out = EvalRun(a, tokenizer=FakeTokenizer(512), device=cuda).run(load_nq_queries(a.data_dir))
+    prefix = a.custom_save_path[:-4]
+    coarse = [l.rstrip("\n").split("\t") for l in open(prefix + "_coarse.tsv")]
+    fine = [l.rstrip("\n").split("\t") for l in open(prefix + "_fine.tsv")]
+    hn = [l.rstrip("\n").split("\t") for l in open(prefix + "_hn50.tsv")]
+    coarse0 = [l.rstrip("\n").split("\t") for l in open(prefix0 + "_coarse.tsv")]
+    cluster = pickle.load(open(a.pq_cluster_path, "rb"))
+    offsets = np.fromfile(data / "test_inverse_offsets.bin", dtype=np.int32)
+    array = np.fromfile(data / "test_inverse_array.bin", dtype=np.int32)
+    res = []
+    for i, q in enumerate(mini["queries"]):
+        assert len(coarse[i]) == 3 and len(fine[i]) == 2 and len(hn[i]) == 4 and hn[i][1] == ""
+        assert coarse[i][:2] == coarse0[i][:2] and coarse[i][2] == coarse0[i][3]       # text, beams; scores
+        assert eval(fine[i][1]) == fine0[i] and [int(x) for x in hn[i][2].split(",")] == fine0[i][:50]
+        cr = None
+        for j, c in enumerate(eval(coarse[i][1])):           # the reference's coarse loop
+            if any(i in lists[d] for d in cluster.get(tuple(c), [])):
+                cr = j
+                break
+        res.append((q, len(fine0[i]), [cr], [nq_first_hit(i, fine0[i], offsets, array)]))
+    want = summarize(res, a.recall_num, 10)
+    assert out == want and want["hitrate"][100] > 0.3 and want["cluster_hitrate"][10] > 0.3
+
+
 def test_dense_cli_and_ensemble_chain(cuda, mini, tmp_path):
     """faiss_search.py (C1-style plumbing on the GPU) -> evaluate.py -> ensemble_marco.py on the files above."""
     d, a = mini["dir"], mini["args"]

@@ -179,3 +179,31 @@ def test_sharded_dense_exchange_on_gloo_world2():
         assert np.array_equal(ret[r][1], ei) and np.array_equal(ret[r][0], es)
         rounds = ret[r][2]                           # all queries truncated, then the skewed few with full lists
         assert rounds[0] == (9, 270) and len(rounds) == 2 and rounds[1][1] == 300 and 1 <= rounds[1][0] <= 3
+
+
+def test_nq_answer_index_matches_the_reference_hit_test(tmp_path):
+    """NqAnswers (question -> docs, one np.isin per list) against the reference's per-document membership loop
+    (metrics.nq_first_hit = ensemble_nqdpr.py:27-31 / main_models.py:4064-4069), incl. padded -1 ids and no-hit lists."""
+    from mevi_amd.evalrun import NqAnswers, load_nq_queries
+    from mevi_amd.metrics import nq_first_hit
+
+    rng = np.random.default_rng(11)
+    ndocs, nquestions = 500, 40
+    lists = [sorted(rng.choice(nquestions, size=rng.integers(0, 4), replace=False).tolist()) for _ in range(ndocs)]
+    offsets = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int32)
+    array = np.array([q for l in lists for q in l], dtype=np.int32)
+    offsets.tofile(tmp_path / "test_inverse_offsets.bin")
+    array.tofile(tmp_path / "test_inverse_array.bin")
+    with open(tmp_path / "nq-test.qa.csv", "w") as f:
+        for i in range(nquestions):
+            f.write(f"question {i}\t['answer {i}']\n")
+    df = load_nq_queries(str(tmp_path))
+    assert df["oldid"].tolist() == list(range(nquestions)) and df["query"][3] == "question 3"
+    nq = NqAnswers(str(tmp_path))
+    for qind in range(nquestions):
+        assert sorted(nq.docs_answering(qind).tolist()) == [d for d, l in enumerate(lists) if qind in l]
+        for _ in range(5):
+            ranked = rng.choice(ndocs, size=rng.integers(0, 60), replace=False).tolist()
+            if ranked and rng.random() < 0.3:
+                ranked[rng.integers(0, len(ranked))] = -1
+            assert nq.first_hit(qind, ranked) == nq_first_hit(qind, ranked, offsets, array)
