@@ -57,6 +57,9 @@ def parsers_parser(argv=None):
     p.add_argument("--doc_multiclus", type=int, default=1)
     p.add_argument("--eval_all_documents", type=int, default=0)
     p.add_argument("--knn_topk_by_step", type=int, default=0)
+    p.add_argument("--only_gen_rq", type=int, default=0)
+    p.add_argument("--co_doc_length", type=int, default=128)
+    p.add_argument("--seed", type=int, default=42)
     p.add_argument("--timing_infer_step", type=int, default=0)
     args, rest = p.parse_known_args(argv)
     # training / ablation flags of marco_eval_nci_rq.sh: accepted, no effect on eval
@@ -84,8 +87,16 @@ def parsers_parser(argv=None):
 
 
 def check_supported(a):
+    if a.mode == "train" and a.only_gen_rq:   # marco_generate_embedding_n_rq.sh: embeddings + RQ codebook + clusters, then exit
+        if a.document_encoder not in ("ance", "cocondenser", "ar2") or a.pq_type != "rq" or not a.codebook:
+            raise SystemExit("main.py --only_gen_rq 1: needs --codebook 1 --pq_type rq --document_encoder ance|cocondenser|ar2")
+        for k in ("pq_path", "pq_cluster_path", "embedding_path", "document_path", "ckpt_dir"):
+            if getattr(a, k) is None:
+                raise SystemExit(f"main.py --only_gen_rq 1: --{k} is required")
+        return
     if a.mode != "eval":
-        raise SystemExit("mevi_amd builds the inference hot path only: use --mode eval (training is out of scope)")
+        raise SystemExit("mevi_amd builds the inference hot path only: use --mode eval, or --mode train --only_gen_rq 1 "
+                         "for the offline index build (training is out of scope)")
     if a.document_encoder not in ("ance", "cocondenser", "ar2"):
         raise SystemExit(f"main.py --mode eval: --document_encoder {a.document_encoder!r} is not built")
     if a.dataset not in ("marco", "nq_dpr"):
@@ -126,6 +137,13 @@ def partial_inference(rank, args):
     if nrank > 1:
         dist.init_process_group("nccl", rank=rank, world_size=nrank)
         barrier = dist.barrier
+    if args.mode == "train":      # --only_gen_rq 1 (check_supported)
+        from mevi_amd.indexbuild import build_index
+
+        build_index(args, rank=rank, nrank=nrank, barrier=barrier, device=torch.device("cuda", gpu))
+        if nrank > 1:
+            dist.destroy_process_group()
+        return
     if args.time_str is None:
         args.time_str = time.strftime("%Y%m%d%H%M%S")
     args.metric_path = default_metric_path(args)

@@ -254,6 +254,54 @@ def test_eval_driver_on_the_nq_dataset_path(cuda, mini, tmp_path):
     assert out == want and want["hitrate"][100] > 0.3 and want["cluster_hitrate"][10] > 0.3
 
 
+def test_offline_index_build(cuda, mini, tmp_path):
+    """`main.py --mode train --only_gen_rq 1` (marco_generate_embedding_n_rq.sh): passage embeddings through per-rank part
+    files, RQ codebook trained when the file is missing, cluster pickles -- then nothing is redone on a second call."""
+    from mevi_amd.evalrun import load_tower_weights
+    from mevi_amd.indexbuild import build_index, doc_rank_range, embed_documents
+    from mevi_amd.t5 import TwinTower
+
+    a0 = mini["args"]
+    rng = np.random.default_rng(21)
+    N, L = 1500, 16
+    tokens = rng.integers(3, 500, size=(N, L)).astype(np.int64)
+    lens = rng.integers(2, L + 1, size=N)
+    masks = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    tokens[masks == 0] = 0
+    tokens.tofile(tmp_path / "all_document_tokens.bin")
+    masks.tofile(tmp_path / "all_document_masks.bin")
+    a = Namespace(document_encoder="ance", dataset="marco", ckpt_dir=a0.ckpt_dir, document_path=str(tmp_path / "all_document"),
+                  co_doc_length=L, embedding_path=str(tmp_path / "docemb.bin"), pq_path=str(tmp_path / "rqcodebook4_5.pt"),
+                  pq_cluster_path=str(tmp_path / "rqclus4_5.pkl"), subvector_num=4, subvector_bits=5, encode_batch_size=64, seed=42)
+    tw, dims = load_tower_weights(os.path.join(a0.ckpt_dir, "t5-ance"))
+    tower = TwinTower(tw, dims=dims, device=cuda)
+    want = tower.encode_passage({"input_ids": torch.from_numpy(tokens), "attention_mask": torch.from_numpy(masks)}).cpu().numpy()
+    # two ranks, run one after the other: rank 1 leaves its part file, rank 0 writes its own and merges
+    assert [doc_rank_range(10, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 10)]
+    two = str(tmp_path / "two.bin")
+    embed_documents(tower, tokens, masks, two, rank=1, nrank=2)
+    embed_documents(tower, tokens, masks, two, rank=0, nrank=2)
+    assert np.array_equal(np.fromfile(two, dtype=np.float32).reshape(N, -1), want)
+    assert not os.path.exists(two[:-4] + "_0.bin") and not os.path.exists(two[:-4] + "_1.bin")
+    n, dim, nclus = build_index(a, device=cuda)
+    emb = np.fromfile(a.embedding_path, dtype=np.float32).reshape(N, dim)
+    assert (n, dim) == (N, 32) and np.array_equal(emb, want)
+    C = torch.load(a.pq_path, map_location="cpu").detach().numpy()
+    assert C.shape == (4, 32, 32) and np.isfinite(C).all()
+    cluster, mapping = orq.cluster_dict(orq.rq_encode(emb, C))           # oracle encode with the trained codebook
+    got_c = pickle.load(open(a.pq_cluster_path, "rb"))
+    got_m = pickle.load(open(a.pq_cluster_path.replace("clus", "mapping"), "rb"))
+    assert nclus == len(got_c) and set(got_m) == set(range(N))
+    differ = [d for d in range(N) if got_m[d] != mapping[d]]              # only f32-rounding near-ties may differ
+    assert len(differ) <= 2 and sum(len(v) for v in got_c.values()) == N
+    # the quantiser is useful: residual error well below the data's variance
+    recon = sum(C[j][[got_m[d][j] for d in range(N)]] for j in range(4))
+    assert ((emb - recon) ** 2).sum() < 0.6 * ((emb - emb.mean(0)) ** 2).sum()
+    stamp = [os.path.getmtime(p) for p in (a.embedding_path, a.pq_path, a.pq_cluster_path)]
+    assert build_index(a, device=cuda) == (n, dim, nclus)
+    assert stamp == [os.path.getmtime(p) for p in (a.embedding_path, a.pq_path, a.pq_cluster_path)]
+
+
 def test_dense_cli_and_ensemble_chain(cuda, mini, tmp_path):
     """faiss_search.py (C1-style plumbing on the GPU) -> evaluate.py -> ensemble_marco.py on the files above."""
     d, a = mini["dir"], mini["args"]

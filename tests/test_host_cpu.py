@@ -34,6 +34,19 @@ def test_main_accepts_every_flag_of_marco_eval_nci_rq_sh():
     assert main.parsers_parser(["--mode", "eval", "--data_dir", "x", "--n_gpu", "[2,5]"]).n_gpu == [2, 5]
     with pytest.raises(SystemExit):
         main.check_supported(main.parsers_parser(["--mode", "train", "--data_dir", "x"]))
+    # marco_generate_embedding_n_rq.sh: the offline index build is the one --mode train configuration that is built
+    gen = """--n_gpu 8 --mode train --query_type gtq --co_neg_from clus --model_info base --id_class bert_k30_c30_1 --dataset marco
+    --encode_batch_size 1024 --recall_level fine --pq_type rq --only_gen_rq 1 --codebook 1 --subvector_num 4 --subvector_bits 5
+    --document_encoder_from_pretrained 0 --not_load_document_encoder 0 --no_nci_loss 1 --query_encoder twin
+    --num_return_sequences 10 --document_encoder ance --pq_path D/ance/rqcodebook4_5.pt --pq_cluster_path D/ance/rqclus4_5.pkl
+    --data_dir D/origin --ckpt_dir D/ckpts --newid_dir D/ance --document_path D/ance/all_document
+    --embedding_path D/ance/docemb.bin""".split()
+    g = main.parsers_parser(gen)
+    main.check_supported(g)
+    assert g.only_gen_rq == 1 and g.co_doc_length == 128 and g.seed == 42
+    with pytest.raises(SystemExit):
+        i = gen.index("--only_gen_rq")
+        main.check_supported(main.parsers_parser(gen[:i] + gen[i + 2:]))        # plain training is not built
     main.check_supported(main.parsers_parser(EVAL_ARGV + ["--document_encoder", "ar2"]))   # BERT-family towers are built
     with pytest.raises(SystemExit):
         main.check_supported(main.parsers_parser(EVAL_ARGV + ["--document_encoder", "dpr"]))
