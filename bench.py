@@ -102,6 +102,31 @@ def cpu_baseline(n_docs, nq_full, target_s=60.0):
     }
 
 
+def tower_leg(device, nq, search_ms):
+    """Untimed extra (N = 1): the other half of the dense arm, `generate.py --gen_query` -- the T5-ANCE query tower
+    (t5-base shapes, 12 + 12 layers, synthetic weights and MS MARCO-like query lengths, tools/synth.py) over the same
+    number of queries, so that the line also carries tower + search queries/s.  `value` stays the search (SURVEY 8(d)
+    C2: query embeddings are the input of faiss_search.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    from mevi_amd import t5
+
+    tower = synth.build_tower(device)
+    ids, mask = synth.query_ids(nq, device, np.random.default_rng(0))
+    tower.encode_query({"input_ids": ids, "attention_mask": mask})
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        tower.encode_query({"input_ids": ids, "attention_mask": mask})
+    torch.cuda.synchronize()
+    tower_ms = (time.perf_counter() - t) / reps * 1e3
+    return {"tower_ms": tower_ms, "tower_queries_per_s": nq / tower_ms * 1e3, "search_ms": search_ms,
+            "queries_per_s": nq / (tower_ms + search_ms) * 1e3, "pass_tokens": t5.DEVICE_PASS_TOKENS,
+            "note": "generate.py --gen_query (T5-ANCE tower, t5-base shapes, f32, synthetic weights) + faiss_search.py; "
+                    "measured after the timed region, not part of `value`"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +135,7 @@ def main():
     ap.add_argument("--docs", type=int, default=N_DOCS, help="corpus rows (default: MSMARCO 8,841,823)")
     ap.add_argument("--queries", type=int, default=N_QUERIES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tower-leg", action="store_true")
     ap.add_argument("--exact-f32-path", action="store_true",
                     help="search with the f32-MFMA kernel only (no f16 pre-filter); same results")
     args = ap.parse_args()
@@ -235,6 +261,10 @@ def main():
                 "other_kernels_ms_per_step": {"compact_kernel": comp_ms / args.steps},
             },
         }
+        if not args.no_tower_leg and world == 1:
+            del index, docs
+            torch.cuda.empty_cache()
+            out["dense_arm_with_tower"] = tower_leg(device, nq, ms_per_step)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n_docs, nq)
         print(json.dumps(out), flush=True)

@@ -8,32 +8,36 @@ from mevi_amd import nci, t5
 d = 768
 
 
+def _t5_weights(W, nl, ndl, rn, dev, prefix_dec="decoder"):
+    for st, n, dec in (("encoder", nl, False), (prefix_dec, ndl, True)):
+        for l in range(n):
+            p = f"{st}.block.{l}.layer"
+            W[f"{p}.0.SelfAttention.q.weight"] = rn(d, d, s=(d * 64) ** -0.5)
+            for nme in "kvo":
+                W[f"{p}.0.SelfAttention.{nme}.weight"] = rn(d, d, s=d ** -0.5)
+            W[f"{p}.0.layer_norm.weight"] = torch.ones(d, device=dev)
+            ff = 1
+            if dec:
+                W[f"{p}.1.EncDecAttention.q.weight"] = rn(d, d, s=(d * 64) ** -0.5)
+                for nme in "kvo":
+                    W[f"{p}.1.EncDecAttention.{nme}.weight"] = rn(d, d, s=d ** -0.5)
+                W[f"{p}.1.layer_norm.weight"] = torch.ones(d, device=dev)
+                ff = 2
+            W[f"{p}.{ff}.DenseReluDense.wi.weight"] = rn(3072, d, s=d ** -0.5)
+            W[f"{p}.{ff}.DenseReluDense.wo.weight"] = rn(d, 3072, s=3072 ** -0.5)
+            W[f"{p}.{ff}.layer_norm.weight"] = torch.ones(d, device=dev)
+        W[f"{st}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] = rn(32, 12, s=0.5)
+        W[f"{st}.final_layer_norm.weight"] = torch.ones(d, device=dev)
+
+
 def build(dev, M, K, batch, seed=0):
     g = torch.Generator(device=dev).manual_seed(seed)
 
     def rn(*shape, s=1.0):
         return torch.randn(shape, device=dev, generator=g) * s
 
-    def t5_weights(W, nl, ndl, prefix_dec="decoder"):
-        for st, n, dec in (("encoder", nl, False), (prefix_dec, ndl, True)):
-            for l in range(n):
-                p = f"{st}.block.{l}.layer"
-                W[f"{p}.0.SelfAttention.q.weight"] = rn(d, d, s=(d * 64) ** -0.5)
-                for nme in "kvo":
-                    W[f"{p}.0.SelfAttention.{nme}.weight"] = rn(d, d, s=d ** -0.5)
-                W[f"{p}.0.layer_norm.weight"] = torch.ones(d, device=dev)
-                ff = 1
-                if dec:
-                    W[f"{p}.1.EncDecAttention.q.weight"] = rn(d, d, s=(d * 64) ** -0.5)
-                    for nme in "kvo":
-                        W[f"{p}.1.EncDecAttention.{nme}.weight"] = rn(d, d, s=d ** -0.5)
-                    W[f"{p}.1.layer_norm.weight"] = torch.ones(d, device=dev)
-                    ff = 2
-                W[f"{p}.{ff}.DenseReluDense.wi.weight"] = rn(3072, d, s=d ** -0.5)
-                W[f"{p}.{ff}.DenseReluDense.wo.weight"] = rn(d, 3072, s=3072 ** -0.5)
-                W[f"{p}.{ff}.layer_norm.weight"] = torch.ones(d, device=dev)
-            W[f"{st}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] = rn(32, 12, s=0.5)
-            W[f"{st}.final_layer_norm.weight"] = torch.ones(d, device=dev)
+    def t5_weights(W, nl, ndl):
+        _t5_weights(W, nl, ndl, rn, dev)
 
     V = K * (M + 2) + 2
     W = {"shared.weight": rn(32128, d), "decode_embeddings.weight": rn(V, d), "adaptor_embeddings": torch.rand((1, 1, d), device=dev, generator=g),
@@ -54,6 +58,18 @@ def build(dev, M, K, batch, seed=0):
     t5_weights(TW, 12, 12)
     tower = t5.TwinTower(TW, device=dev, num_layers=12, num_decoder_layers=12, batch_size=batch)
     return model, tower, g, rn
+
+
+def build_tower(dev, seed=0):
+    """The T5-ANCE-shaped tower alone (12 + 12 layers), same initialiser scales as build()."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+
+    def rn(*shape, s=1.0):
+        return torch.randn(shape, device=dev, generator=g) * s
+
+    TW = {"shared.weight": rn(32128, d)}
+    _t5_weights(TW, 12, 12, rn, dev)
+    return t5.TwinTower(TW, device=dev, num_layers=12, num_decoder_layers=12)
 
 
 def query_ids(nq, dev, rng):
