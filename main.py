@@ -55,6 +55,7 @@ def parsers_parser(argv=None):
     p.add_argument("--n_test", type=int, default=-1)
     p.add_argument("--test_set", type=str, default="dev")
     p.add_argument("--doc_multiclus", type=int, default=1)
+    p.add_argument("--multiclus_score_aggr", type=str, default="add", choices=["add", "max"])
     p.add_argument("--eval_all_documents", type=int, default=0)
     p.add_argument("--knn_topk_by_step", type=int, default=0)
     p.add_argument("--only_gen_rq", type=int, default=0)
@@ -101,7 +102,9 @@ def check_supported(a):
         raise SystemExit(f"main.py --mode eval: --document_encoder {a.document_encoder!r} is not built")
     if a.dataset not in ("marco", "nq_dpr"):
         raise SystemExit(f"main.py --mode eval: --dataset {a.dataset!r} is not built (marco, nq_dpr)")
-    need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both", doc_multiclus=1)
+    need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both")
+    if a.doc_multiclus < 1 or (a.doc_multiclus > 1 and (a.eval_all_documents or a.knn_topk_by_step)):
+        raise SystemExit("main.py --mode eval: --doc_multiclus C > 1 is built for the cluster re-ranking path only")
     if a.eval_all_documents:   # the brute-force ablation; same preconditions as the reference (MEVI/main.py:657-658)
         need.update(recall_level="fine", knn_topk_by_step=1)
     for k, v in need.items():

@@ -219,6 +219,25 @@ class EvalRun:
                     pickle.dump(self.mapping, f)
             self.barrier()
         print("Number of all pq document clusters:", len(self.index.keys))
+        # --doc_multiclus C > 1 (gen_pq_doc_topk, main_models.py:3222-3262): every document also belongs to the clusters of
+        # its top-C code paths; rqtopk<C>*.pt holds the paths, rqmulticlus<C>*.pkl the code -> documents dict
+        self.C = int(getattr(a, "doc_multiclus", 1) or 1)
+        self.aggregate = None
+        if self.C > 1:
+            self.aggregate = getattr(a, "multiclus_score_aggr", "add")
+            topk_path = a.pq_cluster_path.replace("clus", f"topk{self.C}").replace(".pkl", ".pt")
+            multi_path = topk_path.replace("topk", "multiclus").replace(".pt", ".pkl")
+            if not os.path.exists(topk_path):
+                labels = self.pq.get_topk_document_mapping(self.emb, 0, 1, self.C)
+                if rank == 0:
+                    torch.save(labels, topk_path)
+                self.barrier()
+            self.doc_topk = torch.load(topk_path, map_location="cpu").numpy()
+            self.index = ClusterIndex.from_topk_labels(self.doc_topk, self.K)
+            if rank == 0 and not os.path.exists(multi_path):
+                with open(multi_path, "wb") as f:
+                    pickle.dump(self.index.to_dicts()[0], f)
+            self.barrier()
         self.fine = mfine.FineStage(self.emb, self.index)
         self._dense_index = None
         # --dataset nq_dpr: samples carry their question index instead of gt doc ids; hits are answer-based
@@ -294,7 +313,7 @@ class EvalRun:
         codes = decode_token(decoded, self.K).view(B, R, self.M).cpu().numpy()
         scores = np.array(scores).reshape(B, R)
         qemb = self.query_embedding(texts, ids, mask)
-        ranked, ndoc = self.fine.rerank(qemb, codes)
+        ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate)
         nq = self.nq
         gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None and nq is None else None
         results = []
@@ -302,9 +321,13 @@ class EvalRun:
             d = codes[i].tolist()
             docs, sc = ranked[i]
             if nq is None:
-                gt_codes = [list(self.mapping[g]) for g in doc_ids[i]]
+                if self.C > 1:   # use_pq_topk_label (main_models.py:3761-3771): best rank over a gt doc's C paths
+                    gt_codes = [self.doc_topk[g].tolist() for g in doc_ids[i]]
+                    cr = tuple(min((d.index(g) for g in paths if g in d), default=None) for paths in gt_codes)
+                else:
+                    gt_codes = [list(self.mapping[g]) for g in doc_ids[i]]
+                    cr = tuple(d.index(g) if g in d else None for g in gt_codes)
                 self.coarse_log.add((text, d, gt_codes, scores[i].tolist()))
-                cr = tuple(d.index(g) if g in d else None for g in gt_codes)
                 self.fine_log.add((text, docs.tolist(), doc_ids[i]))
                 fr = mfine.fine_ranks(docs, doc_ids[i])
             else:      # main_models.py:3738-3757, 4060-4077: first beam cluster / first ranked doc answering the question

@@ -86,21 +86,41 @@ class FineStage:
         seg = np.concatenate([[0], np.cumsum(ndoc)]).astype(np.int64)
         return cand, cand_q, seg, ndoc
 
-    def rerank(self, query_emb, beam_codes):
+    def rerank(self, query_emb, beam_codes, aggregate=None):
         """query_emb f32[B, dim] (CUDA).  Returns per query: (doc ids i64 ndarray, scores f32 ndarray) -- views of
-        one host copy of the sorted batch --, and ndoc."""
+        one host copy of the sorted batch --, and ndoc (candidates incl. repeats).
+
+        aggregate 'add' | 'max' (--doc_multiclus > 1, main_models.py:3997-4011): a document reached through several
+        beam clusters is listed once, with the sum (sequential f32 adds, as the reference accumulates) or the maximum
+        of its per-cluster scores -- which are all the same q.d."""
         cand_t, cand_q, seg, ndoc = self.candidates_device(beam_codes)
         B = len(ndoc)
         if cand_t.numel() == 0:
             return [(np.zeros(0, np.int64), np.zeros(0, np.float32)) for _ in range(B)], ndoc
         sc = ops.pair_dot(query_emb, cand_q, self.emb, cand_t)
-        longest = int(ndoc.max())
+        seg_len = ndoc
+        if aggregate is not None:
+            n = self.emb.shape[0]
+            key, inverse, count = torch.unique(cand_q * n + cand_t, sorted=True, return_inverse=True, return_counts=True)
+            one = torch.empty(key.shape, dtype=torch.float32, device=self.dev)
+            one[inverse] = sc                                    # duplicates carry the same bits
+            if aggregate == "add":
+                acc = one.clone()
+                for t in range(1, int(count.max().item())):
+                    acc = torch.where(count > t, acc + one, acc)
+                one = acc
+            elif aggregate != "max":
+                raise ValueError(aggregate)
+            sc, cand_t = one, key % n
+            seg_len = torch.bincount(key // n, minlength=B).cpu().numpy()
+            seg = np.concatenate([[0], np.cumsum(seg_len)]).astype(np.int64)
+        longest = int(seg_len.max())
         if longest <= MAX_SEGMENT:
             s_sorted, i_sorted = ops.segment_sort_desc(sc, cand_t, torch.from_numpy(seg), longest)
         else:
             # a beam cluster list above the LDS sort capacity: order the flat list by
             # (segment, -score, id) with one device sort (rare: > 16384 candidates for one query)
-            segid = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int64), ndoc)).to(self.dev)
+            segid = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int64), seg_len)).to(self.dev)
             o = torch.argsort(cand_t, stable=True)
             o = o[torch.argsort(-sc[o], stable=True)]
             o = o[torch.argsort(segid[o], stable=True)]

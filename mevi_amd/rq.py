@@ -171,6 +171,16 @@ class ClusterIndex:
         return cls(codes.shape[1], K, keys, offsets, (order + start).astype(np.int64), codes.astype(np.int32))
 
     @classmethod
+    def from_topk_labels(cls, labels, K):
+        """labels i32[N, C, M] (every document's top-C code paths, pq.get_topk_document_mapping): the multi-cluster
+        index of gen_pq_doc_topk(return_cluster=True) (MEVI/main_models.py:3246-3256) -- a document is listed in each of
+        its C clusters, lists in (document, path rank) order."""
+        labels = np.asarray(labels)
+        N, C, M = labels.shape
+        idx = cls.from_codes(labels.reshape(N * C, M), K)
+        return cls(M, K, idx.keys, idx.offsets, idx.doc_ids // C, None)
+
+    @classmethod
     def from_dict(cls, cluster, M, K):
         """From the reference's pickled dict (rqclus*.pkl)."""
         items = sorted((int(cls.code_keys(np.array(k), K)), v) for k, v in cluster.items())
@@ -330,6 +340,20 @@ class ProductQuantization:
                 resid = nxt
             scores, nb = sc, nb_new
         return (labels, scores) if return_proba else labels
+
+    def get_topk_document_mapping(self, doc_embeddings, rank, nrank, num_return_sequences, batch_size=1 << 16):
+        """Top-R code paths of this rank's contiguous slice of the corpus (pq.py:715-741: rows // nrank each, the last
+        rank takes the rest): i32 [rows, R, M] on the CPU."""
+        n = doc_embeddings.shape[0]
+        per = n // nrank
+        start, end = per * rank, n if rank + 1 == nrank else per * (rank + 1)
+        out = torch.empty((end - start, num_return_sequences, self.subvector_num), dtype=torch.int32)
+        for s in range(start, end, batch_size):
+            e = min(s + batch_size, end)
+            x = doc_embeddings[s:e]
+            x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+            out[s - start:e - start] = self.beam_search(x, num_return_sequences).cpu()
+        return out
 
     def get_reconstruct_vector(self, index, codebook=None):
         cb = self.codebook if codebook is None else codebook

@@ -302,6 +302,64 @@ def test_offline_index_build(cuda, mini, tmp_path):
     assert stamp == [os.path.getmtime(p) for p in (a.embedding_path, a.pq_path, a.pq_cluster_path)]
 
 
+@pytest.mark.parametrize("aggr", ["add", "max"])
+def test_eval_driver_with_multi_cluster_documents(cuda, mini, tmp_path, aggr):
+    """--doc_multiclus 3: documents listed in the clusters of their top-3 code paths (pq.beam_search), gt codes = those
+    paths, a document reached through several beams listed once with its scores summed / maxed
+    (main_models.py:3222-3262,3761-3771,3997-4011), against a CPU restatement from the oracle pieces."""
+    import shutil
+    from collections import defaultdict
+
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    a = Namespace(**vars(mini["args"]))
+    shutil.copy(a.pq_path, tmp_path / "rqcodebook4_5.pt")
+    a.pq_path, a.pq_cluster_path = str(tmp_path / "rqcodebook4_5.pt"), str(tmp_path / "rqclus4_5.pkl")
+    a.custom_save_path, a.metric_path = str(tmp_path / "mc.tsv"), str(tmp_path / "mc_m.txt")
+    a.doc_multiclus, a.multiclus_score_aggr = 3, aggr
+    tok = FakeTokenizer(512)
+    out = EvalRun(a, tokenizer=tok, device=cuda).run(load_queries(a.data_dir))
+    labels, _ = orq.rq_beam_search(mini["emb"], mini["C"], 3)
+    got_labels = torch.load(str(tmp_path / "rqtopk34_5.pt")).numpy()
+    assert got_labels.shape == labels.shape and (got_labels != labels).any(axis=(1, 2)).mean() < 0.01   # near-tie paths only
+    multi = defaultdict(list)
+    for i, paths in enumerate(got_labels.tolist()):
+        for p_ in paths:
+            multi[tuple(p_)].append(i)
+    assert pickle.load(open(tmp_path / "rqmulticlus34_5.pkl", "rb")) == dict(multi)
+    enc = tok.batch_encode_plus(mini["queries"])
+    dec, _, _ = ot5.nci_generate(mini["W"], mini["cfg"], enc["input_ids"], enc["attention_mask"], 10)
+    codes = ot5.decode_token(dec, 32).view(len(mini["queries"]), 10, 4).numpy()
+    qemb = ot5.tower_encode(mini["TW"], mini["tcfg"], enc["input_ids"], enc["attention_mask"]).numpy()
+    prefix = a.custom_save_path[:-4]
+    coarse = [l.rstrip("\n").split("\t") for l in open(prefix + "_coarse.tsv")]
+    hn = [l.rstrip("\n").split("\t") for l in open(f"{prefix}_hn{a.save_hard_neg}.tsv")]
+    nd, repeats = 0, 0
+    for i, q in enumerate(mini["queries"]):
+        d = codes[i].tolist()
+        assert eval(coarse[i][1]) == d
+        gt_paths = [got_labels[g].tolist() for g in mini["gts"][i]]
+        assert eval(coarse[i][2]) == gt_paths
+        docs = [x for c in d for x in multi.get(tuple(c), [])]
+        nd += len(docs)
+        if not docs:
+            continue
+        u, cnt = np.unique(docs, return_counts=True)
+        repeats += int((cnt > 1).sum())
+        base = mini["emb"][u] @ qemb[i]
+        want = base * cnt if aggr == "add" else base
+        got_docs = [int(x) for x in hn[i][2].split(",")]
+        got_s = np.array([float(x) for x in hn[i][3].split(",")])
+        assert sorted(got_docs) == u.tolist()
+        order = np.argsort(-want, kind="stable")
+        assert np.abs(got_s - want[order]).max() <= 5e-4
+        gaps = np.abs(np.diff(want[order]))
+        firm = np.concatenate([[True], gaps > 2e-3]) & np.concatenate([gaps > 2e-3, [True]])
+        assert all(got_docs[j] == int(u[order[j]]) for j in np.nonzero(firm)[0])
+    assert repeats > 5, "fixture should reach some documents through several beams"
+    assert abs(out["ndoc"] - nd / len(mini["queries"])) < 1e-9
+
+
 def test_dense_cli_and_ensemble_chain(cuda, mini, tmp_path):
     """faiss_search.py (C1-style plumbing on the GPU) -> evaluate.py -> ensemble_marco.py on the files above."""
     d, a = mini["dir"], mini["args"]

@@ -54,8 +54,9 @@ def test_main_accepts_every_flag_of_marco_eval_nci_rq_sh():
         main.check_supported(main.parsers_parser(EVAL_ARGV + ["--eval_all_documents", "1"]))
     main.check_supported(main.parsers_parser(EVAL_ARGV + ["--eval_all_documents", "1", "--recall_level", "fine",
                                                           "--knn_topk_by_step", "1"]))
+    main.check_supported(main.parsers_parser(EVAL_ARGV + ["--doc_multiclus", "3", "--multiclus_score_aggr", "max"]))
     with pytest.raises(SystemExit):   # other ablation modes are not built
-        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--doc_multiclus", "3"]))
+        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--pq_type", "opq"]))
 
 
 def test_cli_argument_surfaces_match_reference():
