@@ -102,29 +102,77 @@ def cpu_baseline(n_docs, nq_full, target_s=60.0):
     }
 
 
-def tower_leg(device, nq, search_ms):
-    """Untimed extra (N = 1): the other half of the dense arm, `generate.py --gen_query` -- the T5-ANCE query tower
-    (t5-base shapes, 12 + 12 layers, synthetic weights and MS MARCO-like query lengths, tools/synth.py) over the same
-    number of queries, so that the line also carries tower + search queries/s.  `value` stays the search (SURVEY 8(d)
-    C2: query embeddings are the input of faiss_search.py)."""
+def seq2seq_legs(device, nq, search_ms, with_cpu):
+    """Untimed extras (N = 1), measured after the timed region and not part of `value`: the stages around the dense
+    search at t5-base shapes (synthetic weights, MS MARCO-like query lengths, tools/synth.py) --
+      * `generate.py --gen_query`: the T5-ANCE query tower (12 + 12 layers) over the same number of queries,
+      * `main.py --mode eval`: NCI generate, beams 10, RQ (4,32) (12 + 6 layers, 4 adaptor layers, adaptive head);
+    and, with the CPU baseline on, the oracle's torch-fp32 restatement of both (what §8(c) validated against the
+    reference) on the box's host cores for a small sample of the same queries, with the agreement of the two paths on
+    that sample."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import synth
-    from mevi_amd import t5
+    from mevi_amd import nci, t5
 
-    tower = synth.build_tower(device)
+    M, K, R, gen_batch = 4, 32, 10, 2048
+    W, TW, _, _ = synth.weights(device, M, K)
+    cpu_w = ({k: v.cpu() for k, v in W.items()}, {k: v.cpu() for k, v in TW.items()}) if with_cpu else None
+    model = nci.NCIModel(W, device=device, M=M, K=K, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
+    tower = t5.TwinTower(TW, device=device, num_layers=12, num_decoder_layers=12)
+    del W, TW
     ids, mask = synth.query_ids(nq, device, np.random.default_rng(0))
-    tower.encode_query({"input_ids": ids, "attention_mask": mask})
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        tower.encode_query({"input_ids": ids, "attention_mask": mask})
-    torch.cuda.synchronize()
-    tower_ms = (time.perf_counter() - t) / reps * 1e3
-    return {"tower_ms": tower_ms, "tower_queries_per_s": nq / tower_ms * 1e3, "search_ms": search_ms,
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3, out
+
+    def gen_all():
+        return [model.generate(ids[a:a + gen_batch], mask[a:a + gen_batch], num_beams=R) for a in range(0, nq, gen_batch)]
+
+    tower_ms, qemb = timed(lambda: tower.encode_query({"input_ids": ids, "attention_mask": mask}), 3)
+    nci_ms, gen = timed(gen_all, 1)
+    out = {
+        "dense_arm_with_tower": {
+            "tower_ms": tower_ms, "tower_queries_per_s": nq / tower_ms * 1e3, "search_ms": search_ms,
             "queries_per_s": nq / (tower_ms + search_ms) * 1e3, "pass_tokens": t5.DEVICE_PASS_TOKENS,
-            "note": "generate.py --gen_query (T5-ANCE tower, t5-base shapes, f32, synthetic weights) + faiss_search.py; "
-                    "measured after the timed region, not part of `value`"}
+            "note": "generate.py --gen_query (T5-ANCE tower, t5-base shapes, f32, synthetic weights) + faiss_search.py"},
+        "seq2seq_arm": {
+            "nci_generate_ms": nci_ms, "nci_generate_queries_per_s": nq / nci_ms * 1e3, "beams": R, "rq": [M, K],
+            "queries_per_pass": gen_batch,
+            "note": "main.py --mode eval beam search (t5-base NCI model, f32, synthetic weights); the fine stage adds "
+                    "the tower again + a gather-dot (tools/bench_chain.py, profiles/r01_chain_c4.txt)"},
+    }
+    if with_cpu:
+        from oracle import t5 as ot5
+
+        ncfg, tcfg = synth.oracle_cfgs(M, K)
+        n_t, n_g = min(nq, 64), min(nq, 8)
+        ci, cm = ids.cpu(), mask.cpu()
+        with torch.no_grad():
+            t = time.time()
+            ref_e = ot5.tower_encode(cpu_w[1], tcfg, ci[:n_t], cm[:n_t])
+            t_tower = time.time() - t
+            t = time.time()
+            ref_dec, ref_sc, _ = ot5.nci_generate(cpu_w[0], ncfg, ci[:n_g], cm[:n_g], R)
+            t_gen = time.time() - t
+        dec = gen[0][0][:n_g * R].cpu()
+        sc = np.asarray(gen[0][1][:n_g * R])
+        out["seq2seq_cpu_sample"] = {
+            "kind": "port", "threads": torch.get_num_threads(),
+            "tower_queries_per_s": n_t / t_tower, "nci_generate_queries_per_s": n_g / t_gen,
+            "sample": f"oracle.t5 (torch fp32): tower on {n_t} queries in {t_tower:.2f}s, nci_generate on {n_g} queries "
+                      f"(beams {R}, per-query loop like the reference's infer) in {t_gen:.2f}s",
+            "agreement_on_sample": {
+                "tower_max_abs_diff": float((qemb[:n_t].cpu() - ref_e).abs().max()),
+                "beams_identical": bool(torch.equal(dec, ref_dec)),
+                "beam_score_max_abs_diff": float(np.abs(sc - ref_sc.numpy()).max())},
+        }
+    return out
 
 
 def main():
@@ -135,7 +183,7 @@ def main():
     ap.add_argument("--docs", type=int, default=N_DOCS, help="corpus rows (default: MSMARCO 8,841,823)")
     ap.add_argument("--queries", type=int, default=N_QUERIES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-tower-leg", action="store_true")
+    ap.add_argument("--no-seq2seq-legs", action="store_true", help="skip the untimed tower / beam-search extras")
     ap.add_argument("--exact-f32-path", action="store_true",
                     help="search with the f32-MFMA kernel only (no f16 pre-filter); same results")
     args = ap.parse_args()
@@ -261,12 +309,15 @@ def main():
                 "other_kernels_ms_per_step": {"compact_kernel": comp_ms / args.steps},
             },
         }
-        if not args.no_tower_leg and world == 1:
-            del index, docs
-            torch.cuda.empty_cache()
-            out["dense_arm_with_tower"] = tower_leg(device, nq, ms_per_step)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n_docs, nq)
+        if not args.no_seq2seq_legs and world == 1:
+            del index, docs
+            torch.cuda.empty_cache()
+            try:
+                out.update(seq2seq_legs(device, nq, ms_per_step, with_cpu=not args.no_cpu_baseline))
+            except Exception as e:      # the extras must never cost the headline line
+                out["seq2seq_legs_error"] = f"{type(e).__name__}: {e}"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

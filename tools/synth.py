@@ -30,20 +30,20 @@ def _t5_weights(W, nl, ndl, rn, dev, prefix_dec="decoder"):
         W[f"{st}.final_layer_norm.weight"] = torch.ones(d, device=dev)
 
 
-def build(dev, M, K, batch, seed=0):
+def weights(dev, M, K, seed=0):
+    """(NCI state dict, tower state dict, generator, rn) on `dev`: t5-base widths, 12/6 layers + 4 adaptor layers for the
+    NCI model, 12/12 for the tower (which shares the NCI model's token embedding), the reference's initialiser scales."""
     g = torch.Generator(device=dev).manual_seed(seed)
 
     def rn(*shape, s=1.0):
         return torch.randn(shape, device=dev, generator=g) * s
 
-    def t5_weights(W, nl, ndl):
-        _t5_weights(W, nl, ndl, rn, dev)
-
     V = K * (M + 2) + 2
-    W = {"shared.weight": rn(32128, d), "decode_embeddings.weight": rn(V, d), "adaptor_embeddings": torch.rand((1, 1, d), device=dev, generator=g),
+    W = {"shared.weight": rn(32128, d), "decode_embeddings.weight": rn(V, d),
+         "adaptor_embeddings": torch.rand((1, 1, d), device=dev, generator=g),
          "adaptor_linear.weight": rn(d * V, d, s=d ** -0.5 * 0.3)}
     W["lm_head.weight"] = W["decode_embeddings.weight"]
-    t5_weights(W, 12, 6)
+    _t5_weights(W, 12, 6, rn, dev)
     for l in range(4):
         p = f"adaptor.layers.{l}"
         for a in ("self_attn", "multihead_attn"):
@@ -53,9 +53,21 @@ def build(dev, M, K, batch, seed=0):
         W[f"{p}.linear2.weight"], W[f"{p}.linear2.bias"] = rn(d, 2048, s=2048 ** -0.5), rn(d, s=0.02)
         for n_ in (1, 2, 3):
             W[f"{p}.norm{n_}.weight"], W[f"{p}.norm{n_}.bias"] = torch.ones(d, device=dev), torch.zeros(d, device=dev)
-    model = nci.NCIModel(W, device=dev, M=M, K=K, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
     TW = {"shared.weight": W["shared.weight"]}
-    t5_weights(TW, 12, 12)
+    _t5_weights(TW, 12, 12, rn, dev)
+    return W, TW, g, rn
+
+
+def oracle_cfgs(M, K):
+    """The config dicts oracle/t5.py reads for these shapes (NCI model, tower)."""
+    base = dict(d_model=d, d_ff=3072, num_heads=12, d_kv=64, layer_norm_epsilon=1e-6, relative_attention_num_buckets=32)
+    return (dict(base, M=M, K=K, num_layers=12, num_decoder_layers=6, adaptor_layer_num=4),
+            dict(base, num_layers=12, num_decoder_layers=12))
+
+
+def build(dev, M, K, batch, seed=0):
+    W, TW, g, rn = weights(dev, M, K, seed)
+    model = nci.NCIModel(W, device=dev, M=M, K=K, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
     tower = t5.TwinTower(TW, device=dev, num_layers=12, num_decoder_layers=12, batch_size=batch)
     return model, tower, g, rn
 
