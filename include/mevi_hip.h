@@ -157,6 +157,15 @@ int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, const float *
                        int64_t nb, int64_t tq, int64_t tk, int64_t heads, int64_t dh, int64_t kv_div,
                        const float *bias, int64_t bias_rows, int64_t bias_ld, int64_t q_pos0,
                        const int64_t *key_mask, int causal, float scale, void *stream);
+/* The same attention over PACKED sequences (padding-free encoders): sequence b owns rows seq_off[b] .. seq_off[b+1]-1
+ * (i64 [nseq + 1], device) of q / k / v / out, whose rows are `*_ts` floats apart; every key is real, bias row / column =
+ * position inside the sequence, max_len = longest sequence (<= 256).  Bit-identical to mevi_attention_f32 on the padded
+ * layout with a key mask (masked keys contribute exact zeros there); no reference counterpart -- the reference
+ * attends over the padded [B, S] layout (modeling_t5.py:374-410). */
+int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const float *k, int64_t k_ts, const float *v, int64_t v_ts,
+                              float *out, int64_t o_ts, const int64_t *seq_off, int64_t nseq, int64_t max_len,
+                              int64_t heads, int64_t dh, const float *bias, int64_t bias_rows, int64_t bias_ld,
+                              int causal, float scale, void *stream);
 /* PAWA adaptive head on the valid columns only (modeling_t5.py:1607, 1677-1689):
  * out[row, c] = sum_d s[row, d] * (t[row, c*dim + d] + e[c, d]),  t = adaptor_linear slice, e = lm_head rows */
 int mevi_adaptive_logits_f32(const float *s, int64_t lds, const float *t, int64_t ldt, const float *e,

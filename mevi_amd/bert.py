@@ -6,7 +6,7 @@ attention with the 1/sqrt(d) scale and the key mask)."""
 import torch
 
 from . import ops
-from .t5 import DEVICE_PASS_TOKENS
+from .t5 import DEVICE_PASS_TOKENS, VARLEN_MAX_KEYS, packed_offsets
 
 
 def _dev(w, name, device):
@@ -67,16 +67,22 @@ class BertEncoder:
             tok, pos = input_ids.reshape(-1)[idx], ops.gather_rows(self.pos, idx % S)
         x = ops.gather_rows(self.word, tok)
         x = ops.add_layernorm(x, pos, self.emb_ln[0], self.emb_ln[1], eps=self.eps, cvec=self.type0)
-        qkv = None if idx is None else torch.zeros((B * S, 3 * d), dtype=torch.float32, device=x.device)
+        seq_off, longest = packed_offsets(attention_mask) if idx is not None else (None, 0)
+        varlen = seq_off is not None and longest <= VARLEN_MAX_KEYS     # right-padded, query-length: attend on packed rows
+        qkv = None if idx is None or varlen else torch.zeros((B * S, 3 * d), dtype=torch.float32, device=x.device)
         for L in self.layers:
             if idx is None:
                 q3 = ops.linear(x, L["wqkv"], bias=L["bqkv"]).view(B, S, 3 * d)
+            elif varlen:
+                q2 = ops.linear(x, L["wqkv"], bias=L["bqkv"])
+                ctx = ops.attention_varlen(q2[:, :d], q2[:, d:2 * d], q2[:, 2 * d:], seq_off, longest, self.H, scale=scale)
             else:
                 q3 = ops.scatter_rows(ops.linear(x, L["wqkv"], bias=L["bqkv"]), idx, qkv).view(B, S, 3 * d)
-            ctx = ops.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], self.H, key_mask=attention_mask,
-                                scale=scale).view(B * S, d)
-            if idx is not None:
-                ctx = ops.gather_rows(ctx, idx)
+            if not varlen:
+                ctx = ops.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], self.H, key_mask=attention_mask,
+                                    scale=scale).view(B * S, d)
+                if idx is not None:
+                    ctx = ops.gather_rows(ctx, idx)
             a = ops.linear(ctx, L["wo"], bias=L["bo"])
             x = ops.add_layernorm(a, x, L["ln1"][0], L["ln1"][1], eps=self.eps)
             h = ops.linear(x, L["wi"], bias=L["bi"], gelu=True)

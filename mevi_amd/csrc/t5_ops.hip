@@ -122,6 +122,7 @@ struct AttnArgs {
   const long long *key_mask;  // [nb / kv_div, tk] (1 = attend) or null
   int causal;                 // key j allowed iff j <= q_pos0 + t
   float scale;                // multiplies q before the dot product (1 for T5)
+  const long long *seq_off;   // packed sequences (attention_varlen_kernel): rows seq_off[b] .. seq_off[b+1]-1, else null
 };
 
 constexpr int ATT_KPL = 4;  // keys per lane: key j lives on lane j & 63, slot j >> 6 (tk <= 256)
@@ -256,6 +257,159 @@ __global__ __launch_bounds__(256) void attention_tile_kernel(AttnArgs a) {
     float *o = a.out + (size_t)b * a.o_bs + (size_t)tq * a.o_ts + (size_t)h * dh;
     if (lane < dh) o[lane] = acc0;
     if (lane + 64 < dh) o[lane + 64] = acc1;
+  }
+}
+
+// Self-attention over PACKED sequences (the padding-free encoders): sequence b owns rows seq_off[b] .. seq_off[b+1]-1
+// of q / k / v / out (row strides q_ts ...), every key is real, positions count from 0 inside the sequence.  One wave
+// per (sequence, head) -- queries are ~10 tokens long, a workgroup per pair would idle most of its lanes -- with its own
+// LDS region for Q, K, V.  The arithmetic is attention_tile_kernel's, statement for statement (k-ordered fmaf dots,
+// attn_softmax over lanes = keys, key-ordered fmaf for P.V): on the padded layout the masked keys contribute exact
+// zeros, so both kernels produce the same bits for the real rows.
+__global__ __launch_bounds__(256) void attention_varlen_kernel(AttnArgs a, int max_len, int waves) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= waves) return;
+  const long long pair = (long long)blockIdx.x * waves + wave;
+  if (pair >= (long long)a.nb * a.H) return;
+  const int b = (int)(pair / a.H), h = (int)(pair % a.H);
+  const long long r0 = a.seq_off[b];
+  const int tk = (int)(a.seq_off[b + 1] - r0);
+  const int dh = a.dh, ldk = dh + 1, dh4 = dh >> 2;
+  float *sq = sm + (size_t)wave * max_len * (3 * dh + 1);   // [tk][dh]
+  float *sk = sq + (size_t)max_len * dh;                      // [tk][dh + 1]
+  float *sv = sk + (size_t)max_len * ldk;                     // [tk][dh]
+  const float *qg = a.q + (size_t)r0 * a.q_ts + (size_t)h * dh;
+  const float *kg = a.k + (size_t)r0 * a.k_ts + (size_t)h * dh;
+  const float *vg = a.v + (size_t)r0 * a.v_ts + (size_t)h * dh;
+  for (int i = lane; i < tk * dh4; i += 64) {
+    const int r = i / dh4, d = (i - r * dh4) * 4;
+    const float4 q4 = *reinterpret_cast<const float4 *>(qg + (size_t)r * a.q_ts + d);
+    const float4 k4 = *reinterpret_cast<const float4 *>(kg + (size_t)r * a.k_ts + d);
+    const float4 v4 = *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + d);
+    float *q_ = sq + r * dh + d, *k_ = sk + r * ldk + d, *v_ = sv + r * dh + d;
+    q_[0] = q4.x * a.scale; q_[1] = q4.y * a.scale; q_[2] = q4.z * a.scale; q_[3] = q4.w * a.scale;
+    k_[0] = k4.x; k_[1] = k4.y; k_[2] = k4.z; k_[3] = k4.w;
+    v_[0] = v4.x; v_[1] = v4.y; v_[2] = v4.z; v_[3] = v4.w;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int tq = 0; tq < tk; ++tq) {
+    float s[ATT_KPL];
+    const float *qr = sq + tq * dh;
+#pragma unroll
+    for (int i = 0; i < ATT_KPL; ++i) {
+      const int key = 64 * i + lane;
+      s[i] = -INFINITY;
+      if (key < tk) {
+        float acc = 0.f;
+        const float *kr = sk + key * ldk;
+        for (int d = 0; d < dh; ++d) acc = fmaf(qr[d], kr[d], acc);
+        float add = 0.f;
+        if (a.bias) add = a.bias[((size_t)h * a.bias_rows + tq) * a.bias_ld + key];
+        if (a.causal && key > tq) add += -1e9f;
+        s[i] = acc + add;
+      }
+    }
+    attn_softmax(s, lane, tk);
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < ATT_KPL; ++i) {
+      const int jend = tk - 64 * i < 64 ? tk - 64 * i : 64;
+      for (int j = 0; j < jend; ++j) {
+        const float pj = __shfl(s[i], j);
+        if (lane < dh) acc0 = fmaf(pj, sv[(64 * i + j) * dh + lane], acc0);
+        if (lane + 64 < dh) acc1 = fmaf(pj, sv[(64 * i + j) * dh + lane + 64], acc1);
+      }
+    }
+    float *o = a.out + (size_t)(r0 + tq) * a.o_ts + (size_t)h * dh;
+    if (lane < dh) o[lane] = acc0;
+    if (lane + 64 < dh) o[lane + 64] = acc1;
+  }
+}
+
+// attention_varlen_kernel for sequences of <= 64 tokens and DH-wide heads: lane j keeps key j's row in registers, the
+// query row is read from LDS as broadcast float4s, two query rows advance together (two independent fmaf chains), and
+// the P.V loop takes p_j through v_readlane.  Same operations in the same order per output element as the generic
+// kernel (the k-ordered chain, attn_softmax, the key-ordered chain), so the bits are the same.
+template <int DH>
+__global__ __launch_bounds__(256) void attention_varlen_short_kernel(AttnArgs a, int max_len) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long pair = (long long)blockIdx.x * 4 + wave;
+  if (pair >= (long long)a.nb * a.H) return;
+  const int b = (int)(pair / a.H), h = (int)(pair % a.H);
+  const long long r0 = a.seq_off[b];
+  const int tk = (int)(a.seq_off[b + 1] - r0);
+  constexpr int D4 = DH / 4;
+  float *sq = sm + (size_t)wave * max_len * 2 * DH;   // [tk][DH], pre-scaled
+  float *sv = sq + (size_t)max_len * DH;                // [tk][DH]
+  const float *qg = a.q + (size_t)r0 * a.q_ts + (size_t)h * DH;
+  const float *kg = a.k + (size_t)r0 * a.k_ts + (size_t)h * DH;
+  const float *vg = a.v + (size_t)r0 * a.v_ts + (size_t)h * DH;
+  for (int i = lane; i < tk * D4; i += 64) {
+    const int r = i / D4, d = (i - r * D4) * 4;
+    float4 q4 = *reinterpret_cast<const float4 *>(qg + (size_t)r * a.q_ts + d);
+    q4.x *= a.scale; q4.y *= a.scale; q4.z *= a.scale; q4.w *= a.scale;
+    *reinterpret_cast<float4 *>(sq + r * DH + d) = q4;
+    *reinterpret_cast<float4 *>(sv + r * DH + d) = *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + d);
+  }
+  float kreg[DH];
+  if (lane < tk) {
+#pragma unroll
+    for (int d4 = 0; d4 < D4; ++d4) {
+      const float4 k4 = *reinterpret_cast<const float4 *>(kg + (size_t)lane * a.k_ts + d4 * 4);
+      kreg[4 * d4] = k4.x; kreg[4 * d4 + 1] = k4.y; kreg[4 * d4 + 2] = k4.z; kreg[4 * d4 + 3] = k4.w;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < DH; ++d) kreg[d] = 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int tq = 0; tq < tk; tq += 2) {
+    const int t1 = tq + 1 < tk ? tq + 1 : tq;         // odd length: the last pair repeats a row
+    const float4 *qa = reinterpret_cast<const float4 *>(sq + tq * DH);
+    const float4 *qb = reinterpret_cast<const float4 *>(sq + t1 * DH);
+    float acc_a = 0.f, acc_b = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < D4; ++d4) {
+      const float4 x = qa[d4], y = qb[d4];
+      acc_a = fmaf(x.x, kreg[4 * d4], acc_a);     acc_b = fmaf(y.x, kreg[4 * d4], acc_b);
+      acc_a = fmaf(x.y, kreg[4 * d4 + 1], acc_a); acc_b = fmaf(y.y, kreg[4 * d4 + 1], acc_b);
+      acc_a = fmaf(x.z, kreg[4 * d4 + 2], acc_a); acc_b = fmaf(y.z, kreg[4 * d4 + 2], acc_b);
+      acc_a = fmaf(x.w, kreg[4 * d4 + 3], acc_a); acc_b = fmaf(y.w, kreg[4 * d4 + 3], acc_b);
+    }
+    float sa[ATT_KPL], sb[ATT_KPL];
+#pragma unroll
+    for (int i = 0; i < ATT_KPL; ++i) sa[i] = sb[i] = -INFINITY;
+    if (lane < tk) {
+      float add_a = 0.f, add_b = 0.f;
+      if (a.bias) {
+        add_a = a.bias[((size_t)h * a.bias_rows + tq) * a.bias_ld + lane];
+        add_b = a.bias[((size_t)h * a.bias_rows + t1) * a.bias_ld + lane];
+      }
+      if (a.causal && lane > tq) add_a += -1e9f;
+      if (a.causal && lane > t1) add_b += -1e9f;
+      sa[0] = acc_a + add_a;
+      sb[0] = acc_b + add_b;
+    }
+    attn_softmax(sa, lane, tk);
+    attn_softmax(sb, lane, tk);
+    float oa = 0.f, ob = 0.f;
+    for (int j = 0; j < tk; ++j) {
+      const float pa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sa[0]), j));
+      const float pb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sb[0]), j));
+      const float vj = lane < DH ? sv[j * DH + lane] : 0.f;
+      oa = fmaf(pa, vj, oa);
+      ob = fmaf(pb, vj, ob);
+    }
+    if (lane < DH) {
+      a.out[(size_t)(r0 + tq) * a.o_ts + (size_t)h * DH + lane] = oa;
+      if (t1 != tq) a.out[(size_t)(r0 + t1) * a.o_ts + (size_t)h * DH + lane] = ob;
+    }
   }
 }
 
@@ -627,6 +781,7 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   a.nb = (int)nb; a.tq = (int)tq; a.tk = (int)tk; a.H = (int)heads; a.dh = (int)dh; a.kv_div = (int)kv_div;
   a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = (int)q_pos0;
   a.key_mask = reinterpret_cast<const long long *>(key_mask); a.causal = causal; a.scale = scale;
+  a.seq_off = nullptr;
   const size_t tile_lds = (size_t)tk * (3 * dh + 1) * sizeof(float);
   if (kv_div == 1 && tq == tk && tk > 64 && tk <= AM_S && dh == AM_D) {  // passages: f32 matrix cores
     MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
@@ -647,6 +802,50 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   } else {
     hipLaunchKernelGGL(attention_kernel, dim3(blocks4(nb * heads * tq)), dim3(256), 0, (hipStream_t)stream, a);
   }
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const float *k, int64_t k_ts, const float *v,
+                                         int64_t v_ts, float *out, int64_t o_ts, const int64_t *seq_off, int64_t nseq,
+                                         int64_t max_len, int64_t heads, int64_t dh, const float *bias,
+                                         int64_t bias_rows, int64_t bias_ld, int causal, float scale, void *stream) {
+  MEVI_REQUIRE(nseq >= 0 && max_len > 0 && heads > 0 && dh > 0, MEVI_ERR_INVALID_ARG, "attention_varlen: bad shape");
+  MEVI_REQUIRE(max_len <= 64 * ATT_KPL, MEVI_ERR_UNSUPPORTED, "attention_varlen: %lld > %d keys not supported",
+               (long long)max_len, 64 * ATT_KPL);
+  MEVI_REQUIRE(dh <= 128 && dh % 4 == 0 && q_ts % 4 == 0 && k_ts % 4 == 0 && v_ts % 4 == 0, MEVI_ERR_INVALID_ARG,
+               "attention_varlen: dh (<= 128) and the row strides must be multiples of 4");
+  const size_t per_wave = (size_t)max_len * (3 * dh + 1) * sizeof(float);
+  MEVI_REQUIRE(per_wave <= 160 * 1024, MEVI_ERR_UNSUPPORTED, "attention_varlen: %lld keys x %lld do not fit LDS",
+               (long long)max_len, (long long)dh);
+  if (nseq == 0) return MEVI_OK;
+  MEVI_REQUIRE(q && k && v && out && seq_off, MEVI_ERR_INVALID_ARG, "attention_varlen: null pointer");
+  MEVI_REQUIRE(!bias || (max_len <= bias_rows && max_len <= bias_ld), MEVI_ERR_INVALID_ARG,
+               "attention_varlen: bias table too small");
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out;
+  a.q_bs = a.k_bs = a.v_bs = a.o_bs = 0;
+  a.q_ts = q_ts; a.k_ts = k_ts; a.v_ts = v_ts; a.o_ts = o_ts;
+  a.nb = (int)nseq; a.tq = a.tk = (int)max_len; a.H = (int)heads; a.dh = (int)dh; a.kv_div = 1;
+  a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = 0;
+  a.key_mask = nullptr; a.causal = causal; a.scale = scale;
+  a.seq_off = reinterpret_cast<const long long *>(seq_off);
+  const long long pairs = (long long)nseq * heads;
+  if (max_len <= 64 && dh == 64) {   // t5-base / bert-base heads, query-length sequences
+    hipLaunchKernelGGL(attention_varlen_short_kernel<64>, dim3((unsigned)((pairs + 3) / 4)), dim3(256),
+                       (size_t)4 * max_len * 2 * 64 * sizeof(float), (hipStream_t)stream, a, (int)max_len);
+    MEVI_HIP_CHECK(hipGetLastError());
+    return MEVI_OK;
+  }
+  // as many waves per workgroup as keep two workgroups' LDS regions on a CU (one when the region is large)
+  int waves = (int)(80 * 1024 / per_wave);
+  waves = waves < 1 ? 1 : waves > 4 ? 4 : waves;
+  const size_t lds = per_wave * waves;
+  if (lds > 65536)
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_varlen_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(attention_varlen_kernel, dim3((unsigned)((pairs + waves - 1) / waves)), dim3(256), lds,
+                     (hipStream_t)stream, a, (int)max_len, waves);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

@@ -121,6 +121,27 @@ def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=
     return out
 
 
+def attention_varlen(q, k, v, seq_off, max_len, heads, bias=None, causal=False, scale=1.0, out=None):
+    """Self-attention over packed sequences: q / k / v [T, H*dh] row-strided views, sequence b = rows
+    seq_off[b] .. seq_off[b+1]-1 (i64 [nseq+1] on the device), max_len = longest sequence (<= 256)."""
+    for t in (q, k, v):
+        assert t.dim() == 2 and t.stride(1) == 1 and t.is_cuda and t.dtype == torch.float32
+    T, hd = q.shape
+    assert seq_off.dtype == torch.int64 and seq_off.is_cuda and seq_off.is_contiguous()
+    if out is None:
+        out = torch.empty((T, hd), dtype=torch.float32, device=q.device)
+    brows = bld = 0
+    if bias is not None:
+        assert bias.dim() == 3 and bias.is_contiguous() and bias.shape[0] == heads
+        brows, bld = bias.shape[1], bias.shape[2]
+    st = hip.lib().mevi_attention_varlen_f32(
+        hip.ptr(q), q.stride(0), hip.ptr(k), k.stride(0), hip.ptr(v), v.stride(0), hip.ptr(out), out.stride(0),
+        hip.ptr(seq_off), seq_off.numel() - 1, int(max_len), heads, hd // heads,
+        hip.ptr(bias) if bias is not None else None, brows, bld, 1 if causal else 0, scale, hip.stream_ptr())
+    hip.check(st, "mevi_attention_varlen_f32")
+    return out
+
+
 def adaptive_logits(s, t, e):
     """logits[row, c] = sum_d s[row, d] * (t[row, c*dim + d] + e[c, d])."""
     s, rows, dim, lds = _rows2d(_f32(s))

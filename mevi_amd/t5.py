@@ -115,19 +115,49 @@ class EncoderStack:
                 x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
             return ops.rmsnorm(x, self.final_ln, d.eps).view(B, S, d.d_model)
         x = ops.gather_rows(embeddings, input_ids.reshape(-1)[idx])            # [T, d_model], T real tokens
-        qkv = torch.zeros((B * S, 3 * d.inner), dtype=torch.float32, device=x.device)   # padded rows stay 0 (finite)
-        for L in self.layers:
-            h = ops.rmsnorm(x, L["ln0"], d.eps)
-            ops.scatter_rows(ops.linear(h, L["wqkv"]), idx, qkv)
-            q3 = qkv.view(B, S, 3 * d.inner)
-            ctx = ops.attention(q3[:, :, :d.inner], q3[:, :, d.inner:2 * d.inner], q3[:, :, 2 * d.inner:],
-                                d.num_heads, bias=bias, key_mask=attention_mask)
-            x = ops.linear(ops.gather_rows(ctx.view(B * S, d.inner), idx), L["wo"], residual=x)
-            h = ops.rmsnorm(x, L["ln1"], d.eps)
-            x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
+        seq_off, longest = packed_offsets(attention_mask)
+        if seq_off is not None and longest <= VARLEN_MAX_KEYS:
+            # right-padded sequences (what the tokenizers produce): attention runs on the packed rows too
+            for L in self.layers:
+                h = ops.rmsnorm(x, L["ln0"], d.eps)
+                qkv = ops.linear(h, L["wqkv"])
+                ctx = ops.attention_varlen(qkv[:, :d.inner], qkv[:, d.inner:2 * d.inner], qkv[:, 2 * d.inner:], seq_off,
+                                           longest, d.num_heads, bias=bias)
+                x = ops.linear(ctx, L["wo"], residual=x)
+                h = ops.rmsnorm(x, L["ln1"], d.eps)
+                x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
+        else:
+            qkv = torch.zeros((B * S, 3 * d.inner), dtype=torch.float32, device=x.device)   # padded rows stay 0 (finite)
+            for L in self.layers:
+                h = ops.rmsnorm(x, L["ln0"], d.eps)
+                ops.scatter_rows(ops.linear(h, L["wqkv"]), idx, qkv)
+                q3 = qkv.view(B, S, 3 * d.inner)
+                ctx = ops.attention(q3[:, :, :d.inner], q3[:, :, d.inner:2 * d.inner], q3[:, :, 2 * d.inner:],
+                                    d.num_heads, bias=bias, key_mask=attention_mask)
+                x = ops.linear(ops.gather_rows(ctx.view(B * S, d.inner), idx), L["wo"], residual=x)
+                h = ops.rmsnorm(x, L["ln1"], d.eps)
+                x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
         out = torch.zeros((B * S, d.d_model), dtype=torch.float32, device=x.device)
         ops.scatter_rows(ops.rmsnorm(x, self.final_ln, d.eps), idx, out)
         return out.view(B, S, d.d_model)
+
+
+# sequences up to this many tokens attend on the packed rows (one wave per (sequence, head)); longer ones (passages) keep
+# the padded layout, where the matrix-core attention kernel applies
+VARLEN_MAX_KEYS = 64
+
+
+def packed_offsets(attention_mask):
+    """(seq_off i64[B+1] on the device, longest) when every row of the mask is 1...10...0 (right padding, empty rows
+    allowed), else (None, 0): packed attention numbers positions 0..len-1, which needs the real tokens to lead."""
+    m = attention_mask != 0
+    lens = m.sum(1)
+    S = m.shape[1]
+    prefix = torch.arange(S, device=m.device)[None, :] < lens[:, None]
+    seq_off = torch.zeros(m.shape[0] + 1, dtype=torch.int64, device=m.device)
+    torch.cumsum(lens, 0, out=seq_off[1:])
+    ok, longest = torch.stack([(prefix == m).all().to(torch.int64), lens.max()]).tolist()
+    return (seq_off, int(longest)) if ok else (None, 0)
 
 
 class DecoderStack:

@@ -214,3 +214,36 @@ def test_fine_stage_matches_reference_procedure(cuda):
     assert coarse_ranks(beams[0], [beams[0][2], [K, K, K]]) == (list(map(list, beams[0].tolist())).index(beams[0][2].tolist()), None)
     assert fine_ranks([5, 3, 9, 3], [9, 3, 7]) == (2, 1, None)
     assert f32_repr(np.array([0.1, 100.0], np.float32)) == "0.10000000149011612,100.0"
+
+
+@pytest.mark.parametrize("S,H,dh,causal,scale,with_bias", [(32, 12, 64, False, 1.0, True), (40, 4, 16, False, 0.25, False),
+                                                          (64, 2, 8, True, 1.0, True), (200, 3, 32, False, 1.0, True)])
+def test_packed_attention_equals_padded_attention_bit_for_bit(cuda, S, H, dh, causal, scale, with_bias):
+    """attention_varlen on packed rows (ragged lengths incl. 0, 1 and S) against attention on the zero-padded [B, S]
+    layout with the key mask: identical bits on every real row; and against a torch fp32 softmax (5e-5)."""
+    g = torch.Generator(device=cuda).manual_seed(S)
+    lens = torch.tensor([S, 1, 0, 7, S // 2, 3, S - 1, 11, 0, 2], device=cuda)
+    B, hd = len(lens), H * dh
+    mask = (torch.arange(S, device=cuda)[None, :] < lens[:, None]).to(torch.int64)
+    idx = torch.nonzero(mask.reshape(-1)).view(-1)
+    packed = torch.randn((int(lens.sum()), 3 * hd), device=cuda, generator=g)
+    bias = torch.randn((H, S, S), device=cuda, generator=g) if with_bias else None
+    padded = torch.zeros((B * S, 3 * hd), device=cuda)
+    padded[idx] = packed
+    p3 = padded.view(B, S, 3 * hd)
+    ref = ops.attention(p3[:, :, :hd], p3[:, :, hd:2 * hd], p3[:, :, 2 * hd:], H, bias=bias, key_mask=mask, causal=causal,
+                        scale=scale).view(B * S, hd)[idx]
+    off = torch.zeros(B + 1, dtype=torch.int64, device=cuda)
+    off[1:] = torch.cumsum(lens, 0)
+    got = ops.attention_varlen(packed[:, :hd], packed[:, hd:2 * hd], packed[:, 2 * hd:], off, S, H, bias=bias, causal=causal,
+                               scale=scale)
+    assert torch.equal(got, ref)
+    q, k, v = (p3[:, :, i * hd:(i + 1) * hd].view(B, S, H, dh).transpose(1, 2) for i in range(3))
+    sc = (q * scale) @ k.transpose(-1, -2)
+    if bias is not None:
+        sc = sc + bias[None]
+    sc = sc + (1 - mask[:, None, None, :].float()) * -1e9
+    if causal:
+        sc = sc + torch.triu(torch.full((S, S), -1e9, device=cuda), 1)
+    want = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * S, hd)[idx]
+    assert (got - want).abs().max().item() <= 5e-5
