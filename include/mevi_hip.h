@@ -167,9 +167,11 @@ int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const float *k, int6
                               int64_t heads, int64_t dh, const float *bias, int64_t bias_rows, int64_t bias_ld,
                               int causal, float scale, void *stream);
 /* PAWA adaptive head on the valid columns only (modeling_t5.py:1607, 1677-1689):
- * out[row, c] = sum_d s[row, d] * (t[row, c*dim + d] + e[c, d]),  t = adaptor_linear slice, e = lm_head rows */
-int mevi_adaptive_logits_f32(const float *s, int64_t lds, const float *t, int64_t ldt, const float *e,
-                             int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream);
+ * out[row, c] = sum_d s[row, d] * (t[trow, c*dim + d] + e[c, d]),  t = adaptor_linear slice, e = lm_head rows;
+ * trow = row when t_index is NULL, else t_index[row] (i64, device): the adaptor sees only the code prefix of a beam,
+ * so t can be a table with one row per prefix shared by every beam that carries it (mevi_amd/nci.py PrefixTables). */
+int mevi_adaptive_logits_f32(const float *s, int64_t lds, const float *t, int64_t ldt, const int64_t *t_index,
+                             const float *e, int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream);
 
 /* ------------------------------------------------------------------------
  * Constrained beam step over the shared-layer RQ tree (one decoding step).

@@ -668,9 +668,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     }
 }
 
-// logits[row, c] = sum_d s[row, d] * (T[row, c*dim + d] + E[c, d]); one wave per (row, c)
+// logits[row, c] = sum_d s[row, d] * (T[trow, c*dim + d] + E[c, d]); one wave per (row, c); trow = row, or
+// t_index[row] when the head matrices are looked up in a per-prefix table
 __global__ __launch_bounds__(256) void adaptive_logits_kernel(const float *__restrict__ s, long long lds_,
                                                              const float *__restrict__ T, long long ldt,
+                                                             const long long *__restrict__ t_index,
                                                              const float *__restrict__ E, long long rows,
                                                              int ncol, int dim, float *__restrict__ out) {
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -678,8 +680,9 @@ __global__ __launch_bounds__(256) void adaptive_logits_kernel(const float *__res
   const int lane = threadIdx.x & 63;
   const long long r = wid / ncol;
   const int c = (int)(wid - r * ncol);
+  const long long tr = t_index ? t_index[r] : r;
   const float4 *sv = reinterpret_cast<const float4 *>(s + r * lds_);
-  const float4 *tv = reinterpret_cast<const float4 *>(T + r * ldt + (size_t)c * dim);
+  const float4 *tv = reinterpret_cast<const float4 *>(T + tr * ldt + (size_t)c * dim);
   const float4 *ev = reinterpret_cast<const float4 *>(E + (size_t)c * dim);
   float acc = 0.f;
   for (int i = lane; i < dim / 4; i += 64) {
@@ -850,14 +853,16 @@ extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const flo
   return MEVI_OK;
 }
 
-extern "C" int mevi_adaptive_logits_f32(const float *s, int64_t lds_, const float *t, int64_t ldt, const float *e,
-                                        int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream) {
+extern "C" int mevi_adaptive_logits_f32(const float *s, int64_t lds_, const float *t, int64_t ldt,
+                                        const int64_t *t_index, const float *e, int64_t rows, int64_t ncol,
+                                        int64_t dim, float *out, void *stream) {
   MEVI_REQUIRE(rows >= 0 && ncol > 0 && dim > 0 && dim % 4 == 0 && lds_ % 4 == 0 && ldt % 4 == 0,
                MEVI_ERR_INVALID_ARG, "adaptive_logits: bad shape");
   if (rows == 0) return MEVI_OK;
   MEVI_REQUIRE(s && t && e && out, MEVI_ERR_INVALID_ARG, "adaptive_logits: null pointer");
   hipLaunchKernelGGL(adaptive_logits_kernel, dim3(blocks4(rows * ncol)), dim3(256), 0, (hipStream_t)stream, s,
-                     (long long)lds_, t, (long long)ldt, e, (long long)rows, (int)ncol, (int)dim, out);
+                     (long long)lds_, t, (long long)ldt, reinterpret_cast<const long long *>(t_index), e, (long long)rows,
+                     (int)ncol, (int)dim, out);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

@@ -11,7 +11,9 @@ num_beams = num_return_sequences.  The search is the validated restatement of SU
 
 Differences from the reference that do not change the function computed: KV-cached decoder and
 adaptor (reference: use_cache=False), only the last position and only the K+1 valid columns of the
-adaptive head are evaluated (reference materialises [B*R, t, d, V]), cross K/V once per query.
+adaptive head are evaluated (reference materialises [B*R, t, d, V]), cross K/V once per query, and the
+adaptor side of the head -- which sees nothing but a beam's code prefix -- is evaluated once per PREFIX
+(PrefixTables) instead of once per beam per step.
 """
 import numpy as np
 import torch
@@ -96,13 +98,77 @@ class Adaptor:
         return x
 
 
+class PrefixTables:
+    """The adaptor half of the PAWA head as tables over code prefixes.
+
+    `adaptor(decode_embeddings[prefix])` and the head matrix `adaptor_linear(.)` it yields depend on the decoded prefix
+    (0, c1 .. cp) only -- not on the query (modeling_t5.py:1650-1665: the adaptor's memory is one learned vector).
+    At position p there are K**p prefixes, shared by every beam of every query: 1, 32, 1024, 32768 for the scripts'
+    (M, K) = (4, 32) against 10 beams x thousands of queries per step.  So per level p < `levels`:
+        tmat[p]  f32 [K**p, (K+1)*d]   head matrices  (row = sum_i c_i K**(p-i)), when within the byte budget,
+        avec[p]  f32 [K**p, d]         adaptor outputs otherwise (the head GEMM then runs per beam as before),
+        kv[l][p] f32 [K**p, 2d]        the adaptor layers' self-attention K|V of position p, so that the first position
+                                       beyond the tables continues from a cache assembled by lookup.
+    Every table row is produced by the same Adaptor.step / GEMM a beam would have run (all row-wise operators whose
+    results do not depend on what else is in the batch -- tested), so the beams' logits keep their bits."""
+
+    MAX_PREFIXES = 1 << 17
+
+    def __init__(self, model, table_bytes):
+        c, dev = model.cfg, model.dev
+        d, K = c.d_model, c.K
+        self.levels = 0
+        self.tmat, self.avec, self.kv = [], [], [[] for _ in model.adaptor.layers]
+        cache, spent = None, 0
+        for p in range(c.T):
+            n = K ** p
+            kv_bytes = n * 2 * d * 4 * len(model.adaptor.layers)
+            if n > self.MAX_PREFIXES or spent + kv_bytes + n * d * 4 > table_bytes:
+                break
+            if p == 0:
+                tokens = torch.zeros(1, dtype=torch.int64, device=dev)                    # decoder_start_token_id
+                cache = model.adaptor.new_cache(1)
+            else:
+                rows = torch.arange(n, device=dev)
+                tokens = 2 + (p - 1) * K + rows % K
+                parent = rows // K
+                cache = [ops.gather_rows(k.view(k.shape[0], -1), parent).view(n, c.T, -1) for k in cache]
+            a = model.adaptor.step(ops.gather_rows(model.dec_emb, tokens), p, cache)
+            for l, k in enumerate(cache):
+                self.kv[l].append(k[:, p, :].contiguous())
+            spent += kv_bytes
+            t_bytes = n * (K + 1) * d * 4
+            if spent + t_bytes <= table_bytes:
+                self.tmat.append(ops.linear(a, model.head_w[p]))
+                self.avec.append(None)
+                spent += t_bytes
+            else:
+                self.tmat.append(None)
+                self.avec.append(a)
+                spent += n * d * 4
+            self.levels = p + 1
+        self.bytes = spent
+
+    def cache_rows(self, adaptor, pidx, p):
+        """The adaptor's K|V cache (positions < p filled) of beams whose prefix index at position p is `pidx`."""
+        K = adaptor.cfg.K
+        cache = adaptor.new_cache(pidx.numel())
+        for q in range(p):
+            idx = pidx // (K ** (p - q))
+            for l, k in enumerate(cache):
+                k[:, q, :] = ops.gather_rows(self.kv[l][q], idx)
+        return cache
+
+
 class NCIModel:
     """`generate()` mirrors the reference call; weights use the reference's state_dict names
     (T5ForConditionalGeneration: shared, encoder.*, decoder.*, decode_embeddings, adaptor*, lm_head)."""
 
-    def __init__(self, weights, cfg=None, device=None, **kw):
+    def __init__(self, weights, cfg=None, device=None, prefix_table_bytes=6 << 30, **kw):
         self.dev = torch.device(device if device is not None else "cuda")
         self.cfg = cfg if cfg is not None else NCIConfig(**kw)
+        self.prefix_table_bytes = prefix_table_bytes      # 0: evaluate the adaptor per beam per step
+        self._tables = None
         c = self.cfg
         self.shared = _dev(weights, "shared.weight", self.dev)
         self.dec_emb = _dev(weights, "decode_embeddings.weight", self.dev)
@@ -121,12 +187,24 @@ class NCIModel:
             self.head_e.append(lm[cols].contiguous())
         del aw
 
+    def tables(self):
+        if self._tables is None:
+            self._tables = PrefixTables(self, self.prefix_table_bytes)
+        return self._tables
+
     # -- one decoding position for all live beams -----------------------------------------------
-    def _logits(self, tokens, t, dcache, acache, xkv, mask, kv_div):
+    def _logits(self, tokens, t, dcache, acache, xkv, mask, kv_div, pidx=None):
+        """pidx: the beams' prefix indices at position t when the prefix tables cover it (acache unused then)."""
         c = self.cfg
         tok = ops.gather_rows(self.dec_emb, tokens)
         seq = ops.scale(self.decoder.step(tok, t, dcache, xkv, mask, kv_div), c.d_model ** -0.5)
-        a = self.adaptor.step(tok, t, acache)
+        if pidx is not None:
+            tab = self.tables()
+            if tab.tmat[t] is not None:
+                return ops.adaptive_logits(seq, tab.tmat[t], self.head_e[t], t_index=pidx)
+            a = ops.gather_rows(tab.avec[t], pidx)
+        else:
+            a = self.adaptor.step(tok, t, acache)
         tmat = ops.linear(a, self.head_w[t])                       # [n, (K+1)*d]
         return ops.adaptive_logits(seq, tmat, self.head_e[t])      # [n, K+1]
 
@@ -150,20 +228,28 @@ class NCIModel:
         tokens = torch.zeros(B, dtype=torch.int64, device=self.dev)          # decoder_start_token_id = 0
         scores = torch.zeros((B, 1), dtype=torch.float32, device=self.dev)
         codes = torch.zeros((B, 1, 0), dtype=torch.int64, device=self.dev)
-        dcache, acache = self.decoder.new_cache(B), self.adaptor.new_cache(B)
+        levels = self.tables().levels if self.prefix_table_bytes else 0      # positions the prefix tables cover
+        pidx = torch.zeros(B, dtype=torch.int64, device=self.dev)            # prefix index of every live beam
+        dcache = self.decoder.new_cache(B)
+        acache = self.adaptor.new_cache(B) if levels == 0 else None
         base = torch.arange(B, device=self.dev)[:, None]
-        for p in range(c.M):
-            logits = self._logits(tokens, p, dcache, acache, xkv, mask, nb)
+        for p in range(c.M + 1):
+            if p == levels and p > 0:       # first position beyond the tables: its cache comes from them
+                acache = self.tables().cache_rows(self.adaptor, pidx, p)
+            logits = self._logits(tokens, p, dcache, acache, xkv, mask, nb, pidx if p < levels else None)
+            if p == c.M:
+                break
             scores, parent, code = ops.beam_step(logits, scores, c.K, R)
             parent, code = parent.long(), code.long()
             rows = (base * nb + parent).reshape(-1)                           # surviving parents, [B*R]
             dcache = [ops.gather_rows(k.view(k.shape[0], -1), rows).view(B * R, c.T, -1) for k in dcache]
-            acache = [ops.gather_rows(k.view(k.shape[0], -1), rows).view(B * R, c.T, -1) for k in acache]
+            if p >= levels:
+                acache = [ops.gather_rows(k.view(k.shape[0], -1), rows).view(B * R, c.T, -1) for k in acache]
+            pidx = pidx[rows] * c.K + code.reshape(-1)
             codes = torch.cat([torch.gather(codes, 1, parent[:, :, None].expand(-1, -1, codes.shape[2])),
                                code[:, :, None]], dim=2)
             tokens = (2 + p * c.K + code).reshape(-1)
             nb = R
-        logits = self._logits(tokens, c.M, dcache, acache, xkv, mask, nb)
         final = ops.beam_step(logits, scores, c.K, R, final_step=True)        # [B, R]
         hyp = final.double() / (c.M + 1) ** length_penalty                    # BeamHypotheses.add: len = M+1
         order = torch.argsort(hyp, dim=1, descending=True, stable=True)

@@ -142,13 +142,18 @@ def attention_varlen(q, k, v, seq_off, max_len, heads, bias=None, causal=False, 
     return out
 
 
-def adaptive_logits(s, t, e):
-    """logits[row, c] = sum_d s[row, d] * (t[row, c*dim + d] + e[c, d])."""
+def adaptive_logits(s, t, e, t_index=None):
+    """logits[row, c] = sum_d s[row, d] * (t[trow, c*dim + d] + e[c, d]), trow = row or t_index[row]."""
     s, rows, dim, lds = _rows2d(_f32(s))
     ncol = e.shape[0]
-    assert t.shape == (rows, ncol * dim) and t.stride(1) == 1 and e.is_contiguous()
+    assert t.dim() == 2 and t.shape[1] == ncol * dim and t.stride(1) == 1 and e.is_contiguous()
+    if t_index is None:
+        assert t.shape[0] == rows
+    else:
+        assert t_index.dtype == torch.int64 and t_index.is_cuda and t_index.is_contiguous() and t_index.numel() == rows
     out = torch.empty((rows, ncol), dtype=torch.float32, device=s.device)
-    st = hip.lib().mevi_adaptive_logits_f32(hip.ptr(s), lds, hip.ptr(t), t.stride(0), hip.ptr(e), rows, ncol, dim,
+    st = hip.lib().mevi_adaptive_logits_f32(hip.ptr(s), lds, hip.ptr(t), t.stride(0),
+                                            hip.ptr(t_index) if t_index is not None else None, hip.ptr(e), rows, ncol, dim,
                                             hip.ptr(out), hip.stream_ptr())
     hip.check(st, "mevi_adaptive_logits_f32")
     return out

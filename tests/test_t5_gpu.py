@@ -245,3 +245,14 @@ def test_results_do_not_depend_on_batch_grouping_or_stale_memory_at_base_shapes(
     del junk
     d, s = gen(700)
     assert torch.equal(d, d0) and np.array_equal(s, s0) and torch.equal(emb(700), e0)
+    # the per-prefix adaptor tables (PrefixTables) against the adaptor evaluated per beam per step: same bits
+    tab = model.tables()
+    assert tab.levels == 4 and all(t is not None for t in tab.tmat) and tab.tmat[3].shape == (32 ** 3, 33 * 768)
+    model.prefix_table_bytes = 0
+    d, s = gen(700)
+    assert torch.equal(d, d0) and np.array_equal(s, s0)
+    model.prefix_table_bytes, model._tables = 60 << 20, None           # tables for positions 0..2 only, adaptor vectors at 2
+    d, s = gen(nq)
+    tab = model.tables()
+    assert tab.levels == 3 and tab.tmat[1] is not None and tab.tmat[2] is None and tab.avec[2] is not None
+    assert torch.equal(d, d0) and np.array_equal(s, s0)
