@@ -114,7 +114,7 @@ def seq2seq_legs(device, nq, search_ms, with_cpu):
     import synth
     from mevi_amd import nci, t5
 
-    M, K, R, gen_batch = 4, 32, 10, 2048
+    M, K, R, gen_batch = 4, 32, 10, 8192
     W, TW, _, _ = synth.weights(device, M, K)
     cpu_w = ({k: v.cpu() for k, v in W.items()}, {k: v.cpu() for k, v in TW.items()}) if with_cpu else None
     model = nci.NCIModel(W, device=device, M=M, K=K, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)

@@ -62,7 +62,7 @@ def load_document_encoder(model_path, ckpt_path, device):
 
 
 def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path, output_path, batch_size, dim, gpus,
-                        query_length=32, tokenizer=None):
+                        query_length=32, tokenizer=None, encoder=None):
     import torch
     import torch.distributed as dist
 
@@ -71,7 +71,7 @@ def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path,
         dist.init_process_group("nccl", rank=rank, world_size=nrank)
     device = torch.device(f"cuda:{gpus[rank]}")
     torch.cuda.set_device(device)
-    encoder = load_document_encoder(model_path, ckpt_path, device)
+    encoder = encoder or load_document_encoder(model_path, ckpt_path, device)
     tokenizer = tokenizer or get_tokenizer(tokenizer_path)
     df = pd.read_csv(query_file, names=["query", "oldid"], encoding="utf-8", header=None, sep="\t")["query"]
     start, end = rank_range(len(df), rank, nrank)

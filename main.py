@@ -24,9 +24,12 @@ def parsers_parser(argv=None):
     p.add_argument("--model_info", type=str, default="base", choices=["small", "large", "base", "3b", "11b"])
     p.add_argument("--dataset", type=str, default="marco")
     p.add_argument("--query_type", type=str, default="gtq")
+    p.add_argument("--query_embedding_path", type=str, default=None,
+                   help="(this build) query_emb.bin written by generate.py --gen_query for the same query file: the fine "
+                        "stage reads it instead of running the query tower a second time (same bits)")
     p.add_argument("--eval_batch_size", type=int, default=2)
     p.add_argument("--encode_batch_size", type=int, default=None)
-    p.add_argument("--device_batch_size", type=int, default=2048,
+    p.add_argument("--device_batch_size", type=int, default=8192,
                    help="(this build) queries per GPU pass; results do not depend on it. --eval_batch_size only raises it")
     p.add_argument("--document_encoder", type=str, default=None)
     p.add_argument("--query_encoder", type=str, default="twin")

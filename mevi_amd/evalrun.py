@@ -240,6 +240,13 @@ class EvalRun:
             self.barrier()
         self.fine = mfine.FineStage(self.emb, self.index)
         self._dense_index = None
+        # --query_embedding_path (this build): the file `generate.py --gen_query` wrote for the same query file.  The
+        # reference encodes every query a second time inside infer() (main_models.py:3797-3812); the embeddings are the
+        # same bits either way (deterministic, grouping-independent kernels), so the fine stage can read them.
+        self.query_table = None
+        qpath = getattr(a, "query_embedding_path", None)
+        if qpath:
+            self.query_table = np.memmap(qpath, dtype=np.float32, mode="r").reshape(-1, d_model)
         # --dataset nq_dpr: samples carry their question index instead of gt doc ids; hits are answer-based
         self.nq = NqAnswers(a.data_dir) if getattr(a, "dataset", "marco") == "nq_dpr" else None
         prefix = a.custom_save_path[:-4]
@@ -255,7 +262,9 @@ class EvalRun:
                                                return_tensors="pt")
         return out["input_ids"], out["attention_mask"]
 
-    def query_embedding(self, texts, ids, mask):
+    def query_embedding(self, texts, ids, mask, rows=None):
+        if self.query_table is not None:     # --query_embedding_path: generate.py already encoded these queries
+            return torch.from_numpy(np.ascontiguousarray(self.query_table[np.asarray(rows)])).to(self.dev)
         if self.tower_tokenizer is None:      # T5-ANCE: the tower reads the NCI input ids (main_models.py:3797-3799)
             return self.tower.encode_query({"input_ids": ids, "attention_mask": mask})
         tok = self.tower_tokenizer.batch_encode_plus(list(texts), max_length=32, truncation=True, padding="max_length",
@@ -263,7 +272,7 @@ class EvalRun:
         return self.tower.encode_query({"input_ids": tok["input_ids"], "attention_mask": tok["attention_mask"]})
 
     @torch.no_grad()
-    def infer_all_documents(self, texts, doc_ids, ids, mask):
+    def infer_all_documents(self, texts, doc_ids, ids, mask, rows=None):
         """--eval_all_documents: [(text, N, fine ranks)].  The reference streams the corpus in --encode_batch_size
         blocks through a running top-pool (main_models.py:3818-3876); the result is the exact top-pool of q.d, which
         is what the dense arm's search returns (ties by ascending id here, unspecified `torch.topk` order there).
@@ -273,7 +282,7 @@ class EvalRun:
         a = self.args
         N = self.emb.shape[0]
         pool = max(a.recall_num)
-        qemb = self.query_embedding(texts, ids, mask)
+        qemb = self.query_embedding(texts, ids, mask, rows)
         if self._dense_index is None:
             self._dense_index = mdense.DenseIndex(self.emb)
         _, top_i = self._dense_index.search(qemb, min(N, pool))
@@ -301,18 +310,19 @@ class EvalRun:
         return results
 
     @torch.no_grad()
-    def infer(self, texts, doc_ids):
-        """One batch: returns [(text, ndoc, coarse ranks, fine ranks)] like infer() with recall_level='both'."""
+    def infer(self, texts, doc_ids, rows=None):
+        """One batch: returns [(text, ndoc, coarse ranks, fine ranks)] like infer() with recall_level='both'.
+        rows: the samples' line numbers in the query file (only read with --query_embedding_path)."""
         a, R = self.args, self.R
         ids, mask = self.tokenize(texts)
         if self.eval_all:
-            return self.infer_all_documents(texts, doc_ids, ids, mask)
+            return self.infer_all_documents(texts, doc_ids, ids, mask, rows)
         decoded, scores, _, _ = self.nci.generate(ids, mask, num_beams=R, num_return_sequences=R,
                                                   length_penalty=a.length_penalty, max_length=self.M + 2)
         B = len(texts)
         codes = decode_token(decoded, self.K).view(B, R, self.M).cpu().numpy()
         scores = np.array(scores).reshape(B, R)
-        qemb = self.query_embedding(texts, ids, mask)
+        qemb = self.query_embedding(texts, ids, mask, rows)
         ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate)
         nq = self.nq
         gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None and nq is None else None
@@ -353,7 +363,7 @@ class EvalRun:
         bs = max(1, a.eval_batch_size, getattr(a, "device_batch_size", None) or 1)
         for s in range(0, len(idx), bs):
             rows = df.iloc[idx[s:s + bs]]
-            cache += self.infer(rows["query"].tolist(), rows["oldid"].tolist())
+            cache += self.infer(rows["query"].tolist(), rows["oldid"].tolist(), idx[s:s + bs])
         return self.finish(cache)
 
     # ---- handle_infer_results / validation_epoch_end ----------------------------------------

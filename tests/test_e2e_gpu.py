@@ -155,6 +155,35 @@ def test_eval_outputs_do_not_depend_on_the_device_batch(cuda, mini, tmp_path):
     assert blobs[0] == blobs[1] == blobs[2] and all(len(b) > 0 for b in blobs[0])
 
 
+def test_query_embeddings_of_generate_py_can_replace_the_second_tower_pass(cuda, mini, tmp_path):
+    """main.py --query_embedding_path: the fine stage reads the file generate.py wrote; every output byte-identical to
+    the run that encodes the queries again (the reference's behaviour)."""
+    import generate
+    from mevi_amd.evalrun import EvalRun, load_queries, load_tower_weights
+    from mevi_amd.t5 import TwinTower
+
+    a0 = mini["args"]
+    tok = FakeTokenizer(512)
+    tw, dims = load_tower_weights(os.path.join(a0.ckpt_dir, "t5-ance"))
+    qpath = str(tmp_path / "query_emb.bin")
+    generate.gen_query_embedding(0, os.path.join(a0.data_dir, "dev_mevi_dedup.tsv"), None, None, None, qpath, 128, 32, [0],
+                                 tokenizer=tok, encoder=TwinTower(tw, dims=dims, device=cuda))
+    blobs = []
+    for j, qp in enumerate([None, qpath]):
+        a = Namespace(**vars(a0))
+        a.query_embedding_path = qp
+        a.custom_save_path, a.metric_path = str(tmp_path / f"r{j}" / "out.tsv"), str(tmp_path / f"r{j}" / "m.txt")
+        os.makedirs(tmp_path / f"r{j}")
+        run = EvalRun(a, tokenizer=tok, device=cuda)
+        if qp:
+            run.tower = None                      # must not be needed
+        run.run(load_queries(a.data_dir))
+        prefix = a.custom_save_path[:-4]
+        blobs.append([open(p, "rb").read() for p in (prefix + "_coarse.tsv", prefix + "_fine.tsv",
+                                                     f"{prefix}_hn{a.save_hard_neg}.tsv", a.metric_path)])
+    assert blobs[0] == blobs[1] and all(len(b) > 0 for b in blobs[0])
+
+
 def test_eval_all_documents_mode(cuda, mini, tmp_path):
     """--eval_all_documents 1 (recall_level fine): no beam search, fine list = running top-pool over the corpus streamed
     in --encode_batch_size blocks (main_models.py:3818-3876), restated on the CPU with the oracle tower; the

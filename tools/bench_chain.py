@@ -24,7 +24,7 @@ from mevi_amd import dense, fine, metrics, nci, rq  # noqa: E402
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else bench.N_QUERIES
 N = int(sys.argv[2]) if len(sys.argv) > 2 else bench.N_DOCS
-batch = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 M, K, R, k, d = 4, 32, 10, bench.TOPK, 768
 dev = torch.device("cuda:0")
 model, tower, g, rn = synth.build(dev, M, K, batch)
@@ -93,6 +93,8 @@ total = sum(stages.values())
 for n_, t in stages.items():
     print(f"{n_:36s} {t*1e3:8.1f} ms   {nq/t:9.0f} q/s", flush=True)
 print(f"{'chain':36s} {total*1e3:8.1f} ms   {nq/total:9.0f} q/s   ({ndoc.mean():.1f} fine candidates/query, max {ndoc.max()})", flush=True)
+reuse = total - stages["tower again (main.py fine stage)"]
+print(f"{'chain, main.py --query_embedding_path':36s} {reuse*1e3:7.1f} ms   {nq/reuse:9.0f} q/s   (fine stage reads generate.py's query_emb.bin)", flush=True)
 
 # ---- metrics as marco_ensemble.sh computes them (host side, untimed) -------------------------------------------------
 di_h, ds_h = di.cpu().numpy(), ds.cpu().numpy()
@@ -125,6 +127,7 @@ print("checksums:", {n_: zlib.crc32(np.ascontiguousarray(a_).tobytes()) for n_, 
                      (("qemb", qemb.cpu().numpy()), ("codebook", codebook.cpu().numpy()), ("doc_codes", codes_h),
                       ("beam_codes", bcodes), ("dense_ids", di_h), ("ndoc", ndoc))})
 line = {"workload": f"C4: {nq} queries, corpus {N} x {d}, beams {R}, RQ ({M},{K}), top-{k}",
-        "device_batch": batch, "queries_per_s": round(nq / total, 1), "ms": {n_: round(t * 1e3, 2) for n_, t in stages.items()},
+        "device_batch": batch, "queries_per_s": round(nq / total, 1),
+        "queries_per_s_reusing_query_embeddings": round(nq / reuse, 1), "ms": {n_: round(t * 1e3, 2) for n_, t in stages.items()},
         "fine_candidates_per_query": float(ndoc.mean())}
 print(json.dumps(line))

@@ -13,7 +13,7 @@ if os.environ.get("MEVI_PROBE_LIB"):
     hip.LIB = os.path.abspath(os.environ["MEVI_PROBE_LIB"])
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
-for M in (512, 5120, 16384, 65536):
+for M in [int(x) for x in os.environ.get("GEMM_M", "512,5120,16384,65536").split(",")]:
     for K, N in ((768, 768), (768, 2304), (768, 3072), (3072, 768), (768, 1536)):
         a = torch.randn((M, K), device=dev, generator=g)
         w = torch.randn((N, K), device=dev, generator=g) * K ** -0.5
