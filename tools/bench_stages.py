@@ -67,7 +67,7 @@ def gen_all():
 
 dt, dec = timed(gen_all, reps=1)
 flop = (5.44e9 + 50 * 9.91e7 + 4.53e8 + 50 * 4.40e7 + 50 * 3.89e7) * nq
-print(f"nci gen: {nq} queries (batch {batch}, M={M}, K={K}) in {dt*1e3:.1f} ms -> {nq/dt:.0f} q/s   ({flop/dt/1e12:.1f} TFLOP/s algorithmic)", flush=True)
+print(f"nci gen: {nq} queries (batch {batch}, M={M}, K={K}) in {dt*1e3:.1f} ms -> {nq/dt:.0f} q/s   ({flop/dt/1e12:.1f} TFLOP/s by the per-beam flop count of SURVEY 8(d); the prefix tables execute less)", flush=True)
 
 # RQ encode + fine stage on a synthetic corpus
 N = 1_000_000
