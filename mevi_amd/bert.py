@@ -6,7 +6,7 @@ attention with the 1/sqrt(d) scale and the key mask)."""
 import torch
 
 from . import ops
-from .t5 import DEVICE_PASS_TOKENS, VARLEN_MAX_KEYS, packed_offsets
+from .t5 import DEVICE_PASS_TOKENS, packed_offsets, varlen_ok
 
 
 def _dev(w, name, device):
@@ -68,7 +68,7 @@ class BertEncoder:
         x = ops.gather_rows(self.word, tok)
         x = ops.add_layernorm(x, pos, self.emb_ln[0], self.emb_ln[1], eps=self.eps, cvec=self.type0)
         seq_off, longest = packed_offsets(attention_mask) if idx is not None else (None, 0)
-        varlen = seq_off is not None and longest <= VARLEN_MAX_KEYS     # right-padded, query-length: attend on packed rows
+        varlen = seq_off is not None and varlen_ok(longest, self.dh)    # right-padded: attend on the packed rows
         qkv = None if idx is None or varlen else torch.zeros((B * S, 3 * d), dtype=torch.float32, device=x.device)
         for L in self.layers:
             if idx is None:

@@ -572,10 +572,17 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int lrow = lane & 31, half = lane >> 5;
-  const int tk = a.tk;  // == tq
-  const float *qg = a.q + (size_t)b * a.q_bs + (size_t)h * AM_D;
-  const float *kg = a.k + (size_t)b * a.k_bs + (size_t)h * AM_D;
-  const float *vg = a.v + (size_t)b * a.v_bs + (size_t)h * AM_D;
+  // padded layout: sequence b = rows [b][0 .. tk) with a key mask; packed layout (seq_off): rows seq_off[b] ..
+  // seq_off[b+1]-1, every key real -- only the blocks that hold real rows / keys are computed then, and since the
+  // masked keys of the padded form contribute exact zeros, both give the same bits
+  const long long r0 = a.seq_off ? a.seq_off[b] : 0;
+  const int tk = a.seq_off ? (int)(a.seq_off[b + 1] - r0) : a.tk;  // == tq
+  const int tq = tk;
+  const long long *key_mask = a.seq_off ? nullptr : a.key_mask;
+  const float *qg = a.q + (a.seq_off ? (size_t)r0 * a.q_ts : (size_t)b * a.q_bs) + (size_t)h * AM_D;
+  const float *kg = a.k + (a.seq_off ? (size_t)r0 * a.k_ts : (size_t)b * a.k_bs) + (size_t)h * AM_D;
+  const float *vg = a.v + (a.seq_off ? (size_t)r0 * a.v_ts : (size_t)b * a.v_bs) + (size_t)h * AM_D;
+  float *og = a.out + (a.seq_off ? (size_t)r0 * a.o_ts : (size_t)b * a.o_bs) + (size_t)h * AM_D;
   for (int i = t; i < AM_S * (AM_D / 4); i += 256) {  // rows past tk are zero
     const int r = i >> 4, c4 = (i & 15) * 4;
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     *reinterpret_cast<float4 *>(sv + r * AM_D + c4) = v4;
   }
   __syncthreads();
-  const bool active = 32 * w < a.tq;  // wave-uniform
+  const bool active = 32 * w < tq;  // wave-uniform
   am_f32x16 sc[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n)
@@ -603,7 +610,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     for (int j = 0; j < AM_D / 2; ++j) {
       const float av = qa[2 * j];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) sc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, kb[32 * n * AM_LQ + 2 * j], sc[n], 0, 0, 0);
+      for (int n = 0; n < 4; ++n)
+        if (32 * n < tk) sc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, kb[32 * n * AM_LQ + 2 * j], sc[n], 0, 0, 0);
     }
   }
   __syncthreads();  // every wave is done with Q and K: P may overwrite them
@@ -613,11 +621,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
   for (int n = 0; n < 4; ++n) {
     const int key = 32 * n + lrow;
     if (key < tk) {
-      const float madd = (a.key_mask && a.key_mask[(size_t)b * tk + key] == 0) ? -1e9f : 0.f;
+      const float madd = (key_mask && key_mask[(size_t)b * tk + key] == 0) ? -1e9f : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (qi < a.tq) {
+        if (qi < tq) {
           const int qpos = a.q_pos0 + qi;
           float add = madd;
           if (a.bias) add += a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + key];
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (qi < a.tq) a.out[(size_t)b * a.o_bs + (size_t)qi * a.o_ts + (size_t)h * AM_D + 32 * n + lrow] = o[n][r];
+      if (qi < tq) og[(size_t)qi * a.o_ts + 32 * n + lrow] = o[n][r];
     }
 }
 
@@ -834,6 +842,14 @@ extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const flo
   a.key_mask = nullptr; a.causal = causal; a.scale = scale;
   a.seq_off = reinterpret_cast<const long long *>(seq_off);
   const long long pairs = (long long)nseq * heads;
+  if (max_len > 64 && max_len <= AM_S && dh == AM_D) {   // passage-length sequences: f32 matrix cores
+    a.q_pos0 = 0;
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)pairs), dim3(256), AM_LDS, (hipStream_t)stream, a);
+    MEVI_HIP_CHECK(hipGetLastError());
+    return MEVI_OK;
+  }
   if (max_len <= 64 && dh == 64) {   // t5-base / bert-base heads, query-length sequences
     hipLaunchKernelGGL(attention_varlen_short_kernel<64>, dim3((unsigned)((pairs + 3) / 4)), dim3(256),
                        (size_t)4 * max_len * 2 * 64 * sizeof(float), (hipStream_t)stream, a, (int)max_len);

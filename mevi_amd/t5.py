@@ -116,7 +116,7 @@ class EncoderStack:
             return ops.rmsnorm(x, self.final_ln, d.eps).view(B, S, d.d_model)
         x = ops.gather_rows(embeddings, input_ids.reshape(-1)[idx])            # [T, d_model], T real tokens
         seq_off, longest = packed_offsets(attention_mask)
-        if seq_off is not None and longest <= VARLEN_MAX_KEYS:
+        if seq_off is not None and varlen_ok(longest, d.d_kv):
             # right-padded sequences (what the tokenizers produce): attention runs on the packed rows too
             for L in self.layers:
                 h = ops.rmsnorm(x, L["ln0"], d.eps)
@@ -142,9 +142,15 @@ class EncoderStack:
         return out.view(B, S, d.d_model)
 
 
-# sequences up to this many tokens attend on the packed rows (one wave per (sequence, head)); longer ones (passages) keep
-# the padded layout, where the matrix-core attention kernel applies
+# packed attention: sequences up to 64 tokens run one wave per (sequence, head); 65..128 tokens with 64-wide heads (the
+# passages of t5-base / bert-base towers) use the matrix-core kernel on the real rows and keys; anything else keeps the
+# padded layout
 VARLEN_MAX_KEYS = 64
+VARLEN_MFMA_KEYS, VARLEN_MFMA_DH = 128, 64
+
+
+def varlen_ok(longest, dh):
+    return longest <= VARLEN_MAX_KEYS or (longest <= VARLEN_MFMA_KEYS and dh == VARLEN_MFMA_DH)
 
 
 def packed_offsets(attention_mask):

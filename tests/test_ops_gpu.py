@@ -217,7 +217,8 @@ def test_fine_stage_matches_reference_procedure(cuda):
 
 
 @pytest.mark.parametrize("S,H,dh,causal,scale,with_bias", [(32, 12, 64, False, 1.0, True), (40, 4, 16, False, 0.25, False),
-                                                          (64, 2, 8, True, 1.0, True), (200, 3, 32, False, 1.0, True)])
+                                                          (64, 2, 8, True, 1.0, True), (200, 3, 32, False, 1.0, True),
+                                                          (128, 12, 64, False, 1.0, True), (100, 2, 64, False, 0.125, False)])
 def test_packed_attention_equals_padded_attention_bit_for_bit(cuda, S, H, dh, causal, scale, with_bias):
     """attention_varlen on packed rows (ragged lengths incl. 0, 1 and S) against attention on the zero-padded [B, S]
     layout with the key mask: identical bits on every real row; and against a torch fp32 softmax (5e-5)."""
