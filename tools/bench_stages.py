@@ -12,7 +12,7 @@ import os as _os
 from mevi_amd import hip as _hip
 if _os.environ.get("MEVI_PROBE_LIB"):  # A/B timing of another build of the library on the same device
     _hip.LIB = _os.path.abspath(_os.environ["MEVI_PROBE_LIB"])
-from mevi_amd import fine, nci, rq, t5  # noqa: E402
+from mevi_amd import fine, rq  # noqa: E402
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 512
