@@ -182,13 +182,31 @@ class ClusterIndex:
 
     @classmethod
     def from_dict(cls, cluster, M, K):
-        """From the reference's pickled dict (rqclus*.pkl)."""
-        items = sorted((int(cls.code_keys(np.array(k), K)), v) for k, v in cluster.items())
-        keys = np.array([k for k, _ in items], dtype=np.int64)
-        sizes = np.array([len(v) for _, v in items], dtype=np.int64)
-        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        doc_ids = np.concatenate([np.asarray(v, dtype=np.int64) for _, v in items]) if items else np.zeros(0, np.int64)
-        return cls(M, K, keys, offsets, doc_ids)
+        """From the reference's pickled dict (rqclus*.pkl): vectorised, the dict has ~1 M keys / 8.8 M ids on MS MARCO."""
+        from itertools import chain
+
+        n = len(cluster)
+        if n == 0:
+            return cls(M, K, np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int64))
+        keys = cls.code_keys(np.array(list(cluster.keys()), dtype=np.int64).reshape(n, M), K)
+        sizes = np.fromiter(map(len, cluster.values()), dtype=np.int64, count=n)
+        docs = np.fromiter(chain.from_iterable(cluster.values()), dtype=np.int64, count=int(sizes.sum()))
+        order = np.argsort(keys, kind="stable")
+        start = np.cumsum(sizes) - sizes                   # segment starts in dict order
+        ssz = sizes[order]
+        offsets = np.concatenate([[0], np.cumsum(ssz)]).astype(np.int64)
+        # gather the segments in key order: element j of sorted segment i comes from start[order[i]] + j
+        src = np.repeat(start[order] - offsets[:-1], ssz) + np.arange(len(docs), dtype=np.int64)
+        return cls(M, K, keys[order], offsets, docs[src])
+
+    def doc_codes(self, n_docs):
+        """i32 [n_docs, M]: the code of every document (the inverse map `rqmapping*.pkl` stores as a dict of tuples);
+        rows of documents that appear in no cluster are -1."""
+        w = self.K ** np.arange(self.M - 1, -1, -1, dtype=np.int64)
+        per_cluster = ((self.keys[:, None] // w[None, :]) % self.K).astype(np.int32)
+        out = np.full((n_docs, self.M), -1, dtype=np.int32)
+        out[self.doc_ids] = np.repeat(per_cluster, np.diff(self.offsets), axis=0)
+        return out
 
     def lookup(self, code):
         """doc ids (ascending) of one cluster, empty array when the cluster owns no document."""

@@ -43,3 +43,18 @@ def test_cluster_index_round_trip():
     assert np.array_equal(idx2.doc_ids, idx.doc_ids)
     missing = next(k for k in ((a, b, c) for a in range(8) for b in range(8) for c in range(8)) if k not in cluster)
     assert idx.lookup(missing).size == 0
+    # a pickled dict arrives in insertion (first-seen) order, not key order; lists keep the reference's append order
+    shuffled = dict(sorted(cluster.items(), key=lambda kv: kv[1][0]))
+    idx3 = ClusterIndex.from_dict(shuffled, 3, 8)
+    assert np.array_equal(idx3.keys, idx.keys) and np.array_equal(idx3.offsets, idx.offsets)
+    assert np.array_equal(idx3.doc_ids, idx.doc_ids)
+    assert ClusterIndex.from_dict({}, 3, 8).lookup((0, 0, 0)).size == 0
+    # the inverse map as an array (what rqmapping*.pkl holds as a dict of tuples)
+    idx0 = ClusterIndex.from_codes(codes, 8)
+    dc = idx0.doc_codes(len(codes) + 2)
+    assert np.array_equal(dc[:len(codes)], codes) and (dc[len(codes):] == -1).all()
+    from mevi_amd.evalrun import CodeMap
+    cm = CodeMap(dc)
+    assert cm[17] == tuple(codes[17].tolist()) and len(cm) == len(codes) + 2
+    with pytest.raises(KeyError):
+        cm[len(codes)]
