@@ -241,6 +241,13 @@ void mevi_ip_topk_set_growth(double growth);
 void mevi_ip_topk_set_profiling(int enable); /* record HIP events around every filter/compact launch */
 void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out);
 
+/* ---- host-side text output (no device work) --------------------------------------------------------------------
+ * The ranked TSVs carry Python `str(int)` / `str(float)` renderings (faiss_search.to_file, MEVI/faiss_search.py:71-77:
+ * `','.join(str(x) for x in row.tolist())`, f32 widened to double) -- 14 M numbers per dense file.  These write the same
+ * bytes: comma-joined values into `out` (cap >= 26 n / 21 n bytes), returning the byte count or a negative status. */
+int64_t mevi_format_f32_list(const float *v, int64_t n, char *out, int64_t cap);
+int64_t mevi_format_i64_list(const int64_t *v, int64_t n, char *out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

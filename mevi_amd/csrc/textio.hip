@@ -1,0 +1,104 @@
+// Host-side text formatting of the ranked TSVs (no device code): the dense result file of faiss_search.to_file
+// (MEVI/faiss_search.py:71-77) holds nq x k ids and nq x k scores written as Python `str(int)` / `str(float)` of
+// the f32 widened to double -- 14 M numbers at MS MARCO size, 5.7 s of Python string work per file against a 0.1 s
+// search.  These two functions produce the same bytes (`repr(float)`: shortest digits that round-trip, fixed notation
+// for 1e-4 <= |x| < 1e16 with at least ".0", else d.ddde+XX with a two-digit exponent; inf / nan / -0.0 as Python).
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "common.h"
+
+namespace {
+
+// one double -> Python repr; returns the end pointer (buffer has >= 32 bytes left)
+char *py_repr(double x, char *p) {
+  if (std::isnan(x)) { std::memcpy(p, "nan", 3); return p + 3; }
+  if (std::isinf(x)) {
+    if (x < 0) *p++ = '-';
+    std::memcpy(p, "inf", 3);
+    return p + 3;
+  }
+  if (std::signbit(x)) { *p++ = '-'; x = -x; }
+  if (x == 0.0) { std::memcpy(p, "0.0", 3); return p + 3; }
+  char sci[40];
+  const auto r = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);  // d[.ddd]e[+-]XX, shortest
+  const char *e = sci;
+  while (*e != 'e') ++e;
+  char digits[24];
+  int nd = 0;
+  for (const char *c = sci; c < e; ++c)
+    if (*c != '.') digits[nd++] = *c;
+  int ex = 0;
+  {
+    const char *c = e + 1;
+    const bool neg = *c == '-';
+    ++c;
+    while (c < r.ptr) ex = ex * 10 + (*c++ - '0');
+    if (neg) ex = -ex;
+  }
+  const int decpt = ex + 1;                 // position of the decimal point relative to the digit string
+  if (decpt > -4 && decpt <= 16) {          // float_repr_style 'r': fixed notation
+    if (decpt <= 0) {
+      *p++ = '0'; *p++ = '.';
+      for (int i = 0; i < -decpt; ++i) *p++ = '0';
+      std::memcpy(p, digits, nd);
+      return p + nd;
+    }
+    if (decpt >= nd) {
+      std::memcpy(p, digits, nd);
+      p += nd;
+      for (int i = nd; i < decpt; ++i) *p++ = '0';
+      *p++ = '.'; *p++ = '0';
+      return p;
+    }
+    std::memcpy(p, digits, decpt);
+    p += decpt;
+    *p++ = '.';
+    std::memcpy(p, digits + decpt, nd - decpt);
+    return p + (nd - decpt);
+  }
+  *p++ = digits[0];
+  if (nd > 1) {
+    *p++ = '.';
+    std::memcpy(p, digits + 1, nd - 1);
+    p += nd - 1;
+  }
+  *p++ = 'e';
+  *p++ = ex < 0 ? '-' : '+';
+  const int ax = ex < 0 ? -ex : ex;
+  if (ax >= 100) *p++ = (char)('0' + ax / 100);
+  *p++ = (char)('0' + (ax / 10) % 10);
+  *p++ = (char)('0' + ax % 10);
+  return p;
+}
+
+}  // namespace
+
+// comma-joined Python reprs of the f32 values widened to double; returns the byte count (cap must be >= 26 n, else
+// MEVI_ERR_INVALID_ARG)
+extern "C" int64_t mevi_format_f32_list(const float *v, int64_t n, char *out, int64_t cap) {
+  if (n <= 0) return 0;
+  if (!v || !out) { mevi::set_error("format_f32_list: null pointer"); return MEVI_ERR_INVALID_ARG; }
+  if (cap < n * 26) { mevi::set_error("format_f32_list: buffer too small"); return MEVI_ERR_INVALID_ARG; }  // sign, 17 digits, point, e+XXX, comma
+  char *p = out;
+  for (int64_t i = 0; i < n; ++i) {
+    if (i) *p++ = ',';
+    p = py_repr((double)v[i], p);
+  }
+  return p - out;
+}
+
+// comma-joined decimal i64
+extern "C" int64_t mevi_format_i64_list(const int64_t *v, int64_t n, char *out, int64_t cap) {
+  if (n <= 0) return 0;
+  if (!v || !out) { mevi::set_error("format_i64_list: null pointer"); return MEVI_ERR_INVALID_ARG; }
+  if (cap < n * 21) { mevi::set_error("format_i64_list: buffer too small"); return MEVI_ERR_INVALID_ARG; }
+  char *p = out;
+  for (int64_t i = 0; i < n; ++i) {
+    if (i) *p++ = ',';
+    p = std::to_chars(p, p + 21, v[i]).ptr;
+  }
+  return p - out;
+}

@@ -18,7 +18,7 @@ import torch
 from . import dense as mdense
 from . import fine as mfine
 from . import hip
-from .io import RankLog
+from .io import RankLog, join_i64
 from .nci import NCIModel, config_from_weights, decode_token
 from .rq import ClusterIndex, ProductQuantization
 from .t5 import T5Dims, TwinTower
@@ -321,7 +321,7 @@ class EvalRun:
             self.fine_log.add((text, docs.tolist(), doc_ids[i]) if self.nq is None else (text, docs.tolist()))
             if self.hn_log is not None:
                 n = a.save_hard_neg
-                self.hn_log.add((text, mfine.f32_repr(gt_s[i]) if self.nq is None else "", ",".join(map(str, docs[:n])),
+                self.hn_log.add((text, mfine.f32_repr(gt_s[i]) if self.nq is None else "", join_i64(docs[:n]),
                                  mfine.f32_repr(quirk[i][:n])))
             ranks = mfine.fine_ranks(docs, doc_ids[i]) if self.nq is None else [self.nq.first_hit(doc_ids[i], docs)]
             results.append((text, N, ranks))
@@ -366,7 +366,7 @@ class EvalRun:
                 fr = [nq.first_hit(doc_ids[i], docs)]
             if self.hn_log is not None:
                 n = a.save_hard_neg
-                self.hn_log.add((text, mfine.f32_repr(gt_s[i]) if nq is None else "", ",".join(map(str, docs[:n])),
+                self.hn_log.add((text, mfine.f32_repr(gt_s[i]) if nq is None else "", join_i64(docs[:n]),
                                  mfine.f32_repr(sc[:n])))
             results.append((text, int(ndoc[i]), cr, fr))
         return results

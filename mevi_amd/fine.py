@@ -22,7 +22,9 @@ MAX_SEGMENT = 16384
 
 def f32_repr(values):
     """','.join(str(x.item()) for x in f32 tensor): the reference's way of printing scores."""
-    return ",".join(map(repr, np.asarray(values, dtype=np.float32).astype(np.float64).tolist()))
+    from .io import join_f32
+
+    return join_f32(values)
 
 
 class FineStage:

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "mevi_cluster_means_workspace_bytes": (ctypes.c_size_t, [c_int64, c_int64, c_int64]),
     "mevi_cluster_means_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    "mevi_format_f32_list": (c_int64, [c_void_p, c_int64, c_void_p, c_int64]),
+    "mevi_format_i64_list": (c_int64, [c_void_p, c_int64, c_void_p, c_int64]),
     "mevi_ip_topk_set_growth": (None, [c_double]),
     "mevi_ip_topk_set_profiling": (None, [c_int]),
     "mevi_ip_topk_get_stats": (None, [ctypes.POINTER(IpTopkStats)]),

@@ -20,20 +20,64 @@ def read(path, dim):
     return np.fromfile(path, dtype=np.float32).reshape(-1, dim)
 
 
-def _fmt_f32(values):
-    # the reference prints str(float(x)) of each f32 widened to double (ndarray.tolist())
-    return ",".join(map(repr, values.astype(np.float64).tolist()))
+class _NativeText:
+    """`','.join(str(x) ...)` of a row through libmevi_hip.so's host-side formatters (textio.hip): the same bytes as
+    Python's, ~15x faster -- the dense TSV of MS MARCO dev is 14 M numbers."""
+
+    def __init__(self, width):
+        import ctypes
+
+        from . import hip
+
+        self.lib = hip.lib()
+        self.cap = 26 * max(width, 1)
+        self.buf = ctypes.create_string_buffer(self.cap)
+        self.ctypes = ctypes
+
+    def f32(self, row):
+        row = np.ascontiguousarray(row, dtype=np.float32)
+        n = self.lib.mevi_format_f32_list(row.ctypes.data, row.size, self.buf, self.cap)
+        if n < 0:
+            raise RuntimeError(self.lib.mevi_last_error().decode())
+        return self.ctypes.string_at(self.buf, n).decode("ascii")
+
+    def i64(self, row):
+        row = np.ascontiguousarray(row, dtype=np.int64)
+        n = self.lib.mevi_format_i64_list(row.ctypes.data, row.size, self.buf, self.cap)
+        if n < 0:
+            raise RuntimeError(self.lib.mevi_last_error().decode())
+        return self.ctypes.string_at(self.buf, n).decode("ascii")
+
+
+_text = None
+
+
+def join_f32(values):
+    """','.join(str(float(x)) for x in values) for f32 values (the reference prints each widened to double)."""
+    global _text
+    values = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+    if _text is None or _text.cap < 26 * values.size:
+        _text = _NativeText(max(values.size, 4096))
+    return _text.f32(values)
+
+
+def join_i64(values):
+    global _text
+    values = np.ascontiguousarray(values, dtype=np.int64).reshape(-1)
+    if _text is None or _text.cap < 26 * values.size:
+        _text = _NativeText(max(values.size, 4096))
+    return _text.i64(values)
 
 
 def to_file(query_path, output_path, dists, indices):
     """Dense ranked TSV, one line per line of `query_path` (query text = field 0)."""
     dists = np.asarray(dists)
     indices = np.asarray(indices)
+    text = _NativeText(dists.shape[1] if dists.ndim == 2 else 1)
     with open(query_path, "r") as fr, open(output_path, "w") as fw:
         for i, line in enumerate(fr):
             query = line.split("\t")[0]
-            preds = ",".join(map(str, indices[i].tolist()))
-            fw.write(f"{query}\t\t{preds}\t{_fmt_f32(dists[i])}\n")
+            fw.write(f"{query}\t\t{text.i64(indices[i])}\t{text.f32(dists[i])}\n")
 
 
 class RankLog:

@@ -221,3 +221,21 @@ def test_nq_answer_index_matches_the_reference_hit_test(tmp_path):
             if ranked and rng.random() < 0.3:
                 ranked[rng.integers(0, len(ranked))] = -1
             assert nq.first_hit(qind, ranked) == nq_first_hit(qind, ranked, offsets, array)
+
+
+def test_native_number_formatting_equals_python_str():
+    """textio.hip (host code of libmevi_hip.so) must write what `str(float(x))` / `str(int)` write: random f32 bit
+    patterns (subnormals, huge, tiny), the notation switch points, specials."""
+    from mevi_amd.io import join_f32, join_i64
+
+    rng = np.random.default_rng(0)
+    with np.errstate(invalid="ignore"):
+        rand = rng.integers(0, 2 ** 32, size=50000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.1, 1e-4, 9.999e-5, 1e-5, 1e16, 9.9999999e15, 1.5e16, 123456.0, 1e22, 3.4e38,
+                        1.4e-45, np.inf, -np.inf, np.nan, 100.0, 612.34564, 0.5, 2.0 ** 24, 2.0 ** 53], dtype=np.float32)
+    for arr in (special, rand):
+        with np.errstate(invalid="ignore"):          # signalling-NaN bit patterns in `rand`
+            want = [repr(x) for x in arr.astype(np.float64).tolist()]
+        assert join_f32(arr).split(",") == want
+    ids = np.array([0, -1, 8841822, 2 ** 40, -2 ** 62, 2 ** 63 - 1], dtype=np.int64)
+    assert join_i64(ids) == ",".join(map(str, ids.tolist())) and join_i64(ids[:0]) == "" and join_f32(special[:0]) == ""
