@@ -247,6 +247,11 @@ void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out);
  * bytes: comma-joined values into `out` (cap >= 26 n / 21 n bytes), returning the byte count or a negative status. */
 int64_t mevi_format_f32_list(const float *v, int64_t n, char *out, int64_t cap);
 int64_t mevi_format_i64_list(const int64_t *v, int64_t n, char *out, int64_t cap);
+/* and back: one comma-separated field of such a file -> numbers (the consumers `eval()` every field,
+ * evaluate.py:91-110, ensemble_marco.py:85-110).  Count, or a negative status when a token is not a plain number of
+ * that kind (the caller falls back to Python's parser) or cap is short. */
+int64_t mevi_parse_i64_list(const char *s, int64_t len, int64_t *out, int64_t cap);
+int64_t mevi_parse_f64_list(const char *s, int64_t len, double *out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -102,3 +102,44 @@ extern "C" int64_t mevi_format_i64_list(const int64_t *v, int64_t n, char *out, 
   }
   return p - out;
 }
+
+// ---- readers: one comma-separated TSV field -> numbers (evaluate.py / ensemble_*.py eval() every field; a dense file is
+// 14 M numbers).  Return the count, or MEVI_ERR_INVALID_ARG when a token is not a plain number of that kind or `cap`
+// is short -- the caller then falls back to Python's own parsing, so odd spellings keep their Python meaning.
+extern "C" int64_t mevi_parse_i64_list(const char *s, int64_t len, int64_t *out, int64_t cap) {
+  if (!s || !out || len <= 0) return MEVI_ERR_INVALID_ARG;
+  const char *p = s, *end = s + len;
+  int64_t n = 0;
+  while (true) {
+    while (p < end && *p == ' ') ++p;
+    if (n >= cap) return MEVI_ERR_INVALID_ARG;
+    const char *q = (p < end && *p == '+') ? p + 1 : p;
+    const auto r = std::from_chars(q, end, out[n]);
+    if (r.ec != std::errc() || r.ptr == q || (q != p && *q == '-')) return MEVI_ERR_INVALID_ARG;
+    ++n;
+    p = r.ptr;
+    while (p < end && *p == ' ') ++p;
+    if (p == end) return n;
+    if (*p != ',') return MEVI_ERR_INVALID_ARG;
+    ++p;
+  }
+}
+
+extern "C" int64_t mevi_parse_f64_list(const char *s, int64_t len, double *out, int64_t cap) {
+  if (!s || !out || len <= 0) return MEVI_ERR_INVALID_ARG;
+  const char *p = s, *end = s + len;
+  int64_t n = 0;
+  while (true) {
+    while (p < end && *p == ' ') ++p;
+    if (n >= cap) return MEVI_ERR_INVALID_ARG;
+    const char *q = (p < end && *p == '+') ? p + 1 : p;
+    const auto r = std::from_chars(q, end, out[n], std::chars_format::general);
+    if (r.ec != std::errc() || r.ptr == q || (q != p && *q == '-')) return MEVI_ERR_INVALID_ARG;
+    ++n;
+    p = r.ptr;
+    while (p < end && *p == ' ') ++p;
+    if (p == end) return n;
+    if (*p != ',') return MEVI_ERR_INVALID_ARG;
+    ++p;
+  }
+}

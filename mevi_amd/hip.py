@@ -67,6 +67,8 @@ _SIGNATURES = {
                                c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "mevi_format_f32_list": (c_int64, [c_void_p, c_int64, c_void_p, c_int64]),
     "mevi_format_i64_list": (c_int64, [c_void_p, c_int64, c_void_p, c_int64]),
+    "mevi_parse_i64_list": (c_int64, [ctypes.c_char_p, c_int64, c_void_p, c_int64]),
+    "mevi_parse_f64_list": (c_int64, [ctypes.c_char_p, c_int64, c_void_p, c_int64]),
     "mevi_ip_topk_set_growth": (None, [c_double]),
     "mevi_ip_topk_set_profiling": (None, [c_int]),
     "mevi_ip_topk_get_stats": (None, [ctypes.POINTER(IpTopkStats)]),

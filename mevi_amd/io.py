@@ -131,10 +131,40 @@ class RankLog:
 
 
 # ---- readers ---------------------------------------------------------------
+_parse_buf = None
+
+
+def _native_numbers(field):
+    """Flat comma list through the library's host-side parsers: list of int, else list of float, else None."""
+    global _parse_buf
+    try:
+        from . import hip
+
+        L = hip.lib()
+    except Exception:          # consumers must keep working where the library is not built
+        return None
+    raw = field.encode("ascii", "ignore") if isinstance(field, str) else field
+    cap = raw.count(b",") + 1
+    if _parse_buf is None or len(_parse_buf[0]) < cap:
+        _parse_buf = (np.empty(max(cap, 4096), np.int64), np.empty(max(cap, 4096), np.float64))
+    ib, fb = _parse_buf
+    n = L.mevi_parse_i64_list(raw, len(raw), ib.ctypes.data, cap)
+    if n >= 0:
+        return ib[:n].tolist()
+    n = L.mevi_parse_f64_list(raw, len(raw), fb.ctypes.data, cap)
+    if n >= 0:
+        return fb[:n].tolist()
+    return None
+
+
 def parse_list(field):
     """One TSV field -> Python list, as the reference's eval_list does (ensemble_marco.py:85-89):
-    a bare comma list gets brackets added.  Flat numeric lists take a fast path."""
+    a bare comma list gets brackets added.  Flat numeric lists take a fast path (native for long ones)."""
     if field[0] != "[":
+        if len(field) > 256:
+            out = _native_numbers(field)
+            if out is not None:
+                return out
         try:
             return [int(x) for x in field.split(",")]
         except ValueError:

@@ -239,3 +239,15 @@ def test_native_number_formatting_equals_python_str():
         assert join_f32(arr).split(",") == want
     ids = np.array([0, -1, 8841822, 2 ** 40, -2 ** 62, 2 ** 63 - 1], dtype=np.int64)
     assert join_i64(ids) == ",".join(map(str, ids.tolist())) and join_i64(ids[:0]) == "" and join_f32(special[:0]) == ""
+    # and back (the consumers' field parser): same lists as int() / float() on every token, None for anything else
+    from mevi_amd.io import _native_numbers, parse_list
+
+    finite = rand[np.isfinite(rand)]
+    text = join_f32(finite)
+    assert _native_numbers(text) == [float(x) for x in text.split(",")] == parse_list(text)
+    many = rng.integers(-5, 8841823, size=5000)
+    assert parse_list(join_i64(many)) == many.tolist() and isinstance(parse_list(join_i64(many))[0], int)
+    for odd in ["1,2,x", "1_000,2", "0x10,2", "1,,2", "1,2,", "--1", ""]:
+        assert _native_numbers(odd) is None if odd else True
+    assert _native_numbers(" 3, 4 ,5") == [3, 4, 5] and _native_numbers("+3,-4") == [3, -4]
+    assert str(_native_numbers("inf,-inf,nan,1e5")) == str([float("inf"), float("-inf"), float("nan"), 1e5])
