@@ -242,9 +242,9 @@ class NCIModel:
             scores, parent, code = ops.beam_step(logits, scores, c.K, R)
             parent, code = parent.long(), code.long()
             rows = (base * nb + parent).reshape(-1)                           # surviving parents, [B*R]
-            dcache = [ops.gather_rows(k.view(k.shape[0], -1), rows).view(B * R, c.T, -1) for k in dcache]
+            dcache = _reorder_cache(dcache, rows, p + 1)
             if p >= levels:
-                acache = [ops.gather_rows(k.view(k.shape[0], -1), rows).view(B * R, c.T, -1) for k in acache]
+                acache = _reorder_cache(acache, rows, p + 1)
             pidx = pidx[rows] * c.K + code.reshape(-1)
             codes = torch.cat([torch.gather(codes, 1, parent[:, :, None].expand(-1, -1, codes.shape[2])),
                                code[:, :, None]], dim=2)
@@ -259,6 +259,18 @@ class NCIModel:
         decoded = torch.cat([torch.zeros((B, R, 1), dtype=torch.int64, device=self.dev), toks,
                              torch.ones((B, R, 1), dtype=torch.int64, device=self.dev)], dim=2).view(B * R, c.M + 2)
         return decoded, hyp.reshape(-1).tolist(), enc, None
+
+
+def _reorder_cache(cache, rows, filled):
+    """Beam re-ordering of the K|V caches [n, T, w] (generation_utils.py:927-934 `_reorder_cache`): row r of the result is
+    row rows[r]; only the `filled` positions written so far are copied."""
+    out = []
+    for k in cache:
+        n, T, w = k.shape
+        new = torch.empty((rows.numel(), T, w), dtype=torch.float32, device=k.device)
+        ops.gather_rows(k.view(n, T * w)[:, :filled * w], rows, out=new.view(-1, T * w)[:, :filled * w])
+        out.append(new)
+    return out
 
 
 def decode_token(decoded, K):
