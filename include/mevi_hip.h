@@ -151,12 +151,15 @@ int mevi_scale_f32(const float *x, float alpha, int64_t n, float *out, void *str
  * (T5Attention.forward, modeling_t5.py:374-410: no 1/sqrt(d) scaling, fp32 softmax; also
  * nn.MultiheadAttention of the adaptor with scale = head_dim^-0.5).
  *   q[b, t, h*dh + d] via (q_bs, q_ts); k/v[b / kv_div, j, h*dh + d]; out like q.
- *   key_mask i64 [nb / kv_div, tk] (1 = attend) or NULL; causal: key j allowed iff j <= q_pos0 + t. */
+ *   key_mask i64 [nb / kv_div, tk] (1 = attend) or NULL; causal: key j allowed iff j <= q_pos0 + t.
+ *   kv_off (i64 [nb / kv_div + 1], device) or NULL: K|V are PACKED -- kv batch c owns rows kv_off[c] .. kv_off[c+1]-1
+ *   (k_ts / v_ts apart; k_bs / v_bs and key_mask unused), all keys real, tk = the longest sequence: the cross-attention
+ *   of the decoders over the real encoder positions only (same bits as the padded, masked form). */
 int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, const float *k, int64_t k_bs, int64_t k_ts,
                        const float *v, int64_t v_bs, int64_t v_ts, float *out, int64_t o_bs, int64_t o_ts,
                        int64_t nb, int64_t tq, int64_t tk, int64_t heads, int64_t dh, int64_t kv_div,
                        const float *bias, int64_t bias_rows, int64_t bias_ld, int64_t q_pos0,
-                       const int64_t *key_mask, int causal, float scale, void *stream);
+                       const int64_t *key_mask, int causal, float scale, const int64_t *kv_off, void *stream);
 /* The same attention over PACKED sequences (padding-free encoders): sequence b owns rows seq_off[b] .. seq_off[b+1]-1
  * (i64 [nseq + 1], device) of q / k / v / out, whose rows are `*_ts` floats apart; every key is real, bias row / column =
  * position inside the sequence, max_len = longest sequence (<= 256).  Bit-identical to mevi_attention_f32 on the padded

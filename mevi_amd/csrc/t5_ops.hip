@@ -123,6 +123,7 @@ struct AttnArgs {
   int causal;                 // key j allowed iff j <= q_pos0 + t
   float scale;                // multiplies q before the dot product (1 for T5)
   const long long *seq_off;   // packed sequences (attention_varlen_kernel): rows seq_off[b] .. seq_off[b+1]-1, else null
+  const long long *kv_off;    // packed K|V only (cross-attention): keys of kv batch bk = rows kv_off[bk] .. kv_off[bk+1]-1
 };
 
 constexpr int ATT_KPL = 4;  // keys per lane: key j lives on lane j & 63, slot j >> 6 (tk <= 256)
@@ -156,6 +157,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   const int h = (int)((wid / a.tq) % a.H);
   const int b = (int)(wid / ((long long)a.tq * a.H));
   const int bk = b / a.kv_div;
+  // packed K|V (kv_off): every key is real and there are only tk = the sequence's length of them; the masked keys of
+  // the padded form contribute exact zeros, so both forms give the same bits
+  const long long kr0 = a.kv_off ? a.kv_off[bk] : 0;
+  const int tk = a.kv_off ? (int)(a.kv_off[bk + 1] - kr0) : a.tk;
+  const float *kbase = a.k + (a.kv_off ? (size_t)kr0 * a.k_ts : (size_t)bk * a.k_bs) + (size_t)h * a.dh;
   const float *q = a.q + (size_t)b * a.q_bs + (size_t)t * a.q_ts + (size_t)h * a.dh;
   const int qpos = a.q_pos0 + t;
 
@@ -164,8 +170,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   for (int i = 0; i < ATT_KPL; ++i) {
     const int key = 64 * i + lane;
     s[i] = -INFINITY;
-    if (key < a.tk) {
-      const float *kr = a.k + (size_t)bk * a.k_bs + (size_t)key * a.k_ts + (size_t)h * a.dh;
+    if (key < tk) {
+      const float *kr = kbase + (size_t)key * a.k_ts;
       float acc = 0.f;
       for (int d = 0; d < a.dh; d += 4) {
         const float4 kv = *reinterpret_cast<const float4 *>(kr + d);
@@ -177,20 +183,20 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       }
       float add = 0.f;
       if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + key];
-      if (a.key_mask && a.key_mask[(size_t)bk * a.tk + key] == 0) add += -1e9f;
+      if (a.key_mask && !a.kv_off && a.key_mask[(size_t)bk * a.tk + key] == 0) add += -1e9f;
       if (a.causal && key > qpos) add += -1e9f;
       s[i] = acc + add;
     }
   }
-  attn_softmax(s, lane, a.tk);
+  attn_softmax(s, lane, tk);
 
   float *o = a.out + (size_t)b * a.o_bs + (size_t)t * a.o_ts + (size_t)h * a.dh;
-  const float *vb = a.v + (size_t)bk * a.v_bs + (size_t)h * a.dh;
+  const float *vb = a.v + (a.kv_off ? (size_t)kr0 * a.v_ts : (size_t)bk * a.v_bs) + (size_t)h * a.dh;
   // every lane takes part in the shuffles (a lane outside dh must still SOURCE p for its key)
   float acc0 = 0.f, acc1 = 0.f;  // output dims lane and lane + 64 (dh <= 128)
 #pragma unroll
   for (int i = 0; i < ATT_KPL; ++i) {
-    const int jend = a.tk - 64 * i < 64 ? a.tk - 64 * i : 64;
+    const int jend = tk - 64 * i < 64 ? tk - 64 * i : 64;
     for (int j = 0; j < jend; ++j) {
       const float pj = __shfl(s[i], j);
       const size_t row = (size_t)(64 * i + j) * a.v_ts;
@@ -486,12 +492,14 @@ __global__ __launch_bounds__(256) void attention_group_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int bk = blockIdx.x / a.H, h = blockIdx.x % a.H;  // query group, head
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int dh = a.dh, tk = a.tk, ldk = dh + 4;  // 16-byte aligned rows; 4r mod 64 banks: float4 reads conflict free
-  float *sk = sm;                      // [tk][dh + 4]
-  float *sv = sk + tk * ldk;           // [tk][dh]
-  float *sq = sv + tk * dh;            // [kv_div][dh], pre-scaled
-  const float *kg = a.k + (size_t)bk * a.k_bs + (size_t)h * dh;
-  const float *vg = a.v + (size_t)bk * a.v_bs + (size_t)h * dh;
+  const int dh = a.dh, ldk = dh + 4;  // 16-byte aligned rows; 4r mod 64 banks: float4 reads conflict free
+  const long long kr0 = a.kv_off ? a.kv_off[bk] : 0;     // packed K|V: only the real keys exist (see attention_kernel)
+  const int tk = a.kv_off ? (int)(a.kv_off[bk + 1] - kr0) : a.tk;
+  float *sk = sm;                      // [tk][dh + 4]   (regions sized for a.tk = the longest sequence)
+  float *sv = sk + a.tk * ldk;         // [tk][dh]
+  float *sq = sv + a.tk * dh;          // [kv_div][dh], pre-scaled
+  const float *kg = a.k + (a.kv_off ? (size_t)kr0 * a.k_ts : (size_t)bk * a.k_bs) + (size_t)h * dh;
+  const float *vg = a.v + (a.kv_off ? (size_t)kr0 * a.v_ts : (size_t)bk * a.v_bs) + (size_t)h * dh;
   const int dq = dh / 4;
   for (int i = t; i < tk * dq; i += 256) {
     const int r = i / dq, c4 = (i - r * dq) * 4;
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(256) void attention_group_kernel(AttnArgs a) {
         }
         float add = 0.f;
         if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + key];
-        if (a.key_mask && a.key_mask[(size_t)bk * tk + key] == 0) add += -1e9f;
+        if (a.key_mask && !a.kv_off && a.key_mask[(size_t)bk * tk + key] == 0) add += -1e9f;
         if (a.causal && key > qpos) add += -1e9f;
         s[i] = acc + add;
       }
@@ -775,7 +783,7 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
                                   int64_t o_bs, int64_t o_ts, int64_t nb, int64_t tq, int64_t tk, int64_t heads,
                                   int64_t dh, int64_t kv_div, const float *bias, int64_t bias_rows,
                                   int64_t bias_ld, int64_t q_pos0, const int64_t *key_mask, int causal,
-                                  float scale, void *stream) {
+                                  float scale, const int64_t *kv_off, void *stream) {
   MEVI_REQUIRE(nb >= 0 && tq > 0 && tk > 0 && heads > 0 && dh > 0 && kv_div > 0, MEVI_ERR_INVALID_ARG,
                "attention: bad shape");
   MEVI_REQUIRE(tk <= 64 * ATT_KPL, MEVI_ERR_UNSUPPORTED, "attention: tk=%lld > %d keys not supported", (long long)tk,
@@ -793,19 +801,20 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = (int)q_pos0;
   a.key_mask = reinterpret_cast<const long long *>(key_mask); a.causal = causal; a.scale = scale;
   a.seq_off = nullptr;
+  a.kv_off = reinterpret_cast<const long long *>(kv_off);
   const size_t tile_lds = (size_t)tk * (3 * dh + 1) * sizeof(float);
-  if (kv_div == 1 && tq == tk && tk > 64 && tk <= AM_S && dh == AM_D) {  // passages: f32 matrix cores
+  if (!kv_off && kv_div == 1 && tq == tk && tk > 64 && tk <= AM_S && dh == AM_D) {  // passages: f32 matrix cores
     MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
     hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(nb * heads)), dim3(256), AM_LDS, (hipStream_t)stream, a);
-  } else if (tq == 1 && tk <= 8) {  // a handful of cached keys: eight (row, head) pairs per wave
+  } else if (!kv_off && tq == 1 && tk <= 8) {  // a handful of cached keys: eight (row, head) pairs per wave
     hipLaunchKernelGGL(attention_few_keys_kernel, dim3(blocks4((nb * heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
   } else if (kv_div > 1 && tq == 1 && nb % kv_div == 0 && v_bs % 4 == 0 && v_ts % 4 == 0 &&
              ((size_t)tk * (2 * dh + 4) + (size_t)kv_div * dh) * sizeof(float) <= 65536) {
     // the beams of a query share K|V: stage them once per (query, head)
     hipLaunchKernelGGL(attention_group_kernel, dim3((unsigned)((nb / kv_div) * heads)), dim3(256),
                        ((size_t)tk * (2 * dh + 4) + (size_t)kv_div * dh) * sizeof(float), (hipStream_t)stream, a);
-  } else if (kv_div == 1 && tq == tk && tq >= 8 && tile_lds <= 160 * 1024) {  // self-attention over a whole sequence
+  } else if (!kv_off && kv_div == 1 && tq == tk && tq >= 8 && tile_lds <= 160 * 1024) {  // self-attention over a whole sequence
     if (tile_lds > 65536)  // dynamic LDS beyond 64 KiB must be opted into (128 passage tokens x 64: 97 KiB)
       MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_tile_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
@@ -841,6 +850,7 @@ extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const flo
   a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = 0;
   a.key_mask = nullptr; a.causal = causal; a.scale = scale;
   a.seq_off = reinterpret_cast<const long long *>(seq_off);
+  a.kv_off = nullptr;
   const long long pairs = (long long)nseq * heads;
   if (max_len > 64 && max_len <= AM_S && dh == AM_D) {   // passage-length sequences: f32 matrix cores
     a.q_pos0 = 0;

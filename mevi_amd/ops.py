@@ -95,14 +95,26 @@ def scale(x, alpha):
     return out
 
 
-def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=None, causal=False, scale=1.0):
-    """q [nb, tq, H*dh], k/v [nb/kv_div, tk, H*dh] (any batch/token strides, last dim contiguous)."""
-    for t in (q, k, v):
-        assert t.dim() == 3 and t.stride(2) == 1 and t.is_cuda and t.dtype == torch.float32
+def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=None, causal=False, scale=1.0,
+              kv_off=None, kv_longest=0):
+    """q [nb, tq, H*dh], k/v [nb/kv_div, tk, H*dh] (any batch/token strides, last dim contiguous) -- or, with
+    kv_off (i64 [nb/kv_div + 1], device), PACKED k/v [rows, H*dh]: kv batch c owns rows kv_off[c] .. kv_off[c+1]-1, all
+    real, kv_longest = the longest of them."""
+    assert q.dim() == 3 and q.stride(2) == 1 and q.is_cuda and q.dtype == torch.float32
     nb, tq, hd = q.shape
-    tk = k.shape[1]
     dh = hd // heads
-    assert k.shape[0] * kv_div == nb and v.shape[:2] == k.shape[:2]
+    if kv_off is None:
+        for t in (k, v):
+            assert t.dim() == 3 and t.stride(2) == 1 and t.is_cuda and t.dtype == torch.float32
+        tk = k.shape[1]
+        assert k.shape[0] * kv_div == nb and v.shape[:2] == k.shape[:2]
+        kst, vst = (k.stride(0), k.stride(1)), (v.stride(0), v.stride(1))
+    else:
+        for t in (k, v):
+            assert t.dim() == 2 and t.stride(1) == 1 and t.is_cuda and t.dtype == torch.float32
+        assert kv_off.dtype == torch.int64 and kv_off.is_cuda and kv_off.numel() * kv_div == nb + kv_div and key_mask is None
+        tk = int(kv_longest)
+        kst, vst = (0, k.stride(0)), (0, v.stride(0))
     if out is None:
         out = torch.empty((nb, tq, hd), dtype=torch.float32, device=q.device)
     brows = bld = 0
@@ -113,10 +125,11 @@ def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=
         key_mask = key_mask.to(device=q.device, dtype=torch.int64).contiguous()
         assert key_mask.shape == (nb // kv_div, tk)
     st = hip.lib().mevi_attention_f32(
-        hip.ptr(q), q.stride(0), q.stride(1), hip.ptr(k), k.stride(0), k.stride(1), hip.ptr(v), v.stride(0),
-        v.stride(1), hip.ptr(out), out.stride(0), out.stride(1), nb, tq, tk, heads, dh, kv_div,
+        hip.ptr(q), q.stride(0), q.stride(1), hip.ptr(k), kst[0], kst[1], hip.ptr(v), vst[0], vst[1],
+        hip.ptr(out), out.stride(0), out.stride(1), nb, tq, tk, heads, dh, kv_div,
         hip.ptr(bias) if bias is not None else None, brows, bld, q_pos0,
-        hip.ptr(key_mask) if key_mask is not None else None, 1 if causal else 0, scale, hip.stream_ptr())
+        hip.ptr(key_mask) if key_mask is not None else None, 1 if causal else 0, scale,
+        hip.ptr(kv_off) if kv_off is not None else None, hip.stream_ptr())
     hip.check(st, "mevi_attention_f32")
     return out
 

@@ -166,6 +166,14 @@ def packed_offsets(attention_mask):
     return (seq_off, int(longest)) if ok else (None, 0)
 
 
+class CrossKV:
+    """Cross-attention K|V of a batch: per layer either padded f32[B, S, 2*inner] + the key mask, or packed
+    f32[T_real, 2*inner] + the sequences' row offsets (i64 [B+1]) and the longest length."""
+
+    def __init__(self, layers, mask, kv_off=None, longest=0):
+        self.layers, self.mask, self.kv_off, self.longest = layers, mask, kv_off, longest
+
+
 class DecoderStack:
     """T5Stack(is_decoder=True) evaluated one position at a time with a KV cache.
 
@@ -198,8 +206,9 @@ class DecoderStack:
         self.max_len = max_len
 
     def cross_kv(self, enc, enc_mask=None):
-        """Per-layer cross-attention K|V of the encoder states: list of f32[B, S, 2*inner].  With `enc_mask` only the
-        real positions are projected (masked keys never contribute; their rows stay 0)."""
+        """Per-layer cross-attention K|V of the encoder states, as a CrossKV.  With `enc_mask` only the real positions
+        are projected; for right-padded masks the K|V rows stay PACKED (the attention kernels read a sequence's real
+        keys through its row offsets), otherwise they are scattered into a zeroed [B, S, 2*inner] buffer."""
         B, S, dm = enc.shape
         flat = enc.reshape(B * S, dm)
         idx = None
@@ -208,13 +217,16 @@ class DecoderStack:
             if idx.numel() == 0 or idx.numel() > 0.9 * B * S:
                 idx = None
         if idx is None:
-            return [ops.linear(flat, L["xkv"]).view(B, S, 2 * self.d.inner) for L in self.layers]
+            return CrossKV([ops.linear(flat, L["xkv"]).view(B, S, 2 * self.d.inner) for L in self.layers], enc_mask)
         real = ops.gather_rows(flat, idx)
+        seq_off, longest = packed_offsets(enc_mask)
+        if seq_off is not None and 0 < longest <= 256:
+            return CrossKV([ops.linear(real, L["xkv"]) for L in self.layers], None, seq_off, longest)
         out = []
         for L in self.layers:
             kv = torch.zeros((B * S, 2 * self.d.inner), dtype=torch.float32, device=enc.device)
             out.append(ops.scatter_rows(ops.linear(real, L["xkv"]), idx, kv).view(B, S, 2 * self.d.inner))
-        return out
+        return CrossKV(out, enc_mask)
 
     def new_cache(self, rows):
         return [torch.empty((rows, self.max_len, 2 * self.d.inner), dtype=torch.float32, device=self.dev)
@@ -223,10 +235,11 @@ class DecoderStack:
     def step(self, x, t, cache, xkv, enc_mask, kv_div):
         """x f32[n, d_model]: embeddings of the token at position t of every row; cache[l] f32[n, T, 2*inner]
         holds self-attention K|V of positions < t (position t is written here); rows r attend to the
-        encoder states of query r // kv_div.  Returns the final-normed hidden state f32[n, d_model]."""
+        encoder states of query r // kv_div (`xkv`: the CrossKV of cross_kv, which carries its own mask / offsets;
+        `enc_mask` is kept for callers of the older signature).  Returns the final-normed hidden state f32[n, d_model]."""
         d = self.d
         n = x.shape[0]
-        for L, kvc, xc in zip(self.layers, cache, xkv):
+        for L, kvc, xc in zip(self.layers, cache, xkv.layers):
             h = ops.rmsnorm(x, L["ln0"], d.eps)
             q = ops.linear(h, L["wq"])
             ops.linear(h, L["wkv"], out=kvc[:, t, :])
@@ -235,8 +248,12 @@ class DecoderStack:
             x = ops.linear(ctx.view(n, d.inner), L["wo"], residual=x)
             h = ops.rmsnorm(x, L["ln1"], d.eps)
             q = ops.linear(h, L["xq"])
-            ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :, :d.inner], xc[:, :, d.inner:], d.num_heads,
-                                kv_div=kv_div, key_mask=enc_mask)
+            if xkv.kv_off is None:
+                ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :, :d.inner], xc[:, :, d.inner:], d.num_heads,
+                                    kv_div=kv_div, key_mask=xkv.mask)
+            else:
+                ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :d.inner], xc[:, d.inner:], d.num_heads, kv_div=kv_div,
+                                    kv_off=xkv.kv_off, kv_longest=xkv.longest)
             x = ops.linear(ctx.view(n, d.inner), L["xo"], residual=x)
             h = ops.rmsnorm(x, L["ln2"], d.eps)
             x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)

@@ -248,3 +248,24 @@ def test_packed_attention_equals_padded_attention_bit_for_bit(cuda, S, H, dh, ca
         sc = sc + torch.triu(torch.full((S, S), -1e9, device=cuda), 1)
     want = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * S, hd)[idx]
     assert (got - want).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("kv_div,H,dh,S", [(1, 12, 64, 32), (10, 12, 64, 32), (4, 4, 16, 40), (1, 2, 8, 200)])
+def test_cross_attention_over_packed_keys_equals_the_padded_masked_form(cuda, kv_div, H, dh, S):
+    """Decoder cross-attention (tq = 1) reading a query's real encoder rows through kv_off against the zero-padded K|V
+    with the key mask: identical bits (group kernel for kv_div > 1, generic kernel otherwise)."""
+    g = torch.Generator(device=cuda).manual_seed(S + kv_div)
+    lens = torch.tensor([S, 1, 7, S // 2, 3, S - 1, 11, 2], device=cuda)
+    B, hd = len(lens), H * dh
+    mask = (torch.arange(S, device=cuda)[None, :] < lens[:, None]).to(torch.int64)
+    idx = torch.nonzero(mask.reshape(-1)).view(-1)
+    packed = torch.randn((int(lens.sum()), 2 * hd), device=cuda, generator=g)
+    padded = torch.zeros((B * S, 2 * hd), device=cuda)
+    padded[idx] = packed
+    p3 = padded.view(B, S, 2 * hd)
+    q = torch.randn((B * kv_div, 1, hd), device=cuda, generator=g)
+    ref = ops.attention(q, p3[:, :, :hd], p3[:, :, hd:], H, kv_div=kv_div, key_mask=mask)
+    off = torch.zeros(B + 1, dtype=torch.int64, device=cuda)
+    off[1:] = torch.cumsum(lens, 0)
+    got = ops.attention(q, packed[:, :hd], packed[:, hd:], H, kv_div=kv_div, kv_off=off, kv_longest=S)
+    assert torch.equal(got, ref)
