@@ -241,11 +241,20 @@ class DecoderStack:
         n = x.shape[0]
         for L, kvc, xc in zip(self.layers, cache, xkv.layers):
             h = ops.rmsnorm(x, L["ln0"], d.eps)
-            q = ops.linear(h, L["wq"])
-            ops.linear(h, L["wkv"], out=kvc[:, t, :])
-            ctx = ops.attention(q.view(n, 1, d.inner), kvc[:, :t + 1, :d.inner], kvc[:, :t + 1, d.inner:],
-                                d.num_heads, bias=self.self_bias, q_pos0=t, causal=True)
-            x = ops.linear(ctx.view(n, d.inner), L["wo"], residual=x)
+            if t == 0:
+                # one key: its softmax weight is exp(0) / exp(0) = 1 exactly, so the attention output IS v -- no query
+                # projection, no attention kernel; a single-position decoder (the towers) never needs k either
+                if self.max_len == 1:
+                    ctx = ops.linear(h, L["wkv"][d.inner:])
+                else:
+                    ops.linear(h, L["wkv"], out=kvc[:, 0, :])
+                    ctx = kvc[:, 0, d.inner:]
+            else:
+                q = ops.linear(h, L["wq"])
+                ops.linear(h, L["wkv"], out=kvc[:, t, :])
+                ctx = ops.attention(q.view(n, 1, d.inner), kvc[:, :t + 1, :d.inner], kvc[:, :t + 1, d.inner:],
+                                    d.num_heads, bias=self.self_bias, q_pos0=t, causal=True).view(n, d.inner)
+            x = ops.linear(ctx, L["wo"], residual=x)
             h = ops.rmsnorm(x, L["ln1"], d.eps)
             q = ops.linear(h, L["xq"])
             if xkv.kv_off is None:
