@@ -1,0 +1,139 @@
+"""MS MARCO-sized rehearsal of the CLI-level flow on one GPU, with synthetic files written to a scratch directory:
+docemb.bin (8,841,823 x 768 f32, 27 GB), an RQ codebook, t5-base-shaped NCI / tower checkpoints, 6980 queries.
+Runs EvalRun (= main.py --mode eval) incl. its start-up (corpus upload, RQ encode of the corpus, cluster pickles), the
+dense search + TSV writer (= faiss_search.py) and the ensemble consumer, and prints wall-clock per phase.
+  python tools/e2e_fullsize.py [scratch_dir] [n_docs]"""
+import json
+import os
+import shutil
+import sys
+import time
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench  # noqa: E402
+import synth  # noqa: E402
+from mevi_amd import dense, io as mio, metrics  # noqa: E402
+from mevi_amd.evalrun import EvalRun, load_queries  # noqa: E402
+
+scratch = sys.argv[1] if len(sys.argv) > 1 else "/tmp/mevi_e2e"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else bench.N_DOCS
+nq, M, K, d = bench.N_QUERIES, 4, 32, 768
+dev = torch.device("cuda:0")
+T0 = time.time()
+
+
+def phase(name, t):
+    print(f"{name:58s} {time.time() - t:8.1f} s", flush=True)
+
+
+class HashTokenizer:
+    """Stand-in for the SentencePiece tokenizer (tokenisation is outside the boundary)."""
+
+    def batch_encode_plus(self, texts, max_length=32, padding="max_length", truncation=True, return_tensors="pt", **kw):
+        ids = np.zeros((len(texts), max_length), np.int64)
+        mask = np.zeros((len(texts), max_length), np.int64)
+        for i, t in enumerate(texts):
+            toks = [3 + (hash(w) % 32000) for w in t.split()][: max_length - 1] + [1]
+            ids[i, :len(toks)] = toks
+            mask[i, :len(toks)] = 1
+        return {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+
+
+shutil.rmtree(scratch, ignore_errors=True)
+for sub in ("ckpts/t5-ance", "origin", "ance"):
+    os.makedirs(os.path.join(scratch, sub))
+t = time.time()
+W, TW, g, rn = synth.weights(dev, M, K)
+torch.save({"state_dict": {"model." + k: v.cpu() for k, v in W.items()}}, os.path.join(scratch, "ckpts/nci.ckpt"))
+torch.save({k: v.cpu() for k, v in TW.items()}, os.path.join(scratch, "ckpts/t5-ance/pytorch_model.bin"))
+json.dump(dict(d_model=d, d_ff=3072, num_heads=12, d_kv=64, num_layers=12, num_decoder_layers=12),
+          open(os.path.join(scratch, "ckpts/t5-ance/config.json"), "w"))
+torch.save(torch.nn.Parameter(torch.stack([rn(K, d, s=0.05 / (1 + j)) for j in range(M)]).cpu()),
+           os.path.join(scratch, "ance/rqcodebook4_5.pt"))
+del W, TW
+phase("synthetic checkpoints written", t)
+t = time.time()
+with open(os.path.join(scratch, "ance/docemb.bin"), "wb") as f:
+    for a in range(0, N, 1 << 20):
+        f.write(bench.gen_shard(a, min(a + (1 << 20), N), dev, N).cpu().numpy().tobytes())
+phase(f"docemb.bin written ({N} x {d} f32)", t)
+rng = np.random.default_rng(0)
+with open(os.path.join(scratch, "origin/dev_mevi_dedup.tsv"), "w") as f:
+    for i in range(nq):
+        words = " ".join(f"w{rng.integers(0, 5000)}" for _ in range(int(np.clip(rng.poisson(9) + 1, 2, 30))))
+        f.write(f"{words} q{i}\t{int(rng.integers(0, N))}\n")
+torch.cuda.empty_cache()
+
+args = Namespace(subvector_num=M, subvector_bits=5, num_return_sequences=10, model_info="base", dataset="marco",
+                 document_encoder="ance", nci_ckpt=os.path.join(scratch, "ckpts/nci.ckpt"), ckpt_dir=os.path.join(scratch, "ckpts"),
+                 embedding_path=os.path.join(scratch, "ance/docemb.bin"), pq_path=os.path.join(scratch, "ance/rqcodebook4_5.pt"),
+                 pq_cluster_path=os.path.join(scratch, "ance/rqclus4_5.pkl"),
+                 custom_save_path=os.path.join(scratch, "ance/nci_result_rq45_top10.tsv"), save_hard_neg=N, length_penalty=0.8,
+                 eval_batch_size=2, device_batch_size=8192, recall_num=[1, 5, 10, 20, 50, 100],
+                 metric_path=os.path.join(scratch, "logs/m.txt"), data_dir=os.path.join(scratch, "origin"), n_test=-1)
+tok = HashTokenizer()
+t = time.time()
+run = EvalRun(args, tokenizer=tok, device=dev)
+torch.cuda.synchronize()
+phase("EvalRun start-up (weights, 27 GB corpus upload, RQ encode, pickles)", t)
+t = time.time()
+buf0 = __import__("io").StringIO()
+with __import__("contextlib").redirect_stdout(buf0):
+    out = run.run(load_queries(args.data_dir))
+phase("EvalRun.run: 6980 queries, logs and metrics written", t)
+print("   ndocs@cluster10", out["ndoc"], " recall@100", out["recall"][100])
+t = time.time()
+run2 = EvalRun(args, tokenizer=tok, device=dev)
+torch.cuda.synchronize()
+phase("second start-up (cluster pickle present)", t)
+emb = run2.emb
+tower = run2.tower
+del run, run2
+t = time.time()
+df = load_queries(args.data_dir)
+enc = tok.batch_encode_plus(df["query"].tolist())
+q = tower.encode_query(enc)
+q.cpu().numpy().tofile(os.path.join(scratch, "ance/query_emb.bin"))
+phase("generate.py equivalent: tokenise + tower + write", t)
+t = time.time()
+ds, di = dense.DenseIndex(emb).search(q, 1000)
+ds, di = ds.cpu().numpy(), di.cpu().numpy()
+phase("faiss_search.py equivalent: index build + search", t)
+t = time.time()
+mio.to_file(os.path.join(scratch, "origin/dev_mevi_dedup.tsv"), os.path.join(scratch, "ance/dense.txt"), ds, di)
+phase("   dense TSV written", t)
+t = time.time()
+prefix = args.custom_save_path[:-4]
+# a query whose beam clusters are all empty logs an empty list, which the consumer's field parser rejects exactly like the
+# reference's eval_list('') does (ensemble_marco.py:85-89); a trained model does not emit such beams, the random one
+# here does for a few queries -- give those the first dense hit so that the consumer can run
+hn_path = f"{prefix}_hn{N}.tsv"
+lines = open(hn_path).read().split("\n")
+fixed = 0
+for j, line in enumerate(lines):
+    f_ = line.split("\t")
+    if len(f_) == 4 and f_[2] == "":
+        f_[2], f_[3] = str(int(di[j, 0])), repr(float(ds[j, 0]))
+        lines[j] = "\t".join(f_)
+        fixed += 1
+open(hn_path, "w").write("\n".join(lines))
+print(f"   {fixed} queries with no fine candidate patched", flush=True)
+import contextlib  # noqa: E402
+import io as _io  # noqa: E402
+
+buf = _io.StringIO()
+with contextlib.redirect_stdout(buf):
+    res = metrics.ensemble_main(os.path.join(scratch, "ance"), os.path.join(scratch, "origin/dev_mevi_dedup.tsv"), "dense.txt",
+                                os.path.basename(hn_path), f"{os.path.basename(prefix)}_coarse.tsv",
+                                args.pq_cluster_path.replace("clus", "mapping"), ofile=os.path.join(scratch, "ens.txt"))
+phase("ensemble_marco.py equivalent (parses 3 TSVs + 8.8 M-entry mapping)", t)
+phase("TOTAL", T0)
+for fn in sorted(os.listdir(os.path.join(scratch, "ance"))):
+    print("   ", fn, os.path.getsize(os.path.join(scratch, "ance", fn)) // (1 << 20), "MiB")
+shutil.rmtree(scratch, ignore_errors=True)
