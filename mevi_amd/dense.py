@@ -12,6 +12,10 @@ from . import hip
 
 
 def _as_device_f32(x, device):
+    if isinstance(x, np.ndarray) and x.ndim == 2 and x.dtype == np.float32 and x.nbytes >= (64 << 20):
+        from .io import upload_rows
+
+        return upload_rows(x, device)           # the 27 GB corpus of faiss_search.py: pinned, chunked
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
     x = x.to(device=device, dtype=torch.float32)

@@ -18,7 +18,7 @@ import torch
 from . import dense as mdense
 from . import fine as mfine
 from . import hip
-from .io import RankLog, join_i64
+from .io import RankLog, join_i64, upload_rows
 from .nci import NCIModel, config_from_weights, decode_token
 from .rq import ClusterIndex, ProductQuantization
 from .t5 import T5Dims, TwinTower
@@ -212,10 +212,7 @@ class EvalRun:
         d_model = self.tower.dim     # the corpus embeddings and the RQ codebook live in the tower's output space
         n_docs = os.path.getsize(a.embedding_path) // (4 * d_model)
         emb = np.memmap(a.embedding_path, dtype=np.float32, mode="r", shape=(n_docs, d_model))
-        self.emb = torch.empty((n_docs, d_model), dtype=torch.float32, device=self.dev)
-        step = 1 << 20
-        for s in range(0, n_docs, step):
-            self.emb[s:s + step] = torch.from_numpy(np.array(emb[s:s + step]))
+        self.emb = upload_rows(emb, self.dev)
         # RQ codebook + cluster index (pickles if present, else encode on the GPU and write them)
         self.pq = ProductQuantization("rq", self.M, a.subvector_bits, "l2", d_model, device=self.dev)
         self.pq.initialize(a.pq_path, rank=0)

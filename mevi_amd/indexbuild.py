@@ -124,9 +124,9 @@ def build_index(args, rank=0, nrank=1, barrier=None, device=None, tower=None, to
     need_clusters = not (os.path.exists(args.pq_cluster_path) and os.path.exists(map_path))
     doc_emb = None
     if rank == 0 and (pq_file is None or need_clusters):
-        doc_emb = torch.empty((n_docs, dim), dtype=torch.float32, device=device)
-        for s in range(0, n_docs, 1 << 20):
-            doc_emb[s:s + (1 << 20)] = torch.from_numpy(np.array(emb[s:s + (1 << 20)]))
+        from .io import upload_rows
+
+        doc_emb = upload_rows(emb, device)
     pq.initialize(args.pq_path, doc_emb, rank=rank, seed=getattr(args, "seed", 42) - 1)
     nclus = None
     if need_clusters:
