@@ -148,6 +148,13 @@ def seq2seq_legs(device, nq, search_ms, with_cpu):
             "note": "main.py --mode eval beam search (t5-base NCI model, f32, synthetic weights); the fine stage adds "
                     "the tower again + a gather-dot (tools/bench_chain.py, profiles/r01_chain_c4.txt)"},
     }
+    chain_ms = tower_ms + search_ms + nci_ms + tower_ms
+    out["chain_c4_derived"] = {
+        "ms": chain_ms, "queries_per_s": nq / chain_ms * 1e3,
+        "queries_per_s_reusing_query_embeddings": nq / (chain_ms - tower_ms) * 1e3,
+        "note": "tower + dense search + NCI beam search + tower again (as the reference's fine stage does) from the legs of "
+                "this run; the gather-dot of the fine stage adds 3-4 ms on the C4 corpus (tools/bench_chain.py measures the "
+                "chain with it: profiles/r01_chain_c4.txt)"}
     if with_cpu:
         from oracle import t5 as ot5
 
