@@ -487,3 +487,23 @@ def test_eval_driver_with_a_bert_tower(cuda, mini, tmp_path):
             assert np.abs(got_s - ref).max() <= 3e-4
             checked += 1
     assert checked >= 5
+
+
+def test_cli_level_rehearsal_at_reduced_size(cuda, tmp_path):
+    """tools/e2e_fullsize.py with 300 k documents: t5-base-shaped checkpoints on disk -> EvalRun start-up (pinned corpus
+    upload, RQ encode, pickles), eval run with its logs, tower + dense search + TSV, ensemble consumer -- the flow the
+    MS MARCO-sized profile (profiles/r01_e2e_fullsize.txt) times, kept runnable."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_fullsize.py"), str(tmp_path / "scratch"), "300000"],
+                       capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "TOTAL" in r.stdout and "ensemble_marco.py equivalent" in r.stdout and "dense.txt" in r.stdout
+    assert not os.path.exists(tmp_path / "scratch")          # the scratch directory is removed at the end
+
+
+def test_pinned_upload_equals_plain_copy(cuda):
+    from mevi_amd.io import upload_rows
+
+    rng = np.random.default_rng(4)
+    for rows, chunk in ((0, 8), (5, 8), (1000, 64), (1000, 1000), (1001, 250)):
+        a = rng.standard_normal((rows, 24)).astype(np.float32)
+        assert torch.equal(upload_rows(a, cuda, chunk_rows=chunk).cpu(), torch.from_numpy(a))
