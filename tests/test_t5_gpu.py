@@ -40,6 +40,19 @@ def test_twin_tower_matches_reference_golden(cuda):
     assert np.abs(packed.cpu().numpy()[~valid]).max() == 0 if (~valid).any() else True
     reps = tower.encode_query({"input_ids": ids, "attention_mask": mask})
     assert np.abs(reps.cpu().numpy() - g["reps"]).max() <= 5e-5
+    # a mask with holes (no tokenizer produces one, the API allows it): the packed rows keep the padded layout for
+    # attention, positions are the original ones -- same bits as the unpacked computation, end to end
+    holes = mask.clone()
+    holes[:, 2] = 0
+    holes[0, 5:] = 0
+    enc_h = tower.encoder.forward(tower.shared, ids.to(cuda), holes.to(cuda), pack=False)
+    pk_h = tower.encoder.forward(tower.shared, ids.to(cuda), holes.to(cuda), pack=True)
+    hv = holes.numpy().astype(bool)
+    assert np.array_equal(pk_h.cpu().numpy()[hv], enc_h.cpu().numpy()[hv])
+    tower.encoder.pack = False
+    r0 = tower.encode_query({"input_ids": ids, "attention_mask": holes})
+    tower.encoder.pack = True
+    assert torch.equal(tower.encode_query({"input_ids": ids, "attention_mask": holes}), r0)
 
 
 def test_passage_tower_matches_reference_golden(cuda):
