@@ -7,6 +7,8 @@
 // and adaptor_linear restricted to the valid columns (modeling_t5.py:1677-1682).
 // torch.nn.Linear stores W as [out, in], so both operands are K-contiguous: exactly the shape of
 // the shared ping-pong f32-MFMA loop (mfma_pp.h).  Every output is the sequential fmaf chain over k.
+#include <cstdlib>
+
 #include "mfma_pp.h"
 
 namespace mevi {
@@ -80,6 +82,72 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_kernel(
   }
 }
 
+// Few rows (M <= SK_MAXM: single queries and small batches, the latency path): a 256 x 128 MFMA tile would spend a full tile's time on
+// them.  One workgroup per (64 output columns, 4 rows): lane = column, wave = row; W and X slabs of SK_BK k-values go
+// through LDS (register prefetch of the next slab), every output is the same sequential fmaf chain over k the MFMA
+// kernels produce -- so a row gives the same bits whether it travels alone or inside a large batch.
+constexpr int SK_MAXM = 256, SK_BK = 128, SK_LD = SK_BK + 1;
+
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(
+    const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
+    float *__restrict__ C, long long ldc, int M, int N, int K, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int act) {
+  __shared__ float sw[64 * SK_LD];   // [column][k]
+  __shared__ float sx[4 * SK_BK];    // [row][k]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 4;
+  // staging roles: thread t loads W row (t >> 2), k-quads (t & 3) + 4 j (j < 8); threads 0..127 load X row (t >> 5), quad (t & 31)
+  const int wr = t >> 2, wq = t & 3;
+  const int xr = t >> 5, xq = t & 31;
+  const int wrow = n0 + wr < N ? n0 + wr : N - 1;
+  const float *wp = W + (size_t)wrow * ldw;
+  float4 rw[8], rx;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + 4 * (wq + 4 * j);
+      rw[j] = k < K ? *reinterpret_cast<const float4 *>(wp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int r = m0 + xr, k = k0 + 4 * xq;
+    rx = (t < 128 && r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (size_t)r * lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float *p = sw + wr * SK_LD + 4 * (wq + 4 * j);
+      p[0] = rw[j].x; p[1] = rw[j].y; p[2] = rw[j].z; p[3] = rw[j].w;
+    }
+    if (t < 128) *reinterpret_cast<float4 *>(sx + xr * SK_BK + 4 * xq) = rx;
+  };
+  const int m = m0 + wave;
+  float acc = 0.f;
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += SK_BK) {
+    __syncthreads();                 // the previous slab has been consumed
+    lstore();
+    __syncthreads();
+    if (k0 + SK_BK < K) gload(k0 + SK_BK);
+    const int kn = K - k0 < SK_BK ? K - k0 : SK_BK;     // the chain stops at K
+    if (m < M) {
+      const float *wl = sw + lane * SK_LD, *xl = sx + wave * SK_BK;
+      if (kn == SK_BK) {
+#pragma unroll 16
+        for (int kk = 0; kk < SK_BK; ++kk) acc = fmaf(xl[kk], wl[kk], acc);
+      } else {
+        for (int kk = 0; kk < kn; ++kk) acc = fmaf(xl[kk], wl[kk], acc);
+      }
+    }
+  }
+  const int n = n0 + lane;
+  if (n >= N || m >= M) return;
+  float v = acc;
+  if (bias) v += bias[n];
+  if (act == 1) v = fmaxf(v, 0.f);
+  else if (act == 2) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+  if (residual) v += residual[(size_t)m * ldr + n];
+  C[(size_t)m * ldc + n] = v;
+}
+
 }  // namespace
 }  // namespace mevi
 
@@ -99,6 +167,13 @@ extern "C" int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int
                "gemm_nt: a/w must be 16-byte aligned");
   MEVI_REQUIRE(act >= 0 && act <= 2, MEVI_ERR_INVALID_ARG, "gemm_nt: act must be 0 (none), 1 (relu) or 2 (erf gelu)");
   MEVI_REQUIRE(m < (1LL << 31) && n < (1LL << 31) && k < (1LL << 24), MEVI_ERR_UNSUPPORTED, "gemm_nt: too large");
+  static const int skinny_on = [] { const char *e = getenv("MEVI_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+  if (m <= SK_MAXM && skinny_on) {   // a handful of rows: latency path
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((m + 3) / 4)), dim3(256), 0, stream, a, (long long)lda, w,
+                       (long long)ldw, c, (long long)ldc, (int)m, (int)n, (int)k, bias, residual, (long long)ldr, act);
+    MEVI_HIP_CHECK(hipGetLastError());
+    return MEVI_OK;
+  }
   const int64_t n_mpairs = (m + 2 * BM - 1) / (2 * BM);
   static int n_cu = 0;
   if (n_cu == 0) {

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .t5 import DecoderStack, EncoderStack, T5Dims, _dev
+from .t5 import GRAPH_MAX_ROWS, DecoderStack, EncoderStack, GraphCache, T5Dims, _dev
 
 
 class NCIConfig(T5Dims):
@@ -169,6 +169,7 @@ class NCIModel:
         self.cfg = cfg if cfg is not None else NCIConfig(**kw)
         self.prefix_table_bytes = prefix_table_bytes      # 0: evaluate the adaptor per beam per step
         self._tables = None
+        self._graphs = GraphCache()
         c = self.cfg
         self.shared = _dev(weights, "shared.weight", self.dev)
         self.dec_emb = _dev(weights, "decode_embeddings.weight", self.dev)
@@ -210,19 +211,34 @@ class NCIModel:
 
     @torch.no_grad()
     def generate(self, input_ids, attention_mask, num_beams=10, num_return_sequences=None, length_penalty=0.8,
-                 max_length=None, **reference_kwargs):
+                 max_length=None, graph=False, **reference_kwargs):
         """Returns (decoded i64[B*R, M+2], scores list[float] (descending per query),
         enc_last_hidden_state f32[B*R, S, d] view, None) like the reference's 4-tuple; the last slot
-        (dec_hidden) is only read when query_encoder='nci' and is not produced (SURVEY 8(a') note iii)."""
+        (dec_hidden) is only read when query_encoder='nci' and is not produced (SURVEY 8(a') note iii).
+        graph=True (batches of at most GRAPH_MAX_ROWS queries): replay the whole search as one captured HIP graph
+        (fixed shapes: padded encoder, no host synchronisation inside) -- same kernels, same results, no host jitter;
+        the median latency is the kernels' own time either way (tools/bench_latency.py)."""
         c = self.cfg
         R = num_beams
         assert num_return_sequences in (None, R) and R <= c.K, "needs num_beams == num_return_sequences <= K"
         assert max_length in (None, c.M + 2)
         ids = input_ids.to(self.dev, torch.int64).contiguous()
         mask = attention_mask.to(self.dev, torch.int64).contiguous()
+        if graph and 0 < ids.shape[0] <= GRAPH_MAX_ROWS:
+            if self.prefix_table_bytes:
+                self.tables()
+            decoded, hyp, enc = self._graphs.run(("generate", R, float(length_penalty)) + tuple(ids.shape),
+                                                 lambda i, m: self._search(i, m, R, length_penalty, pack=False), ids, mask)
+        else:
+            decoded, hyp, enc = self._search(ids, mask, R, length_penalty, pack=True)
+        return decoded, hyp.reshape(-1).tolist(), enc, None
+
+    def _search(self, ids, mask, R, length_penalty, pack):
+        """The device part of generate(): (decoded i64[B*R, M+2], hypothesis scores f64[B, R], encoder states)."""
+        c = self.cfg
         B = ids.shape[0]
-        enc = self.encoder.forward(self.shared, ids, mask)
-        xkv = self.decoder.cross_kv(enc, mask)
+        enc = self.encoder.forward(self.shared, ids, mask, pack=None if pack else False)
+        xkv = self.decoder.cross_kv(enc, mask, pack=pack)
 
         nb = 1
         tokens = torch.zeros(B, dtype=torch.int64, device=self.dev)          # decoder_start_token_id = 0
@@ -258,7 +274,7 @@ class NCIModel:
         toks = 2 + torch.arange(c.M, device=self.dev) * c.K + codes
         decoded = torch.cat([torch.zeros((B, R, 1), dtype=torch.int64, device=self.dev), toks,
                              torch.ones((B, R, 1), dtype=torch.int64, device=self.dev)], dim=2).view(B * R, c.M + 2)
-        return decoded, hyp.reshape(-1).tolist(), enc, None
+        return decoded, hyp, enc
 
 
 def _reorder_cache(cache, rows, filled):

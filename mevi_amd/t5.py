@@ -166,6 +166,40 @@ def packed_offsets(attention_mask):
     return (seq_off, int(longest)) if ok else (None, 0)
 
 
+# batches up to this many rows may run as one replayed HIP graph (graph=True); larger ones always run eagerly, packed
+GRAPH_MAX_ROWS = 8
+
+
+class GraphCache:
+    """Captured HIP graphs of fixed-shape device functions, keyed by shape: `run(key, fn, *inputs)` copies the inputs
+    into the graph's static buffers, replays, and returns clones of the outputs.  Capture happens on the second call
+    of a key (the first runs eagerly: it warms kernels, caches and lazily built tables, none of which may happen
+    under capture).  The kernels are issued through the C ABI on torch's current stream, which is the capturing
+    stream inside `torch.cuda.graph`."""
+
+    def __init__(self):
+        self.seen, self.graphs = set(), {}
+
+    def run(self, key, fn, *inputs):
+        if key not in self.seen:
+            self.seen.add(key)
+            return fn(*inputs)
+        if key not in self.graphs:
+            static_in = [t.clone() for t in inputs]
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = fn(*static_in)
+            self.graphs[key] = (g, static_in, static_out)
+        g, static_in, static_out = self.graphs[key]
+        for s, t in zip(static_in, inputs):
+            s.copy_(t)
+        g.replay()
+        if isinstance(static_out, (tuple, list)):
+            return type(static_out)(o.clone() for o in static_out)
+        return static_out.clone()
+
+
 class CrossKV:
     """Cross-attention K|V of a batch: per layer either padded f32[B, S, 2*inner] + the key mask, or packed
     f32[T_real, 2*inner] + the sequences' row offsets (i64 [B+1]) and the longest length."""
@@ -205,14 +239,16 @@ class DecoderStack:
         self.self_bias = bias_table(rel, max_len, max_len, False, dims.buckets)   # [H, T, T]
         self.max_len = max_len
 
-    def cross_kv(self, enc, enc_mask=None):
-        """Per-layer cross-attention K|V of the encoder states, as a CrossKV.  With `enc_mask` only the real positions
-        are projected; for right-padded masks the K|V rows stay PACKED (the attention kernels read a sequence's real
-        keys through its row offsets), otherwise they are scattered into a zeroed [B, S, 2*inner] buffer."""
+    def cross_kv(self, enc, enc_mask=None, pack=True):
+        """Per-layer cross-attention K|V of the encoder states, as a CrossKV.  With `enc_mask` (and pack) only the real
+        positions are projected; for right-padded masks the K|V rows stay PACKED (the attention kernels read a
+        sequence's real keys through its row offsets), otherwise they are scattered into a zeroed [B, S, 2*inner]
+        buffer.  pack=False projects every position and keeps the mask: fixed shapes, no host synchronisation (the
+        graph-replay path of small batches)."""
         B, S, dm = enc.shape
         flat = enc.reshape(B * S, dm)
         idx = None
-        if enc_mask is not None:
+        if enc_mask is not None and pack:
             idx = torch.nonzero(enc_mask.reshape(-1) != 0).view(-1)
             if idx.numel() == 0 or idx.numel() > 0.9 * B * S:
                 idx = None
@@ -289,10 +325,24 @@ class TwinTower:
         self.decoder = DecoderStack(weights, self.d, self.dev, max_len=1)
         self.batch_size = batch_size   # rows per device pass; None: DEVICE_PASS_TOKENS // sequence length
         self.dim = self.d.d_model      # width of the embeddings this tower emits
+        self._graphs = GraphCache()
 
-    def encode_query(self, qry):
+    def _encode_fixed(self, ids, mask):
+        """One pass at fixed shapes (padded layout, no host synchronisation): what a HIP graph can capture."""
+        enc = self.encoder.forward(self.shared, ids, mask, pack=False)
+        B = ids.shape[0]
+        x = ops.gather_rows(self.shared, torch.zeros(B, dtype=torch.int64, device=self.dev))
+        return self.decoder.step(x, 0, self.decoder.new_cache(B), self.decoder.cross_kv(enc, mask, pack=False), mask, 1)
+
+    def encode_query(self, qry, graph=False):
+        """graph=True (batches of at most GRAPH_MAX_ROWS rows): replay a captured HIP graph of the whole forward at
+        fixed, padded shapes.  Same kernels, same bits as the eager pass; measured (tools/bench_latency.py) it does not
+        lower the median latency -- the ~300 kernels of a single query are bound by their own run time (3.8 ms), the
+        asynchronous eager launches already hide the host -- but it removes the host-side jitter (p90 = median)."""
         ids = qry["input_ids"].to(self.dev, torch.int64)
         mask = qry["attention_mask"].to(self.dev, torch.int64)
+        if graph and 0 < ids.shape[0] <= GRAPH_MAX_ROWS:
+            return self._graphs.run(("tower",) + tuple(ids.shape), self._encode_fixed, ids.contiguous(), mask.contiguous())
         outs = []
         step = self.batch_size or max(1, DEVICE_PASS_TOKENS // max(1, ids.shape[1]))
         for a in range(0, ids.shape[0], step):

@@ -269,3 +269,30 @@ def test_results_do_not_depend_on_batch_grouping_or_stale_memory_at_base_shapes(
     tab = model.tables()
     assert tab.levels == 3 and tab.tmat[1] is not None and tab.tmat[2] is None and tab.avec[2] is not None
     assert torch.equal(d, d0) and np.array_equal(s, s0)
+
+
+def test_graph_replay_of_small_batches_equals_the_eager_pass(cuda):
+    """graph=True: batches of <= GRAPH_MAX_ROWS queries replay one captured HIP graph of the whole tower forward / beam
+    search; first call eager, second captures, later ones replay with new inputs -- all bit-identical to the eager,
+    packed pass of the same queries inside a large batch (which also pins the few-row GEMM kernel against the MFMA
+    tiles end to end)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+
+    model, tower, _, _ = synth.build(cuda, 4, 32, None)
+    ids, mask = synth.query_ids(40, cuda, np.random.default_rng(3))
+    big_e = tower.encode_query({"input_ids": ids, "attention_mask": mask})
+    big_d, big_s, _, _ = model.generate(ids, mask, num_beams=10)
+    big_s = np.asarray(big_s).reshape(40, 10)
+    for b in (1, 2):
+        for it, a in enumerate((0, 5, 11, 30)):          # eager, capture, replay, replay
+            q = {"input_ids": ids[a:a + b], "attention_mask": mask[a:a + b]}
+            assert torch.equal(tower.encode_query(q, graph=True), big_e[a:a + b]), (b, it)
+            d, s, enc, _ = model.generate(ids[a:a + b], mask[a:a + b], num_beams=10, graph=True)
+            assert torch.equal(d, big_d[10 * a:10 * (a + b)]) and np.array_equal(np.asarray(s).reshape(b, 10), big_s[a:a + b])
+    assert ("tower", 1, 32) in tower._graphs.graphs and any(k[0] == "generate" for k in model._graphs.graphs)
+    # the default stays eager (packed) for a small batch
+    assert torch.equal(tower.encode_query({"input_ids": ids[:2], "attention_mask": mask[:2]}), big_e[:2])
+    assert len(tower._graphs.graphs) == 2
