@@ -82,11 +82,13 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_kernel(
   }
 }
 
-// Few rows (M <= SK_MAXM: single queries and small batches, the latency path): a 256 x 128 MFMA tile would spend a full tile's time on
+// Few outputs (single queries and small batches, the latency path): a 256 x 128 MFMA tile would spend a full tile's time on
 // them.  One workgroup per (64 output columns, 4 rows): lane = column, wave = row; W and X slabs of SK_BK k-values go
 // through LDS (register prefetch of the next slab), every output is the same sequential fmaf chain over k the MFMA
 // kernels produce -- so a row gives the same bits whether it travels alone or inside a large batch.
-constexpr int SK_MAXM = 256, SK_BK = 128, SK_LD = SK_BK + 1;
+constexpr int SK_BK = 128, SK_LD = SK_BK + 1;
+// taken when m * n <= SK_MAX_OUTPUTS: measured ~0.1 us per 1000 outputs at K = 768 against ~57 us for one round of MFMA tiles
+constexpr long long SK_MAX_OUTPUTS = 500000;
 
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(
     const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
@@ -168,7 +170,7 @@ extern "C" int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int
   MEVI_REQUIRE(act >= 0 && act <= 2, MEVI_ERR_INVALID_ARG, "gemm_nt: act must be 0 (none), 1 (relu) or 2 (erf gelu)");
   MEVI_REQUIRE(m < (1LL << 31) && n < (1LL << 31) && k < (1LL << 24), MEVI_ERR_UNSUPPORTED, "gemm_nt: too large");
   static const int skinny_on = [] { const char *e = getenv("MEVI_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
-  if (m <= SK_MAXM && skinny_on) {   // a handful of rows: latency path
+  if (m * n <= SK_MAX_OUTPUTS && skinny_on) {   // a handful of rows: latency path
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((m + 3) / 4)), dim3(256), 0, stream, a, (long long)lda, w,
                        (long long)ldw, c, (long long)ldc, (int)m, (int)n, (int)k, bias, residual, (long long)ldr, act);
     MEVI_HIP_CHECK(hipGetLastError());

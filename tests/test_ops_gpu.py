@@ -273,13 +273,13 @@ def test_cross_attention_over_packed_keys_equals_the_padded_masked_form(cuda, kv
 
 @pytest.mark.parametrize("K,N", [(768, 768), (768, 3072), (3072, 768), (100, 130), (36, 64), (772, 25344)])
 def test_few_row_gemm_gives_the_rows_of_the_large_gemm(cuda, K, N):
-    """M <= 32 rows take gemm_skinny_kernel; the same rows inside a 1000-row GEMM take the MFMA tiles: identical bits,
-    with bias / ReLU / GELU / residual epilogues, for every M in 1..32."""
+    """Small GEMMs (m * n <= 0.5 M outputs) take gemm_skinny_kernel; the same rows inside a 3000-row GEMM take the MFMA
+    tiles: identical bits, with bias / ReLU / GELU / residual epilogues."""
     g = torch.Generator(device=cuda).manual_seed(K + N)
-    x = torch.randn((1000, K), device=cuda, generator=g)
+    x = torch.randn((3000, K), device=cuda, generator=g)
     w = torch.randn((N, K), device=cuda, generator=g) * K ** -0.5
     b = torch.randn((N,), device=cuda, generator=g)
-    r = torch.randn((1000, N), device=cuda, generator=g)
+    r = torch.randn((3000, N), device=cuda, generator=g)
     for kw in (dict(), dict(bias=b, relu=True), dict(bias=b, gelu=True, residual=r), dict(residual=r)):
         full = ops.linear(x, w, **kw)
         for M in (1, 2, 5, 31, 32, 255, 256, 257):
