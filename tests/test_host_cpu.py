@@ -251,3 +251,60 @@ def test_native_number_formatting_equals_python_str():
         assert _native_numbers(odd) is None if odd else True
     assert _native_numbers(" 3, 4 ,5") == [3, 4, 5] and _native_numbers("+3,-4") == [3, -4]
     assert str(_native_numbers("inf,-inf,nan,1e5")) == str([float("inf"), float("-inf"), float("nan"), 1e5])
+
+
+def _host_flow_worker(rank, world, port, tmp, ret):
+    import torch.distributed as dist
+
+    from mevi_amd import io as mio
+    from mevi_amd.evalrun import rank_slice
+    from mevi_amd.indexbuild import embed_documents
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (1) the per-rank result logs of main.py: every rank appends its DistributedSampler slice, rank 0 concatenates
+    log = mio.RankLog(os.path.join(tmp, "out_fine.tsv"), rank, world, barrier=dist.barrier, tmpdir=tmp)
+    for i in rank_slice(7, rank, world):
+        log.add((f"query {i}", [i, i + 1], [i]))
+    log.merge()
+    # (2) the per-rank part files of the passage embeddings (main.py --only_gen_rq / generate.py --gen_doc)
+
+    class Enc:
+        dim = 3
+
+        def encode_passage(self, psg):
+            t = psg["input_ids"].float()
+            return torch.stack([t.sum(1), t[:, 0], psg["attention_mask"].sum(1).float()], 1)
+
+    tokens = np.arange(11 * 4, dtype=np.int64).reshape(11, 4)
+    masks = (tokens % 3 != 0).astype(np.int64)
+    embed_documents(Enc(), tokens, masks, os.path.join(tmp, "docemb.bin"), rank, world, dist.barrier, batch_size=2)
+    ret[rank] = True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_rank_host_flows_on_gloo_world2(tmp_path):
+    """What main.py / generate.py do around the kernels with N > 1 ranks, with real processes and a gloo barrier: the
+    rank-merged log file keeps rank order with the sampler's padding duplicate, the passage-embedding part files are
+    concatenated in document order and removed."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_host_flow_worker, nprocs=2, args=(2, port, str(tmp_path), ret))
+    assert ret[0] and ret[1]
+    lines = open(tmp_path / "out_fine.tsv").read().splitlines()
+    # DistributedSampler(shuffle=False) over 7 samples, 2 ranks: rank 0 -> 0,2,4,6; rank 1 -> 1,3,5,0 (padding repeats the head)
+    assert [l.split("\t")[0] for l in lines] == [f"query {i}" for i in (0, 2, 4, 6, 1, 3, 5, 0)]
+    assert lines[1] == "query 2\t[2, 3]\t[2]"
+    emb = np.fromfile(tmp_path / "docemb.bin", dtype=np.float32).reshape(11, 3)
+    tokens = np.arange(44, dtype=np.int64).reshape(11, 4)
+    want = np.stack([tokens.sum(1), tokens[:, 0], (tokens % 3 != 0).sum(1)], 1).astype(np.float32)
+    assert np.array_equal(emb, want)
+    assert sorted(os.listdir(tmp_path)) == ["docemb.bin", "out_fine.tsv"]
