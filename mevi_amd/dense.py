@@ -218,5 +218,31 @@ def search(query, doc, dim, topk, param="Flat", device=None):
     print(f"Param {param} trained: True.")  # reference prints index.is_trained
     q = _as_device_f32(np.asarray(query).reshape(-1, dim) if isinstance(query, np.ndarray) else query, device)
     d = _as_device_f32(np.asarray(doc).reshape(-1, dim) if isinstance(doc, np.ndarray) else doc, device)
-    s, i = DenseIndex(d).search(q, topk)      # index.add(doc); index.search(query, topk)
+    if topk > MAX_K:
+        s, i = _search_large_k(q, d, topk)
+    else:
+        s, i = DenseIndex(d).search(q, topk)  # index.add(doc); index.search(query, topk)
     return s.cpu().numpy(), i.cpu().numpy()
+
+
+MAX_K = 4096     # list length the threshold-filter kernels keep per query (include/mevi_hip.h)
+
+
+def _search_large_k(q, d, k, rows_budget=1 << 28):
+    """faiss accepts any k; the filter kernels keep at most MAX_K entries per query.  Beyond that (not a configuration of
+    any reference script) the scores of a few queries at a time are materialised with the f32 GEMM -- the same
+    sequential fmaf chains -- and ordered by (score desc, id asc) with two stable device sorts; -1 / -FLT_MAX padding
+    when k exceeds the corpus, as faiss."""
+    from . import ops
+
+    nq, nd = q.shape[0], d.shape[0]
+    out_s = torch.full((nq, k), torch.finfo(torch.float32).min, dtype=torch.float32, device=q.device)
+    out_i = torch.full((nq, k), -1, dtype=torch.int64, device=q.device)
+    kk = min(k, nd)
+    step = max(1, rows_budget // max(nd, 1))
+    for a in range(0, nq, step):
+        sc = ops.linear(q[a:a + step].contiguous(), d)                        # [b, nd], exact chains
+        order = torch.argsort(sc, dim=1, descending=True, stable=True)         # ties keep ascending id
+        out_i[a:a + step, :kk] = order[:, :kk]
+        out_s[a:a + step, :kk] = torch.gather(sc, 1, order[:, :kk])
+    return out_s, out_i

@@ -282,3 +282,16 @@ def test_rejects_bad_arguments(cuda):
         dense.ip_topk(q, d, 3)                    # dim % 4 != 0
     with pytest.raises(hip.MeviHipError):
         dense.ip_topk(torch.zeros((4, 8), device=cuda), torch.zeros((9, 8), device=cuda), 5000)  # k > 4096
+
+
+def test_search_beyond_the_kernel_list_length(cuda):
+    """faiss_search.py --topk > 4096: dense.search falls back to materialised exact scores; bit-exact vs the oracle,
+    ties by ascending id, -1 padding past the corpus."""
+    rng = np.random.default_rng(12)
+    q = rng.standard_normal((5, 32)).astype(np.float32)
+    d = rng.standard_normal((6000, 32)).astype(np.float32)
+    d[100:140] = d[7]                                   # ties
+    for k in (5000, 6100):
+        s, i = dense.search(q, d, 32, k)
+        es, ei = odense.ip_topk_exact(q, d, k)
+        assert np.array_equal(i, ei) and np.array_equal(s.view(np.int32), es.view(np.int32))
