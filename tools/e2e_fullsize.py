@@ -96,6 +96,12 @@ emb = run2.emb
 tower = run2.tower
 del run, run2
 t = time.time()
+from mevi_amd.io import upload_rows  # noqa: E402
+again = upload_rows(np.memmap(args.embedding_path, dtype=np.float32, mode="r", shape=(N, d)), dev)
+torch.cuda.synchronize()
+phase(f"   of which: corpus file (page cache) -> HBM, {N * d * 4 / 1e9:.1f} GB", t)
+del again
+t = time.time()
 df = load_queries(args.data_dir)
 enc = tok.batch_encode_plus(df["query"].tolist())
 q = tower.encode_query(enc)
