@@ -53,7 +53,11 @@ def upload_rows(src, device, chunk_rows=1 << 18, threads=8):
 
 
 def read(path, dim):
-    """Raw f32 file -> [rows, dim] (raises like numpy if the size does not divide)."""
+    """Raw f32 file -> [rows, dim] (raises like numpy if the size does not divide).  Large files (the 27 GB corpus) come
+    back as a read-only memory map -- an ndarray too -- so that the only copy made is the one into the upload's staging
+    buffers; np.fromfile would first copy the whole file into anonymous memory."""
+    if os.path.getsize(path) >= (1 << 30):
+        return np.memmap(path, dtype=np.float32, mode="r").reshape(-1, dim)
     return np.fromfile(path, dtype=np.float32).reshape(-1, dim)
 
 

@@ -107,6 +107,17 @@ enc = tok.batch_encode_plus(df["query"].tolist())
 q = tower.encode_query(enc)
 q.cpu().numpy().tofile(os.path.join(scratch, "ance/query_emb.bin"))
 phase("generate.py equivalent: tokenise + tower + write", t)
+del emb
+torch.cuda.empty_cache()
+t = time.time()
+import subprocess  # noqa: E402
+r = subprocess.run([sys.executable, os.path.join(ROOT, "faiss_search.py"), "--query_path", os.path.join(scratch, "ance/query_emb.bin"),
+                    "--doc_path", args.embedding_path, "--output_path", os.path.join(scratch, "ance/dense_cli.txt"),
+                    "--raw_query_path", os.path.join(scratch, "origin/dev_mevi_dedup.tsv"), "--param", "Flat"],
+                   capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT))
+assert r.returncode == 0, r.stderr[-2000:]
+phase("faiss_search.py, the CLI itself in a fresh process (import, read, upload, search, TSV)", t)
+emb = upload_rows(np.memmap(args.embedding_path, dtype=np.float32, mode="r", shape=(N, d)), dev)
 t = time.time()
 ds, di = dense.DenseIndex(emb).search(q, 1000)
 ds, di = ds.cpu().numpy(), di.cpu().numpy()
@@ -114,6 +125,7 @@ phase("faiss_search.py equivalent: index build + search", t)
 t = time.time()
 mio.to_file(os.path.join(scratch, "origin/dev_mevi_dedup.tsv"), os.path.join(scratch, "ance/dense.txt"), ds, di)
 phase("   dense TSV written", t)
+assert open(os.path.join(scratch, "ance/dense.txt"), "rb").read() == open(os.path.join(scratch, "ance/dense_cli.txt"), "rb").read()
 t = time.time()
 prefix = args.custom_save_path[:-4]
 # a query whose beam clusters are all empty logs an empty list, which the consumer's field parser rejects exactly like the
