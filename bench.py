@@ -203,11 +203,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     hip.require_gpu()
+    # MEVI_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the
+    # collectives go through host memory) -- for checking the sharded search end to end, not for timing
+    backend = os.environ.get("MEVI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     n_docs, nq = args.docs, args.queries
     start, end = dense.shard_range(n_docs, rank, world)
@@ -249,7 +257,7 @@ def main():
     elapsed = time.perf_counter() - t0
     L.mevi_ip_topk_set_profiling(0)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -296,7 +304,8 @@ def main():
                 "workload": "C2 dense arm (faiss_search.py Flat): %d x %d f32 queries x %d x %d f32 docs, "
                             "exact inner-product top-%d" % (nq, DIM, n_docs, DIM, TOPK),
                 "queries": nq, "docs": n_docs, "dim": DIM, "topk": TOPK,
-                "parallelism": "corpus row-sharded x%d, RCCL all-gather of per-shard top-k" % world
+                "parallelism": ("corpus row-sharded x%d, RCCL all-gather of per-shard top-k" % world
+                                + ("" if backend == "nccl" else " [REHEARSAL over %s, ranks share devices: not a timing]" % backend))
                 if world > 1 else "single GPU",
                 "planted_top1_ok": planted_ok,
             },

@@ -189,8 +189,13 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
         s, i = local(q, kk)
         n = s.shape[0]
         packed = (s.contiguous().view(torch.int32).to(torch.int64) << 32) | (i & 0xFFFFFFFF)
-        gathered = torch.empty((world * n, kk), dtype=torch.int64, device=s.device)   # rank-major concatenation
-        dist.all_gather_into_tensor(gathered, packed.contiguous(), group=group)
+        if packed.is_cuda and dist.get_backend(group) == "gloo":     # rehearsal backend: collectives through host memory
+            host = torch.empty((world * n, kk), dtype=torch.int64)
+            dist.all_gather_into_tensor(host, packed.cpu().contiguous(), group=group)
+            gathered = host.to(s.device)
+        else:
+            gathered = torch.empty((world * n, kk), dtype=torch.int64, device=s.device)   # rank-major concatenation
+            dist.all_gather_into_tensor(gathered, packed.contiguous(), group=group)
         all_s = (gathered >> 32).to(torch.int32).view(torch.float32)
         all_i = gathered & 0xFFFFFFFF
         all_i = torch.where(all_i == 0xFFFFFFFF, torch.full_like(all_i, -1), all_i)
