@@ -295,3 +295,30 @@ def test_search_beyond_the_kernel_list_length(cuda):
         s, i = dense.search(q, d, 32, k)
         es, ei = odense.ip_topk_exact(q, d, k)
         assert np.array_equal(i, ei) and np.array_equal(s.view(np.int32), es.view(np.int32))
+
+
+def test_bench_multi_rank_launch_rehearsal(cuda, tmp_path):
+    """The driver's N > 1 launch line (torch.distributed.run, one process per rank) on a reduced corpus, two ranks sharing
+    this GPU over MEVI_BENCH_BACKEND=gloo: shard generation, per-shard index, the two-round truncated exchange and the
+    merge must return every planted neighbour, and rank 0 prints exactly one JSON line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "1", "--docs", "400000", "--queries", "700"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, MEVI_BENCH_BACKEND="gloo", PYTHONPATH=root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["planted_top1_ok"] == 1.0 and j["scaling"] == "strong"
+    assert j["config"]["docs"] == 400000 and "cpu_baseline" not in j
