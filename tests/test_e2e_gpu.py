@@ -507,3 +507,50 @@ def test_pinned_upload_equals_plain_copy(cuda):
     for rows, chunk in ((0, 8), (5, 8), (1000, 64), (1000, 1000), (1001, 250)):
         a = rng.standard_normal((rows, 24)).astype(np.float32)
         assert torch.equal(upload_rows(a, cuda, chunk_rows=chunk).cpu(), torch.from_numpy(a))
+
+
+def _two_rank_eval_worker(rank, world, port, args_dict, ret):
+    import torch.distributed as dist
+
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a = Namespace(**args_dict)
+    out = EvalRun(a, tokenizer=FakeTokenizer(512), rank=rank, nrank=world, barrier=dist.barrier,
+                  device=torch.device("cuda:0")).run(load_queries(a.data_dir))
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eval_driver_with_two_ranks(cuda, mini, tmp_path):
+    """main.py --n_gpu 2 in miniature (two processes sharing this GPU, gloo barrier): every rank takes its
+    DistributedSampler slice, the per-rank logs are merged in rank order (the sampler's padding repeats a head sample),
+    rank 0 aggregates the metrics from all ranks' results -- same lines and same metrics as the single-rank run."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    a0 = mini["args"]
+    prefix0 = a0.custom_save_path[:-4]
+    if not os.path.exists(prefix0 + "_coarse.tsv"):
+        pytest.skip("eval driver test did not run")
+    a = dict(vars(a0))
+    a["custom_save_path"], a["metric_path"] = str(tmp_path / "two.tsv"), str(tmp_path / "two_m.txt")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_two_rank_eval_worker, nprocs=2, args=(2, port, a, ret))
+    assert ret[1] is None and ret[0] is not None
+    prefix = a["custom_save_path"][:-4]
+    n = len(mini["queries"])                      # 23 queries -> 12 per rank, the last one of rank 1 repeats query 0
+    for suffix in ("_coarse.tsv", "_fine.tsv", f"_hn{a0.save_hard_neg}.tsv"):
+        one = open(prefix0 + suffix).read().splitlines()
+        two = open(prefix + suffix).read().splitlines()
+        assert len(two) == n + 1 and set(two) == set(one)
+        assert two[:12] == one[0::2] and two[12:23] == one[1::2] and two[23] == one[0]
+    assert open(a["metric_path"]).read() == open(a0.metric_path).read()
+    assert ret[0]["nqueries"] == n
