@@ -46,7 +46,7 @@ if __name__ == "__main__":
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"))
         print(f"Param {args.param} trained: True.")
         dists, indices = _distributed_search(query, args.doc_path, args.dim, args.topk)
         if dist.get_rank() == 0:

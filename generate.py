@@ -68,7 +68,7 @@ def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path,
 
     nrank = len(gpus)
     if nrank > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=nrank)
+        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), rank=rank, world_size=nrank)
     device = torch.device(f"cuda:{gpus[rank]}")
     torch.cuda.set_device(device)
     encoder = encoder or load_document_encoder(model_path, ckpt_path, device)
@@ -109,7 +109,7 @@ def gen_doc_embedding(rank, document_dir, model_path, ckpt_path, output_path, ba
 
     nrank = len(gpus)
     if nrank > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=nrank)
+        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), rank=rank, world_size=nrank)
     device = torch.device(f"cuda:{gpus[rank]}")
     torch.cuda.set_device(device)
     encoder = encoder or load_document_encoder(model_path, ckpt_path, device)

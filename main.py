@@ -141,7 +141,7 @@ def partial_inference(rank, args):
     torch.cuda.set_device(gpu)
     barrier = None
     if nrank > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=nrank)
+        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), rank=rank, world_size=nrank)
         barrier = dist.barrier
     if args.mode == "train":      # --only_gen_rq 1 (check_supported)
         from mevi_amd.indexbuild import build_index

@@ -554,3 +554,28 @@ def test_eval_driver_with_two_ranks(cuda, mini, tmp_path):
         assert two[:12] == one[0::2] and two[12:23] == one[1::2] and two[23] == one[0]
     assert open(a["metric_path"]).read() == open(a0.metric_path).read()
     assert ret[0]["nqueries"] == n
+
+
+def test_generate_py_gen_doc_cli_with_two_ranks(cuda, mini, tmp_path):
+    """`generate.py --gen_doc --gpus 0,0` as a real command line (mp.spawn, one process per entry of --gpus, part files
+    merged by rank 0; MEVI_DIST_BACKEND=gloo because both ranks sit on this one GPU) against `--gpus 0`."""
+    rng = np.random.default_rng(8)
+    N, L = 301, 16
+    tokens = rng.integers(3, 500, size=(N, L)).astype(np.int64)
+    lens = rng.integers(2, L + 1, size=N)
+    masks = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    tokens[masks == 0] = 0
+    tokens.tofile(tmp_path / "all_document_tokens.bin")
+    masks.tofile(tmp_path / "all_document_masks.bin")
+    model_dir = os.path.join(mini["args"].ckpt_dir, "t5-ance")
+    outs = []
+    for gpus in ("0", "0,0"):
+        out = str(tmp_path / f"emb_{len(gpus)}.bin")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "generate.py"), "--model_path", model_dir, "--tokenizer_path", model_dir,
+                            "--gen_doc", "--document_dir", str(tmp_path), "--doc_embedding_path", out, "--gpus", gpus, "--dim", "32",
+                            "--doc_length", str(L), "--batch_size", "64"],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT, MEVI_DIST_BACKEND="gloo"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.fromfile(out, dtype=np.float32).reshape(N, 32))
+    assert np.array_equal(outs[0], outs[1]) and np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("emb_")) == ["emb_1.bin", "emb_3.bin"]
