@@ -19,12 +19,17 @@ def _distributed_search(query, doc_path, dim, topk):
     import torch
     import torch.distributed as dist
 
+    from mevi_amd.dense import DenseIndex
+    from mevi_amd.io import upload_rows
+
     rank, world = dist.get_rank(), dist.get_world_size()
     n_rows = os.path.getsize(doc_path) // (4 * dim)
     a, b = shard_range(n_rows, rank, world)
-    shard = np.fromfile(doc_path, dtype=np.float32, count=(b - a) * dim, offset=a * dim * 4).reshape(-1, dim)
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    s, i = sharded_ip_topk(torch.from_numpy(query).to(dev), torch.from_numpy(shard).to(dev), topk, id_offset=a)
+    shard = np.memmap(doc_path, dtype=np.float32, mode="r", offset=a * dim * 4, shape=(b - a, dim))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    index = DenseIndex(upload_rows(shard, dev))                  # this rank's rows of index.add(doc)
+    q = torch.from_numpy(np.ascontiguousarray(query, dtype=np.float32)).to(dev)
+    s, i = sharded_ip_topk(q, index, topk, id_offset=a)
     return s.cpu().numpy(), i.cpu().numpy()
 
 
@@ -45,7 +50,7 @@ if __name__ == "__main__":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"))
         print(f"Param {args.param} trained: True.")
         dists, indices = _distributed_search(query, args.doc_path, args.dim, args.topk)

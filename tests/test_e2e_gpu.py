@@ -579,3 +579,27 @@ def test_generate_py_gen_doc_cli_with_two_ranks(cuda, mini, tmp_path):
         outs.append(np.fromfile(out, dtype=np.float32).reshape(N, 32))
     assert np.array_equal(outs[0], outs[1]) and np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("emb_")) == ["emb_1.bin", "emb_3.bin"]
+
+
+def test_faiss_search_py_under_torchrun_with_two_ranks(cuda, mini, tmp_path):
+    """`torchrun --nproc-per-node 2 faiss_search.py ...`: the corpus file is row-sharded over the ranks, every rank
+    searches its rows with global ids, rank 0 writes the merged TSV -- byte-identical to the single-process run."""
+    import socket
+
+    d, a = mini["dir"], mini["args"]
+    q = np.random.default_rng(2).standard_normal((len(mini["queries"]), 32)).astype(np.float32)
+    q.tofile(tmp_path / "q.bin")
+    base = [os.path.join(ROOT, "faiss_search.py"), "--query_path", str(tmp_path / "q.bin"), "--doc_path", a.embedding_path,
+            "--raw_query_path", str(d / "origin" / "dev_mevi_dedup.tsv"), "--dim", "32", "--topk", "300", "--param", "Flat"]
+    env = dict(os.environ, PYTHONPATH=ROOT, MEVI_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable] + base + ["--output_path", str(tmp_path / "one.txt")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port)] + base + ["--output_path", str(tmp_path / "two.txt")],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert open(tmp_path / "one.txt", "rb").read() == open(tmp_path / "two.txt", "rb").read()
