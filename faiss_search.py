@@ -7,12 +7,13 @@ is answered with EXACT search (the "Flat" result), see SURVEY D2.
 With torch.distributed initialised (torchrun) the corpus file is row-sharded across ranks.
 """
 import argparse
+import datetime
 import os
 
 import numpy as np
 
-from mevi_amd.dense import search, shard_range, sharded_ip_topk  # noqa: F401  (API parity: search)
-from mevi_amd.io import read, to_file  # noqa: F401
+from mevi_amd.dense import is_trained_before_train, search, shard_range, sharded_ip_topk  # noqa: F401  (API parity: search)
+from mevi_amd.io import map_rows, read, to_file  # noqa: F401
 
 
 def _distributed_search(query, doc_path, dim, topk):
@@ -25,7 +26,7 @@ def _distributed_search(query, doc_path, dim, topk):
     rank, world = dist.get_rank(), dist.get_world_size()
     n_rows = os.path.getsize(doc_path) // (4 * dim)
     a, b = shard_range(n_rows, rank, world)
-    shard = np.memmap(doc_path, dtype=np.float32, mode="r", offset=a * dim * 4, shape=(b - a, dim))
+    shard = map_rows(doc_path, dim, rows=b - a, first_row=a)    # zero rows when there are fewer rows than ranks
     dev = torch.device("cuda", torch.cuda.current_device())
     index = DenseIndex(upload_rows(shard, dev))                  # this rank's rows of index.add(doc)
     q = torch.from_numpy(np.ascontiguousarray(query, dtype=np.float32)).to(dev)
@@ -51,8 +52,9 @@ if __name__ == "__main__":
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"))
-        print(f"Param {args.param} trained: True.")
+        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), timeout=datetime.timedelta(hours=24))
+        if dist.get_rank() == 0:
+            print(f"Param {args.param} trained: {is_trained_before_train(args.param)}.")
         dists, indices = _distributed_search(query, args.doc_path, args.dim, args.topk)
         if dist.get_rank() == 0:
             print(indices.dtype, indices.shape, dists.dtype, dists.shape)

@@ -15,10 +15,18 @@ import socket
 import numpy as np
 import pandas as pd
 
+from mevi_amd.io import flush_rows, map_rows
+
 
 # padded tokens per device pass (= mevi_amd.t5.DEVICE_PASS_TOKENS); --batch_size only raises it: the embeddings do not
 # depend on how rows are grouped, the reference's 128 rows per pass would leave the GPU mostly idle
 DEVICE_PASS_TOKENS = 262144
+
+# rank 0 concatenates the part files (27 GB for the corpus) while the others wait in a barrier: the reference's
+# 24-hour collective timeout (generate.py:69,135), not the 10-minute default
+import datetime  # noqa: E402
+
+DIST_TIMEOUT = datetime.timedelta(hours=24)
 
 
 def get_tokenizer(model_path):
@@ -68,7 +76,8 @@ def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path,
 
     nrank = len(gpus)
     if nrank > 1:
-        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), rank=rank, world_size=nrank)
+        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), rank=rank, world_size=nrank,
+                                timeout=DIST_TIMEOUT)
     device = torch.device(f"cuda:{gpus[rank]}")
     torch.cuda.set_device(device)
     encoder = encoder or load_document_encoder(model_path, ckpt_path, device)
@@ -76,24 +85,24 @@ def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path,
     df = pd.read_csv(query_file, names=["query", "oldid"], encoding="utf-8", header=None, sep="\t")["query"]
     start, end = rank_range(len(df), rank, nrank)
     cur_path = output_path[:-4] + f"_{rank}.bin" if nrank > 1 else output_path
-    out = np.memmap(cur_path, dtype=np.float32, mode="w+", shape=(end - start, dim))
+    out = map_rows(cur_path, dim, "w+", rows=end - start)
     batch_size = max(batch_size, DEVICE_PASS_TOKENS // query_length)    # see DEVICE_PASS_TOKENS
     for s in range(start, end, batch_size):
         e = min(s + batch_size, end)
         tok = tokenizer.batch_encode_plus(list(df[s:e]), max_length=query_length, padding="max_length",
                                           truncation=True, return_tensors="pt")
         out[s - start:e - start] = encoder.encode_query(tok).cpu().numpy()
-    out.flush()
+    flush_rows(out)
     if nrank > 1:
         dist.barrier()
         if rank == 0:
-            allq = np.memmap(output_path, dtype=np.float32, mode="w+", shape=(len(df), dim))
+            allq = map_rows(output_path, dim, "w+", rows=len(df))
             at = 0
             for r in range(nrank):
-                part = np.memmap(output_path[:-4] + f"_{r}.bin", dtype=np.float32, mode="r").reshape(-1, dim)
+                part = map_rows(output_path[:-4] + f"_{r}.bin", dim)
                 allq[at:at + part.shape[0]] = part
                 at += part.shape[0]
-            allq.flush()
+            flush_rows(allq)
             for r in range(nrank):
                 os.remove(output_path[:-4] + f"_{r}.bin")
         dist.barrier()
@@ -109,7 +118,8 @@ def gen_doc_embedding(rank, document_dir, model_path, ckpt_path, output_path, ba
 
     nrank = len(gpus)
     if nrank > 1:
-        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), rank=rank, world_size=nrank)
+        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), rank=rank, world_size=nrank,
+                                timeout=DIST_TIMEOUT)
     device = torch.device(f"cuda:{gpus[rank]}")
     torch.cuda.set_device(device)
     encoder = encoder or load_document_encoder(model_path, ckpt_path, device)
@@ -118,26 +128,26 @@ def gen_doc_embedding(rank, document_dir, model_path, ckpt_path, output_path, ba
     n = tokens.shape[0]
     start, end = doc_rank_range(n, rank, nrank)
     part_path = output_path[:-4] + f"_{rank}.bin"
-    part = np.memmap(part_path, dtype=np.float32, mode="w+", shape=(end - start, dim))
+    part = map_rows(part_path, dim, "w+", rows=end - start)
     batch_size = max(batch_size, DEVICE_PASS_TOKENS // doc_length)
     for s in range(start, end, batch_size):
         e = min(s + batch_size, end)
         psg = {"input_ids": torch.from_numpy(np.array(tokens[s:e])),
                "attention_mask": torch.from_numpy(np.array(masks[s:e]))}
         part[s - start:e - start] = encoder.encode_passage(psg).cpu().numpy()
-    part.flush()
+    flush_rows(part)
     del part
     if nrank > 1:
         dist.barrier()
     if rank == 0:
-        allp = np.memmap(output_path, dtype=np.float32, mode="w+", shape=(n, dim))
+        allp = map_rows(output_path, dim, "w+", rows=n)
         at = 0
         for r in range(nrank):
-            p_ = np.memmap(output_path[:-4] + f"_{r}.bin", dtype=np.float32, mode="r").reshape(-1, dim)
+            p_ = map_rows(output_path[:-4] + f"_{r}.bin", dim)
             allp[at:at + p_.shape[0]] = p_
             at += p_.shape[0]
             del p_
-        allp.flush()
+        flush_rows(allp)
         del allp
         for r in range(nrank):
             os.remove(output_path[:-4] + f"_{r}.bin")

@@ -10,6 +10,7 @@ One process per GPU: `--n_gpu N` spawns N ranks itself like the reference (queri
 rank-local TSVs merged by rank 0 between two barriers); torchrun launches are honoured too.
 """
 import argparse
+import datetime
 import os
 import socket
 import sys
@@ -141,7 +142,10 @@ def partial_inference(rank, args):
     torch.cuda.set_device(gpu)
     barrier = None
     if nrank > 1:
-        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), rank=rank, world_size=nrank)
+        # rank 0 alone trains the RQ codebook / pickles 8.8 M-entry dicts while the others wait: 24 h like the reference
+        # (main.py:285-287), not the 10-minute default
+        dist.init_process_group(os.environ.get("MEVI_DIST_BACKEND", "nccl"), rank=rank, world_size=nrank,
+                                timeout=datetime.timedelta(hours=24))
         barrier = dist.barrier
     if args.mode == "train":      # --only_gen_rq 1 (check_supported)
         from mevi_amd.indexbuild import build_index

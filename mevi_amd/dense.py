@@ -210,6 +210,20 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
     return ms, mi
 
 
+def is_trained_before_train(param):
+    """What `faiss.index_factory(dim, param).is_trained` reports BEFORE `index.train` (the value the reference prints,
+    MEVI/faiss_search.py:16): False for every component that learns from data -- IVF coarse quantisers, product /
+    scalar / residual quantisers, OPQ / PCA / ITQ transforms --, True for Flat, HNSW over Flat storage, LSH, IDMap."""
+    learns = ("IVF", "IMI", "PQ", "OPQ", "PCA", "ITQ", "SQ", "RQ", "LSQ", "PRQ", "PLSQ")
+    for comp in str(param).split(","):
+        c = comp.strip()
+        if c.startswith("HNSW") and "_" in c:                  # HNSW32_PQ8 ...: storage given after the underscore
+            c = c.split("_", 1)[1]
+        if c.startswith(learns):
+            return False
+    return True
+
+
 def search(query, doc, dim, topk, param="Flat", device=None):
     """Drop-in for faiss_search.search (MEVI/faiss_search.py:13-21).
 
@@ -220,7 +234,7 @@ def search(query, doc, dim, topk, param="Flat", device=None):
     """
     hip.require_gpu()
     device = torch.device(device if device is not None else "cuda")
-    print(f"Param {param} trained: True.")  # reference prints index.is_trained
+    print(f"Param {param} trained: {is_trained_before_train(param)}.")  # index.is_trained before index.train
     q = _as_device_f32(np.asarray(query).reshape(-1, dim) if isinstance(query, np.ndarray) else query, device)
     d = _as_device_f32(np.asarray(doc).reshape(-1, dim) if isinstance(doc, np.ndarray) else doc, device)
     if topk > MAX_K:

@@ -217,7 +217,11 @@ class EvalRun:
         self.pq = ProductQuantization("rq", self.M, a.subvector_bits, "l2", d_model, device=self.dev)
         self.pq.initialize(a.pq_path, rank=0)
         map_path = a.pq_cluster_path.replace("clus", "mapping")
-        if os.path.exists(a.pq_cluster_path) and os.path.exists(map_path):
+        # every rank looks BEFORE anyone writes (barrier), so all ranks take the same branch and the barriers below pair
+        # up: a rank arriving after rank 0 had written the pickles used to skip rank 0's barrier (one-off from then on)
+        have_clusters = os.path.exists(a.pq_cluster_path) and os.path.exists(map_path)
+        self.barrier()
+        if have_clusters:
             with open(a.pq_cluster_path, "rb") as f:
                 self.index = ClusterIndex.from_dict(pickle.load(f), self.M, self.K)
             # rqmapping*.pkl is the inverse of the cluster dict (gen_pq_doc_cluster writes both from one encode); it is
@@ -231,7 +235,7 @@ class EvalRun:
                 with open(map_path, "wb") as f:
                     pickle.dump(mapping, f)
                 del cluster, mapping
-            self.barrier()
+        self.barrier()
         self.mapping = CodeMap(self.index.doc_codes(n_docs))
         print("Number of all pq document clusters:", len(self.index.keys))
         # --doc_multiclus C > 1 (gen_pq_doc_topk, main_models.py:3222-3262): every document also belongs to the clusters of
@@ -242,11 +246,13 @@ class EvalRun:
             self.aggregate = getattr(a, "multiclus_score_aggr", "add")
             topk_path = a.pq_cluster_path.replace("clus", f"topk{self.C}").replace(".pkl", ".pt")
             multi_path = topk_path.replace("topk", "multiclus").replace(".pt", ".pkl")
-            if not os.path.exists(topk_path):
+            have_topk = os.path.exists(topk_path)
+            self.barrier()                                    # same rule: look first, then write, then meet again
+            if not have_topk:
                 labels = self.pq.get_topk_document_mapping(self.emb, 0, 1, self.C)
                 if rank == 0:
                     torch.save(labels, topk_path)
-                self.barrier()
+            self.barrier()
             self.doc_topk = torch.load(topk_path, map_location="cpu").numpy()
             self.index = ClusterIndex.from_topk_labels(self.doc_topk, self.K)
             if rank == 0 and not os.path.exists(multi_path):

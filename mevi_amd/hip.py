@@ -112,5 +112,21 @@ def stream_ptr():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def on_device(fn):
+    """Run `fn` with its first tensor argument's GPU as the current device, so that `stream_ptr()` and the launch refer
+    to the device the pointers live on (the public classes take `device=`; callers need not torch.cuda.set_device)."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(*args, **kw):
+        t = next((a for a in args if torch.is_tensor(a)), None)
+        if t is None or not t.is_cuda or t.device.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(t.device):
+            return fn(*args, **kw)
+
+    return run
+
+
 def ptr(t):
     return c_void_p(t.data_ptr())

@@ -52,6 +52,27 @@ def upload_rows(src, device, chunk_rows=1 << 18, threads=8):
     return out
 
 
+def map_rows(path, dim, mode="r", rows=None, first_row=0):
+    """np.memmap of rows [first_row, first_row + rows) of a raw f32 [*, dim] file (mode "r"), or a new file of `rows`
+    rows (mode "w+").  A zero-row range -- a rank beyond the data when there are fewer rows than ranks, an empty part
+    file -- is an empty array (np.memmap refuses to map zero bytes); in "w+" mode the (empty) file is still created."""
+    if mode == "r":
+        if rows is None:
+            rows = os.path.getsize(path) // (4 * dim) - first_row
+        if rows <= 0:
+            return np.empty((0, dim), np.float32)
+        return np.memmap(path, dtype=np.float32, mode="r", offset=first_row * dim * 4, shape=(rows, dim))
+    if rows == 0:
+        open(path, "wb").close()
+        return np.empty((0, dim), np.float32)
+    return np.memmap(path, dtype=np.float32, mode=mode, shape=(rows, dim))
+
+
+def flush_rows(a):
+    if isinstance(a, np.memmap):
+        a.flush()
+
+
 def read(path, dim):
     """Raw f32 file -> [rows, dim] (raises like numpy if the size does not divide).  Large files (the 27 GB corpus) come
     back as a read-only memory map -- an ndarray too -- so that the only copy made is the one into the upload's staging

@@ -17,6 +17,7 @@ def _rows2d(t):
     return t, t.shape[0], t.shape[1], t.stride(0)
 
 
+@hip.on_device
 def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False):
     """out = act(x @ weight.T + bias) + residual   (x [M,K], weight [N,K] = nn.Linear layout; act = relu, erf-gelu
     or none)."""
@@ -39,6 +40,7 @@ def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False
     return out
 
 
+@hip.on_device
 def rmsnorm(x, weight, eps, out=None):
     x, M, D, ldx = _rows2d(_f32(x))
     if out is None:
@@ -49,6 +51,7 @@ def rmsnorm(x, weight, eps, out=None):
     return out
 
 
+@hip.on_device
 def add_layernorm(x, y, weight, bias, eps=1e-5, cvec=None, out=None):
     x, M, D, ldx = _rows2d(_f32(x))
     if out is None:
@@ -64,6 +67,7 @@ def add_layernorm(x, y, weight, bias, eps=1e-5, cvec=None, out=None):
     return out
 
 
+@hip.on_device
 def gather_rows(table, idx, out=None):
     table, _, D, ldt = _rows2d(_f32(table))
     idx = idx.to(device=table.device, dtype=torch.int64).contiguous().view(-1)
@@ -76,6 +80,7 @@ def gather_rows(table, idx, out=None):
     return out
 
 
+@hip.on_device
 def scatter_rows(src, idx, out):
     """out[idx[r]] = src[r] (distinct rows); returns `out`."""
     src, n, D, lds_ = _rows2d(_f32(src))
@@ -87,6 +92,7 @@ def scatter_rows(src, idx, out):
     return out
 
 
+@hip.on_device
 def scale(x, alpha):
     x = _f32(x).contiguous()
     out = torch.empty_like(x)
@@ -95,6 +101,7 @@ def scale(x, alpha):
     return out
 
 
+@hip.on_device
 def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=None, causal=False, scale=1.0,
               kv_off=None, kv_longest=0):
     """q [nb, tq, H*dh], k/v [nb/kv_div, tk, H*dh] (any batch/token strides, last dim contiguous) -- or, with
@@ -134,6 +141,7 @@ def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=
     return out
 
 
+@hip.on_device
 def attention_varlen(q, k, v, seq_off, max_len, heads, bias=None, causal=False, scale=1.0, out=None):
     """Self-attention over packed sequences: q / k / v [T, H*dh] row-strided views, sequence b = rows
     seq_off[b] .. seq_off[b+1]-1 (i64 [nseq+1] on the device), max_len = longest sequence (<= 256)."""
@@ -155,6 +163,7 @@ def attention_varlen(q, k, v, seq_off, max_len, heads, bias=None, causal=False, 
     return out
 
 
+@hip.on_device
 def adaptive_logits(s, t, e, t_index=None):
     """logits[row, c] = sum_d s[row, d] * (t[trow, c*dim + d] + e[c, d]), trow = row or t_index[row]."""
     s, rows, dim, lds = _rows2d(_f32(s))
@@ -172,6 +181,7 @@ def adaptive_logits(s, t, e, t_index=None):
     return out
 
 
+@hip.on_device
 def beam_step(logits, beam_scores, K, R, final_step=False):
     """logits [nq*nb, K+1] (col 0 eos), beam_scores [nq, nb] -> (scores, parent, code) [nq, R],
     or final scores [nq, nb] when final_step."""
@@ -195,6 +205,7 @@ def beam_step(logits, beam_scores, K, R, final_step=False):
     return sc, parent, code
 
 
+@hip.on_device
 def pair_dot(a, ia, b, ib):
     a, _, dim, lda = _rows2d(_f32(a))
     b, _, dim2, ldb = _rows2d(_f32(b))
@@ -210,6 +221,7 @@ def pair_dot(a, ia, b, ib):
     return out
 
 
+@hip.on_device
 def segment_sort_desc(scores, ids, seg_offsets, max_seg_len):
     scores = _f32(scores).contiguous()
     ids = ids.to(device=scores.device, dtype=torch.int64).contiguous()

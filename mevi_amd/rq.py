@@ -323,6 +323,10 @@ class ProductQuantization:
         softmax(-distance) times the running beam probability, top-R over beams x K.  Returns labels
         i32[bs, R, M] (and probabilities f32[bs, R])."""
         assert not do_sample and num_beams in (None, num_return_sequences)
+        with torch.cuda.device(self.device):          # stream_ptr() and the launches below refer to the codebook's GPU
+            return self._beam_search(doc_emb, num_return_sequences, return_proba)
+
+    def _beam_search(self, doc_emb, num_return_sequences, return_proba):
         L = hip.lib()
         R, M, K, dim = num_return_sequences, self.subvector_num, self.subvector_cents, self.emb_size
         x = doc_emb.to(self.device, torch.float32).contiguous()

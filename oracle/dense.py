@@ -98,3 +98,35 @@ def ip_topk_blas(query, docs, k, id_offset=0, block=16384):
 
 def num_threads():
     return lib().oracle_num_threads()
+
+
+def pair_dot(query, docs):
+    """<query, docs[j]> for every row j with the sequential fmaf chain (oracle_dot_f32): the scoring call of the
+    fine stage, DocumentEncoder.generate(q, p_reps=rows).scores = torch.matmul (MEVI/document_encoder.py:128-132,
+    213-226), with the summation order pinned like the dense arm's."""
+    from ctypes import c_float
+
+    L = lib()
+    L.oracle_dot_f32.restype = c_float
+    L.oracle_dot_f32.argtypes = [c_void_p, c_void_p, c_int64]
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    d = np.ascontiguousarray(docs, dtype=np.float32).reshape(-1, q.shape[0])
+    return np.array([L.oracle_dot_f32(_p(q), d[j].ctypes.data, q.shape[0]) for j in range(d.shape[0])], np.float32)
+
+
+def fine_stage(query, emb, doc_cluster, beam_codes):
+    """Fine stage of infer() for ONE query (MEVI/main_models.py:3921-4013, single-cluster documents): the documents
+    of the beam clusters in beam order (a repeated cluster is listed -- and scored -- again, an absent one skipped),
+    scored by q.d, sorted descending.  Pinned here: fmaf-chain scores, ties by ascending doc id (torch.sort leaves
+    the order of equal scores unspecified).  Returns (doc ids i64, scores f32, ndoc)."""
+    docs = []
+    for code in beam_codes:
+        cur = doc_cluster.get(tuple(int(x) for x in code))
+        if cur is not None:
+            docs += list(cur)
+    docs = np.array(docs, dtype=np.int64)
+    if docs.size == 0:
+        return docs, np.zeros(0, np.float32), 0
+    sc = pair_dot(query, np.asarray(emb, dtype=np.float32)[docs])
+    order = np.lexsort((docs, -sc))
+    return docs[order], sc[order], int(docs.size)

@@ -108,37 +108,38 @@ def test_nci_generate_matches_reference_golden(cuda, path):
     assert np.array_equal(codes.cpu().numpy(), ot5.decode_token(torch.from_numpy(g["decoded"]), cfg["K"]).numpy())
 
 
-def test_base_shape_model_against_oracle(cuda):
-    """t5-base widths (d 768, ff 3072, 12x64 heads, adaptor heads of 96) with few layers, seeded random
-    weights with the reference's initialiser scales: HIP path vs the torch-fp32 oracle."""
-    torch.manual_seed(0)
-    M, K, R = 4, 32, 10
-    cfg = dict(M=M, K=K, d_model=768, d_ff=3072, num_heads=12, d_kv=64, num_layers=2, num_decoder_layers=2,
-               adaptor_layer_num=2, layer_norm_epsilon=1e-6, relative_attention_num_buckets=32)
-    V, d = K * (M + 2) + 2, 768
+def _seeded_nci_weights(M, K, d, d_ff, heads, enc_layers=2, dec_layers=2, adaptor_layers=2):
+    """Seeded random weights with the reference's initialiser scales (modeling_t5.py:603-633; nn.TransformerDecoder
+    defaults for the adaptor; adaptor_embeddings ~ U(0,1) :1252) under the reference's state_dict names."""
+    inner = heads * 64
+    cfg = dict(M=M, K=K, d_model=d, d_ff=d_ff, num_heads=heads, d_kv=64, num_layers=enc_layers, num_decoder_layers=dec_layers,
+               adaptor_layer_num=adaptor_layers, layer_norm_epsilon=1e-6, relative_attention_num_buckets=32)
+    V = K * (M + 2) + 2
     W = {"shared.weight": torch.randn(1000, d), "decode_embeddings.weight": torch.randn(V, d),
          "adaptor_embeddings": torch.rand(1, 1, d), "adaptor_linear.weight": torch.randn(d * V, d) * d ** -0.5 * 0.3}
     W["lm_head.weight"] = W["decode_embeddings.weight"]
-    for st, nl, dec in (("encoder", 2, False), ("decoder", 2, True)):
-        for l in range(nl):
+    for st, dec, layers in (("encoder", False, enc_layers), ("decoder", True, dec_layers)):
+        for l in range(layers):
             p = f"{st}.block.{l}.layer"
-            W[f"{p}.0.SelfAttention.q.weight"] = torch.randn(d, d) * (d * 64) ** -0.5
-            for n in "kvo":
-                W[f"{p}.0.SelfAttention.{n}.weight"] = torch.randn(d, d) * d ** -0.5
+            W[f"{p}.0.SelfAttention.q.weight"] = torch.randn(inner, d) * (d * 64) ** -0.5
+            for n in "kv":
+                W[f"{p}.0.SelfAttention.{n}.weight"] = torch.randn(inner, d) * d ** -0.5
+            W[f"{p}.0.SelfAttention.o.weight"] = torch.randn(d, inner) * inner ** -0.5
             W[f"{p}.0.layer_norm.weight"] = 1 + 0.1 * torch.randn(d)
             ff = 1
             if dec:
-                W[f"{p}.1.EncDecAttention.q.weight"] = torch.randn(d, d) * (d * 64) ** -0.5
-                for n in "kvo":
-                    W[f"{p}.1.EncDecAttention.{n}.weight"] = torch.randn(d, d) * d ** -0.5
+                W[f"{p}.1.EncDecAttention.q.weight"] = torch.randn(inner, d) * (d * 64) ** -0.5
+                for n in "kv":
+                    W[f"{p}.1.EncDecAttention.{n}.weight"] = torch.randn(inner, d) * d ** -0.5
+                W[f"{p}.1.EncDecAttention.o.weight"] = torch.randn(d, inner) * inner ** -0.5
                 W[f"{p}.1.layer_norm.weight"] = 1 + 0.1 * torch.randn(d)
                 ff = 2
-            W[f"{p}.{ff}.DenseReluDense.wi.weight"] = torch.randn(3072, d) * d ** -0.5
-            W[f"{p}.{ff}.DenseReluDense.wo.weight"] = torch.randn(d, 3072) * 3072 ** -0.5
+            W[f"{p}.{ff}.DenseReluDense.wi.weight"] = torch.randn(d_ff, d) * d ** -0.5
+            W[f"{p}.{ff}.DenseReluDense.wo.weight"] = torch.randn(d, d_ff) * d_ff ** -0.5
             W[f"{p}.{ff}.layer_norm.weight"] = 1 + 0.1 * torch.randn(d)
-        W[f"{st}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] = torch.randn(32, 12) * 0.5
+        W[f"{st}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] = torch.randn(32, heads) * 0.5
         W[f"{st}.final_layer_norm.weight"] = 1 + 0.1 * torch.randn(d)
-    for l in range(2):
+    for l in range(adaptor_layers):
         p = f"adaptor.layers.{l}"
         for a in ("self_attn", "multihead_attn"):
             W[f"{p}.{a}.in_proj_weight"] = torch.randn(3 * d, d) * d ** -0.5
@@ -149,6 +150,26 @@ def test_base_shape_model_against_oracle(cuda):
         W[f"{p}.linear2.weight"], W[f"{p}.linear2.bias"] = torch.randn(d, 2048) * 2048 ** -0.5, torch.randn(d) * 0.02
         for n in (1, 2, 3):
             W[f"{p}.norm{n}.weight"], W[f"{p}.norm{n}.bias"] = 1 + 0.1 * torch.randn(d), 0.05 * torch.randn(d)
+    return W, cfg
+
+
+@pytest.mark.parametrize("M,K,d,d_ff,heads,table_bytes,regime", [
+    (4, 32, 768, 3072, 12, 6 << 30, "head matrices for every tabled position"),
+    (4, 32, 768, 3072, 12, 6 << 30, "full depth: 12 encoder, 6 decoder, 4 adaptor layers (t5-base, marco_eval_nci_rq.sh)"),
+    # BASELINE.json configs[2]: 3 levels of 256 codes.  Position 2 has 65 536 prefixes: its head matrices (17 GB at this
+    # width) exceed the budget, so the tables hold ADAPTOR VECTORS ONLY there and the 257-column head GEMM runs per beam
+    (3, 256, 256, 1024, 4, 6 << 30, "adaptor vectors only at position 2"),
+    # budget too small for position 2 at all: the adaptor continues per beam from a cache assembled by lookup
+    (3, 256, 256, 1024, 4, 200 << 20, "tables end before position 2"),
+])
+def test_base_shape_model_against_oracle(cuda, M, K, d, d_ff, heads, table_bytes, regime):
+    """t5-base widths (d 768, ff 3072, 12x64 heads, adaptor heads of 96) with few layers, and the (3, 256) code shape
+    of BASELINE.json at 64-wide heads, seeded random weights with the reference's initialiser scales: HIP path vs the
+    torch-fp32 oracle, in each regime of the prefix tables."""
+    torch.manual_seed(0)
+    R = 10
+    depth = dict(enc_layers=12, dec_layers=6, adaptor_layers=4) if regime.startswith("full depth") else {}
+    W, cfg = _seeded_nci_weights(M, K, d, d_ff, heads, **depth)
     rng = np.random.default_rng(0)
     B, S = 5, 32
     ids = np.zeros((B, S), np.int64)
@@ -160,8 +181,15 @@ def test_base_shape_model_against_oracle(cuda):
         mask[i, :L] = 1
     ids, mask = torch.from_numpy(ids), torch.from_numpy(mask)
     odec, osc, oenc = ot5.nci_generate(W, cfg, ids, mask, R)
-    model = nci.NCIModel(W, device=cuda, **cfg)
+    model = nci.NCIModel(W, device=cuda, prefix_table_bytes=table_bytes, **cfg)
     dec, sc, enc, _ = model.generate(ids, mask, num_beams=R)
+    tab = model.tables()
+    if "only at position 2" in regime:
+        assert tab.levels == 3 and tab.tmat[1] is not None and tab.tmat[2] is None and tab.avec[2] is not None
+    elif "end before" in regime:
+        assert tab.levels == 2
+    else:
+        assert tab.levels == M and all(t is not None for t in tab.tmat)
     valid = mask.bool()                                            # padded positions: don't-care (0 when packed)
     assert (enc.cpu() - oenc)[valid].abs().max() <= 2e-4 * oenc.abs().max()
     sc = np.array(sc)
@@ -170,7 +198,7 @@ def test_base_shape_model_against_oracle(cuda):
     same = (dec.cpu().numpy() == odec.numpy()).all(1)
     gaps = np.abs(np.diff(osc.numpy().reshape(B, R), axis=1)).min()
     assert same.all() or gaps < 4e-4
-    tower = t5.TwinTower(W, device=cuda, num_layers=2, num_decoder_layers=2)
+    tower = t5.TwinTower(W, device=cuda, num_layers=cfg["num_layers"], num_decoder_layers=cfg["num_decoder_layers"])
     reps = tower.encode_query({"input_ids": ids, "attention_mask": mask}).cpu()
     oreps = ot5.tower_encode(W, dict(cfg), ids, mask)
     assert (reps - oreps).abs().max() <= 2e-4 * oreps.abs().max()

@@ -330,7 +330,7 @@ def g1_nci_generate():
     from transformers import T5Config, T5ForConditionalGeneration
     from main_models import TreeBuilder, encode_single_newid
 
-    for (M, K, beams, seed) in [(4, 32, 10, 0), (3, 16, 4, 1), (4, 32, 4, 2)]:
+    for (M, K, beams, seed) in [(4, 32, 10, 0), (3, 16, 4, 1), (4, 32, 4, 2), (3, 256, 10, 3)]:   # last = BASELINE.json configs[2] code shape
         torch.manual_seed(seed)
         cfg = _mevi_t5_config(T5Config, M, K)
         with io.StringIO() as buf, redirect_stdout(buf):
@@ -517,8 +517,120 @@ def g3_relative_buckets():
     print("g3 ok")
 
 
+# --------------------------------------------------------------------------- G9
+def g9_ip_rank():
+    """Inner-product ranking as the reference itself executes it (pins the dense / fine-stage oracle):
+
+    (i)  fine stage of infer(), main_models.py:3921-4013: per beam cluster `doc_cluster.get(code)`, rows gathered
+         from the embedding matrix, `DocumentEncoder.generate(q, p_reps=rows).scores` (= compute_similarity =
+         torch.matmul, document_encoder.py:128-132,213-226) in encode_batch_size slices, torch.cat, np.concatenate,
+         `torch.sort(scores, descending=True)`; plus the gt-document scores of the hard-negative line (:4024-4045);
+    (ii) the --eval_all_documents streaming loop, main_models.py:3818-3876: chunked generate() scores,
+         get_inference_scores(..., eval_all=True) (:3539-3552), running `torch.topk` over cat(stack, new).
+
+    T5FineTunerWithValidation cannot be constructed here (needs spiece.model), so the driver lines are re-issued
+    around the reference's own DocumentEncoder / get_inference_scores objects and the very torch calls infer() makes.
+    Two data sets: 'int' -- small-integer-valued f32 (every partial sum is exact, so BLAS order and the sequential
+    fmaf chain give the same bits; many exact ties), 'flt' -- anisotropic gaussian embeddings (no ties in practice;
+    compared within f32 summation-order tolerance)."""
+    ref_import.setup()
+    import torch
+    from transformers import T5Config, T5Model
+    from document_encoder import DocumentEncoder
+    import main_models
+
+    torch.manual_seed(9)
+    tiny = T5Model(T5Config(vocab_size=32, d_model=8, d_ff=8, num_heads=2, d_kv=4, num_layers=1, num_decoder_layers=1))
+    denc = DocumentEncoder(lm_q=tiny, lm_p=tiny)
+    denc.eval()
+    fake_self = Namespace(args=Namespace(use_topic_model=0))
+    get_inference_scores = main_models.T5FineTunerWithValidation.get_inference_scores
+
+    for name, N, dim, M, K, R, nq, ebs, pools in [("int", 1200, 768, 3, 5, 6, 12, 7, (50, 2000)),
+                                                   ("flt", 1500, 128, 3, 6, 10, 16, 64, (100, 1000))]:
+        rng = np.random.default_rng(900 + dim)
+        if name == "int":
+            emb = rng.integers(-6, 7, size=(N, dim)).astype(np.float32)
+            q = rng.integers(-6, 7, size=(nq, dim)).astype(np.float32)
+            emb[100:110] = emb[5]                      # duplicated passages (exact ties over different ids)
+            emb[700] = emb[699]
+        else:
+            mean = rng.standard_normal(dim).astype(np.float32)
+            emb = (mean + 0.3 * rng.standard_normal((N, dim))).astype(np.float32)
+            q = (mean + 0.3 * rng.standard_normal((nq, dim))).astype(np.float32)
+            q[:8] = emb[rng.integers(0, N, size=8)] + 0.05 * rng.standard_normal((8, dim)).astype(np.float32)
+        codes = rng.integers(0, K, size=(N, M)).astype(np.int32)
+        codes[codes[:, 0] == K - 1, 0] = 0             # no document has a first code of K-1: those clusters are empty
+        doc_cluster = {}
+        for i, c in enumerate(codes):
+            doc_cluster.setdefault(tuple(int(x) for x in c), []).append(i)
+        beams = rng.integers(0, K, size=(nq, R, M)).astype(np.int64)
+        beams[0] = codes[rng.integers(0, N, size=R)]
+        beams[1, 2] = beams[1, 0]                      # a cluster repeated in one beam list (scored twice by infer())
+        beams[2, :, 0] = K - 1                         # every beam cluster empty
+        beams[3, 1, 0] = K - 1                         # one empty cluster among populated ones
+        gt = [[int(x) for x in rng.integers(0, N, size=1 + (i % 2))] for i in range(nq)]
+
+        all_embeddings = torch.from_numpy(emb)
+        query_embedding = torch.from_numpy(q)
+        # ---- (i) fine stage: main_models.py:3813-3815 expands the query embedding once per beam
+        qe = query_embedding.unsqueeze(1).expand(-1, R, -1).reshape(-1, dim)
+        out_docs, out_scores, out_gt, seg, ndoc_all = [], [], [], [0], []
+        q_ind = 0
+        with torch.no_grad():
+            for didx in range(nq):
+                cur_ndoc, scores, docs = 0, [], []
+                for i in range(R):
+                    cur_docs = doc_cluster.get(tuple(int(x) for x in beams[didx, i]), None)
+                    if cur_docs is not None:
+                        cur_ndoc += len(cur_docs)
+                        doc_embedding = all_embeddings[cur_docs]
+                        for start in range(0, len(doc_embedding), ebs):
+                            output = denc.generate(qe[q_ind], p_reps=doc_embedding[start:start + ebs])
+                            scores.append(get_inference_scores(fake_self, None, 0, output.scores))
+                        docs.append(cur_docs)
+                    q_ind += 1
+                if len(scores) > 0:
+                    scores = torch.cat(scores)
+                    docs = np.concatenate(docs, dtype=int)
+                    scores, index = torch.sort(scores, descending=True)
+                    sorted_docs = docs[index.cpu().numpy()].tolist()
+                    scores = scores.numpy()
+                else:
+                    sorted_docs, scores = [], np.zeros(0, np.float32)
+                out_docs += sorted_docs
+                out_scores.append(np.asarray(scores, np.float32))
+                seg.append(len(out_docs))
+                ndoc_all.append(cur_ndoc)
+                gt_out = denc.generate(qe[q_ind - R], p_reps=all_embeddings[gt[didx]])
+                out_gt.append(gt_out.scores.numpy().astype(np.float32))
+        res = dict(emb=emb, q=q, codes=codes, beams=beams, M=M, K=K, encode_batch_size=ebs,
+                   gt_flat=np.array([d for g in gt for d in g], np.int64), gt_len=np.array([len(g) for g in gt], np.int64),
+                   fine_docs=np.array(out_docs, np.int64), fine_scores=np.concatenate(out_scores), fine_seg=np.array(seg, np.int64),
+                   fine_ndoc=np.array(ndoc_all, np.int64), gt_scores=np.concatenate(out_gt))
+        # ---- (ii) eval_all_documents streaming top-k
+        for pool_size in pools:
+            with torch.no_grad():
+                stack_scores = torch.empty([nq, 0], dtype=torch.float)
+                sorted_docs = torch.empty([nq, 0], dtype=torch.int32)
+                for start in range(0, N, ebs * 16):
+                    ending = min(start + ebs * 16, N)
+                    output = denc.generate(query_embedding, p_reps=all_embeddings[start:ending], bmm=False)
+                    new_scores = get_inference_scores(fake_self, None, 0, output.scores, eval_all=True)
+                    new_docs = torch.arange(start, ending, dtype=sorted_docs.dtype).unsqueeze(0).expand(nq, -1)
+                    scores = torch.cat([stack_scores, new_scores], dim=-1)
+                    docs = torch.cat([sorted_docs, new_docs], dim=-1)
+                    stack_scores, doc_indices = torch.topk(scores, k=min(scores.shape[-1], pool_size), dim=-1)
+                    sorted_docs = docs.gather(-1, doc_indices)
+            res[f"all{pool_size}_docs"] = sorted_docs.numpy().astype(np.int64)
+            res[f"all{pool_size}_scores"] = stack_scores.numpy()
+            res[f"all{pool_size}_last_scores"] = scores.numpy()[:, :8].copy()   # the hn line's `scores` quirk (:3904-3907)
+        np.savez_compressed(os.path.join(GOLD, f"g9_ip_rank_{name}.npz"), **res)
+        print("g9", name, "fine lists", len(out_docs), "ndoc", ndoc_all[:6])
+
+
 ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g6n=g6n_consumers_nq, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower, g2p=g2p_t5_passage, g8=g8_bert_tower,
-           g3=g3_relative_buckets)
+           g3=g3_relative_buckets, g9=g9_ip_rank)
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
