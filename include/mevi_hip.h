@@ -126,6 +126,23 @@ int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int64_t ldw, f
                      int64_t ldr, int act, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Split-precision linear layer (the same reference call sites as mevi_gemm_nt_f32, for the T5 / BERT / adaptor
+ * weights; csrc/gemm_split.hip).  Operands are images of f32 rows made by mevi_split_rows_f16:
+ *   row r of x f32[m, k]  ->  img[r] = [hi (kp halves) | lo (kp halves)], kp = mevi_split_kp(k) = k rounded up to 32,
+ *   x = 2^-exps[r] * (hi + lo), hi = f16(x 2^e), lo = f16(x 2^e - hi): 22 significant bits per element.
+ * mevi_gemm_nt_split_f32 computes C = act(A.W^T + bias) + residual with three f16 MFMAs per product
+ * (a_lo w_hi + a_hi w_lo + a_hi w_hi, f32 accumulate): relative error ~3 * 2^-22 per product instead of the exact
+ * chain's 2^-24; every output depends only on its own two rows (same bits in any batch).  c f32 [m, n] (row stride
+ * ldc); bias / residual (row stride ldr) may be NULL; act as mevi_gemm_nt_f32.
+ *   Requirements: k, ldx multiples of 4; x and the images 16-byte aligned; img holds m * 2 * kp halves.
+ * ---------------------------------------------------------------------- */
+int64_t mevi_split_kp(int64_t k);
+int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int32_t *exps, void *stream);
+int mevi_gemm_nt_split_f32(const void *a_img, const int32_t *a_exp, const void *w_img, const int32_t *w_exp,
+                           float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias,
+                           const float *residual, int64_t ldr, int act, void *stream);
+
+/* ------------------------------------------------------------------------
  * Small-shape T5 / adaptor operators (wave-per-row kernels).  Stream-ordered, no workspace.
  * ---------------------------------------------------------------------- */
 /* T5LayerNorm: out = w * (x / sqrt(mean(x^2) + eps))  (MEVI/transformers/modeling_t5.py:155-171) */

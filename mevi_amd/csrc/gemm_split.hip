@@ -1,0 +1,280 @@
+// Split-precision linear layers:  C[M, N] = act(A[M, K] . W[N, K]^T + bias[N]) + residual[M, N]
+//
+// The f32 matrix pipe (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) bounds gemm.hip; the f16 pipe is 16x faster.  Here both
+// operands are held as PAIRS of f16 images with one power-of-two scale per row,
+//     x = 2^-e * (hi + lo),   hi = f16(x 2^e),   lo = f16(x 2^e - hi),   max_k |x_k| 2^e in [2^14, 2^15)
+// (22 significant bits per element; x 2^e - hi is exact in f32), and a product is THREE f16 MFMAs accumulated in f32:
+//     a.w  ~=  a_lo w_hi + a_hi w_lo + a_hi w_hi          (the a_lo w_lo term, < 2^-22 relative, is dropped)
+// Products of two f16 are exact in f32, so the only errors are the two operand representations (2^-22 each), the
+// dropped term and the f32 accumulation the exact kernel has as well: ~3 * 2^-22 per product against 2^-24 for the
+// f32 chain.  Used for the T5 / BERT / adaptor linear layers (weights are static: split once at load); the dense arm,
+// the fine stage and the RQ kernels keep their exact f32 chains.  Same role in the reference as gemm.hip
+// (MEVI/transformers/modeling_t5.py:181-186, 217-220, 350-358, 412; modeling_bert.py linear layers).
+//
+// Kernel = the persistent LDS-DMA tile stream of the dense pre-filter (mfma_pp_f16.h): 256 x 256 output tiles, 8 waves,
+// one v_mfma_f32_32x32x16_f16 per 16 k.  An image row is [hi (Kp halves) | lo (Kp halves)], Kp = K rounded up to 32;
+// the K loop walks 3 * Kp/32 units: segment 0 = a_lo w_hi, 1 = a_hi w_lo, 2 = a_hi w_hi (small terms first) -- only
+// the unit -> byte-offset map differs from the filter.  Every output depends on its own A row, its own W row and this
+// fixed k order only, so a row has the same bits whatever batch it travels in; gemm_split_skinny_kernel (few
+// outputs: the latency path) issues the identical MFMA sequence from global memory and therefore returns the same bits.
+#include <cstdlib>
+
+#include "mfma_pp_f16.h"
+
+namespace mevi {
+namespace {
+
+__device__ __forceinline__ int pow2_exp(float m) {
+  // e with m * 2^e in [2^14, 2^15); clamped so that 2^e and 2^-e stay finite normal floats
+  if (!(m > 0.f) || isinf(m)) return 0;
+  int e;
+  (void)frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
+  int s = 15 - e;
+  return s > 100 ? 100 : (s < -100 ? -100 : s);
+}
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const float4 v, int e, h4 &hi, h4 &lo) {
+  const float x[4] = {ldexpf(v.x, e), ldexpf(v.y, e), ldexpf(v.z, e), ldexpf(v.w, e)};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (_Float16)x[i];
+    lo[i] = (_Float16)(x[i] - (float)hi[i]);
+  }
+}
+
+// rows of x f32[m, k] (row stride ldx) -> image [m, 2 * kp] halves + exponent per row.  One wave per row.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ x, long long ldx, long long m, int k,
+                                                        int kp, _Float16 *__restrict__ img, int *__restrict__ exps) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= m) return;
+  const int lane = threadIdx.x & 63;
+  const float *xr = x + (size_t)r * ldx;
+  float mx = 0.f;
+  for (int c = lane * 4; c < k; c += 256) {
+    const float4 v = *reinterpret_cast<const float4 *>(xr + c);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  const int e = pow2_exp(mx);
+  _Float16 *o = img + (size_t)r * 2 * kp;
+  for (int c = lane * 4; c < kp; c += 256) {
+    h4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+    if (c < k) split4(*reinterpret_cast<const float4 *>(xr + c), e, hi, lo);
+    *reinterpret_cast<h4 *>(o + c) = hi;
+    *reinterpret_cast<h4 *>(o + kp + c) = lo;
+  }
+  if (lane == 0) exps[r] = e;
+}
+
+struct SplitUnits {
+  int U;         // units per segment (kp / 32)
+  int lo_bytes;  // byte offset of the lo half of a row (kp * 2)
+  bool is_a;     // this wave stages the A operand (waves 0-3) or W (waves 4-7)
+  __device__ __forceinline__ int operator()(int u) const {
+    const int seg = (u >= U) + (u >= 2 * U);
+    const int uu = u - seg * U;
+    const bool lo = is_a ? (seg == 0) : (seg == 1);
+    return uu * 64 + (lo ? lo_bytes : 0);
+  }
+};
+
+__device__ __forceinline__ float epilogue(float acc, int e, float b, bool has_bias, int act) {
+  float v = ldexpf(acc, -e);
+  if (has_bias) v += b;
+  if (act == 1) v = fmaxf(v, 0.f);
+  else if (act == 2) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752f));  // erf GELU (BERT 'gelu')
+  return v;
+}
+
+__global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
+    const _Float16 *__restrict__ A, const int *__restrict__ ea, int M, const _Float16 *__restrict__ W,
+    const int *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int act, int n_mtiles, int n_ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nwg = n_mtiles * n_ntiles;
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int range_base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;  // as xcd_remap
+  const int range_len = q8 + (xcd < r8 ? 1 : 0);
+  int item = blockIdx.x >> 3;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = w8 >> 2, wm = (w8 >> 1) & 1, wn = w8 & 1;
+  const int lrow = lane & 31, half = lane >> 5;
+  const int row_bytes = kp * 4;
+  int head_m = 0, head_n = 0, tail_m = 0, tail_n = 0, n_pend = 0;  // tiles fetched ahead of their epilogue (<= 2)
+
+  auto next = [&](H1Src &s) -> bool {
+    if (item >= range_len) return false;
+    int mt, nt;
+    supertile_order<4, 8>(range_base + item, n_mtiles, n_ntiles, mt, nt);
+    item += per_xcd;
+    if (n_pend == 0) head_m = mt, head_n = nt;
+    else tail_m = mt, tail_n = nt;
+    ++n_pend;
+    long long rows_left;
+    if (w8 < 4) {  // waves 0-3 stage the 256 A rows (LDS rows [0, 256)), waves 4-7 the 256 W rows
+      s.src = reinterpret_cast<const char *>(A) + (size_t)mt * 256 * (size_t)row_bytes;
+      rows_left = (long long)M - (long long)mt * 256;
+    } else {
+      s.src = reinterpret_cast<const char *>(W) + (size_t)nt * 256 * (size_t)row_bytes;
+      rows_left = (long long)N - (long long)nt * 256;
+    }
+    if (rows_left > 256) rows_left = 256;
+    s.bytes = (unsigned int)(rows_left * row_bytes);
+    return true;
+  };
+  auto begin = [&]() {};
+  auto emit = [&](f32x16 (&acc)[2][4]) {
+    const int mt = head_m, nt = head_n;
+    head_m = tail_m, head_n = tail_n;
+    --n_pend;
+    const int mb = mt * 256 + 128 * grp + 64 * wm + 4 * half;
+    const int nb = nt * 256 + 128 * wn + lrow;
+    int em[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + 32 * mi + (r & 3) + 8 * (r >> 2);
+        em[mi][r] = m < M ? ea[m] : 0;
+      }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = nb + 32 * ni;
+      if (n >= N) continue;
+      const int en = ew[n];
+      const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + 32 * mi + (r & 3) + 8 * (r >> 2);
+          if (m < M) {
+            float v = epilogue(acc[mi][ni][r], em[mi][r] + en, b, bias != nullptr, act);
+            if (residual) v += residual[(size_t)m * ldr + n];
+            C[(size_t)m * ldc + n] = v;
+          }
+        }
+      }
+    }
+  };
+  SplitUnits uoff;
+  uoff.U = kp / 32;
+  uoff.lo_bytes = kp * 2;
+  uoff.is_a = w8 < 4;
+  h1_tile_stream(row_bytes, 3 * (kp / 32), lds, next, begin, emit, uoff);
+}
+
+// Few outputs: one wave per 32 x 32 outputs, fragments straight from global memory (the images of a handful of rows
+// sit in L2), the same MFMA sequence as the tile stream: segments 0..2, units in order, k-steps j = 0, 1, lane
+// (row, half) supplying k = 32 u + 16 j + 8 half + [0, 8).
+__global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
+    const _Float16 *__restrict__ A, const int *__restrict__ ea, int M, const _Float16 *__restrict__ W,
+    const int *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lrow = lane & 31, half = lane >> 5;
+  const int n0 = (blockIdx.x * 4 + wave) * 32, m0 = blockIdx.y * 32;
+  if (n0 >= N) return;
+  const int ar = m0 + lrow < M ? m0 + lrow : M - 1;
+  const int wr = n0 + lrow < N ? n0 + lrow : N - 1;
+  const _Float16 *pa = A + (size_t)ar * 2 * kp + 8 * half;
+  const _Float16 *pw = W + (size_t)wr * 2 * kp + 8 * half;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int seg = 0; seg < 3; ++seg) {
+    const _Float16 *a = pa + (seg == 0 ? kp : 0);
+    const _Float16 *w = pw + (seg == 1 ? kp : 0);
+#pragma unroll 4
+    for (int k = 0; k < kp; k += 16) {
+      const f16x8 fa = *reinterpret_cast<const f16x8 *>(a + k);
+      const f16x8 fw = *reinterpret_cast<const f16x8 *>(w + k);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fw, acc, 0, 0, 0);
+    }
+  }
+  const int n = n0 + lrow;
+  if (n >= N) return;
+  const int en = ew[n];
+  const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (m < M) {
+      float v = epilogue(acc[r], ea[m] + en, b, bias != nullptr, act);
+      if (residual) v += residual[(size_t)m * ldr + n];
+      C[(size_t)m * ldc + n] = v;
+    }
+  }
+}
+
+constexpr long long SPLIT_SKINNY_MAX_OUTPUTS = 500000;  // as gemm.hip's SK_MAX_OUTPUTS
+
+}  // namespace
+}  // namespace mevi
+
+using namespace mevi;
+
+extern "C" int64_t mevi_split_kp(int64_t k) { return (k + 31) / 32 * 32; }
+
+extern "C" int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int32_t *exps,
+                                   void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(m >= 0 && k > 0, MEVI_ERR_INVALID_ARG, "split_rows: bad shape");
+  if (m == 0) return MEVI_OK;
+  MEVI_REQUIRE(x && img && exps, MEVI_ERR_INVALID_ARG, "split_rows: null pointer");
+  MEVI_REQUIRE(k % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)img % 16) == 0,
+               MEVI_ERR_UNSUPPORTED, "split_rows: k, ldx must be multiples of 4 and x, img 16-byte aligned");
+  MEVI_REQUIRE(k < (1LL << 22), MEVI_ERR_UNSUPPORTED, "split_rows: k too large");
+  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, x, (long long)ldx,
+                     (long long)m, (int)k, (int)mevi_split_kp(k), reinterpret_cast<_Float16 *>(img), exps);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_gemm_nt_split_f32(const void *a_img, const int32_t *a_exp, const void *w_img, const int32_t *w_exp,
+                                      float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias,
+                                      const float *residual, int64_t ldr, int act, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(m >= 0 && n >= 0 && k > 0, MEVI_ERR_INVALID_ARG, "gemm_nt_split: bad shape");
+  if (m == 0 || n == 0) return MEVI_OK;
+  MEVI_REQUIRE(a_img && a_exp && w_img && w_exp && c, MEVI_ERR_INVALID_ARG, "gemm_nt_split: null pointer");
+  MEVI_REQUIRE(((uintptr_t)a_img % 16) == 0 && ((uintptr_t)w_img % 16) == 0, MEVI_ERR_INVALID_ARG,
+               "gemm_nt_split: images must be 16-byte aligned");
+  MEVI_REQUIRE(act >= 0 && act <= 2, MEVI_ERR_INVALID_ARG, "gemm_nt_split: act must be 0 (none), 1 (relu) or 2 (erf gelu)");
+  MEVI_REQUIRE(m < (1LL << 31) && n < (1LL << 31) && k < (1LL << 20), MEVI_ERR_UNSUPPORTED, "gemm_nt_split: too large");
+  const int kp = (int)mevi_split_kp(k);
+  const _Float16 *A = reinterpret_cast<const _Float16 *>(a_img), *W = reinterpret_cast<const _Float16 *>(w_img);
+  static const int skinny_on = [] { const char *e = getenv("MEVI_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+  if (m * n <= SPLIT_SKINNY_MAX_OUTPUTS && skinny_on) {
+    hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3((unsigned)((n + 127) / 128), (unsigned)((m + 31) / 32)), dim3(256), 0,
+                       stream, A, a_exp, (int)m, W, w_exp, (int)n, kp, c, (long long)ldc, bias, residual, (long long)ldr, act);
+    MEVI_HIP_CHECK(hipGetLastError());
+    return MEVI_OK;
+  }
+  const int64_t n_mtiles = (m + 255) / 256, n_ntiles = (n + 255) / 256;
+  MEVI_REQUIRE(n_mtiles * n_ntiles <= 0x7fffffffLL, MEVI_ERR_UNSUPPORTED, "gemm_nt_split: grid too large");
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  int64_t grid = n_cu / 8 * 8;  // persistent: one workgroup per CU, a multiple of the 8 XCDs
+  if (grid < 8) grid = 8;
+  const int64_t tiles = n_mtiles * n_ntiles;
+  if (tiles < grid) grid = (tiles + 7) / 8 * 8;
+  const size_t lds_bytes = h1_lds_bytes();
+  MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)grid), dim3(PP_THREADS), lds_bytes, stream, A, a_exp, (int)m, W,
+                     w_exp, (int)n, kp, c, (long long)ldc, bias, residual, (long long)ldr, act, (int)n_mtiles,
+                     (int)n_ntiles);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}

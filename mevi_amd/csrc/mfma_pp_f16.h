@@ -72,10 +72,15 @@ struct H1Src {
 //                         called one tile AHEAD of the tile being computed
 // begin()               : the oldest fetched tile starts computing (load what its epilogue will need)
 // emit(acc)             : epilogue of that tile (tiles complete in the order next() returned them)
+// uoff(u)               : byte offset of unit u inside this wave's operand rows (wave-uniform; the filter's images
+//                         are plain rows, u * 64; the split-precision GEMM walks (hi | lo) row halves, gemm_split.hip)
 // nunits >= 3 (the images are padded to at least 96 k).
-template <class Next, class Begin, class Emit>
+struct H1PlainUnits {
+  __device__ __forceinline__ int operator()(int u) const { return u * 64; }
+};
+template <class Next, class Begin, class Emit, class UOff = H1PlainUnits>
 __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float *lds, Next next, Begin begin,
-                                               Emit emit) {
+                                               Emit emit, UOff uoff = UOff()) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -104,7 +109,7 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
 #pragma unroll
     for (int i = p0; i < p0 + 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(base + 16 * i * H1_LD), 16,
-                                               voff[i], u * 64, 0, 0);
+                                               voff[i], uoff(u), 0, 0);
   };
 
   const int sw = (lrow >> 2) & 3;  // fragment rows are lrow + multiples of 32

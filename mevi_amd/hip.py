@@ -41,6 +41,10 @@ _SIGNATURES = {
     "mevi_rq_encode_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "mevi_gemm_nt_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                  c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mevi_split_kp": (c_int64, [c_int64]),
+    "mevi_split_rows_f16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mevi_gemm_nt_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                       c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mevi_rmsnorm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "mevi_add_layernorm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float,
                                        c_int64, c_int64, c_void_p, c_int64, c_void_p]),

@@ -17,11 +17,73 @@ def _rows2d(t):
     return t, t.shape[0], t.shape[1], t.stride(0)
 
 
+class SplitRows:
+    """f32 rows held as (hi | lo) float16 images with one power-of-two exponent per row (csrc/gemm_split.hip):
+    the operand format of the split-precision GEMM.  `img` i16 [rows, 2 * kp], `exp` i32 [rows]."""
+
+    __slots__ = ("img", "exp", "k")
+
+    def __init__(self, img, exp, k):
+        self.img, self.exp, self.k = img, exp, k
+
+    @property
+    def shape(self):
+        return (self.img.shape[0], self.k)
+
+    @property
+    def device(self):
+        return self.img.device
+
+    def __getitem__(self, rows):
+        assert isinstance(rows, slice) and rows.step in (None, 1)
+        return SplitRows(self.img[rows], self.exp[rows], self.k)
+
+    def contiguous(self):
+        return self
+
+
+def split_rows(x):
+    """SplitRows image of x f32 [m, k] (last dim contiguous)."""
+    x, M, K, ldx = _rows2d(_f32(x))
+    with torch.cuda.device(x.device):
+        kp = (K + 31) // 32 * 32
+        img = torch.empty((M, 2 * kp), dtype=torch.int16, device=x.device)
+        exp = torch.empty((M,), dtype=torch.int32, device=x.device)
+        st = hip.lib().mevi_split_rows_f16(hip.ptr(x), ldx, M, K, hip.ptr(img), hip.ptr(exp), hip.stream_ptr())
+    hip.check(st, "mevi_split_rows_f16")
+    return SplitRows(img, exp, K)
+
+
+def _linear_split(x, weight, bias, residual, act, out):
+    xs = x if isinstance(x, SplitRows) else split_rows(x)
+    (M, K), (N, K2) = xs.shape, weight.shape
+    assert K == K2, (xs.shape, weight.shape)
+    dev = weight.device
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        ldr = residual.stride(0)
+    with torch.cuda.device(dev):
+        st = hip.lib().mevi_gemm_nt_split_f32(hip.ptr(xs.img), hip.ptr(xs.exp), hip.ptr(weight.img), hip.ptr(weight.exp),
+                                              hip.ptr(out), out.stride(0), M, N, K,
+                                              hip.ptr(bias) if bias is not None else None,
+                                              hip.ptr(residual) if residual is not None else None, ldr, act, hip.stream_ptr())
+    hip.check(st, "mevi_gemm_nt_split_f32")
+    return out
+
+
 @hip.on_device
 def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False):
     """out = act(x @ weight.T + bias) + residual   (x [M,K], weight [N,K] = nn.Linear layout; act = relu, erf-gelu
-    or none)."""
+    or none).  f32 tensors: the exact sequential-chain GEMM; `weight` a SplitRows (and x f32 or SplitRows): the
+    split-precision GEMM (three f16 MFMAs per product)."""
     assert not (relu and gelu)
+    act = 1 if relu else (2 if gelu else 0)
+    if isinstance(weight, SplitRows):
+        return _linear_split(x, weight, bias, residual, act, out)
     x, M, K, lda = _rows2d(_f32(x))
     w, N, K2, ldw = _rows2d(_f32(weight))
     assert K == K2, (x.shape, weight.shape)
@@ -34,7 +96,7 @@ def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False
         ldr = residual.stride(0)
     st = hip.lib().mevi_gemm_nt_f32(hip.ptr(x), lda, hip.ptr(w), ldw, hip.ptr(out), out.stride(0), M, N, K,
                                     hip.ptr(bias) if bias is not None else None,
-                                    hip.ptr(residual) if residual is not None else None, ldr, 1 if relu else (2 if gelu else 0),
+                                    hip.ptr(residual) if residual is not None else None, ldr, act,
                                     hip.stream_ptr())
     hip.check(st, "mevi_gemm_nt_f32")
     return out

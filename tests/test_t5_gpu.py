@@ -198,7 +198,7 @@ def test_base_shape_model_against_oracle(cuda, M, K, d, d_ff, heads, table_bytes
     same = (dec.cpu().numpy() == odec.numpy()).all(1)
     gaps = np.abs(np.diff(osc.numpy().reshape(B, R), axis=1)).min()
     assert same.all() or gaps < 4e-4
-    tower = t5.TwinTower(W, device=cuda, num_layers=cfg["num_layers"], num_decoder_layers=cfg["num_decoder_layers"])
+    tower = t5.TwinTower(W, device=cuda, **{k: v for k, v in cfg.items() if k not in ("M", "K", "adaptor_layer_num")})
     reps = tower.encode_query({"input_ids": ids, "attention_mask": mask}).cpu()
     oreps = ot5.tower_encode(W, dict(cfg), ids, mask)
     assert (reps - oreps).abs().max() <= 2e-4 * oreps.abs().max()
