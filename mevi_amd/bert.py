@@ -43,6 +43,7 @@ class BertEncoder:
                 wi=g(p + "intermediate.dense.weight"), bi=g(p + "intermediate.dense.bias"),
                 wo2=g(p + "output.dense.weight"), bo2=g(p + "output.dense.bias"),
                 ln2=(g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"))))
+        ops.prepare_weights(self.layers, ("wqkv", "wo", "wi", "wo2"))
         self.d = self.word.shape[1]
         self.pack = True   # padding-free per-token operators (see forward)
         self.dh = self.d // num_heads
@@ -71,13 +72,14 @@ class BertEncoder:
         varlen = seq_off is not None and varlen_ok(longest, self.dh)    # right-padded: attend on the packed rows
         qkv = None if idx is None or varlen else torch.zeros((B * S, 3 * d), dtype=torch.float32, device=x.device)
         for L in self.layers:
+            xg = ops.gemm_input(x)
             if idx is None:
-                q3 = ops.linear(x, L["wqkv"], bias=L["bqkv"]).view(B, S, 3 * d)
+                q3 = ops.linear(xg, L["wqkv"], bias=L["bqkv"]).view(B, S, 3 * d)
             elif varlen:
-                q2 = ops.linear(x, L["wqkv"], bias=L["bqkv"])
+                q2 = ops.linear(xg, L["wqkv"], bias=L["bqkv"])
                 ctx = ops.attention_varlen(q2[:, :d], q2[:, d:2 * d], q2[:, 2 * d:], seq_off, longest, self.H, scale=scale)
             else:
-                q3 = ops.scatter_rows(ops.linear(x, L["wqkv"], bias=L["bqkv"]), idx, qkv).view(B, S, 3 * d)
+                q3 = ops.scatter_rows(ops.linear(xg, L["wqkv"], bias=L["bqkv"]), idx, qkv).view(B, S, 3 * d)
             if not varlen:
                 ctx = ops.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], self.H, key_mask=attention_mask,
                                     scale=scale).view(B * S, d)
@@ -85,7 +87,7 @@ class BertEncoder:
                     ctx = ops.gather_rows(ctx, idx)
             a = ops.linear(ctx, L["wo"], bias=L["bo"])
             x = ops.add_layernorm(a, x, L["ln1"][0], L["ln1"][1], eps=self.eps)
-            h = ops.linear(x, L["wi"], bias=L["bi"], gelu=True)
+            h = ops.linear(ops.gemm_input(x), L["wi"], bias=L["bi"], gelu=True, for_gemm=True)
             o = ops.linear(h, L["wo2"], bias=L["bo2"])
             x = ops.add_layernorm(o, x, L["ln2"][0], L["ln2"][1], eps=self.eps)
         if idx is None:

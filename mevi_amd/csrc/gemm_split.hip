@@ -46,18 +46,24 @@ __device__ __forceinline__ void split4(const float4 v, int e, h4 &hi, h4 &lo) {
 
 // rows of x f32[m, k] (row stride ldx) -> image [m, 2 * kp] halves + exponent per row.  One wave per row.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ x, long long ldx, long long m, int k,
-                                                        int kp, _Float16 *__restrict__ img, int *__restrict__ exps) {
+                                                        int kp, _Float16 *__restrict__ img, int *__restrict__ exps,
+                                                        float *__restrict__ norms) {
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= m) return;
   const int lane = threadIdx.x & 63;
   const float *xr = x + (size_t)r * ldx;
-  float mx = 0.f;
+  float mx = 0.f, ss = 0.f;
   for (int c = lane * 4; c < k; c += 256) {
     const float4 v = *reinterpret_cast<const float4 *>(xr + c);
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, off));
+    ss += __shfl_xor(ss, off);
+  }
+  if (lane == 0 && norms) norms[r] = sqrtf(ss) * 1.0001f;  // rounded up: it bounds the next layer's outputs
   const int e = pow2_exp(mx);
   _Float16 *o = img + (size_t)r * 2 * kp;
   for (int c = lane * 4; c < kp; c += 256) {
@@ -67,6 +73,74 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
     *reinterpret_cast<h4 *>(o + kp + c) = lo;
   }
   if (lane == 0) exps[r] = e;
+}
+
+// T5LayerNorm (t5_ops.hip: rmsnorm_kernel, same arithmetic per element) written straight into the split image:
+// y = w * (x / sqrt(mean(x^2) + eps)).  One wave per row; y is recomputed for the second pass (the row sits in L1).
+__global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float *__restrict__ x, long long ldx,
+                                                           const float *__restrict__ w, float eps, long long rows, int dim,
+                                                           int kp, _Float16 *__restrict__ img, int *__restrict__ exps,
+                                                           float *__restrict__ norms) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float4 *xr = reinterpret_cast<const float4 *>(x + r * ldx);
+  const float4 *wv = reinterpret_cast<const float4 *>(w);
+  float ss = 0.f;
+  for (int i = lane; i < dim / 4; i += 64) {
+    const float4 v = xr[i];
+    ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  const float denom = sqrtf(ss / (float)dim + eps);
+  float mx = 0.f, s2 = 0.f;
+  for (int i = lane; i < dim / 4; i += 64) {
+    const float4 v = xr[i], g = wv[i];
+    const float4 y = make_float4(g.x * (v.x / denom), g.y * (v.y / denom), g.z * (v.z / denom), g.w * (v.w / denom));
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(y.x), fabsf(y.y))), fmaxf(fabsf(y.z), fabsf(y.w)));
+    s2 = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, fmaf(y.w, y.w, s2))));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, off));
+    s2 += __shfl_xor(s2, off);
+  }
+  const int e = pow2_exp(mx);
+  _Float16 *o = img + (size_t)r * 2 * kp;
+  for (int i = lane; i < kp / 4; i += 64) {
+    h4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+    if (i < dim / 4) {
+      const float4 v = xr[i], g = wv[i];
+      split4(make_float4(g.x * (v.x / denom), g.y * (v.y / denom), g.z * (v.z / denom), g.w * (v.w / denom)), e, hi, lo);
+    }
+    *reinterpret_cast<h4 *>(o + 4 * i) = hi;
+    *reinterpret_cast<h4 *>(o + kp + 4 * i) = lo;
+  }
+  if (lane == 0) {
+    exps[r] = e;
+    norms[r] = sqrtf(s2) * 1.0001f;
+  }
+}
+
+// Where an output goes: f32 C (row stride ldc), or -- for a layer whose only consumer is the next GEMM (the FFN's
+// relu(x Wi^T)) -- straight into a split image.  The image needs the row's exponent BEFORE the row is complete (its
+// columns are spread over workgroups), so it comes from a bound instead of the row maximum:
+//   |act(a.w + b)| <= ||a|| * max_n ||w_n|| + max|b|     (Cauchy-Schwarz; relu / gelu do not increase magnitudes)
+// with ||a|| carried by the producer of A (anorm) and the weight-side constants in `obound`.  The bound sits a few
+// binades above the row's real maximum, which costs range, not precision: hi keeps 11 bits down to 2^-29 of the
+// bound, the pair 22 bits down to 2^-18 of it, and below that the absolute error is < 2^-40 of the bound.
+struct SplitOut {
+  _Float16 *img;       // [M, 2 * np] or nullptr
+  int *exps;           // [M]
+  float *norms;        // [M] or nullptr: bound on the output row's l2 norm (for a further split-out layer)
+  const float *anorm;  // [M] l2 norms of the A rows
+  int np;
+  float wnorm_max, babs_max, onorm_scale;
+};
+
+__device__ __forceinline__ int out_exp(const SplitOut &so, int m) {
+  return pow2_exp(fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * 1.001f);
 }
 
 struct SplitUnits {
@@ -92,7 +166,7 @@ __device__ __forceinline__ float epilogue(float acc, int e, float b, bool has_bi
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
     const _Float16 *__restrict__ A, const int *__restrict__ ea, int M, const _Float16 *__restrict__ W,
     const int *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
-    const float *__restrict__ residual, long long ldr, int act, int n_mtiles, int n_ntiles) {
+    const float *__restrict__ residual, long long ldr, int act, int n_mtiles, int n_ntiles, SplitOut so) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nwg = n_mtiles * n_ntiles;
   const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
@@ -135,13 +209,18 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
     --n_pend;
     const int mb = mt * 256 + 128 * grp + 64 * wm + 4 * half;
     const int nb = nt * 256 + 128 * wn + lrow;
-    int em[2][16];
+    int em[2][16], eo[2][16];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mb + 32 * mi + (r & 3) + 8 * (r >> 2);
         em[mi][r] = m < M ? ea[m] : 0;
+        eo[mi][r] = (so.img && m < M) ? out_exp(so, m) : 0;
+        if (so.img && m < M && nt == 0 && wn == 0 && lrow == 0) {  // one writer per row
+          so.exps[m] = eo[mi][r];
+          if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
+        }
       }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -157,7 +236,15 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
           if (m < M) {
             float v = epilogue(acc[mi][ni][r], em[mi][r] + en, b, bias != nullptr, act);
             if (residual) v += residual[(size_t)m * ldr + n];
-            C[(size_t)m * ldc + n] = v;
+            if (so.img) {
+              const float xs = ldexpf(v, eo[mi][r]);
+              const _Float16 hi = (_Float16)xs;
+              _Float16 *o = so.img + (size_t)m * 2 * so.np + n;
+              o[0] = hi;
+              o[so.np] = (_Float16)(xs - (float)hi);
+            } else {
+              C[(size_t)m * ldc + n] = v;
+            }
           }
         }
       }
@@ -176,7 +263,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
 __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
     const _Float16 *__restrict__ A, const int *__restrict__ ea, int M, const _Float16 *__restrict__ W,
     const int *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
-    const float *__restrict__ residual, long long ldr, int act) {
+    const float *__restrict__ residual, long long ldr, int act, SplitOut so) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lrow = lane & 31, half = lane >> 5;
   const int n0 = (blockIdx.x * 4 + wave) * 32, m0 = blockIdx.y * 32;
@@ -208,7 +295,20 @@ __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
     if (m < M) {
       float v = epilogue(acc[r], ea[m] + en, b, bias != nullptr, act);
       if (residual) v += residual[(size_t)m * ldr + n];
-      C[(size_t)m * ldc + n] = v;
+      if (so.img) {
+        const int eo = out_exp(so, m);
+        if (n == 0) {
+          so.exps[m] = eo;
+          if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
+        }
+        const float xs = ldexpf(v, eo);
+        const _Float16 hi = (_Float16)xs;
+        _Float16 *o = so.img + (size_t)m * 2 * so.np + n;
+        o[0] = hi;
+        o[so.np] = (_Float16)(xs - (float)hi);
+      } else {
+        C[(size_t)m * ldc + n] = v;
+      }
     }
   }
 }
@@ -223,7 +323,7 @@ using namespace mevi;
 extern "C" int64_t mevi_split_kp(int64_t k) { return (k + 31) / 32 * 32; }
 
 extern "C" int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int32_t *exps,
-                                   void *stream_) {
+                                   float *norms, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   MEVI_REQUIRE(m >= 0 && k > 0, MEVI_ERR_INVALID_ARG, "split_rows: bad shape");
   if (m == 0) return MEVI_OK;
@@ -232,18 +332,31 @@ extern "C" int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64
                MEVI_ERR_UNSUPPORTED, "split_rows: k, ldx must be multiples of 4 and x, img 16-byte aligned");
   MEVI_REQUIRE(k < (1LL << 22), MEVI_ERR_UNSUPPORTED, "split_rows: k too large");
   hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, x, (long long)ldx,
-                     (long long)m, (int)k, (int)mevi_split_kp(k), reinterpret_cast<_Float16 *>(img), exps);
+                     (long long)m, (int)k, (int)mevi_split_kp(k), reinterpret_cast<_Float16 *>(img), exps, norms);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }
 
-extern "C" int mevi_gemm_nt_split_f32(const void *a_img, const int32_t *a_exp, const void *w_img, const int32_t *w_exp,
-                                      float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias,
-                                      const float *residual, int64_t ldr, int act, void *stream_) {
+extern "C" int mevi_rmsnorm_split_f16(const float *x, int64_t ldx, const float *w, float eps, int64_t rows, int64_t dim,
+                                      void *img, int32_t *exps, float *norms, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(rows >= 0 && dim > 0 && dim % 4 == 0 && ldx % 4 == 0, MEVI_ERR_INVALID_ARG,
+               "rmsnorm_split: dim/ld must be multiples of 4");
+  if (rows == 0) return MEVI_OK;
+  MEVI_REQUIRE(x && w && img && exps && norms, MEVI_ERR_INVALID_ARG, "rmsnorm_split: null pointer");
+  hipLaunchKernelGGL(rmsnorm_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, (long long)ldx, w,
+                     eps, (long long)rows, (int)dim, (int)mevi_split_kp(dim), reinterpret_cast<_Float16 *>(img), exps, norms);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+static int gemm_split_launch(const void *a_img, const int32_t *a_exp, const void *w_img, const int32_t *w_exp,
+                             float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias,
+                             const float *residual, int64_t ldr, int act, SplitOut so, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   MEVI_REQUIRE(m >= 0 && n >= 0 && k > 0, MEVI_ERR_INVALID_ARG, "gemm_nt_split: bad shape");
   if (m == 0 || n == 0) return MEVI_OK;
-  MEVI_REQUIRE(a_img && a_exp && w_img && w_exp && c, MEVI_ERR_INVALID_ARG, "gemm_nt_split: null pointer");
+  MEVI_REQUIRE(a_img && a_exp && w_img && w_exp && (c || so.img), MEVI_ERR_INVALID_ARG, "gemm_nt_split: null pointer");
   MEVI_REQUIRE(((uintptr_t)a_img % 16) == 0 && ((uintptr_t)w_img % 16) == 0, MEVI_ERR_INVALID_ARG,
                "gemm_nt_split: images must be 16-byte aligned");
   MEVI_REQUIRE(act >= 0 && act <= 2, MEVI_ERR_INVALID_ARG, "gemm_nt_split: act must be 0 (none), 1 (relu) or 2 (erf gelu)");
@@ -253,7 +366,7 @@ extern "C" int mevi_gemm_nt_split_f32(const void *a_img, const int32_t *a_exp, c
   static const int skinny_on = [] { const char *e = getenv("MEVI_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
   if (m * n <= SPLIT_SKINNY_MAX_OUTPUTS && skinny_on) {
     hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3((unsigned)((n + 127) / 128), (unsigned)((m + 31) / 32)), dim3(256), 0,
-                       stream, A, a_exp, (int)m, W, w_exp, (int)n, kp, c, (long long)ldc, bias, residual, (long long)ldr, act);
+                       stream, A, a_exp, (int)m, W, w_exp, (int)n, kp, c, (long long)ldc, bias, residual, (long long)ldr, act, so);
     MEVI_HIP_CHECK(hipGetLastError());
     return MEVI_OK;
   }
@@ -274,7 +387,32 @@ extern "C" int mevi_gemm_nt_split_f32(const void *a_img, const int32_t *a_exp, c
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)grid), dim3(PP_THREADS), lds_bytes, stream, A, a_exp, (int)m, W,
                      w_exp, (int)n, kp, c, (long long)ldc, bias, residual, (long long)ldr, act, (int)n_mtiles,
-                     (int)n_ntiles);
+                     (int)n_ntiles, so);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
+}
+
+extern "C" int mevi_gemm_nt_split_f32(const void *a_img, const int32_t *a_exp, const void *w_img, const int32_t *w_exp,
+                                      float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias,
+                                      const float *residual, int64_t ldr, int act, void *stream) {
+  SplitOut so = {};
+  return gemm_split_launch(a_img, a_exp, w_img, w_exp, c, ldc, m, n, k, bias, residual, ldr, act, so, stream);
+}
+
+extern "C" int mevi_gemm_nt_split_to_split(const void *a_img, const int32_t *a_exp, const float *a_norm, const void *w_img,
+                                           const int32_t *w_exp, float w_norm_max, int64_t m, int64_t n, int64_t k,
+                                           const float *bias, float bias_abs_max, int act, void *out_img,
+                                           int32_t *out_exp, float *out_norm, void *stream) {
+  MEVI_REQUIRE(m == 0 || (a_norm && out_img && out_exp), MEVI_ERR_INVALID_ARG, "gemm_nt_split_to_split: null pointer");
+  MEVI_REQUIRE(w_norm_max >= 0.f && bias_abs_max >= 0.f, MEVI_ERR_INVALID_ARG, "gemm_nt_split_to_split: negative bound");
+  SplitOut so = {};
+  so.img = reinterpret_cast<_Float16 *>(out_img);
+  so.exps = out_exp;
+  so.norms = out_norm;
+  so.anorm = a_norm;
+  so.np = (int)mevi_split_kp(n);
+  so.wnorm_max = w_norm_max;
+  so.babs_max = bias_abs_max;
+  so.onorm_scale = sqrtf((float)n) * 1.0001f;  // ||row||_2 <= sqrt(n) * max|element|
+  return gemm_split_launch(a_img, a_exp, w_img, w_exp, nullptr, 0, m, n, k, bias, nullptr, 0, act, so, stream);
 }

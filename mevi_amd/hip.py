@@ -42,7 +42,11 @@ _SIGNATURES = {
     "mevi_gemm_nt_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                  c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mevi_split_kp": (c_int64, [c_int64]),
-    "mevi_split_rows_f16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mevi_split_rows_f16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mevi_rmsnorm_split_f16": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
+    "mevi_gemm_nt_split_to_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64,
+                                            c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mevi_gemm_nt_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                        c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mevi_rmsnorm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_int64, c_int64, c_void_p, c_int64, c_void_p]),

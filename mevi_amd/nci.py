@@ -75,7 +75,9 @@ class Adaptor:
                                           bias=_dev(w, f"{p}.multihead_attn.out_proj.bias", device)).reshape(d).contiguous()
             L["wq"], L["bq"] = L["self_attn.in_proj_weight"][:d].contiguous(), L["self_attn.in_proj_bias"][:d].contiguous()
             L["wkv"], L["bkv"] = L["self_attn.in_proj_weight"][d:].contiguous(), L["self_attn.in_proj_bias"][d:].contiguous()
+            del L["self_attn.in_proj_weight"]
             self.layers.append(L)
+        ops.prepare_weights(self.layers, ("wq", "wkv", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"))
 
     def new_cache(self, rows):
         return [torch.empty((rows, self.cfg.T, 2 * self.cfg.d_model), dtype=torch.float32, device=self.dev)
@@ -85,14 +87,15 @@ class Adaptor:
         d = self.cfg.d_model
         n = x.shape[0]
         for L, kvc in zip(self.layers, cache):
-            q = ops.linear(x, L["wq"], bias=L["bq"])
-            ops.linear(x, L["wkv"], bias=L["bkv"], out=kvc[:, t, :])
+            xg = ops.gemm_input(x)
+            q = ops.linear(xg, L["wq"], bias=L["bq"])
+            ops.linear(xg, L["wkv"], bias=L["bkv"], out=kvc[:, t, :])
             ctx = ops.attention(q.view(n, 1, d), kvc[:, :t + 1, :d], kvc[:, :t + 1, d:], self.NHEAD,
                                 q_pos0=t, causal=True, scale=(d // self.NHEAD) ** -0.5)
             sa = ops.linear(ctx.view(n, d), L["self_attn.out_proj.weight"], bias=L["self_attn.out_proj.bias"])
             x = ops.add_layernorm(x, sa, L["norm1.weight"], L["norm1.bias"])
             x = ops.add_layernorm(x, None, L["norm2.weight"], L["norm2.bias"], cvec=L["cross_const"])
-            ff = ops.linear(ops.linear(x, L["linear1.weight"], bias=L["linear1.bias"], relu=True),
+            ff = ops.linear(ops.linear(ops.gemm_input(x), L["linear1.weight"], bias=L["linear1.bias"], relu=True, for_gemm=True),
                             L["linear2.weight"], bias=L["linear2.bias"])
             x = ops.add_layernorm(x, ff, L["norm3.weight"], L["norm3.bias"])
         return x
@@ -184,7 +187,7 @@ class NCIModel:
         for p in range(c.M + 1):
             cols = torch.tensor([1] + list(range(2 + p * c.K, 2 + (p + 1) * c.K)), device=self.dev)
             # rows ordered (column, d): W_p[c*d_model + d, e] = adaptor_linear.weight[d*V + v_c, e]
-            self.head_w.append(aw[:, cols, :].permute(1, 0, 2).reshape((c.K + 1) * c.d_model, c.d_model).contiguous())
+            self.head_w.append(ops.weight(aw[:, cols, :].permute(1, 0, 2).reshape((c.K + 1) * c.d_model, c.d_model).contiguous()))
             self.head_e.append(lm[cols].contiguous())
         del aw
 

@@ -1,9 +1,17 @@
 """Thin tensor-level wrappers over the C ABI (include/mevi_hip.h).  torch supplies device memory
 and the current stream only; every function launches hand-written HIP kernels and raises
 MeviHipError when the extension or the GPU is missing."""
+import os
+
 import torch
 
 from . import hip
+
+# How the linear layers of the T5 / BERT / adaptor stacks multiply (read when a model prepares its weights):
+#   "split" (default) -- split-precision GEMM, three f16 MFMAs per product on (hi, lo) f16 images (csrc/gemm_split.hip)
+#   "exact"           -- the sequential f32 fmaf-chain GEMM on the f32 matrix cores (csrc/gemm.hip)
+# The dense arm, the fine stage and the RQ kernels always use their exact f32 chains.
+GEMM_MODE = os.environ.get("MEVI_GEMM", "split")
 
 
 def _f32(t):
@@ -19,12 +27,14 @@ def _rows2d(t):
 
 class SplitRows:
     """f32 rows held as (hi | lo) float16 images with one power-of-two exponent per row (csrc/gemm_split.hip):
-    the operand format of the split-precision GEMM.  `img` i16 [rows, 2 * kp], `exp` i32 [rows]."""
+    the operand format of the split-precision GEMM.  `img` i16 [rows, 2 * kp], `exp` i32 [rows]; `norm` f32 [rows]
+    (activations: l2 norm of every row, rounded up) and `norm_max` / `bias_abs_max` (weights: the largest row norm)
+    feed the exponent bound of a GEMM that writes its result as an image (linear(..., for_gemm=True))."""
 
-    __slots__ = ("img", "exp", "k")
+    __slots__ = ("img", "exp", "k", "norm", "norm_max")
 
-    def __init__(self, img, exp, k):
-        self.img, self.exp, self.k = img, exp, k
+    def __init__(self, img, exp, k, norm=None, norm_max=None):
+        self.img, self.exp, self.k, self.norm, self.norm_max = img, exp, k, norm, norm_max
 
     @property
     def shape(self):
@@ -36,29 +46,79 @@ class SplitRows:
 
     def __getitem__(self, rows):
         assert isinstance(rows, slice) and rows.step in (None, 1)
-        return SplitRows(self.img[rows], self.exp[rows], self.k)
+        return SplitRows(self.img[rows], self.exp[rows], self.k, None if self.norm is None else self.norm[rows], self.norm_max)
 
     def contiguous(self):
         return self
+
+
+def weight(w):
+    """A linear layer's [out, in] weight in the operand format of the current GEMM_MODE (static: converted once)."""
+    if GEMM_MODE == "split":
+        ws = split_rows(w.contiguous())
+        ws.norm_max = float(ws.norm.max().item()) if ws.norm.numel() else 0.0
+        ws.norm = None
+        return ws
+    assert GEMM_MODE == "exact", f"MEVI_GEMM must be 'split' or 'exact', not {GEMM_MODE!r}"
+    return w
+
+
+def prepare_weights(layers, keys):
+    for L in layers:
+        for k in keys:
+            L[k] = weight(L[k])
+
+
+_ABS_MAX = {}
+
+
+def _abs_max(t):
+    """max |t| of a static tensor (a bias), computed once (keyed by storage: no host synchronisation per call)."""
+    key = (t.data_ptr(), t.numel())
+    if key not in _ABS_MAX:
+        _ABS_MAX[key] = float(t.abs().max().item())
+    return _ABS_MAX[key]
+
+
+def gemm_input(x):
+    """x f32 [m, k] as the A operand of linear() under the current GEMM_MODE: itself, or its split image (made once
+    for all the layers that read it)."""
+    return split_rows(x) if GEMM_MODE == "split" and not isinstance(x, SplitRows) else x
+
+
+def _split_buffers(M, K, dev, zero=False):
+    kp = (K + 31) // 32 * 32
+    img = (torch.zeros if zero and kp != K else torch.empty)((M, 2 * kp), dtype=torch.int16, device=dev)
+    return img, torch.empty((M,), dtype=torch.int32, device=dev), torch.empty((M,), dtype=torch.float32, device=dev)
 
 
 def split_rows(x):
     """SplitRows image of x f32 [m, k] (last dim contiguous)."""
     x, M, K, ldx = _rows2d(_f32(x))
     with torch.cuda.device(x.device):
-        kp = (K + 31) // 32 * 32
-        img = torch.empty((M, 2 * kp), dtype=torch.int16, device=x.device)
-        exp = torch.empty((M,), dtype=torch.int32, device=x.device)
-        st = hip.lib().mevi_split_rows_f16(hip.ptr(x), ldx, M, K, hip.ptr(img), hip.ptr(exp), hip.stream_ptr())
+        img, exp, norm = _split_buffers(M, K, x.device)
+        st = hip.lib().mevi_split_rows_f16(hip.ptr(x), ldx, M, K, hip.ptr(img), hip.ptr(exp), hip.ptr(norm), hip.stream_ptr())
     hip.check(st, "mevi_split_rows_f16")
-    return SplitRows(img, exp, K)
+    return SplitRows(img, exp, K, norm)
 
 
-def _linear_split(x, weight, bias, residual, act, out):
+def _linear_split(x, weight, bias, residual, act, out, for_gemm):
     xs = x if isinstance(x, SplitRows) else split_rows(x)
     (M, K), (N, K2) = xs.shape, weight.shape
     assert K == K2, (xs.shape, weight.shape)
     dev = weight.device
+    L = hip.lib()
+    if for_gemm:       # act(x W^T + b) as the next GEMM's operand
+        assert residual is None and out is None and xs.norm is not None and weight.norm_max is not None
+        babs = _abs_max(bias) if bias is not None else 0.0
+        with torch.cuda.device(dev):
+            img, exp, norm = _split_buffers(M, N, dev, zero=True)
+            st = L.mevi_gemm_nt_split_to_split(hip.ptr(xs.img), hip.ptr(xs.exp), hip.ptr(xs.norm), hip.ptr(weight.img),
+                                               hip.ptr(weight.exp), weight.norm_max, M, N, K,
+                                               hip.ptr(bias) if bias is not None else None, babs, act, hip.ptr(img),
+                                               hip.ptr(exp), hip.ptr(norm), hip.stream_ptr())
+        hip.check(st, "mevi_gemm_nt_split_to_split")
+        return SplitRows(img, exp, N, norm)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
     assert out.shape == (M, N) and out.stride(1) == 1
@@ -67,23 +127,24 @@ def _linear_split(x, weight, bias, residual, act, out):
         assert residual.shape == (M, N) and residual.stride(1) == 1
         ldr = residual.stride(0)
     with torch.cuda.device(dev):
-        st = hip.lib().mevi_gemm_nt_split_f32(hip.ptr(xs.img), hip.ptr(xs.exp), hip.ptr(weight.img), hip.ptr(weight.exp),
-                                              hip.ptr(out), out.stride(0), M, N, K,
-                                              hip.ptr(bias) if bias is not None else None,
-                                              hip.ptr(residual) if residual is not None else None, ldr, act, hip.stream_ptr())
+        st = L.mevi_gemm_nt_split_f32(hip.ptr(xs.img), hip.ptr(xs.exp), hip.ptr(weight.img), hip.ptr(weight.exp),
+                                      hip.ptr(out), out.stride(0), M, N, K,
+                                      hip.ptr(bias) if bias is not None else None,
+                                      hip.ptr(residual) if residual is not None else None, ldr, act, hip.stream_ptr())
     hip.check(st, "mevi_gemm_nt_split_f32")
     return out
 
 
 @hip.on_device
-def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False):
+def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False, for_gemm=False):
     """out = act(x @ weight.T + bias) + residual   (x [M,K], weight [N,K] = nn.Linear layout; act = relu, erf-gelu
     or none).  f32 tensors: the exact sequential-chain GEMM; `weight` a SplitRows (and x f32 or SplitRows): the
-    split-precision GEMM (three f16 MFMAs per product)."""
+    split-precision GEMM (three f16 MFMAs per product).  for_gemm: the result only feeds another linear() -- with
+    split weights it is written as a SplitRows image directly (no f32 round trip)."""
     assert not (relu and gelu)
     act = 1 if relu else (2 if gelu else 0)
     if isinstance(weight, SplitRows):
-        return _linear_split(x, weight, bias, residual, act, out)
+        return _linear_split(x, weight, bias, residual, act, out, for_gemm)
     x, M, K, lda = _rows2d(_f32(x))
     w, N, K2, ldw = _rows2d(_f32(weight))
     assert K == K2, (x.shape, weight.shape)
@@ -103,8 +164,16 @@ def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False
 
 
 @hip.on_device
-def rmsnorm(x, weight, eps, out=None):
+def rmsnorm(x, weight, eps, out=None, for_gemm=False):
+    """T5LayerNorm.  for_gemm: the normed rows only feed linear() -- under GEMM_MODE 'split' they are written as a
+    SplitRows image directly."""
     x, M, D, ldx = _rows2d(_f32(x))
+    if for_gemm and GEMM_MODE == "split":
+        img, exp, norm = _split_buffers(M, D, x.device)
+        st = hip.lib().mevi_rmsnorm_split_f16(hip.ptr(x), ldx, hip.ptr(weight), eps, M, D, hip.ptr(img), hip.ptr(exp),
+                                              hip.ptr(norm), hip.stream_ptr())
+        hip.check(st, "mevi_rmsnorm_split_f16")
+        return SplitRows(img, exp, D, norm)
     if out is None:
         out = torch.empty((M, D), dtype=torch.float32, device=x.device)
     st = hip.lib().mevi_rmsnorm_f32(hip.ptr(x), ldx, hip.ptr(weight), eps, M, D, hip.ptr(out), out.stride(0),

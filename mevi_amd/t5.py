@@ -74,6 +74,7 @@ class EncoderStack:
                 ln1=_dev(w, f"{p}.1.layer_norm.weight", device),
                 wi=_dev(w, f"{p}.1.DenseReluDense.wi.weight", device),
                 wo2=_dev(w, f"{p}.1.DenseReluDense.wo.weight", device)))
+        ops.prepare_weights(self.layers, ("wqkv", "wo", "wi", "wo2"))
         self.final_ln = _dev(w, f"{prefix}.final_layer_norm.weight", device)
         self.rel = _dev(w, f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight", device)
         self._bias = {}
@@ -106,37 +107,37 @@ class EncoderStack:
         if idx is None:
             x = ops.gather_rows(embeddings, input_ids.reshape(-1))
             for L in self.layers:
-                h = ops.rmsnorm(x, L["ln0"], d.eps)
+                h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
                 qkv = ops.linear(h, L["wqkv"]).view(B, S, 3 * d.inner)
                 ctx = ops.attention(qkv[:, :, :d.inner], qkv[:, :, d.inner:2 * d.inner], qkv[:, :, 2 * d.inner:],
                                     d.num_heads, bias=bias, key_mask=attention_mask)
                 x = ops.linear(ctx.view(B * S, d.inner), L["wo"], residual=x)
-                h = ops.rmsnorm(x, L["ln1"], d.eps)
-                x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
+                h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
+                x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
             return ops.rmsnorm(x, self.final_ln, d.eps).view(B, S, d.d_model)
         x = ops.gather_rows(embeddings, input_ids.reshape(-1)[idx])            # [T, d_model], T real tokens
         seq_off, longest = packed_offsets(attention_mask)
         if seq_off is not None and varlen_ok(longest, d.d_kv):
             # right-padded sequences (what the tokenizers produce): attention runs on the packed rows too
             for L in self.layers:
-                h = ops.rmsnorm(x, L["ln0"], d.eps)
+                h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
                 qkv = ops.linear(h, L["wqkv"])
                 ctx = ops.attention_varlen(qkv[:, :d.inner], qkv[:, d.inner:2 * d.inner], qkv[:, 2 * d.inner:], seq_off,
                                            longest, d.num_heads, bias=bias)
                 x = ops.linear(ctx, L["wo"], residual=x)
-                h = ops.rmsnorm(x, L["ln1"], d.eps)
-                x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
+                h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
+                x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
         else:
             qkv = torch.zeros((B * S, 3 * d.inner), dtype=torch.float32, device=x.device)   # padded rows stay 0 (finite)
             for L in self.layers:
-                h = ops.rmsnorm(x, L["ln0"], d.eps)
+                h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
                 ops.scatter_rows(ops.linear(h, L["wqkv"]), idx, qkv)
                 q3 = qkv.view(B, S, 3 * d.inner)
                 ctx = ops.attention(q3[:, :, :d.inner], q3[:, :, d.inner:2 * d.inner], q3[:, :, 2 * d.inner:],
                                     d.num_heads, bias=bias, key_mask=attention_mask)
                 x = ops.linear(ops.gather_rows(ctx.view(B * S, d.inner), idx), L["wo"], residual=x)
-                h = ops.rmsnorm(x, L["ln1"], d.eps)
-                x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
+                h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
+                x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
         out = torch.zeros((B * S, d.d_model), dtype=torch.float32, device=x.device)
         ops.scatter_rows(ops.rmsnorm(x, self.final_ln, d.eps), idx, out)
         return out.view(B, S, d.d_model)
@@ -234,6 +235,7 @@ class DecoderStack:
                 ln2=_dev(w, f"{p}.2.layer_norm.weight", device),
                 wi=_dev(w, f"{p}.2.DenseReluDense.wi.weight", device),
                 wo2=_dev(w, f"{p}.2.DenseReluDense.wo.weight", device)))
+        ops.prepare_weights(self.layers, ("wq", "wkv", "wo", "xq", "xkv", "xo", "wi", "wo2"))
         self.final_ln = _dev(w, f"{prefix}.final_layer_norm.weight", device)
         rel = _dev(w, f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight", device)
         self.self_bias = bias_table(rel, max_len, max_len, False, dims.buckets)   # [H, T, T]
@@ -253,8 +255,9 @@ class DecoderStack:
             if idx.numel() == 0 or idx.numel() > 0.9 * B * S:
                 idx = None
         if idx is None:
+            flat = ops.gemm_input(flat)        # one operand image for all layers
             return CrossKV([ops.linear(flat, L["xkv"]).view(B, S, 2 * self.d.inner) for L in self.layers], enc_mask)
-        real = ops.gather_rows(flat, idx)
+        real = ops.gemm_input(ops.gather_rows(flat, idx))
         seq_off, longest = packed_offsets(enc_mask)
         if seq_off is not None and 0 < longest <= 256:
             return CrossKV([ops.linear(real, L["xkv"]) for L in self.layers], None, seq_off, longest)
@@ -276,7 +279,7 @@ class DecoderStack:
         d = self.d
         n = x.shape[0]
         for L, kvc, xc in zip(self.layers, cache, xkv.layers):
-            h = ops.rmsnorm(x, L["ln0"], d.eps)
+            h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
             if t == 0:
                 # one key: its softmax weight is exp(0) / exp(0) = 1 exactly, so the attention output IS v -- no query
                 # projection, no attention kernel; a single-position decoder (the towers) never needs k either
@@ -291,7 +294,7 @@ class DecoderStack:
                 ctx = ops.attention(q.view(n, 1, d.inner), kvc[:, :t + 1, :d.inner], kvc[:, :t + 1, d.inner:],
                                     d.num_heads, bias=self.self_bias, q_pos0=t, causal=True).view(n, d.inner)
             x = ops.linear(ctx, L["wo"], residual=x)
-            h = ops.rmsnorm(x, L["ln1"], d.eps)
+            h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
             q = ops.linear(h, L["xq"])
             if xkv.kv_off is None:
                 ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :, :d.inner], xc[:, :, d.inner:], d.num_heads,
@@ -300,8 +303,8 @@ class DecoderStack:
                 ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :d.inner], xc[:, d.inner:], d.num_heads, kv_div=kv_div,
                                     kv_off=xkv.kv_off, kv_longest=xkv.longest)
             x = ops.linear(ctx.view(n, d.inner), L["xo"], residual=x)
-            h = ops.rmsnorm(x, L["ln2"], d.eps)
-            x = ops.linear(ops.linear(h, L["wi"], relu=True), L["wo2"], residual=x)
+            h = ops.rmsnorm(x, L["ln2"], d.eps, for_gemm=True)
+            x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
         return ops.rmsnorm(x, self.final_ln, d.eps)
 
 
