@@ -129,7 +129,7 @@ int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int64_t ldw, f
  * Split-precision linear layer (the same reference call sites as mevi_gemm_nt_f32, for the T5 / BERT / adaptor
  * weights; csrc/gemm_split.hip).  Operands are images of f32 rows made by mevi_split_rows_f16:
  *   row r of x f32[m, k]  ->  img[r] = [hi (kp halves) | lo (kp halves)], kp = mevi_split_kp(k) = k rounded up to 32,
- *   x = 2^-exps[r] * (hi + lo), hi = f16(x 2^e), lo = f16(x 2^e - hi): 22 significant bits per element.
+ *   x = 2^-exps[r] * (hi + lo) (exps int8, |e| <= 100), hi = f16(x 2^e), lo = f16(x 2^e - hi): 22 significant bits per element.
  * mevi_gemm_nt_split_f32 computes C = act(A.W^T + bias) + residual with three f16 MFMAs per product
  * (a_lo w_hi + a_hi w_lo + a_hi w_hi, f32 accumulate): relative error ~3 * 2^-22 per product instead of the exact
  * chain's 2^-24; every output depends only on its own two rows (same bits in any batch).  c f32 [m, n] (row stride
@@ -137,22 +137,22 @@ int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int64_t ldw, f
  *   Requirements: k, ldx multiples of 4; x and the images 16-byte aligned; img holds m * 2 * kp halves.
  * ---------------------------------------------------------------------- */
 int64_t mevi_split_kp(int64_t k);
-int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int32_t *exps, float *norms,
+int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int8_t *exps, float *norms,
                         void *stream);   /* norms (may be NULL): l2 norm of every row, rounded up */
 /* T5LayerNorm (mevi_rmsnorm_f32, modeling_t5.py:155-171) written straight into a split image: the normed states only
  * ever feed linear layers. */
 int mevi_rmsnorm_split_f16(const float *x, int64_t ldx, const float *w, float eps, int64_t rows, int64_t dim,
-                           void *img, int32_t *exps, float *norms, void *stream);
+                           void *img, int8_t *exps, float *norms, void *stream);
 /* The same GEMM writing act(A.W^T + bias) as a split image [m, 2 * kp(n)] for a following GEMM (the FFN's
  * relu(x Wi^T), T5DenseReluDense modeling_t5.py:181-186 / BertIntermediate).  A row's exponent is fixed before its
  * columns exist, from |out| <= a_norm[r] * w_norm_max + bias_abs_max (Cauchy-Schwarz; w_norm_max = largest l2 norm of
  * a W row).  out_norm (may be NULL) receives a bound on the output rows' l2 norms.  When n % 32 != 0 the caller zeroes
  * out_img first (columns n .. kp(n) are not written). */
-int mevi_gemm_nt_split_to_split(const void *a_img, const int32_t *a_exp, const float *a_norm, const void *w_img,
-                                const int32_t *w_exp, float w_norm_max, int64_t m, int64_t n, int64_t k,
-                                const float *bias, float bias_abs_max, int act, void *out_img, int32_t *out_exp,
+int mevi_gemm_nt_split_to_split(const void *a_img, const int8_t *a_exp, const float *a_norm, const void *w_img,
+                                const int8_t *w_exp, float w_norm_max, int64_t m, int64_t n, int64_t k,
+                                const float *bias, float bias_abs_max, int act, void *out_img, int8_t *out_exp,
                                 float *out_norm, void *stream);
-int mevi_gemm_nt_split_f32(const void *a_img, const int32_t *a_exp, const void *w_img, const int32_t *w_exp,
+int mevi_gemm_nt_split_f32(const void *a_img, const int8_t *a_exp, const void *w_img, const int8_t *w_exp,
                            float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias,
                            const float *residual, int64_t ldr, int act, void *stream);
 

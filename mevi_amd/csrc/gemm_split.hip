@@ -46,7 +46,7 @@ __device__ __forceinline__ void split4(const float4 v, int e, h4 &hi, h4 &lo) {
 
 // rows of x f32[m, k] (row stride ldx) -> image [m, 2 * kp] halves + exponent per row.  One wave per row.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ x, long long ldx, long long m, int k,
-                                                        int kp, _Float16 *__restrict__ img, int *__restrict__ exps,
+                                                        int kp, _Float16 *__restrict__ img, signed char *__restrict__ exps,
                                                         float *__restrict__ norms) {
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= m) return;
@@ -72,14 +72,14 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
     *reinterpret_cast<h4 *>(o + c) = hi;
     *reinterpret_cast<h4 *>(o + kp + c) = lo;
   }
-  if (lane == 0) exps[r] = e;
+  if (lane == 0) exps[r] = (signed char)e;
 }
 
 // T5LayerNorm (t5_ops.hip: rmsnorm_kernel, same arithmetic per element) written straight into the split image:
 // y = w * (x / sqrt(mean(x^2) + eps)).  One wave per row; y is recomputed for the second pass (the row sits in L1).
 __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float *__restrict__ x, long long ldx,
                                                            const float *__restrict__ w, float eps, long long rows, int dim,
-                                                           int kp, _Float16 *__restrict__ img, int *__restrict__ exps,
+                                                           int kp, _Float16 *__restrict__ img, signed char *__restrict__ exps,
                                                            float *__restrict__ norms) {
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float *__restr
     *reinterpret_cast<h4 *>(o + kp + 4 * i) = lo;
   }
   if (lane == 0) {
-    exps[r] = e;
+    exps[r] = (signed char)e;
     norms[r] = sqrtf(s2) * 1.0001f;
   }
 }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float *__restr
 // bound, the pair 22 bits down to 2^-18 of it, and below that the absolute error is < 2^-40 of the bound.
 struct SplitOut {
   _Float16 *img;       // [M, 2 * np] or nullptr
-  int *exps;           // [M]
+  signed char *exps;   // [M]
   float *norms;        // [M] or nullptr: bound on the output row's l2 norm (for a further split-out layer)
   const float *anorm;  // [M] l2 norms of the A rows
   int np;
@@ -146,27 +146,43 @@ __device__ __forceinline__ int out_exp(const SplitOut &so, int m) {
 struct SplitUnits {
   int U;         // units per segment (kp / 32)
   int lo_bytes;  // byte offset of the lo half of a row (kp * 2)
-  bool is_a;     // this wave stages the A operand (waves 0-3) or W (waves 4-7)
+  bool is_w;     // this wave stages the W operand (waves 0-3) or the activations (waves 4-7)
   __device__ __forceinline__ int operator()(int u) const {
     const int seg = (u >= U) + (u >= 2 * U);
     const int uu = u - seg * U;
-    const bool lo = is_a ? (seg == 0) : (seg == 1);
+    const bool lo = is_w ? (seg == 1) : (seg == 0);   // segment 0 = a_lo w_hi, 1 = a_hi w_lo, 2 = a_hi w_hi
     return uu * 64 + (lo ? lo_bytes : 0);
   }
 };
 
-__device__ __forceinline__ float epilogue(float acc, int e, float b, bool has_bias, int act) {
-  float v = ldexpf(acc, -e);
-  if (has_bias) v += b;
-  if (act == 1) v = fmaxf(v, 0.f);
-  else if (act == 2) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752f));  // erf GELU (BERT 'gelu')
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int OOB = (int)0x80000000;  // voffset beyond every descriptor below: the load returns 0, the store is dropped
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7ffffff0, 0x00020000);
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+  if constexpr (ACT == 1) return fmaxf(v, 0.f);
+  if constexpr (ACT == 2) return v * 0.5f * (1.0f + erff(v * 0.70710678118654752f));  // erf GELU (BERT 'gelu')
   return v;
 }
 
+// Roles inside the tile stream: the MFMA's first operand (the stream's 2 x 128-row "A" tile) is W, the second (its
+// 256-row "B" tile) the activations, so a lane ends up with ONE output row m = m0 + 128 wn + 32 ni + (lane & 31) per
+// ni and, per accumulator register quad, FOUR CONSECUTIVE columns n = n0 + 128 grp + 64 wm + 32 mi + 8 q + 4 half + j:
+// the epilogue moves 16 bytes per lane and instruction (32 stores per wave and tile instead of 128), the row exponent
+// / norm are per-lane scalars.  All of its memory operations are buffer operations on a per-tile descriptor with a
+// 32-bit offset (one VGPR of addressing; masked lanes get an out-of-range offset instead of a branch: a load under a
+// per-element condition makes the compiler wait vmcnt(0) for each one).
+template <int ACT, int OUT>   // OUT: 0 = f32 C, 1 = f32 C + residual, 2 = split image
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
-    const _Float16 *__restrict__ A, const int *__restrict__ ea, int M, const _Float16 *__restrict__ W,
-    const int *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
-    const float *__restrict__ residual, long long ldr, int act, int n_mtiles, int n_ntiles, SplitOut so) {
+    const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
+    const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int n_mtiles, int n_ntiles, SplitOut so) {
+  constexpr bool SPLIT_OUT = OUT == 2, HAS_RES = OUT == 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nwg = n_mtiles * n_ntiles;
   const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
@@ -185,18 +201,18 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
   auto next = [&](H1Src &s) -> bool {
     if (item >= range_len) return false;
     int mt, nt;
-    supertile_order<4, 8>(range_base + item, n_mtiles, n_ntiles, mt, nt);
+    supertile_order<4, 8>(range_base + item, n_ntiles, n_mtiles, nt, mt);
     item += per_xcd;
     if (n_pend == 0) head_m = mt, head_n = nt;
     else tail_m = mt, tail_n = nt;
     ++n_pend;
     long long rows_left;
-    if (w8 < 4) {  // waves 0-3 stage the 256 A rows (LDS rows [0, 256)), waves 4-7 the 256 W rows
-      s.src = reinterpret_cast<const char *>(A) + (size_t)mt * 256 * (size_t)row_bytes;
-      rows_left = (long long)M - (long long)mt * 256;
-    } else {
+    if (w8 < 4) {  // waves 0-3 stage the 256 W rows (LDS rows [0, 256)), waves 4-7 the 256 activation rows
       s.src = reinterpret_cast<const char *>(W) + (size_t)nt * 256 * (size_t)row_bytes;
       rows_left = (long long)N - (long long)nt * 256;
+    } else {
+      s.src = reinterpret_cast<const char *>(A) + (size_t)mt * 256 * (size_t)row_bytes;
+      rows_left = (long long)M - (long long)mt * 256;
     }
     if (rows_left > 256) rows_left = 256;
     s.bytes = (unsigned int)(rows_left * row_bytes);
@@ -207,45 +223,93 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
     const int mt = head_m, nt = head_n;
     head_m = tail_m, head_n = tail_n;
     --n_pend;
-    const int mb = mt * 256 + 128 * grp + 64 * wm + 4 * half;
-    const int nb = nt * 256 + 128 * wn + lrow;
-    int em[2][16], eo[2][16];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + 32 * mi + (r & 3) + 8 * (r >> 2);
-        em[mi][r] = m < M ? ea[m] : 0;
-        eo[mi][r] = (so.img && m < M) ? out_exp(so, m) : 0;
-        if (so.img && m < M && nt == 0 && wn == 0 && lrow == 0) {  // one writer per row
-          so.exps[m] = eo[mi][r];
-          if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
-        }
-      }
+    const int m0 = mt * 256 + 128 * wn + lrow;           // + 32 ni
+    const int n0 = nt * 256 + 128 * grp + 64 * wm + 4 * half;  // + 32 mi + 8 q (+ j)
+    const bool interior = (mt + 1) * 256 <= M && (nt + 1) * 256 <= N;
+    const int ldc4 = (int)ldc * 4, ldr4 = (int)ldr * 4;
+    // per-tile descriptors (64-bit origin in SGPRs) + 32-bit lane offsets
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(SPLIT_OUT ? nullptr : C + (size_t)mt * 256 * ldc + (size_t)nt * 256);
+    const __amdgpu_buffer_rsrc_t rr =
+        tile_rsrc(residual ? residual + (size_t)mt * 256 * ldr + (size_t)nt * 256 : nullptr);
+    const __amdgpu_buffer_rsrc_t ri =
+        tile_rsrc(SPLIT_OUT ? so.img + (size_t)mt * 256 * 2 * so.np + (size_t)nt * 256 : nullptr);
+    const __amdgpu_buffer_rsrc_t rw = tile_rsrc(ew + nt * 256);
+    const __amdgpu_buffer_rsrc_t rb = tile_rsrc(bias ? bias + nt * 256 : nullptr);
+    const int ncol = 128 * grp + 64 * wm + 4 * half;     // column of the lane's first quad inside the tile
+    const int nvalid = N - nt * 256;                      // columns of this tile that exist (edge tiles)
+    int em[4], eo[SPLIT_OUT ? 4 : 1];
+    bool mok[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      const int n = nb + 32 * ni;
-      if (n >= N) continue;
-      const int en = ew[n];
-      const float b = bias ? bias[n] : 0.f;
+      const int m = m0 + 32 * ni;
+      mok[ni] = interior || m < M;
+      em[ni] = ea[min(m, M - 1)];
+      if constexpr (SPLIT_OUT) {
+        const float bound = fmaf(so.anorm[min(m, M - 1)], so.wnorm_max, so.babs_max);
+        eo[ni] = pow2_exp(bound * 1.001f);
+        if (nt == 0 && grp == 0 && wm == 0 && half == 0 && mok[ni]) {  // one writer per row
+          so.exps[m] = (signed char)eo[ni];
+          if (so.norms) so.norms[m] = bound * so.onorm_scale;
+        }
+      }
+    }
+    // Every load is issued BEFORE the stores it does not depend on: vmcnt retires in issue order, so a load placed
+    // after a store waits for that store's write acknowledgement (microseconds under load).  The column exponents /
+    // bias of all eight quads are fetched up front (the fragment registers are dead here), the residual rows of
+    // quad i + 1 before the stores of quad i.
+    unsigned int wq[8];   // four int8 exponents per quad
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+    for (int i = 0; i < 8; ++i) {
+      const int c = ncol + 32 * (i >> 2) + 8 * (i & 3);
+      wq[i] = __builtin_amdgcn_raw_buffer_load_b32(rw, (interior || c < nvalid) ? c : OOB, 0, 0);
+    }
+    u32x4 bq[2], res[2][HAS_RES ? 4 : 1];
+    auto load_res = [&](int i, u32x4 &b, u32x4 (&r)[HAS_RES ? 4 : 1]) {
+      const int c = ncol + 32 * (i >> 2) + 8 * (i & 3);
+      const bool cok = interior || c < nvalid;
+      b = u32x4{0u, 0u, 0u, 0u};
+      if (bias) b = __builtin_amdgcn_raw_buffer_load_b128(rb, cok ? c * 4 : OOB, 0, 0);
+      if constexpr (HAS_RES) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + 32 * mi + (r & 3) + 8 * (r >> 2);
-          if (m < M) {
-            float v = epilogue(acc[mi][ni][r], em[mi][r] + en, b, bias != nullptr, act);
-            if (residual) v += residual[(size_t)m * ldr + n];
-            if (so.img) {
-              const float xs = ldexpf(v, eo[mi][r]);
-              const _Float16 hi = (_Float16)xs;
-              _Float16 *o = so.img + (size_t)m * 2 * so.np + n;
-              o[0] = hi;
-              o[so.np] = (_Float16)(xs - (float)hi);
-            } else {
-              C[(size_t)m * ldc + n] = v;
-            }
+        for (int ni = 0; ni < 4; ++ni) {
+          const int rowt = 128 * wn + 32 * ni + lrow;
+          r[ni] = __builtin_amdgcn_raw_buffer_load_b128(rr, (cok && mok[ni]) ? rowt * ldr4 + c * 4 : OOB, 0, 0);
+        }
+      }
+    };
+    load_res(0, bq[0], res[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int mi = i >> 2, q = i & 3;
+      const int c = ncol + 32 * mi + 8 * q;
+      const bool cok = interior || c < nvalid;
+      if (i + 1 < 8) load_res(i + 1, bq[(i + 1) & 1], res[(i + 1) & 1]);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int rowt = 128 * wn + 32 * ni + lrow;      // row inside the tile
+        const bool ok = cok && mok[ni];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = ldexpf(acc[mi][ni][4 * q + j], -(em[ni] + ((int)(wq[i] << (24 - 8 * j)) >> 24))) + __uint_as_float(bq[i & 1][j]);
+          x = act_fn<ACT>(x);
+          if constexpr (HAS_RES) x += __uint_as_float(res[i & 1][ni][j]);
+          v[j] = x;
+        }
+        if constexpr (SPLIT_OUT) {
+          h4 hi, lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xs = ldexpf(v[j], eo[ni]);
+            hi[j] = (_Float16)xs;
+            lo[j] = (_Float16)(xs - (float)hi[j]);
           }
+          const int off = ok ? rowt * (so.np * 4) + c * 2 : OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), ri, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), ri, off, so.np * 2, 0);
+        } else {
+          const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rc, ok ? rowt * ldc4 + c * 4 : OOB, 0, 0);
         }
       }
     }
@@ -253,16 +317,16 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
   SplitUnits uoff;
   uoff.U = kp / 32;
   uoff.lo_bytes = kp * 2;
-  uoff.is_a = w8 < 4;
+  uoff.is_w = w8 < 4;
   h1_tile_stream(row_bytes, 3 * (kp / 32), lds, next, begin, emit, uoff);
 }
 
 // Few outputs: one wave per 32 x 32 outputs, fragments straight from global memory (the images of a handful of rows
-// sit in L2), the same MFMA sequence as the tile stream: segments 0..2, units in order, k-steps j = 0, 1, lane
-// (row, half) supplying k = 32 u + 16 j + 8 half + [0, 8).
+// sit in L2), the same MFMA sequence as the tile stream (W first, activations second): segments 0..2, units in order,
+// k-steps j = 0, 1, lane (row, half) supplying k = 32 u + 16 j + 8 half + [0, 8).
 __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
-    const _Float16 *__restrict__ A, const int *__restrict__ ea, int M, const _Float16 *__restrict__ W,
-    const int *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
+    const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
+    const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
     const float *__restrict__ residual, long long ldr, int act, SplitOut so) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lrow = lane & 31, half = lane >> 5;
@@ -282,25 +346,30 @@ __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
     for (int k = 0; k < kp; k += 16) {
       const f16x8 fa = *reinterpret_cast<const f16x8 *>(a + k);
       const f16x8 fw = *reinterpret_cast<const f16x8 *>(w + k);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fw, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fa, acc, 0, 0, 0);
     }
   }
-  const int n = n0 + lrow;
-  if (n >= N) return;
-  const int en = ew[n];
-  const float b = bias ? bias[n] : 0.f;
+  const int m = m0 + lrow;
+  if (m >= M) return;
+  const int em = ea[m];
+  int eo = 0;
+  if (so.img) {
+    eo = out_exp(so, m);
+    if (n0 == 0 && half == 0) {
+      so.exps[m] = (signed char)eo;
+      if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (m < M) {
-      float v = epilogue(acc[r], ea[m] + en, b, bias != nullptr, act);
+    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (n < N) {
+      float v = ldexpf(acc[r], -(em + ew[n]));
+      if (bias) v += bias[n];
+      const int a8 = act;
+      v = a8 == 1 ? act_fn<1>(v) : (a8 == 2 ? act_fn<2>(v) : v);
       if (residual) v += residual[(size_t)m * ldr + n];
       if (so.img) {
-        const int eo = out_exp(so, m);
-        if (n == 0) {
-          so.exps[m] = eo;
-          if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
-        }
         const float xs = ldexpf(v, eo);
         const _Float16 hi = (_Float16)xs;
         _Float16 *o = so.img + (size_t)m * 2 * so.np + n;
@@ -322,7 +391,7 @@ using namespace mevi;
 
 extern "C" int64_t mevi_split_kp(int64_t k) { return (k + 31) / 32 * 32; }
 
-extern "C" int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int32_t *exps,
+extern "C" int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int8_t *exps,
                                    float *norms, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   MEVI_REQUIRE(m >= 0 && k > 0, MEVI_ERR_INVALID_ARG, "split_rows: bad shape");
@@ -332,25 +401,25 @@ extern "C" int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64
                MEVI_ERR_UNSUPPORTED, "split_rows: k, ldx must be multiples of 4 and x, img 16-byte aligned");
   MEVI_REQUIRE(k < (1LL << 22), MEVI_ERR_UNSUPPORTED, "split_rows: k too large");
   hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, x, (long long)ldx,
-                     (long long)m, (int)k, (int)mevi_split_kp(k), reinterpret_cast<_Float16 *>(img), exps, norms);
+                     (long long)m, (int)k, (int)mevi_split_kp(k), reinterpret_cast<_Float16 *>(img), reinterpret_cast<signed char *>(exps), norms);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }
 
 extern "C" int mevi_rmsnorm_split_f16(const float *x, int64_t ldx, const float *w, float eps, int64_t rows, int64_t dim,
-                                      void *img, int32_t *exps, float *norms, void *stream_) {
+                                      void *img, int8_t *exps, float *norms, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   MEVI_REQUIRE(rows >= 0 && dim > 0 && dim % 4 == 0 && ldx % 4 == 0, MEVI_ERR_INVALID_ARG,
                "rmsnorm_split: dim/ld must be multiples of 4");
   if (rows == 0) return MEVI_OK;
   MEVI_REQUIRE(x && w && img && exps && norms, MEVI_ERR_INVALID_ARG, "rmsnorm_split: null pointer");
   hipLaunchKernelGGL(rmsnorm_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, (long long)ldx, w,
-                     eps, (long long)rows, (int)dim, (int)mevi_split_kp(dim), reinterpret_cast<_Float16 *>(img), exps, norms);
+                     eps, (long long)rows, (int)dim, (int)mevi_split_kp(dim), reinterpret_cast<_Float16 *>(img), reinterpret_cast<signed char *>(exps), norms);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }
 
-static int gemm_split_launch(const void *a_img, const int32_t *a_exp, const void *w_img, const int32_t *w_exp,
+static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void *w_img, const int8_t *w_exp,
                              float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias,
                              const float *residual, int64_t ldr, int act, SplitOut so, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -361,12 +430,17 @@ static int gemm_split_launch(const void *a_img, const int32_t *a_exp, const void
                "gemm_nt_split: images must be 16-byte aligned");
   MEVI_REQUIRE(act >= 0 && act <= 2, MEVI_ERR_INVALID_ARG, "gemm_nt_split: act must be 0 (none), 1 (relu) or 2 (erf gelu)");
   MEVI_REQUIRE(m < (1LL << 31) && n < (1LL << 31) && k < (1LL << 20), MEVI_ERR_UNSUPPORTED, "gemm_nt_split: too large");
+  MEVI_REQUIRE(n % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ((uintptr_t)c % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
+                   ((uintptr_t)bias % 16) == 0 && ((uintptr_t)w_exp % 4) == 0,
+               MEVI_ERR_UNSUPPORTED, "gemm_nt_split: n, ldc, ldr must be multiples of 4 and c, residual, bias 16-byte (w_exp 4-byte) aligned");
+  MEVI_REQUIRE(ldc < (1LL << 20) && ldr < (1LL << 20), MEVI_ERR_UNSUPPORTED, "gemm_nt_split: row stride too large");
   const int kp = (int)mevi_split_kp(k);
   const _Float16 *A = reinterpret_cast<const _Float16 *>(a_img), *W = reinterpret_cast<const _Float16 *>(w_img);
   static const int skinny_on = [] { const char *e = getenv("MEVI_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
   if (m * n <= SPLIT_SKINNY_MAX_OUTPUTS && skinny_on) {
     hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3((unsigned)((n + 127) / 128), (unsigned)((m + 31) / 32)), dim3(256), 0,
-                       stream, A, a_exp, (int)m, W, w_exp, (int)n, kp, c, (long long)ldc, bias, residual, (long long)ldr, act, so);
+                       stream, A, reinterpret_cast<const signed char *>(a_exp), (int)m, W, reinterpret_cast<const signed char *>(w_exp), (int)n, kp, c,
+                       (long long)ldc, bias, residual, (long long)ldr, act, so);
     MEVI_HIP_CHECK(hipGetLastError());
     return MEVI_OK;
   }
@@ -383,31 +457,38 @@ static int gemm_split_launch(const void *a_img, const int32_t *a_exp, const void
   const int64_t tiles = n_mtiles * n_ntiles;
   if (tiles < grid) grid = (tiles + 7) / 8 * 8;
   const size_t lds_bytes = h1_lds_bytes();
-  MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)grid), dim3(PP_THREADS), lds_bytes, stream, A, a_exp, (int)m, W,
-                     w_exp, (int)n, kp, c, (long long)ldc, bias, residual, (long long)ldr, act, (int)n_mtiles,
+  const int a8 = act;
+  typedef void (*kern_t)(const _Float16 *, const signed char *, int, const _Float16 *, const signed char *, int, int, float *,
+                         long long, const float *, const float *, long long, int, int, SplitOut);
+  static const kern_t table[3][3] = {{gemm_split_kernel<0, 0>, gemm_split_kernel<0, 1>, gemm_split_kernel<0, 2>},
+                                     {gemm_split_kernel<1, 0>, gemm_split_kernel<1, 1>, gemm_split_kernel<1, 2>},
+                                     {gemm_split_kernel<2, 0>, gemm_split_kernel<2, 1>, gemm_split_kernel<2, 2>}};
+  const kern_t fn = table[a8][so.img ? 2 : (residual ? 1 : 0)];
+  MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes));
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(PP_THREADS), lds_bytes, stream, A, reinterpret_cast<const signed char *>(a_exp), (int)m, W,
+                     reinterpret_cast<const signed char *>(w_exp), (int)n, kp, c, (long long)ldc, bias, residual, (long long)ldr, (int)n_mtiles,
                      (int)n_ntiles, so);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }
 
-extern "C" int mevi_gemm_nt_split_f32(const void *a_img, const int32_t *a_exp, const void *w_img, const int32_t *w_exp,
+extern "C" int mevi_gemm_nt_split_f32(const void *a_img, const int8_t *a_exp, const void *w_img, const int8_t *w_exp,
                                       float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias,
                                       const float *residual, int64_t ldr, int act, void *stream) {
   SplitOut so = {};
   return gemm_split_launch(a_img, a_exp, w_img, w_exp, c, ldc, m, n, k, bias, residual, ldr, act, so, stream);
 }
 
-extern "C" int mevi_gemm_nt_split_to_split(const void *a_img, const int32_t *a_exp, const float *a_norm, const void *w_img,
-                                           const int32_t *w_exp, float w_norm_max, int64_t m, int64_t n, int64_t k,
+extern "C" int mevi_gemm_nt_split_to_split(const void *a_img, const int8_t *a_exp, const float *a_norm, const void *w_img,
+                                           const int8_t *w_exp, float w_norm_max, int64_t m, int64_t n, int64_t k,
                                            const float *bias, float bias_abs_max, int act, void *out_img,
-                                           int32_t *out_exp, float *out_norm, void *stream) {
+                                           int8_t *out_exp, float *out_norm, void *stream) {
   MEVI_REQUIRE(m == 0 || (a_norm && out_img && out_exp), MEVI_ERR_INVALID_ARG, "gemm_nt_split_to_split: null pointer");
   MEVI_REQUIRE(w_norm_max >= 0.f && bias_abs_max >= 0.f, MEVI_ERR_INVALID_ARG, "gemm_nt_split_to_split: negative bound");
   SplitOut so = {};
   so.img = reinterpret_cast<_Float16 *>(out_img);
-  so.exps = out_exp;
+  so.exps = reinterpret_cast<signed char *>(out_exp);
   so.norms = out_norm;
   so.anorm = a_norm;
   so.np = (int)mevi_split_kp(n);

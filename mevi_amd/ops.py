@@ -27,7 +27,7 @@ def _rows2d(t):
 
 class SplitRows:
     """f32 rows held as (hi | lo) float16 images with one power-of-two exponent per row (csrc/gemm_split.hip):
-    the operand format of the split-precision GEMM.  `img` i16 [rows, 2 * kp], `exp` i32 [rows]; `norm` f32 [rows]
+    the operand format of the split-precision GEMM.  `img` i16 [rows, 2 * kp], `exp` i8 [rows]; `norm` f32 [rows]
     (activations: l2 norm of every row, rounded up) and `norm_max` / `bias_abs_max` (weights: the largest row norm)
     feed the exponent bound of a GEMM that writes its result as an image (linear(..., for_gemm=True))."""
 
@@ -52,13 +52,18 @@ class SplitRows:
         return self
 
 
+def weight_split(w):
+    """Split image of a static [out, in] weight, with the largest row norm (the bound of image-writing GEMMs)."""
+    ws = split_rows(w.contiguous())
+    ws.norm_max = float(ws.norm.max().item()) if ws.norm.numel() else 0.0
+    ws.norm = None
+    return ws
+
+
 def weight(w):
     """A linear layer's [out, in] weight in the operand format of the current GEMM_MODE (static: converted once)."""
     if GEMM_MODE == "split":
-        ws = split_rows(w.contiguous())
-        ws.norm_max = float(ws.norm.max().item()) if ws.norm.numel() else 0.0
-        ws.norm = None
-        return ws
+        return weight_split(w)
     assert GEMM_MODE == "exact", f"MEVI_GEMM must be 'split' or 'exact', not {GEMM_MODE!r}"
     return w
 
@@ -89,7 +94,7 @@ def gemm_input(x):
 def _split_buffers(M, K, dev, zero=False):
     kp = (K + 31) // 32 * 32
     img = (torch.zeros if zero and kp != K else torch.empty)((M, 2 * kp), dtype=torch.int16, device=dev)
-    return img, torch.empty((M,), dtype=torch.int32, device=dev), torch.empty((M,), dtype=torch.float32, device=dev)
+    return img, torch.empty((M,), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev)
 
 
 def split_rows(x):

@@ -1,0 +1,117 @@
+"""Split-precision GEMM (csrc/gemm_split.hip: three f16 MFMAs per product on (hi, lo) float16 row images) against a
+float64 reference.  Bar (stated per assertion): |error| <= 2e-6 * sum_k |a_k w_k| per output -- the f32 chain's own
+worst case at these K is ~4e-7 of that sum, the split form measures ~1.5e-7 --, every epilogue, both kernels (tile
+stream / few-rows), ragged shapes, strided outputs; and a row gives the same BITS alone or inside a large batch."""
+import numpy as np
+import pytest
+import torch
+
+from mevi_amd import ops
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+
+
+def _ref(x, w, bias, act, residual):
+    y = x.double() @ w.double().T
+    den = x.double().abs() @ w.double().abs().T
+    if bias is not None:
+        y, den = y + bias.double(), den + bias.double().abs()
+    if act == "relu":
+        y = torch.relu(y)
+    elif act == "gelu":
+        y = torch.nn.functional.gelu(y)
+    if residual is not None:
+        y, den = y + residual.double(), den + residual.double().abs()
+    return y, den
+
+
+def _image_value(s):
+    """f64 value of a SplitRows image: 2^-e (hi + lo)."""
+    kp = s.img.shape[1] // 2
+    h = s.img.view(torch.float16).double()
+    return ((h[:, :kp] + h[:, kp:]) * torch.exp2(-s.exp.double())[:, None])[:, :s.k]
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 768, 768), (517, 100, 36), (256, 96, 32), (1030, 2304, 768), (7, 3072, 768),
+                                   (70000, 256, 64), (300, 36, 64), (1, 768, 3072), (2100, 260, 2048)])
+def test_split_gemm_matches_float64(cuda, M, N, K):
+    g = torch.Generator(device=cuda).manual_seed(M + N + K)
+    x = torch.randn((M, K), device=cuda, generator=g) * torch.exp(2 * torch.randn((M, 1), device=cuda, generator=g))
+    w = torch.randn((N, K), device=cuda, generator=g) * K ** -0.5 * torch.exp(torch.randn((N, 1), device=cuda, generator=g))
+    b = torch.randn((N,), device=cuda, generator=g)
+    r = torch.randn((M, N), device=cuda, generator=g)
+    ws = ops.split_rows(w)
+    xs = ops.split_rows(x)
+    assert (_image_value(xs) - x.double()).abs().max() <= 2.0 ** -21 * x.abs().max()      # 22-bit operand images
+    for kw, act in ((dict(), None), (dict(bias=b, relu=True), "relu"), (dict(bias=b, gelu=True), "gelu"),
+                    (dict(residual=r), None), (dict(bias=b, residual=r), None)):
+        got = ops.linear(xs, ws, **kw)
+        ref, den = _ref(x, w, kw.get("bias"), act, kw.get("residual"))
+        assert torch.isfinite(got).all()
+        err = ((got.double() - ref).abs() / den.clamp_min(1e-30)).max().item()
+        assert err <= TOL, (sorted(kw), err)
+        assert torch.equal(ops.linear(x, ws, **kw), got)                                     # f32 input: split on the way in
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 3072, 768), (300, 64, 32), (5, 2048, 768), (1100, 100, 768)])
+@pytest.mark.parametrize("act", ["relu", "gelu", None])
+def test_gemm_writing_a_split_image(cuda, M, N, K, act):
+    """linear(..., for_gemm=True): the result as the next GEMM's operand image (exponent from the Cauchy-Schwarz
+    bound): its value equals the f32 result to 22 bits of the row BOUND, and feeding it on gives the second layer."""
+    g = torch.Generator(device=cuda).manual_seed(M + N)
+    x = torch.randn((M, K), device=cuda, generator=g) * torch.exp(torch.randn((M, 1), device=cuda, generator=g))
+    w1 = torch.randn((N, K), device=cuda, generator=g) * K ** -0.5
+    b1 = torch.randn((N,), device=cuda, generator=g) * 0.1
+    w2 = torch.randn((40, N), device=cuda, generator=g) * N ** -0.5
+    xs, w1s, w2s = ops.split_rows(x), ops.weight_split(w1), ops.weight_split(w2)
+    kw = dict(bias=b1, relu=act == "relu", gelu=act == "gelu")
+    h32 = ops.linear(xs, w1s, **kw)
+    hs = ops.linear(xs, w1s, for_gemm=True, **kw)
+    assert isinstance(hs, ops.SplitRows) and hs.shape == (M, N)
+    hv = _image_value(hs)
+    bound = torch.exp2(15 - hs.exp.double())[:, None]                      # the row's exponent puts the bound below 2^15
+    assert (h32.double().abs() <= bound).all()
+    assert ((hv - h32.double()).abs() <= bound * 2.0 ** -36 + h32.double().abs() * 2.0 ** -21).all()
+    assert (hs.norm.double() >= torch.linalg.vector_norm(h32.double(), dim=1)).all()
+    y = ops.linear(hs, w2s)
+    ref, den = _ref(h32, w2, None, None, None)
+    assert ((y.double() - ref).abs() / den.clamp_min(1e-30)).max().item() <= TOL
+
+
+def test_rows_keep_their_bits_in_any_batch(cuda):
+    """Few rows (gemm_split_skinny_kernel) and the same rows inside a large batch (the tile stream): identical bits,
+    for the f32 and the image output, with every epilogue."""
+    g = torch.Generator(device=cuda).manual_seed(5)
+    x = torch.randn((4000, 768), device=cuda, generator=g)
+    b = torch.randn((3072,), device=cuda, generator=g)
+    r = torch.randn((4000, 768), device=cuda, generator=g)
+    wi, wo = ops.weight_split(torch.randn((3072, 768), device=cuda, generator=g) * 768 ** -0.5), \
+        ops.weight_split(torch.randn((768, 3072), device=cuda, generator=g) * 3072 ** -0.5)
+    xs = ops.split_rows(x)
+    h = ops.linear(xs, wi, bias=b, relu=True, for_gemm=True)
+    y = ops.linear(h, wo, residual=r)
+    for m in (1, 5, 33, 100):
+        hm = ops.linear(xs[:m], wi, bias=b, relu=True, for_gemm=True)
+        assert torch.equal(hm.img, h.img[:m]) and torch.equal(hm.exp, h.exp[:m]) and torch.equal(hm.norm, h.norm[:m])
+        assert torch.equal(ops.linear(hm, wo, residual=r[:m]), y[:m])
+        assert torch.equal(ops.linear(xs[:m], wi, bias=b, relu=True), ops.linear(xs, wi, bias=b, relu=True)[:m])
+
+
+def test_strided_output_and_fused_rmsnorm(cuda):
+    g = torch.Generator(device=cuda).manual_seed(9)
+    x = torch.randn((1500, 768), device=cuda, generator=g) * 30
+    lnw = 1 + 0.1 * torch.randn((768,), device=cuda, generator=g)
+    w = ops.weight_split(torch.randn((1536, 768), device=cuda, generator=g) * 768 ** -0.5)
+    h = ops.rmsnorm(x, lnw, 1e-6)
+    old = ops.GEMM_MODE
+    try:
+        ops.GEMM_MODE = "split"
+        hs = ops.rmsnorm(x, lnw, 1e-6, for_gemm=True)                       # the norm written as an operand image
+    finally:
+        ops.GEMM_MODE = old
+    ref = ops.split_rows(h)
+    assert torch.equal(hs.img, ref.img) and torch.equal(hs.exp, ref.exp) and torch.equal(hs.norm, ref.norm)
+    cache = torch.full((1500, 5, 1536), float("nan"), device=cuda)
+    ops.linear(hs, w, out=cache[:, 2, :])                                   # the decoder's K|V cache slot
+    assert torch.equal(cache[:, 2, :], ops.linear(hs, w)) and torch.isnan(cache[:, 1, :]).all() and torch.isnan(cache[:, 3, :]).all()
