@@ -71,9 +71,9 @@ def gen_queries(nq, device, n_docs):
     return (blk0[gid] + 0.005 * torch.randn((nq, DIM), device=device, generator=g)).contiguous()
 
 
-def cpu_baseline(n_docs, nq_full, target_s=60.0):
+def cpu_baseline(n_docs, nq_full, target_s=20.0):
     """faiss-Flat-style CPU evaluation (BLAS sgemm blocks + per-query heaps = oracle.dense.ip_topk_blas)
-    on a bounded sample, scaled linearly in rows to the full corpus."""
+    on a bounded sample, scaled linearly in rows to the full corpus; sgemm and heap seconds reported apart."""
     from oracle import dense as odense
 
     nd_s = min(n_docs, 500_000)
@@ -85,8 +85,9 @@ def cpu_baseline(n_docs, nq_full, target_s=60.0):
     odense.ip_topk_blas(q_all[:128], d, TOPK)
     cal = time.time() - t
     nq_s = int(min(nq_full, max(128, 128 * target_s / max(cal, 1e-3))))
+    parts = {}
     t = time.time()
-    odense.ip_topk_blas(q_all[:nq_s], d, TOPK)
+    odense.ip_topk_blas(q_all[:nq_s], d, TOPK, timing=parts)
     dt = time.time() - t
     qps_sample = nq_s / dt
     qps_full = qps_sample * nd_s / n_docs
@@ -99,62 +100,147 @@ def cpu_baseline(n_docs, nq_full, target_s=60.0):
         "value": qps_full, "unit": "queries/s", "cores": int(cores), "kind": "port",
         "sample": f"{nq_s} queries x {nd_s} docs x {DIM} f32, top-{TOPK}, BLAS sgemm blocks + per-query heaps "
                   f"(faiss Flat-IP algorithm) took {dt:.2f}s; scaled x{nd_s}/{n_docs} rows to the full corpus",
+        "sgemm_s": parts.get("sgemm_s"), "heap_s": parts.get("heap_s"),
+        "sgemm_tflops": 2.0 * nq_s * nd_s * DIM / max(parts.get("sgemm_s", 0.0), 1e-9) / 1e12,
         "host_cpus": os.cpu_count(),
     }
 
 
-def seq2seq_legs(device, nq, search_ms, with_cpu):
-    """Untimed extras (N = 1), measured after the timed region and not part of `value`: the stages around the dense
-    search at t5-base shapes (synthetic weights, MS MARCO-like query lengths, tools/synth.py) --
-      * `generate.py --gen_query`: the T5-ANCE query tower (12 + 12 layers) over the same number of queries,
-      * `main.py --mode eval`: NCI generate, beams 10, RQ (4,32) (12 + 6 layers, 4 adaptor layers, adaptive head);
-    and, with the CPU baseline on, the oracle's torch-fp32 restatement of both (what §8(c) validated against the
-    reference) on the box's host cores for a small sample of the same queries, with the agreement of the two paths on
-    that sample."""
+# ---- per-query arithmetic of the seq2seq arm (KV-cached, last-position, valid-column formulation) -----
+def seq2seq_flops(M, K, R, real_tokens_per_query, d=768, dff=3072, enc_layers=12, dec_layers=6, adaptor_layers=4, S=32):
+    """(padded, executed) FLOP per query of NCI generate.  `padded` is SURVEY 8(d)'s budget (every query 32 tokens, the
+    adaptor and the head per beam and step); `executed` counts what this build runs: real tokens only in the encoder
+    and the cross-attention K|V, the adaptor / head matrices per PREFIX (amortised to ~0 over a pass, PrefixTables)
+    except on the last position, where the (K+1)-column head GEMM runs per beam."""
+    lin_enc = 2 * (4 * d * d + 2 * d * dff)                    # q,k,v,o + wi,wo per token and layer
+    enc_pad = enc_layers * S * (lin_enc + 4 * S * d)
+    t = real_tokens_per_query
+    enc_real = enc_layers * t * (lin_enc + 4 * t * d)
+    lin_dec = 2 * (4 * d * d + 2 * d * d + 2 * d * dff)        # self q,k,v,o + cross q,o + wi,wo per beam-step
+    steps = 1 + R * M                                           # position 0 has one beam, positions 1..M have R
+    dec = dec_layers * steps * (lin_dec + 4 * S * d)
+    xkv_pad, xkv_real = dec_layers * S * 4 * d * d, dec_layers * t * 4 * d * d
+    adaptor = adaptor_layers * steps * 2 * (4 * d * d + 2 * d * 2048)
+    head = steps * 2 * (K + 1) * d * d
+    head_exec = R * 2 * (K + 1) * d * d                         # last position only
+    return enc_pad + dec + xkv_pad + adaptor + head, enc_real + dec + xkv_real + head_exec
+
+
+def gemm_roofline(device, rows):
+    """HIP-event time of the linear layers of one encoder block at the arm's pass size: the split-precision GEMM
+    (three f16 MFMAs per product).  achieved = algorithmic 2MNK / time; executed = 3x that on the f16 matrix cores."""
+    from mevi_amd import ops
+
+    g = torch.Generator(device=device).manual_seed(3)
+    shapes = [(rows, 2304, 768, "q|k|v"), (rows, 768, 768, "o"), (rows, 3072, 768, "wi"), (rows, 768, 3072, "wo")]
+    per, flops, ms_total = [], 0.0, 0.0
+    for M_, N_, K_, name in shapes:
+        x = ops.split_rows(torch.randn((M_, K_), device=device, generator=g))
+        w = ops.weight_split(torch.randn((N_, K_), device=device, generator=g) * K_ ** -0.5)
+        ops.linear(x, w)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.linear(x, w)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        f = 2.0 * M_ * N_ * K_
+        per.append({"layer": name, "m": M_, "n": N_, "k": K_, "ms": ms, "algorithmic_tflops": f / ms / 1e9})
+        flops, ms_total = flops + f, ms_total + ms
+        del x, w
+    return {"kernel": "gemm_split_kernel", "bound": "mfma", "achieved": flops / ms_total / 1e9, "unit": "TFLOP/s",
+            "executed_f16_tflops": 3 * flops / ms_total / 1e9, "peak": PEAK_F16_MFMA_TFLOPS,
+            "peak_note": "f16 MFMA dense peak; the kernel issues three f16 MFMAs per f32 product, so frac = 3 x achieved / peak",
+            "frac": 3 * flops / ms_total / 1e9 / PEAK_F16_MFMA_TFLOPS,
+            "exact_f32_kernel_note": "MEVI_GEMM=exact runs gemm_nt_kernel (sequential f32 chains) at 110-126 TFLOP/s = 0.70-0.80 "
+                                     "of the 157.3 TFLOP/s f32 matrix peak (profiles/r01_gemm_clock_util.txt)",
+            "layers": per}
+
+
+def cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs):
+    """What one `faiss_search.py` process pays around the resident-corpus search: corpus upload (host -> HBM through the
+    pinned, threaded staging of mevi_amd.io.upload_rows, measured on a 2 GB sample and scaled), index build, search."""
+    from mevi_amd import io as mio
+
+    rows = min(docs.shape[0], (2 << 30) // (4 * DIM))
+    host = docs[:rows].cpu().numpy()
+    mio.upload_rows(host[: rows // 8], device)
+    t = time.perf_counter()
+    mio.upload_rows(host, device)
+    torch.cuda.synchronize()
+    gbs = rows * DIM * 4 / (time.perf_counter() - t) / 1e9
+    upload_s = n_docs * DIM * 4 / 1e9 / gbs
+    total = upload_s + index_build_s + search_ms / 1e3
+    return {"upload_gb_per_s": gbs, "upload_s": upload_s, "upload_sample": f"{rows} rows ({rows * DIM * 4 / 1e9:.2f} GB) from pageable host memory",
+            "index_build_s": index_build_s, "search_s": search_ms / 1e3, "queries_per_s": nq / total,
+            "note": "PCIe-inclusive rate of ONE faiss_search.py invocation (corpus file in the page cache); every further "
+                    "search on the resident corpus runs at `value`"}
+
+
+def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu):
+    """Untimed extras (N = 1), measured after the timed region and not part of `value`: the path around the dense search at
+    t5-base shapes (synthetic weights, MS MARCO-like query lengths, tools/synth.py) --
+      * query tower and NCI generate alone, with the arm's roofline entries (GEMM kernel, per-query FLOP budget),
+      * config C4 timed directly: tower -> dense search -> beam search -> tower again -> fine stage (+ the ensemble's host time),
+      * NCI generate at BASELINE.json's configs[2] code shape (3 levels x 256 codes),
+      * the CLI-inclusive rate of faiss_search.py (upload + index build + search),
+      * the oracle's torch-fp32 restatement of tower / generate on the host cores for a small sample, with the agreement of
+        the two paths on that sample."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import chain_c4
     import synth
-    from mevi_amd import nci, t5
+    from mevi_amd import nci, ops, t5
 
     M, K, R, gen_batch = 4, 32, 10, 8192
-    W, TW, _, _ = synth.weights(device, M, K)
+    out = {"gemm_mode": ops.GEMM_MODE}
+    W, TW, _, rn = synth.weights(device, M, K)
     cpu_w = ({k: v.cpu() for k, v in W.items()}, {k: v.cpu() for k, v in TW.items()}) if with_cpu else None
     model = nci.NCIModel(W, device=device, M=M, K=K, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
     tower = t5.TwinTower(TW, device=device, num_layers=12, num_decoder_layers=12)
     del W, TW
-    ids, mask = synth.query_ids(nq, device, np.random.default_rng(0))
+    rng = np.random.default_rng(0)
+    ids, mask = synth.query_ids(nq, device, rng)
+    real_tokens = int(mask.sum().item())
 
     def timed(fn, reps):
         fn()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(reps):
-            out = fn()
+            o = fn()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t) / reps * 1e3, out
+        return (time.perf_counter() - t) / reps * 1e3, o
 
-    def gen_all():
-        return [model.generate(ids[a:a + gen_batch], mask[a:a + gen_batch], num_beams=R) for a in range(0, nq, gen_batch)]
+    def gen_all(mdl):
+        return [mdl.generate(ids[a:a + gen_batch], mask[a:a + gen_batch], num_beams=R) for a in range(0, nq, gen_batch)]
 
     tower_ms, qemb = timed(lambda: tower.encode_query({"input_ids": ids, "attention_mask": mask}), 3)
-    nci_ms, gen = timed(gen_all, 1)
-    out = {
-        "dense_arm_with_tower": {
-            "tower_ms": tower_ms, "tower_queries_per_s": nq / tower_ms * 1e3, "search_ms": search_ms,
-            "queries_per_s": nq / (tower_ms + search_ms) * 1e3, "pass_tokens": t5.DEVICE_PASS_TOKENS,
-            "note": "generate.py --gen_query (T5-ANCE tower, t5-base shapes, f32, synthetic weights) + faiss_search.py"},
-        "seq2seq_arm": {
-            "nci_generate_ms": nci_ms, "nci_generate_queries_per_s": nq / nci_ms * 1e3, "beams": R, "rq": [M, K],
-            "queries_per_pass": gen_batch,
-            "note": "main.py --mode eval beam search (t5-base NCI model, f32, synthetic weights); the fine stage adds "
-                    "the tower again + a gather-dot (tools/bench_chain.py, profiles/r01_chain_c4.txt)"},
-    }
-    chain_ms = tower_ms + search_ms + nci_ms + tower_ms
-    out["chain_c4_derived"] = {
-        "ms": chain_ms, "queries_per_s": nq / chain_ms * 1e3,
-        "queries_per_s_reusing_query_embeddings": nq / (chain_ms - tower_ms) * 1e3,
-        "note": "tower + dense search + NCI beam search + tower again (as the reference's fine stage does) from the legs of "
-                "this run; the gather-dot of the fine stage adds 3-4 ms on the C4 corpus (tools/bench_chain.py measures the "
-                "chain with it: profiles/r01_chain_c4.txt)"}
+    nci_ms, gen = timed(lambda: gen_all(model), 2)
+    pad, exe = seq2seq_flops(M, K, R, real_tokens / nq)
+    peak3 = PEAK_F16_MFMA_TFLOPS / 3
+    out["dense_arm_with_tower"] = {
+        "tower_ms": tower_ms, "tower_queries_per_s": nq / tower_ms * 1e3, "search_ms": search_ms,
+        "queries_per_s": nq / (tower_ms + search_ms) * 1e3, "pass_tokens": t5.DEVICE_PASS_TOKENS,
+        "note": "generate.py --gen_query (T5-ANCE tower, t5-base shapes, synthetic weights) + faiss_search.py"}
+    out["seq2seq_arm"] = {
+        "nci_generate_ms": nci_ms, "nci_generate_queries_per_s": nq / nci_ms * 1e3, "beams": R, "rq": [M, K],
+        "queries_per_pass": gen_batch,
+        "roofline": {
+            "bound": "mfma", "unit": "TFLOP/s", "flop_per_query_survey_8d_padded": pad, "flop_per_query_executed": exe,
+            "achieved": exe * nq / nci_ms / 1e9, "achieved_padded_equivalent": pad * nq / nci_ms / 1e9,
+            "peak": peak3, "frac": exe * nq / nci_ms / 1e9 / peak3,
+            "peak_note": "f16 MFMA dense peak / 3 (three f16 MFMAs per f32 product in the split-precision GEMM); `achieved` "
+                         "counts the arithmetic executed (real tokens, per-prefix adaptor tables), not the padded budget"},
+        "note": "main.py --mode eval beam search (t5-base NCI model, synthetic weights), all queries resident"}
+    out["gemm_roofline"] = gemm_roofline(device, real_tokens)
+
+    # ---- C4, timed directly on the resident corpus ---------------------------------------------------------------------
+    chain, dindex = chain_c4.run(model, tower, docs, ids, mask, planted_ids(nq, n_docs), rn, M, K, R, TOPK, gen_batch, rng)
+    out["chain_c4"] = chain
+    out["faiss_search_cli_inclusive"] = cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs)
+    del dindex
+
     if with_cpu:
         from oracle import t5 as ot5
 
@@ -180,6 +266,27 @@ def seq2seq_legs(device, nq, search_ms, with_cpu):
                 "beams_identical": bool(torch.equal(dec, ref_dec)),
                 "beam_score_max_abs_diff": float(np.abs(sc - ref_sc.numpy()).max())},
         }
+        del cpu_w
+
+    # ---- BASELINE.json configs[2]: 3 levels x 256 codes ------------------------------------------------------------------
+    del model, gen
+    torch.cuda.empty_cache()
+    M2, K2 = 3, 256
+    W2, _, _, _ = synth.weights(device, M2, K2, tower=False)
+    model2 = nci.NCIModel(W2, device=device, M=M2, K=K2, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
+    del W2
+    nci2_ms, _ = timed(lambda: gen_all(model2), 1)
+    pad2, exe2 = seq2seq_flops(M2, K2, R, real_tokens / nq)
+    tab = model2.tables()
+    out["seq2seq_arm_rq_3x256"] = {
+        "nci_generate_ms": nci2_ms, "nci_generate_queries_per_s": nq / nci2_ms * 1e3, "beams": R, "rq": [M2, K2],
+        "queries_per_pass": gen_batch,
+        "prefix_tables": {"levels": tab.levels, "head_matrices_at": [p for p in range(tab.levels) if tab.tmat[p] is not None],
+                          "adaptor_vectors_only_at": [p for p in range(tab.levels) if tab.tmat[p] is None],
+                          "bytes": tab.bytes},
+        "flop_per_query_survey_8d_padded": pad2,
+        "note": "BASELINE.json configs[2] code shape (3-level RQ-256): the 257-column head GEMM runs per beam from "
+                "position 2 on (65 536 prefixes: adaptor vectors tabled, head matrices not)"}
     return out
 
 
@@ -226,11 +333,13 @@ def main():
     L = hip.lib()
 
     # index build (= faiss index.add): split image of the shard, untimed like the corpus upload
+    t_index = time.perf_counter()
     index = docs if args.exact_f32_path else dense.DenseIndex(docs)
     torch.cuda.synchronize()
+    index_build_s = time.perf_counter() - t_index
 
-    def step():
-        return dense.sharded_ip_topk(query, index, TOPK, id_offset=start)
+    def step(trace=None):
+        return dense.sharded_ip_topk(query, index, TOPK, id_offset=start, trace=trace)
 
     def barrier():
         if world > 1:
@@ -241,25 +350,44 @@ def main():
         s, i = step()
     barrier()
     L.mevi_ip_topk_set_profiling(1)
-    filt_ms = filt_flops = comp_ms = 0.0
-    launches = n_unproven = 0
+    trace = dense.SearchTrace()                 # kernel counters of every local search (first AND second round)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        s, i = step()
-        st = hip.IpTopkStats()
-        L.mevi_ip_topk_get_stats(st)
-        filt_ms += st.filter_ms
-        comp_ms += st.compact_ms
-        filt_flops += st.filter_flops
-        launches += st.n_chunks
-        n_unproven += st.n_failed_queries
+        s, i = step(trace)
     barrier()
     elapsed = time.perf_counter() - t0
     L.mevi_ip_topk_set_profiling(0)
+    filt_ms, comp_ms, filt_flops = trace.stats["filter_ms"], trace.stats["compact_ms"], trace.stats["filter_flops"]
+    launches, n_unproven = int(trace.stats["n_chunks"]), int(trace.stats["n_failed_queries"])
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # N > 1, untimed: one more search with a device synchronisation after every phase, so that a sub-linear point of the
+    # scaling curve can be attributed (local search vs all-gather vs merge vs second round) without another round
+    multi_gpu = None
+    if world > 1:
+        barrier()
+        tr = dense.SearchTrace(timed=True)
+        step(tr)
+        barrier()
+        mine = {"rank": rank, "shard_rows": end - start, **{k + "_ms": round(v, 3) for k, v in tr.ms.items()},
+                "rounds": tr.rounds, "second_round_queries": tr.second_round_queries,
+                "filter_kernel_ms": round(tr.stats["filter_ms"], 3), "filter_launches": int(tr.stats["n_chunks"])}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        if rank == 0:
+            ls = [r["local_search_ms"] for r in allr]
+            kl = dense.truncated_list_len(TOPK, world)
+            multi_gpu = {
+                "local_search_ms": {"max": max(ls), "min": min(ls)},
+                "all_gather_ms": max(r["all_gather_ms"] for r in allr), "merge_ms": max(r["merge_ms"] for r in allr),
+                "rounds": allr[0]["rounds"], "second_round_queries": allr[0]["second_round_queries"],
+                "first_round_list_len": kl, "all_gather_bytes_per_rank": nq * kl * 8,
+                "note": "one extra, untimed search with a device synchronisation after every phase (phases therefore do "
+                        "not overlap as they do in the timed steps); per_rank holds every rank's own numbers",
+                "per_rank": allr}
 
     # sanity (untimed): every query's planted neighbour must be its rank-1 hit
     top1 = i[:, 0].cpu().numpy()
@@ -276,12 +404,14 @@ def main():
         # HBM-side bytes per filter launch: PMC (FETCH_SIZE x 2 on gfx950) of THIS command, recorded by
         # tools/prof_traffic.sh + tools/traffic_summary.py; PMC passes cannot run inside the timed bench.
         traffic, traffic_note = None, "PMC not collected for this configuration"
-        tfile = os.path.join(ROOT, "profiles", "r01_filter_h1_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r02_filter_h1_traffic.json")
+        if not os.path.exists(tfile):
+            tfile = os.path.join(ROOT, "profiles", "r01_filter_h1_traffic.json")
         if (not args.exact_f32_path and world == 1 and n_docs == N_DOCS and nq == N_QUERIES and os.path.exists(tfile)):
             with open(tfile) as f:
                 tj = json.load(f)
             traffic = tj["hbm_side_bytes_per_launch"]
-            traffic_note = ("bytes per launch, recorded PMC pass (profiles/r01_filter_h1_traffic.json): L2 memory-side "
+            traffic_note = ("bytes per launch, recorded PMC pass (profiles/%s): L2 memory-side " % os.path.basename(tfile) +
                             "requests incl. Infinity Cache hits; L2 hit rate %.2f; the corpus image itself is %.2f GB per "
                             "launch" % (tj["l2_hit_rate"], n_docs * DIM * 2 / 1e9 / (launches / args.steps)))
         out = {
@@ -326,15 +456,19 @@ def main():
                 "other_kernels_ms_per_step": {"compact_kernel": comp_ms / args.steps},
             },
         }
+        if multi_gpu is not None:
+            out["multi_gpu"] = multi_gpu
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n_docs, nq)
         if not args.no_seq2seq_legs and world == 1:
-            del index, docs
+            del index
             torch.cuda.empty_cache()
             try:
-                out.update(seq2seq_legs(device, nq, ms_per_step, with_cpu=not args.no_cpu_baseline))
+                out.update(extras(device, docs, nq, n_docs, ms_per_step, index_build_s, with_cpu=not args.no_cpu_baseline))
             except Exception as e:      # the extras must never cost the headline line
-                out["seq2seq_legs_error"] = f"{type(e).__name__}: {e}"
+                import traceback
+
+                out["extras_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc()[-600:]}"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

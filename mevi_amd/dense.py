@@ -157,7 +157,40 @@ def merge_truncated(all_s, all_i, k, merge=None):
     return ms, mi, unproven
 
 
-def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=None, merge=None):
+class SearchTrace:
+    """What bench.py asks a search to record (never set by the CLIs): the kernel counters of EVERY local search of a call
+    (mevi_ip_topk_get_stats restarts per library call, so a second round would otherwise overwrite the first) and,
+    with `timed`, the wall-clock of each phase of the sharded search -- every phase is then followed by a device
+    synchronisation, so a traced call is for diagnosis, not for the timed region."""
+
+    FIELDS = ("n_chunks", "n_failed_queries", "n_fallback_chunks", "filter_ms", "compact_ms", "filter_flops",
+              "n_second_pass_queries")
+
+    def __init__(self, timed=False):
+        self.timed = timed
+        self.stats = {f: 0.0 for f in self.FIELDS}
+        self.ms = {"local_search": 0.0, "all_gather": 0.0, "merge": 0.0}
+        self.second_round_queries = 0
+        self.rounds = 0
+
+    def add_stats(self):
+        st = hip.IpTopkStats()
+        hip.lib().mevi_ip_topk_get_stats(st)
+        for f in self.FIELDS:
+            self.stats[f] += getattr(st, f)
+
+    def lap(self, name, t0):
+        import time
+
+        if not self.timed:
+            return t0
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        self.ms[name] += (t1 - t0) * 1e3
+        return t1
+
+
+def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=None, merge=None, trace=None):
     """Row-sharded search: local top lists with global ids, all-gather, merge.
 
     Every rank passes the full (replicated) query matrix and its own shard; every rank returns the
@@ -169,14 +202,20 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
     `local_search` / `merge` default to the HIP kernels; they are injection points for the CPU (gloo)
     test of the collective plumbing and are never set by product code.
     """
+    import time
+
     import torch.distributed as dist
 
     def local(q, kk):
         if local_search is not None:
             return local_search(q, local_docs, kk, id_offset=id_offset)
         if isinstance(local_docs, DenseIndex):
-            return local_docs.search(q, kk, id_offset=id_offset)
-        return ip_topk(q, local_docs, kk, id_offset=id_offset)
+            out = local_docs.search(q, kk, id_offset=id_offset)
+        else:
+            out = ip_topk(q, local_docs, kk, id_offset=id_offset)
+        if trace is not None:
+            trace.add_stats()
+        return out
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local(query, k)
@@ -186,7 +225,11 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
         # one collective per round: (score bits << 32 | id as u32) in an i64 per entry -- 8 bytes instead of the 12
         # of separate f32 + i64 tensors, and half the launches.  Ids fit 32 bits (the C ABI enforces it); the
         # padding id -1 travels as 0xFFFFFFFF.
+        t0 = time.perf_counter() if trace is not None else 0.0
         s, i = local(q, kk)
+        if trace is not None:
+            t0 = trace.lap("local_search", t0)
+            trace.rounds += 1
         n = s.shape[0]
         packed = (s.contiguous().view(torch.int32).to(torch.int64) << 32) | (i & 0xFFFFFFFF)
         if packed.is_cuda and dist.get_backend(group) == "gloo":     # rehearsal backend: collectives through host memory
@@ -196,16 +239,28 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
         else:
             gathered = torch.empty((world * n, kk), dtype=torch.int64, device=s.device)   # rank-major concatenation
             dist.all_gather_into_tensor(gathered, packed.contiguous(), group=group)
+        if trace is not None:
+            trace.lap("all_gather", t0)
         all_s = (gathered >> 32).to(torch.int32).view(torch.float32)
         all_i = gathered & 0xFFFFFFFF
         all_i = torch.where(all_i == 0xFFFFFFFF, torch.full_like(all_i, -1), all_i)
         return all_s.view(world, n, kk), all_i.view(world, n, kk)
 
+    def merged(q, kk):
+        lists = exchange(q, kk)
+        t0 = time.perf_counter() if trace is not None else 0.0
+        out = merge_truncated(*lists, k, merge=merge)
+        if trace is not None:
+            trace.lap("merge", t0)
+        return out
+
     kl = truncated_list_len(k, world)
-    ms, mi, unproven = merge_truncated(*exchange(query, kl), k, merge=merge)
+    ms, mi, unproven = merged(query, kl)
     redo = torch.nonzero(unproven).flatten()
+    if trace is not None:
+        trace.second_round_queries += int(redo.numel())
     if redo.numel() > 0:                       # identical on every rank
-        rs, ri, _ = merge_truncated(*exchange(query[redo].contiguous(), k), k, merge=merge)
+        rs, ri, _ = merged(query[redo].contiguous(), k)
         ms[redo], mi[redo] = rs, ri
     return ms, mi
 

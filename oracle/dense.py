@@ -78,10 +78,13 @@ def topk_merge(scores, ids, k_out):
     return out_s, out_i
 
 
-def ip_topk_blas(query, docs, k, id_offset=0, block=16384):
+def ip_topk_blas(query, docs, k, id_offset=0, block=16384, timing=None):
     """faiss-style Flat-IP on the CPU, the way faiss evaluates it: blocked sgemm (numpy -> BLAS, all host
     threads) and per-query heaps of the k best updated block by block (oracle_heap_update_f32, OpenMP over
-    queries).  Ties by ascending id.  Summation order is BLAS's."""
+    queries).  Ties by ascending id.  Summation order is BLAS's.  `timing` (a dict) receives the seconds spent in
+    the sgemm blocks and in the heap updates separately."""
+    import time
+
     q = np.ascontiguousarray(query, dtype=np.float32)
     d = np.asarray(docs, dtype=np.float32)
     nq = q.shape[0]
@@ -89,10 +92,18 @@ def ip_topk_blas(query, docs, k, id_offset=0, block=16384):
     heap_s = np.empty((nq, k), np.float32)
     heap_i = np.empty((nq, k), np.int64)
     heap_n = np.zeros(nq, np.int64)
+    t_gemm = t_heap = 0.0
     for b0 in range(0, d.shape[0], block):
+        t0 = time.perf_counter()
         sc = np.ascontiguousarray(q @ d[b0:b0 + block].T)
+        t1 = time.perf_counter()
         L.oracle_heap_update_f32(_p(sc), nq, sc.shape[1], id_offset + b0, k, _p(heap_s), _p(heap_i), _p(heap_n))
+        t_gemm, t_heap = t_gemm + (t1 - t0), t_heap + (time.perf_counter() - t1)
+    t1 = time.perf_counter()
     L.oracle_heap_finalize_f32(nq, k, _p(heap_s), _p(heap_i), _p(heap_n))
+    if timing is not None:
+        timing["sgemm_s"] = timing.get("sgemm_s", 0.0) + t_gemm
+        timing["heap_s"] = timing.get("heap_s", 0.0) + t_heap + (time.perf_counter() - t1)
     return heap_s, heap_i
 
 

@@ -30,7 +30,7 @@ def _t5_weights(W, nl, ndl, rn, dev, prefix_dec="decoder"):
         W[f"{st}.final_layer_norm.weight"] = torch.ones(d, device=dev)
 
 
-def weights(dev, M, K, seed=0):
+def weights(dev, M, K, seed=0, tower=True):
     """(NCI state dict, tower state dict, generator, rn) on `dev`: t5-base widths, 12/6 layers + 4 adaptor layers for the
     NCI model, 12/12 for the tower (which shares the NCI model's token embedding), the reference's initialiser scales."""
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -53,8 +53,10 @@ def weights(dev, M, K, seed=0):
         W[f"{p}.linear2.weight"], W[f"{p}.linear2.bias"] = rn(d, 2048, s=2048 ** -0.5), rn(d, s=0.02)
         for n_ in (1, 2, 3):
             W[f"{p}.norm{n_}.weight"], W[f"{p}.norm{n_}.bias"] = torch.ones(d, device=dev), torch.zeros(d, device=dev)
-    TW = {"shared.weight": W["shared.weight"]}
-    _t5_weights(TW, 12, 12, rn, dev)
+    TW = None
+    if tower:
+        TW = {"shared.weight": W["shared.weight"]}
+        _t5_weights(TW, 12, 12, rn, dev)
     return W, TW, g, rn
 
 
