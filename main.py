@@ -48,6 +48,7 @@ def parsers_parser(argv=None):
     p.add_argument("--pq_cluster_path", type=str, default=None)
     p.add_argument("--nci_ckpt", type=str, default=None)
     p.add_argument("--infer_ckpt", type=str, default=None)
+    p.add_argument("--not_load_document_encoder", type=int, default=0)
     p.add_argument("--data_dir", type=str, required=True)
     p.add_argument("--newid_dir", type=str, default=None)
     p.add_argument("--document_path", type=str, default=None)
@@ -67,19 +68,29 @@ def parsers_parser(argv=None):
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--timing_infer_step", type=int, default=0)
     args, rest = p.parse_known_args(argv)
-    # training / ablation flags of marco_eval_nci_rq.sh: accepted, no effect on eval
+    # the rest must be flags of the reference's own parser; those that change the evaluation must carry the built value
     ignored = []
     i = 0
     while i < len(rest):
         tok = rest[i]
-        if not tok.startswith("--"):
-            raise SystemExit(f"main.py: unexpected argument {tok!r}")
-        if i + 1 < len(rest) and not rest[i + 1].startswith("--"):
-            ignored.append((tok, rest[i + 1]))
-            i += 2
-        else:
+        name = tok[2:].split("=", 1)[0] if tok.startswith("--") else None
+        if name in PASS_THROUGH_SWITCHES:
             ignored.append((tok, None))
             i += 1
+            continue
+        if name not in PASS_THROUGH_VALUE_FLAGS:
+            raise SystemExit(f"main.py: unrecognized argument {tok!r} (not a flag of the reference's main.py)")
+        if "=" in tok:
+            value, i = tok.split("=", 1)[1], i + 1
+        elif i + 1 < len(rest) and not (rest[i + 1].startswith("--") and rest[i + 1][2:3].isalpha()):
+            value, i = rest[i + 1], i + 2
+        else:
+            raise SystemExit(f"main.py: argument {tok}: expected one argument")
+        allowed = EVAL_AFFECTING.get(name, ())
+        if allowed and value not in allowed:
+            raise SystemExit(f"main.py --mode eval: --{name} {value} changes what is evaluated and is not built "
+                             f"(built: {' | '.join(allowed)})")
+        ignored.append(("--" + name, value))
     args.ignored_flags = ignored
     args.recall_num = sorted(int(r) for r in args.recall_num.split(","))
     n = eval(args.n_gpu) if not args.n_gpu.isdigit() else int(args.n_gpu)  # int or list literal (MEVI/main.py:734-737)
@@ -89,6 +100,58 @@ def parsers_parser(argv=None):
     if args.document_encoder and args.encode_batch_size is None:
         args.encode_batch_size = 64
     return args
+
+
+# Flags of the reference's parser (MEVI/main.py:343-731) that this build does not read.  They are accepted -- the eval
+# scripts pass many training hyper-parameters -- but nothing else is: a flag outside the reference's parser (a typo)
+# ends the run, as argparse ends the reference's.
+PASS_THROUGH_VALUE_FLAGS = frozenset((
+    "wandb_token wandb_id output_dir model_name_or_path tokenizer_name_or_path freeze_encoder freeze_embeds "
+    "weight_decay adam_epsilon warmup_steps num_train_epochs gradient_accumulation_steps "
+    "resume_from_checkpoint n_val n_train early_stop_callback fp_16 opt_level max_grad_norm pretrain_encoder "
+    "limit_val_batches softmax aug accelerator num_layers num_decoder_layers d_ff d_model num_heads num_cls "
+    "decode_embedding output_vocab_size hierarchic_decode tie_word_embedding tie_decode_embedding gen_method "
+    "random_gen label_length_cutoff check_val_every_n_epoch val_check_interval train_batch_size "
+    "max_input_length inf_max_input_length max_output_length doc_length contrastive_variant learning_rate "
+    "decoder_learning_rate document_encoder_learning_rate projection_learning_rate certain_epoch given_ckpt "
+    "qenc_ckpt penc_ckpt load_encoder_only id_class ckpt_monitor monitor_name "
+    "Rdrop dropout_rate Rdrop_only_decoder Rdrop_loss adaptor_decode adaptor_efficient test1000 position "
+    "contrastive embedding_distillation weight_distillation hard_negative aug_query aug_query_type "
+    "sample_neg_num query_tloss weight_tloss ranking_loss disc_loss input_dropout denoising multiple_decoder "
+    "decoder_num loss_weight kary tree mapping_path cluster_path tree_path eval_train_data drop_data_rate "
+    "num_sanity_val_steps timing_step save_top_k drop_last reserve_decoder decoder_integration tie_encoders "
+    "document_encoder_from_pretrained negatives_x_sample alt_granularity alt_train nci_twin_train_ratio "
+    "qtower query_embed_accum co_neg_num co_neg_from co_neg_file co_neg_clus_file simans_hyper_a "
+    "simans_hyper_b co_loss_scale no_nci_loss no_twin_loss pq_update_method pq_update_after_eval "
+    "pq_init_method pq_dist_mode pq_loss pq_twin_loss pq_runtime_label pq_runtime_update_cluster "
+    "use_gumbel_softmax pq_softmax_tau pq_hard_softmax_topk topk_sequence pq_negative pq_negative_margin "
+    "pq_negative_loss tie_nci_pq_centroid aug_topk_clus aug_find_topk_from aug_sample_topk "
+    "reconstruct_for_embeddings centroid_update_loss centroid_loss_scale infer_reconstruct_vector "
+    "align_clustering query_vq_label nci_twin_alt_epoch nci_vq_alt_epoch rq_topk_score multiclus_label "
+    "use_topic_model topic_score_ratio cat_cluster_centroid cluster_position_topk cluster_position_embedding "
+    "cluster_position_rank_reciprocal cluster_position_proj_style use_cluster_adaptor "
+    "cluster_adaptor_decouple cluster_adaptor_trainable_token_embedding "
+    "cluster_adaptor_trainable_position_embedding cluster_adaptor_head_num cluster_adaptor_layer_num use_ort "
+    "use_deepspeed ads_info"
+).split())
+PASS_THROUGH_SWITCHES = frozenset((
+    "split_data validation_release_traindataset no_validation fixnci fixdocenc fixncienc fixncit5 fixpq "
+    "fixlmq fixlmp fixproj fp16_opt"
+).split())
+# ... of which these CHANGE what --mode eval computes (model structure, decoding, scoring ablations).  Only the value
+# the shipped eval scripts run with (= the reference's default unless noted) is built; anything else is refused
+# instead of being silently ignored.
+EVAL_AFFECTING = {
+    "fp_16": ("0",), "decode_embedding": ("2",), "hierarchic_decode": ("0",), "tie_word_embedding": ("0",),
+    "tie_decode_embedding": ("1",), "adaptor_decode": ("1",), "adaptor_efficient": ("1",), "position": ("1",),
+    "multiple_decoder": ("0",), "decoder_num": ("1",), "reserve_decoder": ("0",), "decoder_integration": ("series",),
+    "softmax": ("0",), "tree": ("1",), "topk_sequence": ("0",), "test1000": ("0",), "gen_method": ("greedy",),
+    "use_topic_model": ("0",), "topic_score_ratio": ("0", "0.", "0.0"), "cat_cluster_centroid": ("0",),
+    "cluster_position_topk": ("0",), "use_cluster_adaptor": ("0",), "infer_reconstruct_vector": ("0",),
+    "rq_topk_score": ("prod",), "multiclus_label": ("top1",), "reconstruct_for_embeddings": ("0",),
+    "tie_encoders": ("1",), "input_dropout": ("0", "1"), "denoising": ("0",), "load_encoder_only": ("0",),
+    "pq_dist_mode": ("l2",), "use_ort": ("0",), "eval_train_data": ("0",),
+}
 
 
 def check_supported(a):
@@ -114,9 +177,11 @@ def check_supported(a):
     for k, v in need.items():
         if getattr(a, k) != v:
             raise SystemExit(f"main.py --mode eval: --{k} {getattr(a, k)!r} is not built (only {v!r}, as in marco_eval_nci_rq.sh)")
-    for k in ("nci_ckpt", "pq_path", "pq_cluster_path", "embedding_path", "custom_save_path"):
+    for k in ("pq_path", "pq_cluster_path", "embedding_path", "custom_save_path"):
         if getattr(a, k) is None:
             raise SystemExit(f"main.py --mode eval: --{k} is required")
+    if a.nci_ckpt is None and a.infer_ckpt is None:   # try_load_ckpt asserts one of them (MEVI/main.py:201)
+        raise SystemExit("main.py --mode eval: --nci_ckpt or --infer_ckpt is required")
     if a.num_return_sequences > 2 ** a.subvector_bits:
         raise SystemExit("num_return_sequences > 2**subvector_bits is not pinned by the reference (SURVEY 8(a') note ii)")
 

@@ -19,27 +19,61 @@ from . import dense as mdense
 from . import fine as mfine
 from . import hip
 from .io import RankLog, join_i64, upload_rows
-from .nci import NCIModel, config_from_weights, decode_token
+from .nci import MODEL_INFO, NCIModel, check_weights, config_from_weights, decode_token
 from .rq import ClusterIndex, ProductQuantization
 from .t5 import T5Dims, TwinTower
 
 
 # ---- loading -------------------------------------------------------------------------------
-def load_nci_weights(path):
-    """The NCI checkpoint: a Lightning ckpt ('state_dict' with 'model.' prefixes) or a bare state dict;
-    same key handling as try_load_ckpt's nci_path branch (MEVI/main.py:232-248)."""
+MODEL_PREFIXES = ("shared.", "encoder.", "decoder.", "lm_head.", "decode_embeddings.", "adaptor")
+BAD_WHOLE_KEYS = (   # dropped by try_load_ckpt's whole-model branch (MEVI/main.py:207-214)
+    "model.decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight",
+    "model.ori_decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight",
+    "document_encoder.lm_q.decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight",
+    "document_encoder.lm_p.decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight")
+
+
+def _state_dict(path):
     sd = torch.load(path, map_location="cpu")
-    if "state_dict" in sd:
-        sd = sd["state_dict"]
+    return sd["state_dict"] if "state_dict" in sd else sd
+
+
+def nci_weights_from_state_dict(sd, report=print):
+    """try_load_ckpt's nci_path branch (MEVI/main.py:232-248): strip the Lightning 'model.' prefix; a key the NCI model
+    does not have (another module's tensors inside the checkpoint) is reported as `Bad parameter <k>.` and skipped, as
+    the reference does.  Shape mismatches are judged by nci.check_weights once the model's dimensions are known."""
     out = {}
     for k, v in sd.items():
         if k.startswith("model."):
             k = k[6:]
-        if torch.is_tensor(v):
-            out[k] = v
+        if not torch.is_tensor(v):
+            continue
+        if not k.startswith(MODEL_PREFIXES):
+            report(f"Bad parameter {k}.")
+            continue
+        out[k] = v
     if "lm_head.weight" not in out and "decode_embeddings.weight" in out:  # tie_decode_embedding=1
         out["lm_head.weight"] = out["decode_embeddings.weight"]
     return out
+
+
+def load_nci_weights(path, report=print):
+    """The NCI checkpoint: a Lightning ckpt ('state_dict' with 'model.' prefixes) or a bare state dict."""
+    return nci_weights_from_state_dict(_state_dict(path), report)
+
+
+def split_whole_checkpoint(sd, not_load_document_encoder=False):
+    """try_load_ckpt's whole-model branch (--infer_ckpt, MEVI/main.py:203-230): the state dict of the full
+    T5FineTunerWithValidation -> (NCI weights, query-tower overrides, RQ codebook or None).  The four
+    relative_attention_bias keys the reference filters are dropped; with not_load_document_encoder the
+    `document_encoder.` tensors are left at what the tower directory holds."""
+    sd = {k: v for k, v in sd.items() if k not in BAD_WHOLE_KEYS and torch.is_tensor(v)}
+    nci_w = {k[6:]: v for k, v in sd.items() if k.startswith("model.")}
+    if "lm_head.weight" not in nci_w and "decode_embeddings.weight" in nci_w:
+        nci_w["lm_head.weight"] = nci_w["decode_embeddings.weight"]
+    pre = "document_encoder.lm_q."
+    tower = {} if not_load_document_encoder else {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    return nci_w, tower, sd.get("pq.codebook")
 
 
 def load_tower_weights(model_dir):
@@ -175,8 +209,25 @@ class EvalRun:
         self.dev = torch.device(device if device is not None else "cuda")
         a = args
         self.M, self.K, self.R = a.subvector_num, 2 ** a.subvector_bits, a.num_return_sequences
-        nci_w = load_nci_weights(a.nci_ckpt)
-        self.cfg = config_from_weights(nci_w, self.M, self.K)   # shapes of the checkpoint are authoritative
+        tower_override, ckpt_codebook = {}, None
+        if getattr(a, "infer_ckpt", None):        # whole-model checkpoint (MEVI/main.py:203-230) takes precedence
+            nci_w, tower_override, ckpt_codebook = split_whole_checkpoint(
+                _state_dict(a.infer_ckpt), bool(getattr(a, "not_load_document_encoder", 0)))
+        else:
+            nci_w = load_nci_weights(a.nci_ckpt)
+        self.cfg = config_from_weights(nci_w, self.M, self.K)
+        info = MODEL_INFO.get(getattr(a, "model_info", None))
+        if info is not None and info[3] == self.cfg.d_model:
+            # --model_info defines the model the reference builds (MEVI/main.py:755-773); a checkpoint of another width
+            # (the miniature models of the tests) defines its own
+            self.cfg.num_layers, self.cfg.num_decoder_layers, self.cfg.d_ff = info[0], info[1], info[2]
+            self.cfg.adaptor_layers = getattr(a, "adaptor_layer_num", self.cfg.adaptor_layers)
+        bad = check_weights(nci_w, self.cfg)
+        if bad:
+            raise SystemExit(f"{len(bad)} tensor(s) of the NCI model are missing from the checkpoint or have another shape "
+                             f"(first: {bad[0]}): the reference would leave them at their random initialisation and go on "
+                             f"(MEVI/main.py:243-246); check --subvector_num / --subvector_bits / --model_info / "
+                             f"--adaptor_layer_num against the checkpoint")
         d_model = self.cfg.d_model
         self.nci = NCIModel(nci_w, cfg=self.cfg, device=self.dev)
         del nci_w
@@ -185,6 +236,7 @@ class EvalRun:
         tower_dir = os.path.join(a.ckpt_dir, "t5-ance")       # NCI shares the T5-ANCE vocabulary in every configuration
         if enc == "ance":
             tw, tdims = load_tower_weights(tower_dir)
+            tw.update(tower_override)             # document_encoder.lm_q.* of a whole-model checkpoint
             self.tower = TwinTower(tw, dims=tdims, device=self.dev)
         elif enc == "cocondenser":
             self.tower = load_bert_tower(os.path.join(a.ckpt_dir, "co-condenser-marco-retriever"), self.dev)
@@ -215,7 +267,10 @@ class EvalRun:
         self.emb = upload_rows(emb, self.dev)
         # RQ codebook + cluster index (pickles if present, else encode on the GPU and write them)
         self.pq = ProductQuantization("rq", self.M, a.subvector_bits, "l2", d_model, device=self.dev)
-        self.pq.initialize(a.pq_path, rank=0)
+        if ckpt_codebook is not None:             # --infer_ckpt carries pq.codebook: pq.initialize is skipped (main_models.py:4252)
+            self.pq.load_codebook(ckpt_codebook)
+        else:
+            self.pq.initialize(a.pq_path, rank=0)
         map_path = a.pq_cluster_path.replace("clus", "mapping")
         # every rank looks BEFORE anyone writes (barrier), so all ranks take the same branch and the barriers below pair
         # up: a rank arriving after rank 0 had written the pickles used to skip rank 0's barrier (one-off from then on)

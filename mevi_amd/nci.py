@@ -50,6 +50,59 @@ def config_from_weights(w, M, K):
                      relative_attention_num_buckets=w["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].shape[0])
 
 
+MODEL_INFO = {   # --model_info (MEVI/main.py:755-773): layers, decoder layers, d_ff, d_model, heads (d_kv = 64)
+    "small": (6, 3, 2048, 512, 8), "base": (12, 6, 3072, 768, 12), "large": (24, 12, 4096, 1024, 16)}
+
+
+def expected_shapes(c):
+    """name -> shape of every tensor NCIModel reads (the reference's T5ForConditionalGeneration state_dict names);
+    a leading None = any size (the token vocabulary)."""
+    d, inner, ff, H = c.d_model, c.inner, c.d_ff, c.num_heads
+    out = {"shared.weight": (None, d), "decode_embeddings.weight": (c.V, d), "lm_head.weight": (c.V, d),
+           "adaptor_embeddings": (1, 1, d), "adaptor_linear.weight": (d * c.V, d)}
+    for st, n, dec in (("encoder", c.num_layers, False), ("decoder", c.num_decoder_layers, True)):
+        for l in range(n):
+            p = f"{st}.block.{l}.layer"
+            atts = [f"{p}.0.SelfAttention"] + ([f"{p}.1.EncDecAttention"] if dec else [])
+            for a in atts:
+                for w in "qkv":
+                    out[f"{a}.{w}.weight"] = (inner, d)
+                out[f"{a}.o.weight"] = (d, inner)
+            ffl = 2 if dec else 1
+            for j in range(ffl + 1):
+                out[f"{p}.{j}.layer_norm.weight"] = (d,)
+            out[f"{p}.{ffl}.DenseReluDense.wi.weight"] = (ff, d)
+            out[f"{p}.{ffl}.DenseReluDense.wo.weight"] = (d, ff)
+        out[f"{st}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] = (c.buckets, H)
+        out[f"{st}.final_layer_norm.weight"] = (d,)
+    for l in range(c.adaptor_layers):
+        p = f"adaptor.layers.{l}"
+        for a in ("self_attn", "multihead_attn"):
+            out[f"{p}.{a}.in_proj_weight"], out[f"{p}.{a}.in_proj_bias"] = (3 * d, d), (3 * d,)
+            out[f"{p}.{a}.out_proj.weight"], out[f"{p}.{a}.out_proj.bias"] = (d, d), (d,)
+        ffa = None   # dim_feedforward of nn.TransformerDecoderLayer: read off the checkpoint (torch default 2048)
+        out[f"{p}.linear1.weight"], out[f"{p}.linear1.bias"] = (ffa, d), (ffa,)
+        out[f"{p}.linear2.weight"], out[f"{p}.linear2.bias"] = (d, ffa), (d,)
+        for n_ in (1, 2, 3):
+            out[f"{p}.norm{n_}.weight"] = out[f"{p}.norm{n_}.bias"] = (d,)
+    return out
+
+
+def check_weights(w, c, report=print):
+    """The rule of try_load_ckpt's NCI branch (MEVI/main.py:243-246) for the tensors the inference path reads: a tensor
+    that is absent or whose shape differs from the model's is reported as `Bad parameter <name>.` -- the reference then
+    CONTINUES with that parameter at its random initialisation, which no build can reproduce, so here the list is
+    returned for the caller to refuse."""
+    bad = []
+    for name, shape in expected_shapes(c).items():
+        t = w.get(name)
+        ok = t is not None and len(t.shape) == len(shape) and all(e is None or e == g for e, g in zip(shape, t.shape))
+        if not ok:
+            report(f"Bad parameter {name}.")
+            bad.append(name)
+    return bad
+
+
 class Adaptor:
     """nn.TransformerDecoder(TransformerDecoderLayer(d, nhead=8), L) over the decode-token embeddings
     (modeling_t5.py:1252-1255, 1650-1665), one position at a time with cached K|V.  Its memory is the

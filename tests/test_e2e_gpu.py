@@ -4,6 +4,7 @@ the consumers exactly like marco_ensemble.sh does."""
 import json
 import os
 import pickle
+import shutil
 import subprocess
 import sys
 from argparse import Namespace
@@ -182,6 +183,47 @@ def test_query_embeddings_of_generate_py_can_replace_the_second_tower_pass(cuda,
         blobs.append([open(p, "rb").read() for p in (prefix + "_coarse.tsv", prefix + "_fine.tsv",
                                                      f"{prefix}_hn{a.save_hard_neg}.tsv", a.metric_path)])
     assert blobs[0] == blobs[1] and all(len(b) > 0 for b in blobs[0])
+
+
+def test_whole_model_checkpoint_and_bad_checkpoints(cuda, mini, tmp_path):
+    """--infer_ckpt (try_load_ckpt's whole-model branch, MEVI/main.py:198-230): NCI weights under `model.`, the query
+    tower under `document_encoder.lm_q.`, the RQ codebook as `pq.codebook` (pq.initialize is skipped), the filtered
+    relative_attention_bias keys ignored -- every output byte-identical to the --nci_ckpt run.  A checkpoint whose
+    tensors do not fit the model is refused with the reference's `Bad parameter` report instead of being copied blindly."""
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    a0 = mini["args"]
+    tok = FakeTokenizer(512)
+    whole = {"model." + k: v for k, v in mini["W"].items()}
+    whole.update({"document_encoder.lm_q." + k: v for k, v in mini["TW"].items()})
+    whole.update({"document_encoder.lm_p." + k: v for k, v in mini["TW"].items()})
+    whole["pq.codebook"] = torch.from_numpy(mini["C"])
+    whole["model.decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight"] = torch.full((32, 4), float("nan"))
+    torch.save({"state_dict": whole}, tmp_path / "whole.ckpt")
+    # the tower directory and the codebook file hold OTHER values: the run must take them from the checkpoint
+    os.makedirs(tmp_path / "ckpts" / "t5-ance")
+    torch.save({k: v + 1.0 for k, v in mini["TW"].items()}, tmp_path / "ckpts" / "t5-ance" / "pytorch_model.bin")
+    shutil.copy(os.path.join(a0.ckpt_dir, "t5-ance", "config.json"), tmp_path / "ckpts" / "t5-ance" / "config.json")
+    blobs = []
+    for j in range(2):
+        a = Namespace(**vars(a0))
+        a.custom_save_path, a.metric_path = str(tmp_path / f"r{j}" / "out.tsv"), str(tmp_path / f"r{j}" / "m.txt")
+        os.makedirs(tmp_path / f"r{j}")
+        if j == 1:
+            a.nci_ckpt, a.infer_ckpt, a.ckpt_dir, a.pq_path = None, str(tmp_path / "whole.ckpt"), str(tmp_path / "ckpts"), "/nonexistent.pt"
+        EvalRun(a, tokenizer=tok, device=cuda).run(load_queries(a.data_dir))
+        prefix = a.custom_save_path[:-4]
+        blobs.append([open(p, "rb").read() for p in (prefix + "_coarse.tsv", prefix + "_fine.tsv",
+                                                     f"{prefix}_hn{a.save_hard_neg}.tsv", a.metric_path)])
+    assert blobs[0] == blobs[1] and all(len(b) > 0 for b in blobs[0])
+    # a checkpoint trained with another codebook size (decode vocabulary of K = 16 instead of 32)
+    bad = {"model." + k: v for k, v in mini["W"].items()}
+    bad["model.decode_embeddings.weight"] = bad["model.decode_embeddings.weight"][:16 * 6 + 2].clone()
+    torch.save({"state_dict": bad}, tmp_path / "bad.ckpt")
+    a = Namespace(**vars(a0))
+    a.nci_ckpt = str(tmp_path / "bad.ckpt")
+    with pytest.raises(SystemExit, match="decode_embeddings.weight"):
+        EvalRun(a, tokenizer=tok, device=cuda)
 
 
 def test_eval_all_documents_mode(cuda, mini, tmp_path):

@@ -308,3 +308,54 @@ def test_multi_rank_host_flows_on_gloo_world2(tmp_path):
     want = np.stack([tokens.sum(1), tokens[:, 0], (tokens % 3 != 0).sum(1)], 1).astype(np.float32)
     assert np.array_equal(emb, want)
     assert sorted(os.listdir(tmp_path)) == ["docemb.bin", "out_fine.tsv"]
+
+
+def test_main_py_rejects_what_it_does_not_build():
+    """Only flags of the reference's own parser are accepted (a typo ends the run as argparse would); ablation flags that
+    change what --mode eval computes are refused unless they carry the built value (VERDICT r1 #7)."""
+    import main
+
+    base = ["--mode", "eval", "--data_dir", "x"]
+    a = main.parsers_parser(base + ["--learning_rate", "2e-4", "--fixnci", "--simans_hyper_b", "-1", "--Rdrop=0.1"])
+    assert ("--learning_rate", "2e-4") in a.ignored_flags and ("--simans_hyper_b", "-1") in a.ignored_flags
+    assert ("--Rdrop", "0.1") in a.ignored_flags
+    for argv in (["--lerning_rate", "1"], ["stray"], ["--learning_rate"], ["--use_topic_model", "1"], ["--fp_16", "1"],
+                 ["--cat_cluster_centroid", "2"], ["--cluster_position_topk", "5"], ["--decode_embedding", "1"],
+                 ["--infer_reconstruct_vector", "1"], ["--load_encoder_only", "1"]):
+        with pytest.raises(SystemExit):
+            main.parsers_parser(base + argv)
+    main.parsers_parser(base + ["--use_topic_model", "0", "--fp_16", "0", "--decode_embedding", "2"])   # the built values
+    with pytest.raises(SystemExit):            # try_load_ckpt asserts a checkpoint (MEVI/main.py:201)
+        main.check_supported(main.parsers_parser([t for t in EVAL_ARGV if not t.startswith("--nci_ckpt")][:0] + base + [
+            "--codebook", "1", "--pq_type", "rq", "--query_encoder", "twin", "--recall_level", "both", "--document_encoder",
+            "ance", "--pq_path", "p", "--pq_cluster_path", "c", "--embedding_path", "e", "--custom_save_path", "o.tsv"]))
+
+
+def test_checkpoint_loading_rules():
+    """try_load_ckpt (MEVI/main.py:198-248): the NCI branch strips 'model.', reports foreign keys and shape mismatches as
+    `Bad parameter <k>.`; the whole-model branch (--infer_ckpt) routes model. / document_encoder.lm_q. / pq.codebook and
+    drops the four filtered relative_attention_bias keys."""
+    import torch
+
+    from mevi_amd import nci
+    from mevi_amd.evalrun import nci_weights_from_state_dict, split_whole_checkpoint
+
+    M, K = 3, 4
+    cfg = nci.NCIConfig(M=M, K=K, adaptor_layer_num=1, num_decoder_layers=1, num_layers=1, d_model=8, d_ff=16, num_heads=2, d_kv=4)
+    good = {n: torch.zeros([s if s is not None else 5 for s in shape]) for n, shape in nci.expected_shapes(cfg).items()}
+    said = []
+    sd = {"model." + k: v for k, v in good.items()}
+    sd.update({"document_encoder.lm_q.shared.weight": torch.zeros(3, 8), "pq.codebook": torch.zeros(M, K, 8), "epoch": 3})
+    w = nci_weights_from_state_dict(sd, said.append)
+    assert sorted(said) == ["Bad parameter document_encoder.lm_q.shared.weight.", "Bad parameter pq.codebook."]
+    assert set(w) == set(good) and nci.check_weights(w, cfg, said.append) == []
+    w["decode_embeddings.weight"] = torch.zeros(cfg.V + 4, 8)             # a checkpoint trained with another codebook size
+    del w["decoder.final_layer_norm.weight"]
+    said.clear()
+    assert nci.check_weights(w, cfg, said.append) == ["decode_embeddings.weight", "decoder.final_layer_norm.weight"]
+    assert said == ["Bad parameter decode_embeddings.weight.", "Bad parameter decoder.final_layer_norm.weight."]
+    bad_key = "model.decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight"
+    sd[bad_key] = torch.zeros(32, 2)
+    nw, tower, cb = split_whole_checkpoint(sd)
+    assert bad_key[6:] not in nw and set(nw) == set(good) and list(tower) == ["shared.weight"] and cb.shape == (M, K, 8)
+    assert split_whole_checkpoint(sd, not_load_document_encoder=True)[1] == {}
