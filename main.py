@@ -62,6 +62,8 @@ def parsers_parser(argv=None):
     p.add_argument("--doc_multiclus", type=int, default=1)
     p.add_argument("--multiclus_score_aggr", type=str, default="add", choices=["add", "max"])
     p.add_argument("--eval_all_documents", type=int, default=0)
+    p.add_argument("--use_topic_model", type=int, default=0)
+    p.add_argument("--topic_score_ratio", type=float, default=0.)
     p.add_argument("--knn_topk_by_step", type=int, default=0)
     p.add_argument("--only_gen_rq", type=int, default=0)
     p.add_argument("--co_doc_length", type=int, default=128)
@@ -128,7 +130,7 @@ PASS_THROUGH_VALUE_FLAGS = frozenset((
     "pq_negative_loss tie_nci_pq_centroid aug_topk_clus aug_find_topk_from aug_sample_topk "
     "reconstruct_for_embeddings centroid_update_loss centroid_loss_scale infer_reconstruct_vector "
     "align_clustering query_vq_label nci_twin_alt_epoch nci_vq_alt_epoch rq_topk_score multiclus_label "
-    "use_topic_model topic_score_ratio cat_cluster_centroid cluster_position_topk cluster_position_embedding "
+    "cat_cluster_centroid cluster_position_topk cluster_position_embedding "
     "cluster_position_rank_reciprocal cluster_position_proj_style use_cluster_adaptor "
     "cluster_adaptor_decouple cluster_adaptor_trainable_token_embedding "
     "cluster_adaptor_trainable_position_embedding cluster_adaptor_head_num cluster_adaptor_layer_num use_ort "
@@ -146,7 +148,7 @@ EVAL_AFFECTING = {
     "tie_decode_embedding": ("1",), "adaptor_decode": ("1",), "adaptor_efficient": ("1",), "position": ("1",),
     "multiple_decoder": ("0",), "decoder_num": ("1",), "reserve_decoder": ("0",), "decoder_integration": ("series",),
     "softmax": ("0",), "tree": ("1",), "topk_sequence": ("0",), "test1000": ("0",), "gen_method": ("greedy",),
-    "use_topic_model": ("0",), "topic_score_ratio": ("0", "0.", "0.0"), "cat_cluster_centroid": ("0",),
+    "cat_cluster_centroid": ("0",),
     "cluster_position_topk": ("0",), "use_cluster_adaptor": ("0",), "infer_reconstruct_vector": ("0",),
     "rq_topk_score": ("prod",), "multiclus_label": ("top1",), "reconstruct_for_embeddings": ("0",),
     "tie_encoders": ("1",), "input_dropout": ("0", "1"), "denoising": ("0",), "load_encoder_only": ("0",),
@@ -172,6 +174,9 @@ def check_supported(a):
     need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both")
     if a.doc_multiclus < 1 or (a.doc_multiclus > 1 and (a.eval_all_documents or a.knn_topk_by_step)):
         raise SystemExit("main.py --mode eval: --doc_multiclus C > 1 is built for the cluster re-ranking path only")
+    if a.use_topic_model and (a.topic_score_ratio != 0 or a.doc_multiclus > 1):
+        raise SystemExit("main.py --mode eval: --use_topic_model 1 is built for --topic_score_ratio 0 --doc_multiclus 1 "
+                         "(cluster score x q.d; the reconstruct-vector term is not)")
     if a.eval_all_documents:   # the brute-force ablation; same preconditions as the reference (MEVI/main.py:657-658)
         need.update(recall_level="fine", knn_topk_by_step=1)
     for k, v in need.items():

@@ -329,6 +329,13 @@ class EvalRun:
         # --eval_all_documents 1 (recall_level 'fine'): the brute-force ablation -- no beam search, the fine list is the
         # exact top-max(recall_num) of q.d over the whole corpus (main_models.py:3570,3818-3876)
         self.eval_all = bool(getattr(a, "eval_all_documents", 0))
+        # --use_topic_model 1 (topic_score_ratio 0, doc_multiclus 1): document score = NCI score of its cluster x q.d
+        # (get_inference_scores, main_models.py:3539-3552) -- the beam scores on the cluster path, the scores of ALL
+        # code paths (_generate_all) with --eval_all_documents
+        self.topic = bool(getattr(a, "use_topic_model", 0))
+        if self.topic:
+            assert self.C == 1 and not float(getattr(a, "topic_score_ratio", 0) or 0), "use_topic_model: doc_multiclus 1, topic_score_ratio 0"
+            self.doc_path = None
         self.coarse_log = None if self.eval_all else RankLog(f"{prefix}_coarse.tsv", rank, nrank, self.barrier)
         self.fine_log = RankLog(f"{prefix}_fine.tsv", rank, nrank, self.barrier)
         self.hn_log = RankLog(f"{prefix}_hn{a.save_hard_neg}.tsv", rank, nrank, self.barrier) if a.save_hard_neg else None
@@ -359,6 +366,8 @@ class EvalRun:
         N = self.emb.shape[0]
         pool = max(a.recall_num)
         qemb = self.query_embedding(texts, ids, mask, rows)
+        if self.topic:
+            return self._all_documents_topic(texts, doc_ids, ids, mask, qemb, pool)
         if self._dense_index is None:
             self._dense_index = mdense.DenseIndex(self.emb)
         _, top_i = self._dense_index.search(qemb, min(N, pool))
@@ -372,6 +381,55 @@ class EvalRun:
                 head_s, _ = mdense.ip_topk(qemb, self.emb[:last], min(last, pool))
                 tail = torch.cat([head_s, tail], dim=1)
             quirk = tail.cpu().numpy()
+            gt_s = self.fine.gt_scores(qemb, doc_ids) if self.nq is None else None
+        results = []
+        for i, text in enumerate(texts):
+            docs = top_i[i]
+            self.fine_log.add((text, docs.tolist(), doc_ids[i]) if self.nq is None else (text, docs.tolist()))
+            if self.hn_log is not None:
+                n = a.save_hard_neg
+                self.hn_log.add((text, mfine.f32_repr(gt_s[i]) if self.nq is None else "", join_i64(docs[:n]),
+                                 mfine.f32_repr(quirk[i][:n])))
+            ranks = mfine.fine_ranks(docs, doc_ids[i]) if self.nq is None else [self.nq.first_hit(doc_ids[i], docs)]
+            results.append((text, N, ranks))
+        return results
+
+    def _all_documents_topic(self, texts, doc_ids, ids, mask, qemb, pool):
+        """--use_topic_model 1 --eval_all_documents 1 (main_models.py:3565,3653-3656,3818-3876): score(q, d) =
+        all_scores[q, path(d)] * (q.d), all_scores = the NCI scores of all K**M code paths (_generate_all), path(d) the
+        document's RQ code as a mixed-radix index (gen_doc2index_mapping :3311-3372, kary = K); streamed over the corpus
+        in --encode_batch_size blocks through a running top-pool.  Order: score desc, ties by ascending id (torch.topk
+        leaves ties unspecified)."""
+        from . import ops
+
+        a, N, K, M = self.args, self.emb.shape[0], self.K, self.M
+        _, all_scores, _, _ = self.nci.generate(ids, mask, num_beams=1, num_return_sequences=1,
+                                                length_penalty=a.length_penalty, eval_all_documents=True)
+        if self.doc_path is None:
+            codes = torch.from_numpy(self.index.doc_codes(N).astype(np.int64)).to(self.dev)
+            self.doc_path = sum(codes[:, p] * K ** (M - 1 - p) for p in range(M))
+        B = qemb.shape[0]
+        bs = max(1, min(a.encode_batch_size or 64, 8192))
+        kk = min(pool, N)
+        run_s = torch.full((B, kk), -torch.finfo(torch.float32).max, dtype=torch.float32, device=self.dev)
+        run_i = torch.full((B, kk), -1, dtype=torch.int64, device=self.dev)
+        last_scores = None
+        for start in range(0, N, bs):
+            end = min(N, start + bs)
+            new = all_scores[:, self.doc_path[start:end]] * ops.linear(qemb, self.emb[start:end])   # one f32 multiply
+            if self.hn_log is not None and end == N:
+                filled = min(start, kk)                                         # rows seen so far, capped by the pool
+                last_scores = torch.cat([run_s[:, :filled], new], dim=1)        # the reference's `scores` (:3872,3905)
+            width = max(kk, end - start)
+            pad = lambda t, v: torch.nn.functional.pad(t, (0, width - t.shape[1]), value=v)   # noqa: E731
+            ids_new = torch.arange(start, end, device=self.dev)[None].expand(B, -1)
+            ls = torch.stack([pad(run_s, -torch.finfo(torch.float32).max), pad(new, -torch.finfo(torch.float32).max)])
+            li = torch.stack([pad(run_i, -1), pad(ids_new, -1)])
+            run_s, run_i = mdense.topk_merge(ls, li, kk)
+        top_i = run_i.cpu().numpy()
+        gt_s = quirk = None
+        if self.hn_log is not None:
+            quirk = last_scores.cpu().numpy()
             gt_s = self.fine.gt_scores(qemb, doc_ids) if self.nq is None else None
         results = []
         for i, text in enumerate(texts):
@@ -399,7 +457,8 @@ class EvalRun:
         codes = decode_token(decoded, self.K).view(B, R, self.M).cpu().numpy()
         scores = np.array(scores).reshape(B, R)
         qemb = self.query_embedding(texts, ids, mask, rows)
-        ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate)
+        weights = torch.tensor(scores, dtype=torch.float32) if self.topic else None     # nci_scores (main_models.py:3681-3682)
+        ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate, beam_weights=weights)
         nq = self.nq
         gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None and nq is None else None
         results = []

@@ -56,7 +56,7 @@ class FineStage:
         seg = np.concatenate([[0], np.cumsum(ndoc)]).astype(np.int64)
         return cand, cand_q, seg, ndoc
 
-    def candidates_device(self, beam_codes):
+    def candidates_device(self, beam_codes, with_beam=False):
         """candidates() with the expansion done on the GPU (the CSR arrays are uploaded once): the candidate list of
         a batch is tens of millions of ids -- building it with numpy and shipping two i64 arrays over PCIe
         dominated the fine stage.  Returns (cand i64[total] CUDA, cand_q i64[total] CUDA, seg, ndoc) with seg / ndoc
@@ -72,7 +72,8 @@ class FineStage:
         keys = (codes * w).sum(-1).reshape(-1)
         n = keys_t.numel()
         if n == 0:
-            return (torch.zeros(0, dtype=torch.int64, device=self.dev),) * 2 + (np.zeros(B + 1, np.int64), np.zeros(B, np.int64))
+            empty = (torch.zeros(0, dtype=torch.int64, device=self.dev),) * 2 + (np.zeros(B + 1, np.int64), np.zeros(B, np.int64))
+            return empty + (torch.zeros(0, dtype=torch.int64, device=self.dev),) if with_beam else empty
         pos = torch.searchsorted(keys_t, keys)
         pos_c = pos.clamp(max=n - 1)
         found = (pos < n) & (keys_t[pos_c] == keys)
@@ -86,20 +87,28 @@ class FineStage:
         cand_q = torch.repeat_interleave(torch.arange(B, dtype=torch.int64, device=self.dev).repeat_interleave(R), size)
         ndoc = size.view(B, R).sum(1).cpu().numpy()
         seg = np.concatenate([[0], np.cumsum(ndoc)]).astype(np.int64)
+        if with_beam:      # which entry of the query's beam list each candidate came from
+            return cand, cand_q, seg, ndoc, torch.repeat_interleave(torch.arange(R, dtype=torch.int64, device=self.dev).repeat(B), size)
         return cand, cand_q, seg, ndoc
 
-    def rerank(self, query_emb, beam_codes, aggregate=None):
+    def rerank(self, query_emb, beam_codes, aggregate=None, beam_weights=None):
         """query_emb f32[B, dim] (CUDA).  Returns per query: (doc ids i64 ndarray, scores f32 ndarray) -- views of
         one host copy of the sorted batch --, and ndoc (candidates incl. repeats).
 
         aggregate 'add' | 'max' (--doc_multiclus > 1, main_models.py:3997-4011): a document reached through several
         beam clusters is listed once, with the sum (sequential f32 adds, as the reference accumulates) or the maximum
-        of its per-cluster scores -- which are all the same q.d."""
-        cand_t, cand_q, seg, ndoc = self.candidates_device(beam_codes)
+        of its per-cluster scores -- which are all the same q.d.
+
+        beam_weights f32[B, R] (--use_topic_model 1, main_models.py:3539-3552,3952: get_inference_scores with
+        topic_score_ratio 0): every document's score is its cluster's beam score times q.d (one f32 multiply)."""
+        cand_t, cand_q, seg, ndoc, cand_beam = self.candidates_device(beam_codes, with_beam=True)
         B = len(ndoc)
         if cand_t.numel() == 0:
             return [(np.zeros(0, np.int64), np.zeros(0, np.float32)) for _ in range(B)], ndoc
         sc = ops.pair_dot(query_emb, cand_q, self.emb, cand_t)
+        if beam_weights is not None:
+            w = torch.as_tensor(beam_weights, dtype=torch.float32, device=self.dev)
+            sc = w[cand_q, cand_beam] * sc
         seg_len = ndoc
         if aggregate is not None:
             n = self.emb.shape[0]

@@ -275,6 +275,10 @@ class NCIModel:
         (fixed shapes: padded encoder, no host synchronisation inside) -- same kernels, same results, no host jitter;
         the median latency is the kernels' own time either way (tools/bench_latency.py)."""
         c = self.cfg
+        if reference_kwargs.get("eval_all_documents"):      # generation_utils.py:507-521 -> _generate_all
+            assert num_beams == 1 and num_return_sequences in (None, 1)
+            scores, enc = self.generate_all(input_ids, attention_mask, length_penalty)
+            return None, scores, enc, None
         R = num_beams
         assert num_return_sequences in (None, R) and R <= c.K, "needs num_beams == num_return_sequences <= K"
         assert max_length in (None, c.M + 2)
@@ -288,6 +292,73 @@ class NCIModel:
         else:
             decoded, hyp, enc = self._search(ids, mask, R, length_penalty, pack=True)
         return decoded, hyp.reshape(-1).tolist(), enc, None
+
+    @torch.no_grad()
+    def generate_all(self, input_ids, attention_mask, length_penalty=0.8, max_rows=1 << 16):
+        """`_generate_all` (MEVI/transformers/generation_utils.py:1013-1136; the `use_topic_model` ablation): the score
+        of EVERY code path of every query, f32 [B, K**M] with path index sum_p c_p K**(M-1-p) -- per level the
+        log-softmax over the position's valid columns added to the running score, the eos term at the end, divided by
+        (M + 1) ** length_penalty in f32.  The reference re-runs the whole decoder on every prefix (use_cache=False, 128
+        rows at a time); here the tree is walked depth-first in blocks of at most `max_rows` prefixes with the K|V caches
+        of a block's ancestors kept, the adaptor side from the prefix tables where they reach.
+        Returns (scores, encoder states)."""
+        c = self.cfg
+        M, K = c.M, c.K
+        ids = input_ids.to(self.dev, torch.int64).contiguous()
+        mask = attention_mask.to(self.dev, torch.int64).contiguous()
+        B = ids.shape[0]
+        enc = self.encoder.forward(self.shared, ids, mask)
+        out = torch.empty((B, K ** M), dtype=torch.float32, device=self.dev)
+        levels = self.tables().levels if self.prefix_table_bytes else 0
+        for a in range(0, B, max_rows):                      # position 0: one row per query
+            m_ = mask[a:a + max_rows]
+            xkv = self.decoder.cross_kv(enc[a:a + max_rows], m_, pack=True)
+            self._all_paths(out[a:a + m_.shape[0]], xkv, levels, max_rows, length_penalty)
+        return out, enc
+
+    def _all_paths(self, out, xkv, levels, max_rows, length_penalty):
+        """Expansion of the code tree for the queries of one CrossKV.  A block holds rows in query-major order, the same
+        number (kv_div) per query, so row r reads the encoder states of the block's query r // kv_div.  Levels are
+        expanded whole while they fit `max_rows`; beyond that a block is split by query, then inside a query by prefix."""
+        c = self.cfg
+        M, K = c.M, c.K
+        scale = (M + 1) ** length_penalty
+
+        def expand(p, xkv, kv_div, q0, pidx, tokens, score, dcache, acache):
+            n = tokens.numel()
+            if p >= levels and acache is None:               # the adaptor runs per row from here on
+                acache = self.adaptor.new_cache(n) if p == 0 else self.tables().cache_rows(self.adaptor, pidx, p)
+            logits = self._logits(tokens, p, dcache, acache, xkv, None, kv_div, pidx if p < levels else None)
+            lsm = torch.log_softmax(logits, dim=-1)          # columns: eos, then the K codes of position p
+            qrow = q0 + torch.arange(n, device=self.dev) // kv_div
+            if p == M:
+                out[qrow, pidx] = (lsm[:, 0] + score) / scale
+                return
+            child = lsm[:, 1:] + score[:, None]              # [n, K]: running scores of the children
+
+            def descend(xkv_, kv_div_, q0_, lo, hi):         # children of parent rows [lo, hi)
+                rows = torch.arange(lo, hi, device=self.dev).repeat_interleave(K)
+                code = torch.arange(K, device=self.dev).repeat(hi - lo)
+                expand(p + 1, xkv_, kv_div_, q0_, pidx[rows] * K + code, 2 + p * K + code, child[lo:hi].reshape(-1),
+                       _reorder_cache(dcache, rows, p + 1), _reorder_cache(acache, rows, p + 1) if p >= levels else None)
+
+            nq = n // kv_div
+            if n * K <= max_rows:
+                descend(xkv, kv_div * K, q0, 0, n)
+            elif nq > 1:                                      # split by query
+                g = max(1, max_rows // (kv_div * K))
+                for a in range(0, nq, g):
+                    b = min(nq, a + g)
+                    descend(_slice_cross_kv(xkv, a, b), kv_div * K, q0 + a, a * kv_div, b * kv_div)
+            else:                                             # one query, too many prefixes: split by prefix
+                per = max(1, max_rows // K)
+                for lo in range(0, n, per):
+                    hi = min(n, lo + per)
+                    descend(xkv, (hi - lo) * K, q0, lo, hi)
+
+        nq = out.shape[0]
+        zeros = torch.zeros(nq, dtype=torch.int64, device=self.dev)
+        expand(0, xkv, 1, 0, zeros, zeros, torch.zeros(nq, dtype=torch.float32, device=self.dev), self.decoder.new_cache(nq), None)
 
     def _search(self, ids, mask, R, length_penalty, pack):
         """The device part of generate(): (decoded i64[B*R, M+2], hypothesis scores f64[B, R], encoder states)."""
@@ -331,6 +402,16 @@ class NCIModel:
         decoded = torch.cat([torch.zeros((B, R, 1), dtype=torch.int64, device=self.dev), toks,
                              torch.ones((B, R, 1), dtype=torch.int64, device=self.dev)], dim=2).view(B * R, c.M + 2)
         return decoded, hyp, enc
+
+
+def _slice_cross_kv(xkv, a, b):
+    """The CrossKV of queries [a, b) of `xkv` (views)."""
+    from .t5 import CrossKV
+
+    if xkv.kv_off is None:
+        return CrossKV([l[a:b] for l in xkv.layers], None if xkv.mask is None else xkv.mask[a:b])
+    lo, hi = int(xkv.kv_off[a].item()), int(xkv.kv_off[b].item())
+    return CrossKV([l[lo:hi] for l in xkv.layers], None, (xkv.kv_off[a:b + 1] - lo).contiguous(), xkv.longest)
 
 
 def _reorder_cache(cache, rows, filled):

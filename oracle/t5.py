@@ -214,6 +214,35 @@ def nci_generate(W, cfg, ids, mask, beams, length_penalty=0.8, return_steps=Fals
     return (dec, sc, enc, steps) if return_steps else (dec, sc, enc)
 
 
+def nci_generate_all(W, cfg, ids, mask, length_penalty=0.8):
+    """_generate_all (MEVI/transformers/generation_utils.py:1013-1136; generate(..., eval_all_documents=True), the
+    `use_topic_model` ablation): the score of EVERY code path, f32 [B, K**M] with path index sum_p c_p K**(M-1-p):
+    sum of the per-level log-softmax terms (over the position's valid columns) plus the final eos term, divided by
+    (max_length - 1) ** length_penalty = (M + 1) ** length_penalty -- all in f32 tensors, as the reference."""
+    M, K = cfg["M"], cfg["K"]
+    enc = encoder(W, cfg, ids, mask)
+    out = []
+    for b in range(ids.shape[0]):
+        e, m = enc[b:b + 1], mask[b:b + 1]
+        prefix = torch.zeros((1, 1), dtype=torch.long)
+        score = torch.zeros(1)
+        for p in range(M + 1):
+            n = prefix.shape[0]
+            rows = []
+            for a in range(0, n, 128):                       # local_batch_size (generation_utils.py:1029)
+                rows.append(nci_last_logits(W, cfg, prefix[a:a + 128], e.expand(min(128, n - a), -1, -1),
+                                            m.expand(min(128, n - a), -1)))
+            lsm = F.log_softmax(torch.cat(rows), dim=-1)
+            if p == M:
+                score = (lsm[:, 1:2] + score[:, None]).view(-1)
+                break
+            score = (lsm[:, 2 + p * K: 2 + (p + 1) * K] + score[:, None]).view(-1)
+            new = torch.arange(2 + p * K, 2 + (p + 1) * K).repeat(n)[:, None]
+            prefix = torch.cat([prefix[:, None, :].repeat(1, K, 1).view(-1, p + 1), new], dim=-1)
+        out.append(score / (M + 1) ** length_penalty)
+    return torch.stack(out), enc
+
+
 def decode_token(decoded, K):
     """main_models.decode_token for codebook models (main_models.py:117-136): strip bos/eos, undo the
     position offset, clamp negatives to 0 -> codes i64[n, M]."""

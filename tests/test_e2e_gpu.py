@@ -45,11 +45,12 @@ def hash_(w):
     return h
 
 
-@pytest.fixture(scope="module")
-def mini(tmp_path_factory):
-    d = tmp_path_factory.mktemp("marco")
-    g = np.load(os.path.join(GOLD, "g1_nci_M4_K32_R10.npz"))
+def _build_mini(d, nci_golden, M, bits, R, n_random=2000):
+    """A miniature MS MARCO: NCI checkpoint from a reference golden, T5-ANCE-shaped tower, corpus built around the clusters
+    the (random-weight) model actually emits, RQ codebook, query file."""
+    g = np.load(os.path.join(GOLD, nci_golden))
     cfg = json.loads(str(g["cfg"]))
+    cfg.pop("beams", None)
     W = ot5.load_weights(g)
     tw = np.load(os.path.join(GOLD, "g2_t5_tower.npz"))
     TW = ot5.load_weights(tw)
@@ -61,32 +62,43 @@ def mini(tmp_path_factory):
     torch.save(TW, d / "ckpts" / "t5-ance" / "pytorch_model.bin")
     json.dump(dict(d_model=32, d_ff=64, num_heads=4, d_kv=8, num_layers=2, num_decoder_layers=2), open(d / "ckpts" / "t5-ance" / "config.json", "w"))
     rng = np.random.default_rng(0)
-    dim, M, K = 32, 4, 32
+    dim, K = 32, 2 ** bits
     queries = [" ".join(f"w{rng.integers(0, 50)}" for _ in range(rng.integers(3, 12))) + f" q{i}" for i in range(23)]
     # corpus built around the clusters the (random-weight) model actually emits, so that the fine
     # stage has documents to rank: doc = sum_j C[j][code_j] + noise for beam code paths + random paths
     enc = FakeTokenizer(512).batch_encode_plus(queries)
-    dec, _, _ = ot5.nci_generate(W, cfg, enc["input_ids"], enc["attention_mask"], 10)
+    dec, _, _ = ot5.nci_generate(W, cfg, enc["input_ids"], enc["attention_mask"], R)
     beam_codes = ot5.decode_token(dec, K).numpy()
     C = (rng.standard_normal((M, K, dim)) * (1.0 / np.arange(1, M + 1))[:, None, None]).astype(np.float32)
     C[0] *= 3.0
-    paths = np.concatenate([np.repeat(beam_codes[::3], 6, axis=0), rng.integers(0, K, size=(2000, M))])
+    paths = np.concatenate([np.repeat(beam_codes[::3], 6, axis=0), rng.integers(0, K, size=(n_random, M))])
     rng.shuffle(paths)
     N = len(paths)
     emb = sum(C[j][paths[:, j]] for j in range(M)).astype(np.float32) + 0.01 * rng.standard_normal((N, dim)).astype(np.float32)
     emb.tofile(d / "ance" / "docemb.bin")
-    torch.save(torch.nn.Parameter(torch.from_numpy(C)), d / "ance" / "rqcodebook4_5.pt")
+    torch.save(torch.nn.Parameter(torch.from_numpy(C)), d / "ance" / f"rqcodebook{M}_{bits}.pt")
     gts = [[int(x) for x in rng.choice(N, size=1 + i % 2, replace=False)] for i in range(len(queries))]
     with open(d / "origin" / "dev_mevi_dedup.tsv", "w") as f:
         for q, g_ in zip(queries, gts):
             f.write(f"{q}\t{','.join(map(str, g_))}\n")
-    args = Namespace(subvector_num=M, subvector_bits=5, num_return_sequences=10, adaptor_layer_num=2, model_info="base",
+    args = Namespace(subvector_num=M, subvector_bits=bits, num_return_sequences=R, adaptor_layer_num=2, model_info="base",
                      nci_ckpt=str(d / "ckpts" / "nci.ckpt"), ckpt_dir=str(d / "ckpts"), embedding_path=str(d / "ance" / "docemb.bin"),
-                     pq_path=str(d / "ance" / "rqcodebook4_5.pt"), pq_cluster_path=str(d / "ance" / "rqclus4_5.pkl"),
+                     pq_path=str(d / "ance" / f"rqcodebook{M}_{bits}.pt"), pq_cluster_path=str(d / "ance" / f"rqclus{M}_{bits}.pkl"),
                      custom_save_path=str(d / "ance" / "nci_result_rq45_top10.tsv"), save_hard_neg=N, length_penalty=0.8,
                      eval_batch_size=4, recall_num=[1, 5, 10, 20, 50, 100], metric_path=str(d / "logs" / "m.txt"),
                      data_dir=str(d / "origin"), n_test=-1)
     return dict(dir=d, args=args, W=W, cfg=cfg, TW=TW, tcfg=tcfg, emb=emb, C=C, queries=queries, gts=gts, N=N)
+
+
+@pytest.fixture(scope="module")
+def mini(tmp_path_factory):
+    return _build_mini(tmp_path_factory.mktemp("marco"), "g1_nci_M4_K32_R10.npz", 4, 5, 10)
+
+
+@pytest.fixture(scope="module")
+def mini_small(tmp_path_factory):
+    """3 levels of 4 codes (64 code paths): small enough for _generate_all, which scores EVERY path of every query."""
+    return _build_mini(tmp_path_factory.mktemp("marco_small"), "g1a_nci_all_M3_K4.npz", 3, 2, 4, n_random=600)
 
 
 def test_eval_driver_matches_cpu_restatement(cuda, mini):
@@ -268,6 +280,86 @@ def test_eval_all_documents_mode(cuda, mini, tmp_path):
     assert out["ndoc"] == N and "cluster_recall" not in out
     hit10 = np.mean([min([r for r in rk if r is not None], default=10 ** 9) < 10 for rk in ranks])
     assert abs(out["hitrate"][10] - hit10) < 1e-12 and "recallcluster10" in open(a.metric_path).read()
+
+
+def _firm(ref_s, tol):
+    g = np.abs(np.diff(ref_s)) > tol
+    return np.concatenate([[True], g]) & np.concatenate([g, [True]])
+
+
+def test_use_topic_model_ablation(cuda, mini_small, tmp_path):
+    mini = mini_small
+    M, K, R = 3, 4, 4
+    """--use_topic_model 1 (topic_score_ratio 0; main_models.py:3539-3552): a document's score is the NCI score of its
+    cluster times q.d -- on the cluster path the beam score (:3952), with --eval_all_documents the score of its code
+    path among ALL K**M paths (_generate_all, generation_utils.py:1013-1136; doc2index :3311-3372), streamed through
+    the running top-pool (:3818-3876).  Both against a CPU restatement from the oracle pieces, literally as the
+    reference loops."""
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    tok = FakeTokenizer(512)
+    enc = tok.batch_encode_plus(mini["queries"])
+    ids, mask = enc["input_ids"], enc["attention_mask"]
+    qemb = ot5.tower_encode(mini["TW"], mini["tcfg"], ids, mask)
+    emb = torch.from_numpy(mini["emb"])
+    codes_doc = orq.rq_encode(mini["emb"], mini["C"])
+    cluster, _ = orq.cluster_dict(codes_doc)
+    # ---- cluster path: beam score x q.d
+    a = Namespace(**vars(mini["args"]))
+    a.use_topic_model, a.topic_score_ratio = 1, 0.0
+    a.custom_save_path, a.metric_path = str(tmp_path / "t.tsv"), str(tmp_path / "m.txt")
+    EvalRun(a, tokenizer=tok, device=cuda).run(load_queries(a.data_dir))
+    hn = [l.rstrip("\n").split("\t") for l in open(f"{a.custom_save_path[:-4]}_hn{a.save_hard_neg}.tsv")]
+    dec, sc, _ = ot5.nci_generate(mini["W"], mini["cfg"], ids, mask, R)
+    bcodes = ot5.decode_token(dec, K).view(len(ids), R, M).numpy()
+    nci_scores = torch.tensor(sc.tolist(), dtype=torch.float32).reshape(len(ids), R)
+    checked = 0
+    for i in range(len(ids)):
+        scores, docs = [], []
+        for r in range(R):
+            cur = cluster.get(tuple(bcodes[i, r].tolist()))
+            if cur is not None:
+                scores.append(nci_scores[i][r].item() * (qemb[i] @ emb[cur].T))     # get_inference_scores, ratio 0
+                docs += cur
+        if not docs:
+            assert hn[i][2] == ""
+            continue
+        ref_s, order = torch.sort(torch.cat(scores), descending=True)
+        ref_d = np.array(docs)[order.numpy()]
+        got_d = [int(x) for x in hn[i][2].split(",")]
+        got_s = np.array([float(x) for x in hn[i][3].split(",")])
+        assert sorted(got_d) == sorted(docs) and np.abs(got_s - ref_s.numpy()).max() <= 2e-4
+        firm = _firm(ref_s.numpy(), 1e-3)
+        assert all(got_d[j] == int(ref_d[j]) for j in np.nonzero(firm)[0])
+        checked += int(firm.sum())
+    assert checked > 100
+    # ---- all documents: score of the document's code path among all K**M x q.d
+    a = Namespace(**vars(mini["args"]))
+    a.use_topic_model, a.topic_score_ratio, a.eval_all_documents, a.recall_level, a.encode_batch_size = 1, 0.0, 1, "fine", 64
+    a.recall_num, a.save_hard_neg = [1, 5, 10, 20, 50, 100], 150
+    a.custom_save_path, a.metric_path = str(tmp_path / "ta.tsv"), str(tmp_path / "ma.txt")
+    EvalRun(a, tokenizer=tok, device=cuda).run(load_queries(a.data_dir))
+    fine = [l.rstrip("\n").split("\t") for l in open(a.custom_save_path[:-4] + "_fine.tsv")]
+    hn = [l.rstrip("\n").split("\t") for l in open(a.custom_save_path[:-4] + "_hn150.tsv")]
+    all_scores, _ = ot5.nci_generate_all(mini["W"], mini["cfg"], ids, mask)
+    path = torch.from_numpy(sum(codes_doc[:, p].astype(np.int64) * K ** (M - 1 - p) for p in range(M)))
+    N, pool = len(emb), 100
+    stack = torch.empty((len(qemb), 0))
+    docs = torch.empty((len(qemb), 0), dtype=torch.int64)
+    for st in range(0, N, 64):                       # the reference's loop with use_topic_model (main_models.py:3826-3876)
+        topic = all_scores[:, path[st:st + 64]]
+        new = topic * (qemb @ emb[st:st + 64].T)
+        scs = torch.cat([stack, new], -1)
+        dd = torch.cat([docs, torch.arange(st, min(st + 64, N)).unsqueeze(0).expand(len(qemb), -1)], -1)
+        stack, idx = torch.topk(scs, k=min(scs.shape[-1], pool), dim=-1)
+        docs = dd.gather(-1, idx)
+    for i in range(len(ids)):
+        got = eval(fine[i][1])
+        firm = _firm(stack[i].numpy(), 2e-4)
+        assert len(got) == pool and all(got[j] == int(docs[i, j]) for j in np.nonzero(firm)[0]) and firm.mean() > 0.5
+        got_sc = np.array([float(x) for x in hn[i][3].split(",")])
+        want = scs[i, :150].numpy()
+        assert len(got_sc) == len(want) and np.abs(got_sc - want).max() <= 5e-4
 
 
 def test_eval_driver_on_the_nq_dataset_path(cuda, mini, tmp_path):

@@ -324,3 +324,33 @@ def test_graph_replay_of_small_batches_equals_the_eager_pass(cuda):
     # the default stays eager (packed) for a small batch
     assert torch.equal(tower.encode_query({"input_ids": ids[:2], "attention_mask": mask[:2]}), big_e[:2])
     assert len(tower._graphs.graphs) == 2
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1a_nci_all_*.npz"))))
+def test_nci_generate_all_matches_reference_golden(cuda, path):
+    """generate(..., eval_all_documents=True) = _generate_all (generation_utils.py:1013-1136, the use_topic_model
+    ablation): scores of all K**M code paths vs the reference's golden; the depth-first block splitting (by query, by
+    prefix) and the prefix tables change nothing."""
+    g = np.load(path)
+    cfg = json.loads(str(g["cfg"]))
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    outs = []
+    for table_bytes, max_rows in ((6 << 30, 1 << 16), (0, 1 << 16), (6 << 30, 16), (0, 5), (1 << 14, 2 * cfg["K"])):
+        model = nci.NCIModel(nci.load_npz_weights(g), device=cuda, prefix_table_bytes=table_bytes, **cfg)
+        if max_rows == 1 << 16:
+            dec, sc, enc, _ = model.generate(ids, mask, num_beams=1, num_return_sequences=1, eval_all_documents=True,
+                                             max_length=cfg["M"] + 2)
+            assert dec is None
+        else:
+            sc, enc = model.generate_all(ids, mask, max_rows=max_rows)
+        assert np.abs(sc.cpu().numpy() - g["all_scores"]).max() <= 1e-5
+        outs.append(sc)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])          # row-wise operators: the blocking changes no bit
+    # the beam search's best hypothesis is the best of all paths
+    model = nci.NCIModel(nci.load_npz_weights(g), device=cuda, **cfg)
+    dec, bsc, _, _ = model.generate(ids, mask, num_beams=cfg["K"])
+    best = outs[0].max(1)
+    assert np.abs(np.array(bsc).reshape(len(ids), -1)[:, 0] - best.values.cpu().numpy()).max() <= 2e-6
+    codes = nci.decode_token(dec, cfg["K"]).view(len(ids), cfg["K"], cfg["M"])[:, 0]
+    idx = sum(codes[:, p] * cfg["K"] ** (cfg["M"] - 1 - p) for p in range(cfg["M"]))
+    assert torch.equal(idx.cpu(), best.indices.cpu())

@@ -80,3 +80,21 @@ def test_bert_tower_oracle_matches_reference_bertmodel():
     valid = g["attention_mask"].astype(bool)
     assert np.abs(hid.numpy() - g["hidden"])[valid].max() <= 2e-5      # padded positions are not defined outputs
     assert np.abs(obert.tower_encode(W, cfg, ids, mask).numpy() - g["reps"]).max() <= 2e-5
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1a_nci_all_*.npz"))))
+def test_nci_generate_all_matches_reference(path):
+    """_generate_all (the use_topic_model ablation): the oracle's scores of all K**M code paths against the reference's
+    generate(..., eval_all_documents=True) golden."""
+    g = np.load(path)
+    cfg = json.loads(str(g["cfg"]))
+    W = ot5.load_weights(g)
+    sc, _ = ot5.nci_generate_all(W, cfg, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]))
+    assert sc.shape == g["all_scores"].shape and np.abs(sc.numpy() - g["all_scores"]).max() <= 5e-6
+    # consistency with the beam search: its best hypothesis is the best of all paths
+    dec, bsc, _ = ot5.nci_generate(W, cfg, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]), cfg["K"])
+    R = cfg["K"]
+    for b in range(len(g["input_ids"])):
+        codes = ot5.decode_token(dec[b * R:b * R + 1], cfg["K"])[0]
+        idx = int(sum(int(c) * cfg["K"] ** (cfg["M"] - 1 - p) for p, c in enumerate(codes)))
+        assert abs(float(bsc[b * R]) - float(sc[b, idx])) <= 2e-6

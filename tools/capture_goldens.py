@@ -386,6 +386,50 @@ def g1_nci_generate():
         print("g1", M, K, beams, "decoded", tuple(outs.shape), "steps", len(step_logits), "score0", scores[0])
 
 
+def g1a_nci_generate_all():
+    """generate(..., eval_all_documents=True, num_beams=1, num_return_sequences=1) -> _generate_all
+    (generation_utils.py:507-521,1013-1136): the scores of all K**M code paths per query, as infer() asks for them under
+    --use_topic_model 1 --eval_all_documents 1 (main_models.py:3653-3656)."""
+    ref_import.setup()
+    import torch
+    from transformers import T5Config, T5ForConditionalGeneration
+
+    for (M, K, seed) in [(3, 4, 11), (2, 8, 12)]:
+        torch.manual_seed(seed)
+        cfg = _mevi_t5_config(T5Config, M, K)
+        with io.StringIO() as buf, redirect_stdout(buf):
+            model = T5ForConditionalGeneration(cfg)
+        model.eval()
+        with torch.no_grad():
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("layer_norm.weight") or "final_layer_norm" in n_:
+                    p_.copy_(1.0 + 0.2 * torch.randn_like(p_))
+                if "relative_attention_bias" in n_:
+                    p_.copy_(torch.randn_like(p_))
+                if n_.startswith("adaptor.") and n_.endswith("bias"):
+                    p_.copy_(0.05 * torch.randn_like(p_))
+        rng = np.random.default_rng(seed + 50)
+        ids, mask = _synthetic_queries(rng, 3, 32, cfg.vocab_size)
+        kwargs = dict(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), use_cache=False,
+                      max_length=M + 2, length_penalty=0.8, num_return_sequences=1, early_stopping=False,
+                      decode_embedding=2, decode_vocab_size=cfg.decode_vocab_size, decode_tree=None,
+                      output_hidden_states=True, output_scores=True, decoder_integration="series",
+                      decoder_attention_mask=torch.tensor([[1] * (M + 1) + [0]] * 3), num_beams=1, eval_all_documents=True)
+        with torch.no_grad():
+            outs, scores, enc_h, _ = model.generate(**kwargs)
+        assert outs is None and tuple(scores.shape) == (3, K ** M)
+        sd = {k_: v_.detach().numpy() for k_, v_ in model.state_dict().items()}
+        np.savez(os.path.join(GOLD, f"g1a_nci_all_M{M}_K{K}.npz"), input_ids=ids, attention_mask=mask,
+                 all_scores=scores.numpy(), **{"w." + k_: v_ for k_, v_ in sd.items()},
+                 cfg=np.array(json.dumps(dict(M=M, K=K, d_model=cfg.d_model, d_ff=cfg.d_ff,
+                                              num_heads=cfg.num_heads, d_kv=cfg.d_kv, num_layers=cfg.num_layers,
+                                              num_decoder_layers=cfg.num_decoder_layers,
+                                              adaptor_layer_num=cfg.adaptor_layer_num, vocab_size=cfg.vocab_size,
+                                              layer_norm_epsilon=cfg.layer_norm_epsilon,
+                                              relative_attention_num_buckets=cfg.relative_attention_num_buckets))))
+        print("g1a", M, K, "all_scores", tuple(scores.shape), float(scores.max()), float(scores.min()))
+
+
 def g2_t5_tower():
     """T5Model forward as DocumentEncoder.encode does it (document_encoder.py:104-120): decoder_input_ids = 0,
     reps = last_hidden_state[:, 0, :]; plus encoder/decoder per-layer hidden states."""
@@ -630,7 +674,7 @@ def g9_ip_rank():
 
 
 ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g6n=g6n_consumers_nq, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower, g2p=g2p_t5_passage, g8=g8_bert_tower,
-           g3=g3_relative_buckets, g9=g9_ip_rank)
+           g3=g3_relative_buckets, g9=g9_ip_rank, g1a=g1a_nci_generate_all)
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
