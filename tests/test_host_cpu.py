@@ -319,12 +319,15 @@ def test_main_py_rejects_what_it_does_not_build():
     a = main.parsers_parser(base + ["--learning_rate", "2e-4", "--fixnci", "--simans_hyper_b", "-1", "--Rdrop=0.1"])
     assert ("--learning_rate", "2e-4") in a.ignored_flags and ("--simans_hyper_b", "-1") in a.ignored_flags
     assert ("--Rdrop", "0.1") in a.ignored_flags
-    for argv in (["--lerning_rate", "1"], ["stray"], ["--learning_rate"], ["--use_topic_model", "1"], ["--fp_16", "1"],
+    for argv in (["--lerning_rate", "1"], ["stray"], ["--learning_rate"], ["--fp_16", "1"],
                  ["--cat_cluster_centroid", "2"], ["--cluster_position_topk", "5"], ["--decode_embedding", "1"],
                  ["--infer_reconstruct_vector", "1"], ["--load_encoder_only", "1"]):
         with pytest.raises(SystemExit):
             main.parsers_parser(base + argv)
     main.parsers_parser(base + ["--use_topic_model", "0", "--fp_16", "0", "--decode_embedding", "2"])   # the built values
+    main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1"]))                  # cluster score x q.d
+    with pytest.raises(SystemExit):            # the reconstruct-vector term of the topic model is not built
+        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1", "--topic_score_ratio", "0.3"]))
     with pytest.raises(SystemExit):            # try_load_ckpt asserts a checkpoint (MEVI/main.py:201)
         main.check_supported(main.parsers_parser([t for t in EVAL_ARGV if not t.startswith("--nci_ckpt")][:0] + base + [
             "--codebook", "1", "--pq_type", "rq", "--query_encoder", "twin", "--recall_level", "both", "--document_encoder",
