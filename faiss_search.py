@@ -2,9 +2,10 @@
 """Dense search CLI -- same argv, Python API and output file as the reference's
 MEVI/faiss_search.py:80-98, served by the MI355X inner-product top-k instead of faiss-cpu.
 
-`--param` is accepted as the reference forwards it to faiss.index_factory; every index string
-is answered with EXACT search (the "Flat" result), see SURVEY D2.
-With torch.distributed initialised (torchrun) the corpus file is row-sharded across ranks.
+`--param` is the faiss factory string: "Flat" is the exact search; "IVF<n>,Flat" (the default, as in the reference)
+builds an IVF-Flat index with faiss's structure and defaults (mevi_amd/ivf.py; nprobe from MEVI_IVF_NPROBE, default 1)
+and reports its recall against the exact search on stderr; any other index type is answered with EXACT search.
+With torch.distributed initialised (torchrun) the corpus file is row-sharded across ranks and searched exactly.
 """
 import argparse
 import datetime

@@ -282,9 +282,10 @@ def is_trained_before_train(param):
 def search(query, doc, dim, topk, param="Flat", device=None):
     """Drop-in for faiss_search.search (MEVI/faiss_search.py:13-21).
 
-    `param` is the faiss factory string the reference forwards; every index type
-    is served by exact search here (recall >= the approximate index it names;
-    result parity is only defined for "Flat").
+    `param` is the faiss factory string the reference forwards: "Flat" -> exact search (result parity defined);
+    "IVF<n>,Flat" (the script's default) -> IVF-Flat with faiss's structure and defaults (mevi_amd/ivf.py: inner-
+    product k-means, nprobe = MEVI_IVF_NPROBE or 1; recall vs the exact search is reported on stderr); every other
+    index type (HNSW*, PQ*, ...) is served by exact search (recall >= the approximate index it names).
     Returns numpy (dists f32[nq,topk], indices i64[nq,topk]).
     """
     hip.require_gpu()
@@ -292,7 +293,12 @@ def search(query, doc, dim, topk, param="Flat", device=None):
     print(f"Param {param} trained: {is_trained_before_train(param)}.")  # index.is_trained before index.train
     q = _as_device_f32(np.asarray(query).reshape(-1, dim) if isinstance(query, np.ndarray) else query, device)
     d = _as_device_f32(np.asarray(doc).reshape(-1, dim) if isinstance(doc, np.ndarray) else doc, device)
-    if topk > MAX_K:
+    from . import ivf
+
+    nlist = ivf.parse_factory(param)
+    if nlist is not None and topk <= MAX_K and 0 < nlist <= d.shape[0]:
+        s, i = ivf.search(q, d, topk, nlist)
+    elif topk > MAX_K:
         s, i = _search_large_k(q, d, topk)
     else:
         s, i = DenseIndex(d).search(q, topk)  # index.add(doc); index.search(query, topk)

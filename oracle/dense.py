@@ -141,3 +141,27 @@ def fine_stage(query, emb, doc_cluster, beam_codes):
     sc = pair_dot(query, np.asarray(emb, dtype=np.float32)[docs])
     order = np.lexsort((docs, -sc))
     return docs[order], sc[order], int(docs.size)
+
+
+def ivf_flat_search(query, docs, centroids, k, nprobe):
+    """IVF-Flat given its centroids (faiss IndexIVFFlat with an IndexFlatIP quantiser, METRIC_INNER_PRODUCT; the
+    factory string 'IVF<n>,Flat' of MEVI/faiss_search.py:13-21,89): a document lives in the list of its best centroid
+    (largest inner product, lowest list on ties), a query scans its `nprobe` best lists and returns the exact top-k among
+    their documents (score desc, id asc; -FLT_MAX / -1 padding).  Scores are the pinned fmaf chains.  Returns
+    (scores, ids, list_of)."""
+    q = np.ascontiguousarray(query, np.float32)
+    d = np.ascontiguousarray(docs, np.float32)
+    c = np.ascontiguousarray(centroids, np.float32)
+    _, best = ip_topk_exact(d, c, 1)
+    list_of = best[:, 0]
+    _, probe = ip_topk_exact(q, c, nprobe)
+    out_s = np.full((len(q), k), -FLT_MAX, np.float32)
+    out_i = np.full((len(q), k), -1, np.int64)
+    for i in range(len(q)):
+        rows = np.flatnonzero(np.isin(list_of, probe[i]))
+        if rows.size == 0:
+            continue
+        s = pair_dot(q[i], d[rows])
+        order = np.lexsort((rows, -s))[:k]
+        out_s[i, :len(order)], out_i[i, :len(order)] = s[order], rows[order]
+    return out_s, out_i, list_of

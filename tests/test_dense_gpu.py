@@ -322,3 +322,57 @@ def test_bench_multi_rank_launch_rehearsal(cuda, tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["planted_top1_ok"] == 1.0 and j["scaling"] == "strong"
     assert j["config"]["docs"] == 400000 and "cpu_baseline" not in j
+
+
+@pytest.mark.parametrize("nlist,nprobe,k", [(16, 1, 50), (16, 4, 100), (7, 7, 30), (40, 3, 1000)])
+def test_ivf_flat_equals_the_oracle_given_its_centroids(cuda, nlist, nprobe, k):
+    """--param IVF<n>,Flat: with the centroids the index trained, list membership (argmax inner product) and the search
+    (exact top-k among the documents of the nprobe best lists) equal the CPU restatement bit for bit; probing every list
+    is the Flat search."""
+    from mevi_amd import ivf
+
+    rng = np.random.default_rng(nlist * 31 + nprobe)
+    centres = rng.standard_normal((12, 64)).astype(np.float32) * 2
+    d = (centres[rng.integers(0, 12, size=6000)] + rng.standard_normal((6000, 64))).astype(np.float32)
+    q = (centres[rng.integers(0, 12, size=90)] + rng.standard_normal((90, 64))).astype(np.float32)
+    dt, qt = torch.from_numpy(d).to(cuda), torch.from_numpy(q).to(cuda)
+    index = ivf.IVFFlatIndex(dt, nlist)
+    s, i = index.search(qt, k, nprobe)
+    es, ei, list_of = odense.ivf_flat_search(q, d, index.centroids.cpu().numpy(), k, nprobe)
+    assert np.array_equal(index.list_of.cpu().numpy(), list_of)
+    np.testing.assert_array_equal(i.cpu().numpy(), ei)
+    np.testing.assert_array_equal(s.cpu().numpy().view(np.uint32), es.view(np.uint32))
+    sizes = np.bincount(list_of, minlength=nlist)
+    assert sizes.min() > 0 and sizes.max() < 0.6 * len(d)                    # the k-means produced usable lists
+    if nprobe == nlist:
+        fs, fi = odense.ip_topk_exact(q, d, k)
+        np.testing.assert_array_equal(ei, fi)
+    rec = ivf.recall_report(i, dense.ip_topk(qt, dt, k)[1])
+    assert rec[1] > 0.5 and all(0.0 <= v <= 1.0 for v in rec.values())      # clustered data: the best list holds the top hit
+    assert ivf.parse_factory("IVF100,Flat") == 100 and ivf.parse_factory("HNSW256") is None and ivf.parse_factory("IVF8,PQ4") is None
+
+
+def test_search_api_serves_ivf_factory_strings(cuda, capsys):
+    """faiss_search.search(..., param='IVF<n>,Flat'): prints what the reference prints (is_trained False before
+    training), returns the IVF result and reports recall vs exact on stderr; MEVI_IVF_NPROBE = nlist gives Flat."""
+    import os
+
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((3000, 32)).astype(np.float32)
+    q = rng.standard_normal((40, 32)).astype(np.float32)
+    s1, i1 = dense.search(q, d, 32, 20, "IVF10,Flat", device=cuda)
+    out = capsys.readouterr()
+    assert out.out == "Param IVF10,Flat trained: False.\n" and "recall vs exact search" in out.err and "nprobe=1" in out.err
+    es, ei = odense.ip_topk_exact(q, d, 20)
+    assert (i1[:, 0] == ei[:, 0]).mean() < 1.0 or True                        # approximate by construction
+    old = os.environ.get("MEVI_IVF_NPROBE")
+    os.environ["MEVI_IVF_NPROBE"] = "10"
+    try:
+        s2, i2 = dense.search(q, d, 32, 20, "IVF10,Flat", device=cuda)
+    finally:
+        if old is None:
+            del os.environ["MEVI_IVF_NPROBE"]
+        else:
+            os.environ["MEVI_IVF_NPROBE"] = old
+    np.testing.assert_array_equal(i2, ei)
+    np.testing.assert_array_equal(s2.view(np.uint32), es.view(np.uint32))
