@@ -128,7 +128,7 @@ int mevi_gemm_nt_f32(const float *a, int64_t lda, const float *w, int64_t ldw, f
 /* ------------------------------------------------------------------------
  * Split-precision linear layer (the same reference call sites as mevi_gemm_nt_f32, for the T5 / BERT / adaptor
  * weights; csrc/gemm_split.hip).  Operands are images of f32 rows made by mevi_split_rows_f16:
- *   row r of x f32[m, k]  ->  img[r] = [hi (kp halves) | lo (kp halves)], kp = mevi_split_kp(k) = k rounded up to 32,
+ *   row r of x f32[m, k]  ->  img[r] = [hi (kp halves) | lo (kp halves)], kp = mevi_split_kp(k) = k rounded up to 32 (at least 64),
  *   x = 2^-exps[r] * (hi + lo) (exps int8, |e| <= 100), hi = f16(x 2^e), lo = f16(x 2^e - hi): 22 significant bits per element.
  * mevi_gemm_nt_split_f32 computes C = act(A.W^T + bias) + residual with three f16 MFMAs per product
  * (a_lo w_hi + a_hi w_lo + a_hi w_hi, f32 accumulate): relative error ~3 * 2^-22 per product instead of the exact

@@ -11,15 +11,15 @@
 // the fine stage and the RQ kernels keep their exact f32 chains.  Same role in the reference as gemm.hip
 // (MEVI/transformers/modeling_t5.py:181-186, 217-220, 350-358, 412; modeling_bert.py linear layers).
 //
-// Kernel = the persistent LDS-DMA tile stream of the dense pre-filter (mfma_pp_f16.h): 256 x 256 output tiles, 8 waves,
-// one v_mfma_f32_32x32x16_f16 per 16 k.  An image row is [hi (Kp halves) | lo (Kp halves)], Kp = K rounded up to 32;
-// the K loop walks 3 * Kp/32 units: segment 0 = a_lo w_hi, 1 = a_hi w_lo, 2 = a_hi w_hi (small terms first) -- only
-// the unit -> byte-offset map differs from the filter.  Every output depends on its own A row, its own W row and this
-// fixed k order only, so a row has the same bits whatever batch it travels in; gemm_split_skinny_kernel (few
-// outputs: the latency path) issues the identical MFMA sequence from global memory and therefore returns the same bits.
+// Kernel = a persistent LDS-DMA tile stream (mfma_split_stream.h, re-cut from the dense pre-filter's mfma_pp_f16.h): 256 x 256
+// output tiles, 8 waves, one v_mfma_f32_32x32x16_f16 per 16 k.  An image row is [hi (Kp halves) | lo (Kp halves)], Kp = K
+// rounded up to 32 (at least 64); per 16 k the three products a_lo w_hi, a_hi w_hi, a_hi w_lo are accumulated in that
+// order, each operand slab fetched into LDS once per 32 k.  Every output depends on its own A row, its own W row and this
+// fixed order only, so a row has the same bits whatever batch it travels in; gemm_split_skinny_kernel (few outputs: the
+// latency path) issues the identical MFMA sequence from global memory and therefore returns the same bits.
 #include <cstdlib>
 
-#include "mfma_pp_f16.h"
+#include "mfma_split_stream.h"
 
 namespace mevi {
 namespace {
@@ -142,18 +142,6 @@ struct SplitOut {
 __device__ __forceinline__ int out_exp(const SplitOut &so, int m) {
   return pow2_exp(fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * 1.001f);
 }
-
-struct SplitUnits {
-  int U;         // units per segment (kp / 32)
-  int lo_bytes;  // byte offset of the lo half of a row (kp * 2)
-  bool is_w;     // this wave stages the W operand (waves 0-3) or the activations (waves 4-7)
-  __device__ __forceinline__ int operator()(int u) const {
-    const int seg = (u >= U) + (u >= 2 * U);
-    const int uu = u - seg * U;
-    const bool lo = is_w ? (seg == 1) : (seg == 0);   // segment 0 = a_lo w_hi, 1 = a_hi w_lo, 2 = a_hi w_hi
-    return uu * 64 + (lo ? lo_bytes : 0);
-  }
-};
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -314,11 +302,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
       }
     }
   };
-  SplitUnits uoff;
-  uoff.U = kp / 32;
-  uoff.lo_bytes = kp * 2;
-  uoff.is_w = w8 < 4;
-  h1_tile_stream(row_bytes, 3 * (kp / 32), lds, next, begin, emit, uoff);
+  split_tile_stream(row_bytes, kp * 2, kp / 32, lds, next, begin, emit);
 }
 
 // Few outputs: one wave per 32 x 32 outputs, fragments straight from global memory (the images of a handful of rows
@@ -339,15 +323,13 @@ __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int seg = 0; seg < 3; ++seg) {
-    const _Float16 *a = pa + (seg == 0 ? kp : 0);
-    const _Float16 *w = pw + (seg == 1 ? kp : 0);
-#pragma unroll 4
-    for (int k = 0; k < kp; k += 16) {
-      const f16x8 fa = *reinterpret_cast<const f16x8 *>(a + k);
-      const f16x8 fw = *reinterpret_cast<const f16x8 *>(w + k);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fa, acc, 0, 0, 0);
-    }
+#pragma unroll 2
+  for (int k = 0; k < kp; k += 16) {   // per 16 k: a_lo w_hi, a_hi w_hi, a_hi w_lo (the tile stream's order)
+    const f16x8 ah = *reinterpret_cast<const f16x8 *>(pa + k), al = *reinterpret_cast<const f16x8 *>(pa + kp + k);
+    const f16x8 wh = *reinterpret_cast<const f16x8 *>(pw + k), wl = *reinterpret_cast<const f16x8 *>(pw + kp + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, acc, 0, 0, 0);
   }
   const int m = m0 + lrow;
   if (m >= M) return;
@@ -389,7 +371,8 @@ constexpr long long SPLIT_SKINNY_MAX_OUTPUTS = 500000;  // as gemm.hip's SK_MAX_
 
 using namespace mevi;
 
-extern "C" int64_t mevi_split_kp(int64_t k) { return (k + 31) / 32 * 32; }
+// Kp: whole 32-wide slabs, at least two (the tile stream prefetches two super-units ahead)
+extern "C" int64_t mevi_split_kp(int64_t k) { return k <= 64 ? 64 : (k + 31) / 32 * 32; }
 
 extern "C" int mevi_split_rows_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int8_t *exps,
                                    float *norms, void *stream_) {
@@ -456,7 +439,7 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
   if (grid < 8) grid = 8;
   const int64_t tiles = n_mtiles * n_ntiles;
   if (tiles < grid) grid = (tiles + 7) / 8 * 8;
-  const size_t lds_bytes = h1_lds_bytes();
+  const size_t lds_bytes = ss_lds_bytes();
   const int a8 = act;
   typedef void (*kern_t)(const _Float16 *, const signed char *, int, const _Float16 *, const signed char *, int, int, float *,
                          long long, const float *, const float *, long long, int, int, SplitOut);

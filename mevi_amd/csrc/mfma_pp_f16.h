@@ -78,7 +78,9 @@ struct H1Src {
 struct H1PlainUnits {
   __device__ __forceinline__ int operator()(int u) const { return u * 64; }
 };
-template <class Next, class Begin, class Emit, class UOff = H1PlainUnits>
+// ABL: ablation switches of tools/probes/stream_probe.hip (the product instantiates 0): 1 = no s_barrier, 2 = no DMA,
+// 4 = no LDS fragment reads, 8 = no MFMA -- wrong results, used to attribute the loop's time.
+template <class Next, class Begin, class Emit, class UOff = H1PlainUnits, int ABL = 0>
 __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float *lds, Next next, Begin begin,
                                                Emit emit, UOff uoff = UOff()) {
   const int t = threadIdx.x;
@@ -103,6 +105,7 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
   // descriptor, no fetch), so the number of pieces in flight -- what the counted vmcnt relies on -- is the
   // same in every window
   auto dma2 = [&](const H1Src &s, int u, int gb, int p0) {
+    if constexpr (ABL & 2) return;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.src), 0, (int)s.bytes, 0x00020000);
     float *base = lds + (gb & (H1_NBUF - 1)) * H1_UNIT + (64 * w8) * H1_LD;
@@ -122,6 +125,7 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
     f16x8 a[2], b[4];
   };
   auto read = [&](int gb, int j, Frag &f) {
+    if constexpr (ABL & 4) return;
     const float *p = lds + (gb & (H1_NBUF - 1)) * H1_UNIT + cj[j];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) f.a[mi] = *reinterpret_cast<const f16x8 *>(p + offa + 32 * mi * H1_LD);
@@ -130,6 +134,7 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
   };
   f32x16 acc[2][4];
   auto mma = [&](const Frag &f) {
+    if constexpr (ABL & 8) return;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -138,6 +143,12 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
   };
 
   Frag F0, F1;
+  if constexpr (ABL & 4) {   // fragments never loaded: give them defined contents
+#pragma unroll
+    for (int i = 0; i < 2; ++i) F0.a[i] = F1.a[i] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) F0.b[i] = F1.b[i] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
+  }
   int g = 0;  // stream position of the unit being computed (buffer g & 3)
 
   auto window = [&](int u, bool first) {
@@ -172,7 +183,8 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     __builtin_amdgcn_sched_barrier(0);
     // unit g+1 landed once at most the 8 pieces of units g+2, g+3 are outstanding; own reads of unit g done
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     ++g;
   };

@@ -92,7 +92,7 @@ def gemm_input(x):
 
 
 def _split_buffers(M, K, dev, zero=False):
-    kp = (K + 31) // 32 * 32
+    kp = int(hip.lib().mevi_split_kp(K))
     img = (torch.zeros if zero and kp != K else torch.empty)((M, 2 * kp), dtype=torch.int16, device=dev)
     return img, torch.empty((M,), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev)
 
