@@ -83,3 +83,51 @@ def test_scores_are_exact_chains_and_lists_are_complete(c2):
         kth = s[r, -1]
         full[i[r]] = -float("inf")
         assert float(full.max()) <= float(kth) + 2e-5 * max(1.0, abs(float(kth)))
+
+
+def _bench_two_ranks(backend_env):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=root, **backend_env)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--docs", "700000", "--queries", "600", "--no-cpu-baseline", "--no-seq2seq-legs"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def _check_two_rank_line(d):
+    assert d["n_gpus"] == 2 and d["config"]["planted_top1_ok"] == 1.0 and d["value"] > 0
+    m = d["multi_gpu"]
+    assert m["rounds"] >= 1 and len(m["per_rank"]) == 2 and {r["rank"] for r in m["per_rank"]} == {0, 1}
+    assert sum(r["shard_rows"] for r in m["per_rank"]) == 700000
+    assert m["local_search_ms"]["max"] >= m["local_search_ms"]["min"] > 0 and m["all_gather_ms"] >= 0 and m["merge_ms"] > 0
+    assert d["roofline"]["launches"] > 0 and d["roofline"]["achieved"] > 0
+
+
+def test_bench_launch_line_with_two_ranks_sharing_the_device():
+    """The driver's multi-GPU launch line (torch.distributed.run ... bench.py --gpus 2) with both ranks on this GPU and the
+    collectives over gloo: the sharded search, its per-rank phase breakdown and the single JSON line -- a rehearsal of
+    the N > 1 path, not a timing."""
+    _check_two_rank_line(_bench_two_ranks({"MEVI_BENCH_BACKEND": "gloo"}))
+
+
+def test_bench_over_rccl_when_two_gpus_are_visible():
+    """The same line over the real `nccl` (RCCL) backend, one rank per GPU -- runs wherever two devices are visible."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the RCCL path is exercised by the driver's 8-GPU run")
+    d = _bench_two_ranks({})
+    _check_two_rank_line(d)
+    assert "REHEARSAL" not in d["config"]["parallelism"]

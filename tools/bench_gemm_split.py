@@ -5,7 +5,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mevi_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
