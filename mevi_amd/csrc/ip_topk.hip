@@ -573,21 +573,31 @@ __global__ void doc_scale_kernel(const unsigned int *__restrict__ bits, float *_
   }
 }
 
-// docs -> f16((d - mu) * S_d), row-major [n, dimp], zero padded.  One wave per row.
+// The f16 images are UNIT-MAJOR: rows in blocks of 256 (one operand tile of the filter), and inside a block the 32 k of
+// unit u of all 256 rows together -- element (r, k) at halves ((r / 256 * U + k / 32) * 256 + r % 256) * 32 + k % 32,
+// U = dimp / 32.  A tile's unit is then one contiguous 16 KiB block and every LDS-DMA piece (16 rows x 64 B) 1 KiB of
+// consecutive memory instead of 16 segments dimp * 2 bytes apart: the DMA, which bounds the loop, moves 49 -> 62 GB/s per
+// CU (tools/probes/stream_probe.hip, profiles/r02_stream_ablation.txt).  Rows up to the end of the last block exist and are zero.
+__device__ __forceinline__ size_t image_at(long long r, int k, int dimp) {
+  return ((size_t)((r >> 8) * (dimp >> 5) + (k >> 5)) * 256 + (size_t)(r & 255)) * 32 + (k & 31);
+}
+inline int64_t image_rows(int64_t n) { return (n + 255) / 256 * 256; }
+
+// docs -> f16((d - mu) * S_d), unit-major, zero padded (columns to dimp, rows to the end of the block).  One wave per row.
 __global__ __launch_bounds__(256) void split_docs_f16_kernel(const float *__restrict__ x, long long n, int dim, int dimp,
                                                             const float *__restrict__ mu,
                                                             const float *__restrict__ scal,
                                                             _Float16 *__restrict__ out) {
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n) return;
+  if (r >= ((n + 255) >> 8 << 8)) return;
   const int lane = threadIdx.x & 63;
   const float *xr = x + (size_t)r * dim;
-  _Float16 *o = out + (size_t)r * dimp;
   const float s = scal[0];
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   for (int k = lane * 4; k < dimp; k += 256) {
+    _Float16 *o = out + image_at(r, k, dimp) - k;
     h4 h = {0, 0, 0, 0};
-    if (k < dim) {
+    if (k < dim && r < n) {
       const float4 v = *reinterpret_cast<const float4 *>(xr + k);
       const float4 m = *reinterpret_cast<const float4 *>(mu + k);
       h[0] = (_Float16)((v.x - m.x) * s);
@@ -607,10 +617,14 @@ __global__ __launch_bounds__(256) void split_queries_f16_kernel(const float *__r
                                                                _Float16 *__restrict__ out, float *__restrict__ qnorm,
                                                                float *__restrict__ qinv, double *__restrict__ qshift) {
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n) return;
+  if (r >= ((n + 255) >> 8 << 8)) return;
   const int lane = threadIdx.x & 63;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  if (r >= n) {  // rows up to the end of the last 256-row block: zero (the tile stream reads whole blocks)
+    for (int k = lane * 4; k < dimp; k += 256) *reinterpret_cast<h4 *>(out + image_at(r, k, dimp)) = h4{0, 0, 0, 0};
+    return;
+  }
   const float *xr = x + (size_t)r * dim;
-  _Float16 *o = out + (size_t)r * dimp;
   float ss = 0.f, mx = 0.f;
   double sh = 0.0;
   for (int k = lane * 4; k < dim; k += 256) {
@@ -627,7 +641,6 @@ __global__ __launch_bounds__(256) void split_queries_f16_kernel(const float *__r
     sh += __shfl_xor(sh, off);
   }
   const float s = pow2_scale(mx);
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   for (int k = lane * 4; k < dimp; k += 256) {
     h4 h = {0, 0, 0, 0};
     if (k < dim) {
@@ -637,7 +650,7 @@ __global__ __launch_bounds__(256) void split_queries_f16_kernel(const float *__r
       h[2] = (_Float16)(v.z * s);
       h[3] = (_Float16)(v.w * s);
     }
-    *reinterpret_cast<h4 *>(o + k) = h;
+    *reinterpret_cast<h4 *>(out + image_at(r, k, dimp)) = h;
   }
   if (lane == 0) {
     qnorm[r] = sqrtf(ss) * 1.00001f;
@@ -666,7 +679,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
   const int t = threadIdx.x;
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
   const int grp = w8 >> 2, wm = (w8 >> 1) & 1, wn = w8 & 1;
-  const int row_bytes = dimp * 2;
+  const size_t block_bytes = (size_t)256 * dimp * 2;  // one 256-row block of a unit-major image
   // tiles fetched ahead of their epilogue: (dpair, qtile) FIFO of at most two entries, head and tail in
   // scalars (an indexed array would live in scratch and drain the DMA queue on every access)
   int head_d = 0, head_q = 0, tail_d = 0, tail_q = 0, n_pend = 0;
@@ -679,19 +692,15 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
     if (n_pend == 0) head_d = dpair, head_q = qtile;
     else tail_d = dpair, tail_q = qtile;
     ++n_pend;
-    // DMA duty of this wave: waves 0-3 stage the two corpus tiles (LDS rows [0,256)), waves 4-7 the query tile
-    long long rows_left;
+    // DMA duty of this wave: waves 0-3 stage the two corpus tiles (LDS rows [0,256)), waves 4-7 the query tile.  A tile
+    // is one 256-row block of its unit-major image (doc_begin is a multiple of 256; rows past the operand are zero)
     if (w8 < 4) {
       const long long first = doc_begin + (long long)dpair * 2 * BM;
-      s.src = reinterpret_cast<const char *>(Dh) + (size_t)first * (size_t)row_bytes;
-      rows_left = doc_end - first;
+      s.src = reinterpret_cast<const char *>(Dh) + (size_t)(first >> 8) * block_bytes;
     } else {
-      const int qrow0 = qtile * H1_QT;
-      s.src = reinterpret_cast<const char *>(Qh) + (size_t)qrow0 * (size_t)row_bytes;
-      rows_left = nq - qrow0;
+      s.src = reinterpret_cast<const char *>(Qh) + (size_t)qtile * block_bytes;
     }
-    if (rows_left > 2 * BM) rows_left = 2 * BM;
-    s.bytes = (unsigned int)(rows_left * row_bytes);
+    s.bytes = (unsigned int)block_bytes;
     return true;
   };
   float tq[4];
@@ -712,7 +721,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
     const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
     emit_tile<4>(acc, tq, qtile * H1_QT + 128 * wn, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base, &stash);
   };
-  h1_tile_stream(row_bytes, dimp / 32, lds, next, begin, emit);
+  h1_tile_stream(64, dimp / 32, lds, next, begin, emit, H1BlockedUnits());
   stash_flush(stash, buf, count, S, k, cap);
 }
 
@@ -1071,7 +1080,7 @@ extern "C" int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, i
 // shard scalars.
 namespace {
 struct IndexView {
-  const float *image;        // [nd, dimp] f16 (held as raw bytes)
+  const float *image;        // f16 image of the shard, unit-major, whole 256-row blocks (held as raw bytes)
   const float *norms_c;      // [nd]  ||d - mu||
   const float *mu;           // [dimp]
   const unsigned int *bits;  // [0] max ||d - mu||, [1] max ||d||, [2] max |d_k - mu_k|   (float bits)
@@ -1081,7 +1090,7 @@ struct IndexView {
 inline int64_t pad32(int64_t d) { return (d + 31) / 32 * 32; }
 // k extent of the f16 images: whole 32-wide units, at least three (h1_tile_stream prefetches three units ahead)
 inline int64_t pad_k(int64_t d) { return pad32(d) < 96 ? 96 : pad32(d); }
-inline size_t index_image_bytes(int64_t nd, int64_t dim) { return align_up((size_t)nd * pad_k(dim) * 2, 256); }
+inline size_t index_image_bytes(int64_t nd, int64_t dim) { return align_up((size_t)image_rows(nd) * pad_k(dim) * 2, 256); }
 inline IndexView view_index(const void *index, int64_t nd, int64_t dim) {
   const char *p = reinterpret_cast<const char *>(index);
   IndexView v;
@@ -1133,7 +1142,7 @@ extern "C" int mevi_ip_index_build_f32(const float *docs, int64_t nd, int64_t di
   }
   hipLaunchKernelGGL(doc_scale_kernel, dim3(1), dim3(64), 0, stream, v.bits, const_cast<float *>(v.scal));
   if (nd > 0)
-    hipLaunchKernelGGL(split_docs_f16_kernel, dim3((unsigned)((nd + 3) / 4)), dim3(256), 0, stream, docs, (long long)nd,
+    hipLaunchKernelGGL(split_docs_f16_kernel, dim3((unsigned)(image_rows(nd) / 4)), dim3(256), 0, stream, docs, (long long)nd,
                        (int)dim, dimp, v.mu, v.scal, reinterpret_cast<_Float16 *>(const_cast<float *>(v.image)));
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
@@ -1153,7 +1162,7 @@ inline size_t h1_second_pass_bytes(int64_t nq, int64_t dim, int64_t k) {
   const int64_t n2 = h1_second_pass_max(nq);
   // state + exact lists + f32 and f16 query rows + norm / scale / shift + row indices
   return state_bytes(n2, make_geom(kp2)) + align_up((size_t)n2 * k * 8, 256) + align_up((size_t)n2 * dim * 4, 256) +
-         align_up((size_t)n2 * pad_k(dim) * 2, 256) + 2 * align_up((size_t)(n2 + 1) * 4, 256) +
+         align_up((size_t)image_rows(n2) * pad_k(dim) * 2, 256) + 2 * align_up((size_t)(n2 + 1) * 4, 256) +
          align_up((size_t)n2 * 8, 256) + align_up((size_t)n2 * 4, 256);
 }
 }  // namespace
@@ -1163,7 +1172,7 @@ extern "C" size_t mevi_ip_topk_indexed_workspace_bytes(int64_t nq, int64_t dim, 
   const TopkGeom gp = make_geom(h1_kprime((int)k));
   // approx state (K' geometry) + exact top lists + f16 queries + per-query norm / scale / shift, the second
   // pass, then the exact-path workspace for the fallback
-  return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)nq * pad_k(dim) * 2, 256) +
+  return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)image_rows(nq) * pad_k(dim) * 2, 256) +
          2 * align_up((size_t)(nq + 1) * 4, 256) + align_up((size_t)nq * 8, 256) + h1_second_pass_bytes(nq, dim, k) +
          mevi_ip_topk_workspace_bytes(nq, dim, k) + 256;
 }
@@ -1195,8 +1204,8 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   SearchState st = carve_state(p, nq, gp);
   unsigned long long *top = reinterpret_cast<unsigned long long *>(p);  // [nq, k] exact keys
   p += align_up((size_t)nq * k * 8, 256);
-  float *qimage = reinterpret_cast<float *>(p);  // [nq, dimp] f16
-  p += align_up((size_t)nq * dimp * 2, 256);
+  float *qimage = reinterpret_cast<float *>(p);  // f16 image of the queries, unit-major, whole 256-row blocks
+  p += align_up((size_t)image_rows(nq) * dimp * 2, 256);
   float *qnorm = reinterpret_cast<float *>(p);  // [nq] + 1 slot for the observed error ratio
   p += align_up((size_t)(nq + 1) * 4, 256);
   float *qinv = reinterpret_cast<float *>(p);   // [nq] 1 / (S_q S_d)
@@ -1209,7 +1218,7 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   const size_t exact_ws_bytes = mevi_ip_topk_workspace_bytes(nq, dim, k);
   const float c1 = h1_c1(dimp), c2 = h1_c2(dim);
 
-  hipLaunchKernelGGL(split_queries_f16_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, (long long)nq,
+  hipLaunchKernelGGL(split_queries_f16_kernel, dim3((unsigned)(image_rows(nq) / 4)), dim3(256), 0, stream, q, (long long)nq,
                      (int)dim, (int)dimp, iv.mu, iv.scal, reinterpret_cast<_Float16 *>(qimage), qnorm, qinv, qshift);
   int64_t launches = run_pass(qimage, nq, iv.image, nd, (int)dimp, gp, (uint32_t)id_offset, st, false, stream, true);
   if (launches < 0) return MEVI_ERR_HIP;
@@ -1262,7 +1271,7 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
     float *q2 = reinterpret_cast<float *>(w);
     w += align_up((size_t)h1_second_pass_max(nq) * dim * 4, 256);
     float *qimage2 = reinterpret_cast<float *>(w);
-    w += align_up((size_t)h1_second_pass_max(nq) * dimp * 2, 256);
+    w += align_up((size_t)image_rows(h1_second_pass_max(nq)) * dimp * 2, 256);
     float *qnorm2 = reinterpret_cast<float *>(w);
     w += align_up((size_t)(h1_second_pass_max(nq) + 1) * 4, 256);
     float *qinv2 = reinterpret_cast<float *>(w);
@@ -1272,7 +1281,7 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
     int *idx2 = reinterpret_cast<int *>(w);
     MEVI_HIP_CHECK(hipMemcpyAsync(idx2, idx.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n2), dim3(256), 0, stream, q, idx2, (int)n2, (int)dim, q2);
-    hipLaunchKernelGGL(split_queries_f16_kernel, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, stream, q2, (long long)n2,
+    hipLaunchKernelGGL(split_queries_f16_kernel, dim3((unsigned)(image_rows(n2) / 4)), dim3(256), 0, stream, q2, (long long)n2,
                        (int)dim, (int)dimp, iv.mu, iv.scal, reinterpret_cast<_Float16 *>(qimage2), qnorm2, qinv2, qshift2);
     const double keep_flops = g_stats.filter_flops;
     const int64_t l2 = run_pass(qimage2, n2, iv.image, nd, (int)dimp, g2, (uint32_t)id_offset, s2, false, stream, true);

@@ -78,11 +78,19 @@ struct H1Src {
 struct H1PlainUnits {
   __device__ __forceinline__ int operator()(int u) const { return u * 64; }
 };
+// unit-major images (ip_topk.hip: image_at): unit u of a 256-row block is one contiguous 16 KiB; rows 64 B apart (row_bytes = 64)
+struct H1BlockedUnits {
+  __device__ __forceinline__ int operator()(int u) const { return u * 16384; }
+};
 // ABL: ablation switches of tools/probes/stream_probe.hip (the product instantiates 0): 1 = no s_barrier, 2 = no DMA,
 // 4 = no LDS fragment reads, 8 = no MFMA -- wrong results, used to attribute the loop's time.
-template <class Next, class Begin, class Emit, class UOff = H1PlainUnits, int ABL = 0>
+// NBUF: unit buffers in LDS (NBUF - 1 units in flight while one is read); 4 = 128 KiB (the filter, which keeps its
+// candidate stash behind them), 5 = 160 KiB.  nunits >= NBUF - 1.
+template <class Next, class Begin, class Emit, class UOff = H1PlainUnits, int ABL = 0, int NBUF = H1_NBUF>
 __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float *lds, Next next, Begin begin,
                                                Emit emit, UOff uoff = UOff()) {
+  static_assert(NBUF == 4 || NBUF == 5, "vmcnt immediates below are written for 4 and 5 buffers");
+  constexpr int DEPTH = NBUF - 1;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -108,7 +116,7 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
     if constexpr (ABL & 2) return;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.src), 0, (int)s.bytes, 0x00020000);
-    float *base = lds + (gb & (H1_NBUF - 1)) * H1_UNIT + (64 * w8) * H1_LD;
+    float *base = lds + gb * H1_UNIT + (64 * w8) * H1_LD;   // gb = buffer index
 #pragma unroll
     for (int i = p0; i < p0 + 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(base + 16 * i * H1_LD), 16,
@@ -126,7 +134,7 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
   };
   auto read = [&](int gb, int j, Frag &f) {
     if constexpr (ABL & 4) return;
-    const float *p = lds + (gb & (H1_NBUF - 1)) * H1_UNIT + cj[j];
+    const float *p = lds + gb * H1_UNIT + cj[j];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) f.a[mi] = *reinterpret_cast<const f16x8 *>(p + offa + 32 * mi * H1_LD);
 #pragma unroll
@@ -149,18 +157,20 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
 #pragma unroll
     for (int i = 0; i < 4; ++i) F0.b[i] = F1.b[i] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
   }
-  int g = 0;  // stream position of the unit being computed (buffer g & 3)
+  int rb = 0;  // buffer of the unit being computed (stream position mod NBUF)
 
   auto window = [&](int u, bool first) {
-    // stream unit g+3: unit u+3 of this tile, or unit u+3-nunits of the next one
-    const bool spill = u + 3 >= nunits;
+    // stream unit g+DEPTH: unit u+DEPTH of this tile, or unit u+DEPTH-nunits of the next one; its buffer is the one
+    // before rb in the ring (free since the last barrier)
+    const bool spill = u + DEPTH >= nunits;
     H1Src tgt;
     tgt.src = spill ? nxt.src : cur.src;
     tgt.bytes = spill ? nxt.bytes : cur.bytes;
-    const int tu = spill ? u + 3 - nunits : u + 3;
-    read(g, 0, F0);
+    const int tu = spill ? u + DEPTH - nunits : u + DEPTH;
+    const int wb = rb == 0 ? NBUF - 1 : rb - 1;
+    read(rb, 0, F0);
     if (!first) mma(F1);
-    dma2(tgt, tu, g + 3, 0);
+    dma2(tgt, tu, wb, 0);
     if (!first) {
       __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -170,9 +180,9 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    read(g, 1, F1);
+    read(rb, 1, F1);
     mma(F0);
-    dma2(tgt, tu, g + 3, 2);
+    dma2(tgt, tu, wb, 2);
     // first MFMA ahead of the reads: its wait covers the fragments issued a group ago, not these
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
@@ -184,17 +194,19 @@ __device__ __forceinline__ void h1_tile_stream(int row_bytes, int nunits, float 
     __builtin_amdgcn_sched_barrier(0);
     // unit g+1 landed once at most the 8 pieces of units g+2, g+3 are outstanding; own reads of unit g done
     if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (NBUF == 5) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    ++g;
+    rb = rb == NBUF - 1 ? 0 : rb + 1;
   };
 
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < DEPTH; ++u) {
     dma2(cur, u, u, 0);
     dma2(cur, u, u, 2);
   }
-  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // unit 0 landed
+  if constexpr (NBUF == 5) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // unit 0 landed
   __builtin_amdgcn_sched_barrier(0);
   while (true) {
 #pragma unroll

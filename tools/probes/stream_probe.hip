@@ -11,7 +11,11 @@
 
 using namespace mevi;
 
-template <int ABL>
+struct BlockedUnits {   // unit-major image: a 256-row tile's unit u is one contiguous 16 KiB block (rows 64 B apart)
+  __device__ __forceinline__ int operator()(int u) const { return u * 16384; }
+};
+
+template <int ABL, int NBUF = 4, bool BLOCKED = false>
 __global__ __launch_bounds__(PP_THREADS, 2) void probe_kernel(const _Float16 *A, int M, const _Float16 *W, int N, int kp,
                                                               float *sink, int n_mtiles, int n_ntiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -45,7 +49,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void probe_kernel(const _Float16 *A,
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) keep += acc[mi][ni][0] + acc[mi][ni][7];
   };
-  h1_tile_stream<decltype(next), decltype(begin), decltype(emit), H1PlainUnits, ABL>(row_bytes, kp / 32, lds, next, begin, emit);
+  if constexpr (BLOCKED)
+    h1_tile_stream<decltype(next), decltype(begin), decltype(emit), BlockedUnits, ABL, NBUF>(64, kp / 32, lds, next, begin, emit);
+  else
+    h1_tile_stream<decltype(next), decltype(begin), decltype(emit), H1PlainUnits, ABL, NBUF>(row_bytes, kp / 32, lds, next, begin, emit);
   if (keep == 12345.678f) sink[threadIdx.x] = keep;
 }
 
@@ -105,18 +112,19 @@ float run_split(const _Float16 *A, int M, const _Float16 *W, int N, int kp, floa
   return best;
 }
 
-template <int ABL>
+template <int ABL, int NBUF = 4, bool BLOCKED = false>
 float run(const _Float16 *A, int M, const _Float16 *W, int N, int kp, float *sink) {
   const int n_mtiles = M / 256, n_ntiles = N / 256;
-  hipFuncSetAttribute(reinterpret_cast<const void *>(probe_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)h1_lds_bytes());
+  const size_t lds_b = (size_t)NBUF * H1_UNIT * sizeof(float);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(probe_kernel<ABL, NBUF, BLOCKED>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)lds_b);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(probe_kernel<ABL>, dim3(256), dim3(PP_THREADS), h1_lds_bytes(), 0, A, M, W, N, kp, sink, n_mtiles, n_ntiles);
+    hipLaunchKernelGGL((probe_kernel<ABL, NBUF, BLOCKED>), dim3(256), dim3(PP_THREADS), lds_b, 0, A, M, W, N, kp, sink, n_mtiles, n_ntiles);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -149,6 +157,10 @@ int main() {
       {"no MFMA (data movement + barriers only)", run<8>(A, M, W, N, kp, sink)}, {"no MFMA, no barrier", run<9>(A, M, W, N, kp, sink)},
       {"no MFMA, no LDS reads (DMA + barriers)", run<12>(A, M, W, N, kp, sink)}};
   for (auto &x : r) printf("%-48s %8.3f ms  %7.1f TFLOP/s (f16)\n", x.name, x.ms, flop / x.ms / 1e9);
+  printf("five unit buffers (160 KiB, four units in flight): full loop %8.3f ms, DMA + barriers only %8.3f ms\n",
+         run<0, 5>(A, M, W, N, kp, sink), run<12, 5>(A, M, W, N, kp, sink));
+  printf("unit-major (blocked) images, every DMA piece 1 KiB contiguous: full loop %8.3f ms, DMA + barriers only %8.3f ms\n",
+         run<0, 4, true>(A, M, W, N, kp, sink), run<12, 4, true>(A, M, W, N, kp, sink));
   // the same problem through the split stream: rows [hi | lo] of 768 halves each (the buffers above hold 2304 halves per
   // row, of which 1536 are read), 3 x 768 / 16 MFMA k-steps per tile as before
   printf("split stream (each operand slab fetched once per 32 k):\n");
