@@ -187,8 +187,9 @@ def check_supported(a):
             raise SystemExit(f"main.py --mode eval: --{k} is required")
     if a.nci_ckpt is None and a.infer_ckpt is None:   # try_load_ckpt asserts one of them (MEVI/main.py:201)
         raise SystemExit("main.py --mode eval: --nci_ckpt or --infer_ckpt is required")
-    if a.num_return_sequences > 2 ** a.subvector_bits:
-        raise SystemExit("num_return_sequences > 2**subvector_bits is not pinned by the reference (SURVEY 8(a') note ii)")
+    if a.num_return_sequences > (2 ** a.subvector_bits) ** a.subvector_num:
+        raise SystemExit("num_return_sequences exceeds the number of code paths (2**subvector_bits)**subvector_num: the "
+                         "reference would return -1e9 placeholder hypotheses")
 
 
 def _free_port():

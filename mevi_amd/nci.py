@@ -280,7 +280,10 @@ class NCIModel:
             scores, enc = self.generate_all(input_ids, attention_mask, length_penalty)
             return None, scores, enc, None
         R = num_beams
-        assert num_return_sequences in (None, R) and R <= c.K, "needs num_beams == num_return_sequences <= K"
+        assert num_return_sequences in (None, R), "needs num_beams == num_return_sequences"
+        # K < R (SURVEY 8(a') note ii): the reference carries -1e9 placeholder beams until K**p real prefixes exist; they
+        # never win against a real candidate, so the search keeps min(R, live * K) beams per level (golden G1 (3,8,10), (2,4,10))
+        assert R <= c.K ** c.M, "fewer code paths than beams: the reference would return -1e9 placeholder hypotheses"
         assert max_length in (None, c.M + 2)
         ids = input_ids.to(self.dev, torch.int64).contiguous()
         mask = attention_mask.to(self.dev, torch.int64).contiguous()
@@ -382,9 +385,10 @@ class NCIModel:
             logits = self._logits(tokens, p, dcache, acache, xkv, mask, nb, pidx if p < levels else None)
             if p == c.M:
                 break
-            scores, parent, code = ops.beam_step(logits, scores, c.K, R)
+            Rp = min(R, nb * c.K)                                             # beams alive after this level
+            scores, parent, code = ops.beam_step(logits, scores, c.K, Rp)
             parent, code = parent.long(), code.long()
-            rows = (base * nb + parent).reshape(-1)                           # surviving parents, [B*R]
+            rows = (base * nb + parent).reshape(-1)                           # surviving parents, [B*Rp]
             dcache = _reorder_cache(dcache, rows, p + 1)
             if p >= levels:
                 acache = _reorder_cache(acache, rows, p + 1)
@@ -392,7 +396,7 @@ class NCIModel:
             codes = torch.cat([torch.gather(codes, 1, parent[:, :, None].expand(-1, -1, codes.shape[2])),
                                code[:, :, None]], dim=2)
             tokens = (2 + p * c.K + code).reshape(-1)
-            nb = R
+            nb = Rp
         final = ops.beam_step(logits, scores, c.K, R, final_step=True)        # [B, R]
         hyp = final.double() / (c.M + 1) ** length_penalty                    # BeamHypotheses.add: len = M+1
         order = torch.argsort(hyp, dim=1, descending=True, stable=True)

@@ -330,7 +330,7 @@ def g1_nci_generate():
     from transformers import T5Config, T5ForConditionalGeneration
     from main_models import TreeBuilder, encode_single_newid
 
-    for (M, K, beams, seed) in [(4, 32, 10, 0), (3, 16, 4, 1), (4, 32, 4, 2), (3, 256, 10, 3)]:   # last = BASELINE.json configs[2] code shape
+    for (M, K, beams, seed) in [(4, 32, 10, 0), (3, 16, 4, 1), (4, 32, 4, 2), (3, 256, 10, 3), (3, 8, 10, 4), (2, 4, 10, 5)]:   # (3, 256) = BASELINE.json configs[2] code shape; the last two: K < R (SURVEY 8a' note ii)
         torch.manual_seed(seed)
         cfg = _mevi_t5_config(T5Config, M, K)
         with io.StringIO() as buf, redirect_stdout(buf):
