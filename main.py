@@ -174,9 +174,8 @@ def check_supported(a):
     need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both")
     if a.doc_multiclus < 1 or (a.doc_multiclus > 1 and (a.eval_all_documents or a.knn_topk_by_step)):
         raise SystemExit("main.py --mode eval: --doc_multiclus C > 1 is built for the cluster re-ranking path only")
-    if a.use_topic_model and (a.topic_score_ratio != 0 or a.doc_multiclus > 1):
-        raise SystemExit("main.py --mode eval: --use_topic_model 1 is built for --topic_score_ratio 0 --doc_multiclus 1 "
-                         "(cluster score x q.d; the reconstruct-vector term is not)")
+    if a.use_topic_model and a.doc_multiclus > 1:
+        raise SystemExit("main.py --mode eval: --use_topic_model 1 is built for --doc_multiclus 1")
     if a.eval_all_documents:   # the brute-force ablation; same preconditions as the reference (MEVI/main.py:657-658)
         need.update(recall_level="fine", knn_topk_by_step=1)
     for k, v in need.items():

@@ -334,8 +334,12 @@ class EvalRun:
         # code paths (_generate_all) with --eval_all_documents
         self.topic = bool(getattr(a, "use_topic_model", 0))
         if self.topic:
-            assert self.C == 1 and not float(getattr(a, "topic_score_ratio", 0) or 0), "use_topic_model: doc_multiclus 1, topic_score_ratio 0"
+            assert self.C == 1, "use_topic_model is built for doc_multiclus 1"
+            self.ratio = float(getattr(a, "topic_score_ratio", 0) or 0)
             self.doc_path = None
+            # topic_score_ratio > 0 (`additional_reconstruct`, main_models.py:1270): doc_proba[d] = <reconstruct(codes(d)), emb[d]>
+            # (gen_all_reconstruct :3272-3307 + gen_doc2index_mapping :3360-3364, bmm form of compute_similarity)
+            self.doc_proba = self._doc_proba() if self.ratio else None
         self.coarse_log = None if self.eval_all else RankLog(f"{prefix}_coarse.tsv", rank, nrank, self.barrier)
         self.fine_log = RankLog(f"{prefix}_fine.tsv", rank, nrank, self.barrier)
         self.hn_log = RankLog(f"{prefix}_hn{a.save_hard_neg}.tsv", rank, nrank, self.barrier) if a.save_hard_neg else None
@@ -394,6 +398,23 @@ class EvalRun:
             results.append((text, N, ranks))
         return results
 
+    def _doc_proba(self, chunk=1 << 20):
+        """<sum_j codebook[j][code_j(d)] (level 0 first), emb[d]> for every document, f32 [N] (exact fmaf chains)."""
+        from . import ops
+
+        N = self.emb.shape[0]
+        codes = torch.from_numpy(self.index.doc_codes(N).astype(np.int64)).to(self.dev)
+        cb = self.pq.get_codebook().to(self.dev)
+        out = torch.empty(N, dtype=torch.float32, device=self.dev)
+        for a in range(0, N, chunk):
+            c = codes[a:a + chunk]
+            rec = cb[0][c[:, 0]]
+            for j in range(1, self.M):
+                rec = rec + cb[j][c[:, j]]
+            idx = torch.arange(c.shape[0], dtype=torch.int64, device=self.dev)
+            out[a:a + chunk] = ops.pair_dot(rec.contiguous(), idx, self.emb[a:a + chunk], idx)
+        return out
+
     def _all_documents_topic(self, texts, doc_ids, ids, mask, qemb, pool):
         """--use_topic_model 1 --eval_all_documents 1 (main_models.py:3565,3653-3656,3818-3876): score(q, d) =
         all_scores[q, path(d)] * (q.d), all_scores = the NCI scores of all K**M code paths (_generate_all), path(d) the
@@ -416,7 +437,10 @@ class EvalRun:
         last_scores = None
         for start in range(0, N, bs):
             end = min(N, start + bs)
-            new = all_scores[:, self.doc_path[start:end]] * ops.linear(qemb, self.emb[start:end])   # one f32 multiply
+            qd = ops.linear(qemb, self.emb[start:end])
+            if self.ratio:
+                qd = self.ratio * self.doc_proba[None, start:end] + (1 - self.ratio) * qd
+            new = all_scores[:, self.doc_path[start:end]] * qd                                        # f32 tensor ops, this order
             if self.hn_log is not None and end == N:
                 filled = min(start, kk)                                         # rows seen so far, capped by the pool
                 last_scores = torch.cat([run_s[:, :filled], new], dim=1)        # the reference's `scores` (:3872,3905)
@@ -458,7 +482,8 @@ class EvalRun:
         scores = np.array(scores).reshape(B, R)
         qemb = self.query_embedding(texts, ids, mask, rows)
         weights = torch.tensor(scores, dtype=torch.float32) if self.topic else None     # nci_scores (main_models.py:3681-3682)
-        ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate, beam_weights=weights)
+        ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate, beam_weights=weights,
+                                        doc_proba=self.doc_proba if self.topic else None, ratio=self.ratio if self.topic else 0.0)
         nq = self.nq
         gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None and nq is None else None
         results = []

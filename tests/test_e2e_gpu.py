@@ -287,7 +287,8 @@ def _firm(ref_s, tol):
     return np.concatenate([[True], g]) & np.concatenate([g, [True]])
 
 
-def test_use_topic_model_ablation(cuda, mini_small, tmp_path):
+@pytest.mark.parametrize("ratio", [0.0, 0.3])
+def test_use_topic_model_ablation(cuda, mini_small, tmp_path, ratio):
     mini = mini_small
     M, K, R = 3, 4, 4
     """--use_topic_model 1 (topic_score_ratio 0; main_models.py:3539-3552): a document's score is the NCI score of its
@@ -306,8 +307,12 @@ def test_use_topic_model_ablation(cuda, mini_small, tmp_path):
     cluster, _ = orq.cluster_dict(codes_doc)
     # ---- cluster path: beam score x q.d
     a = Namespace(**vars(mini["args"]))
-    a.use_topic_model, a.topic_score_ratio = 1, 0.0
+    a.use_topic_model, a.topic_score_ratio = 1, ratio
     a.custom_save_path, a.metric_path = str(tmp_path / "t.tsv"), str(tmp_path / "m.txt")
+    # all_doc_proba (gen_all_reconstruct + gen_doc2index_mapping): <reconstruct vector of the document's codes, its embedding>
+    Ct = torch.from_numpy(mini["C"])
+    recon = sum(Ct[j][torch.from_numpy(codes_doc[:, j].astype(np.int64))] for j in range(M))
+    doc_proba = torch.sum(recon * emb, dim=-1) if ratio else 0
     EvalRun(a, tokenizer=tok, device=cuda).run(load_queries(a.data_dir))
     hn = [l.rstrip("\n").split("\t") for l in open(f"{a.custom_save_path[:-4]}_hn{a.save_hard_neg}.tsv")]
     dec, sc, _ = ot5.nci_generate(mini["W"], mini["cfg"], ids, mask, R)
@@ -319,7 +324,8 @@ def test_use_topic_model_ablation(cuda, mini_small, tmp_path):
         for r in range(R):
             cur = cluster.get(tuple(bcodes[i, r].tolist()))
             if cur is not None:
-                scores.append(nci_scores[i][r].item() * (qemb[i] @ emb[cur].T))     # get_inference_scores, ratio 0
+                dp = doc_proba[cur] if ratio else 0
+                scores.append(nci_scores[i][r].item() * (ratio * dp + (1 - ratio) * (qemb[i] @ emb[cur].T)))   # get_inference_scores
                 docs += cur
         if not docs:
             assert hn[i][2] == ""
@@ -335,7 +341,7 @@ def test_use_topic_model_ablation(cuda, mini_small, tmp_path):
     assert checked > 100
     # ---- all documents: score of the document's code path among all K**M x q.d
     a = Namespace(**vars(mini["args"]))
-    a.use_topic_model, a.topic_score_ratio, a.eval_all_documents, a.recall_level, a.encode_batch_size = 1, 0.0, 1, "fine", 64
+    a.use_topic_model, a.topic_score_ratio, a.eval_all_documents, a.recall_level, a.encode_batch_size = 1, ratio, 1, "fine", 64
     a.recall_num, a.save_hard_neg = [1, 5, 10, 20, 50, 100], 150
     a.custom_save_path, a.metric_path = str(tmp_path / "ta.tsv"), str(tmp_path / "ma.txt")
     EvalRun(a, tokenizer=tok, device=cuda).run(load_queries(a.data_dir))
@@ -348,7 +354,8 @@ def test_use_topic_model_ablation(cuda, mini_small, tmp_path):
     docs = torch.empty((len(qemb), 0), dtype=torch.int64)
     for st in range(0, N, 64):                       # the reference's loop with use_topic_model (main_models.py:3826-3876)
         topic = all_scores[:, path[st:st + 64]]
-        new = topic * (qemb @ emb[st:st + 64].T)
+        dp = doc_proba[st:st + 64] if ratio else 0
+        new = topic * (ratio * dp + (1 - ratio) * (qemb @ emb[st:st + 64].T))
         scs = torch.cat([stack, new], -1)
         dd = torch.cat([docs, torch.arange(st, min(st + 64, N)).unsqueeze(0).expand(len(qemb), -1)], -1)
         stack, idx = torch.topk(scs, k=min(scs.shape[-1], pool), dim=-1)

@@ -326,8 +326,9 @@ def test_main_py_rejects_what_it_does_not_build():
             main.parsers_parser(base + argv)
     main.parsers_parser(base + ["--use_topic_model", "0", "--fp_16", "0", "--decode_embedding", "2"])   # the built values
     main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1"]))                  # cluster score x q.d
-    with pytest.raises(SystemExit):            # the reconstruct-vector term of the topic model is not built
-        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1", "--topic_score_ratio", "0.3"]))
+    main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1", "--topic_score_ratio", "0.3"]))
+    with pytest.raises(SystemExit):            # the topic model over multi-cluster documents is not built
+        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1", "--doc_multiclus", "3"]))
     with pytest.raises(SystemExit):            # try_load_ckpt asserts a checkpoint (MEVI/main.py:201)
         main.check_supported(main.parsers_parser([t for t in EVAL_ARGV if not t.startswith("--nci_ckpt")][:0] + base + [
             "--codebook", "1", "--pq_type", "rq", "--query_encoder", "twin", "--recall_level", "both", "--document_encoder",
