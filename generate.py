@@ -15,7 +15,7 @@ import socket
 import numpy as np
 import pandas as pd
 
-from mevi_amd.io import flush_rows, map_rows
+from mevi_amd.io import encode_batch, flush_rows, map_rows
 
 
 # padded tokens per device pass (= mevi_amd.t5.DEVICE_PASS_TOKENS); --batch_size only raises it: the embeddings do not
@@ -89,8 +89,7 @@ def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path,
     batch_size = max(batch_size, DEVICE_PASS_TOKENS // query_length)    # see DEVICE_PASS_TOKENS
     for s in range(start, end, batch_size):
         e = min(s + batch_size, end)
-        tok = tokenizer.batch_encode_plus(list(df[s:e]), max_length=query_length, padding="max_length",
-                                          truncation=True, return_tensors="pt")
+        tok = encode_batch(tokenizer, df[s:e], query_length)
         out[s - start:e - start] = encoder.encode_query(tok).cpu().numpy()
     flush_rows(out)
     if nrank > 1:
@@ -174,8 +173,7 @@ def profile_generate_query(query_file, model_path, ckpt_path, tokenizer_path, st
     for start in range(0, step_num):
         batch = list(df[start:min(start + 1, step_num)])
         t0 = time()
-        tok = tokenizer.batch_encode_plus(batch, max_length=query_length, padding="max_length", truncation=True,
-                                          return_tensors="pt")
+        tok = encode_batch(tokenizer, batch, query_length)
         encoder.encode_query(tok).cpu().numpy()
         timer.append(time() - t0)
     with open(out_path, "wb") as fw:

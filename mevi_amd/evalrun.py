@@ -18,7 +18,7 @@ import torch
 from . import dense as mdense
 from . import fine as mfine
 from . import hip
-from .io import RankLog, join_i64, upload_rows
+from .io import RankLog, encode_batch, join_i64, upload_rows
 from .nci import MODEL_INFO, NCIModel, check_weights, config_from_weights, decode_token
 from .rq import ClusterIndex, ProductQuantization
 from .t5 import T5Dims, TwinTower
@@ -345,8 +345,7 @@ class EvalRun:
         self.hn_log = RankLog(f"{prefix}_hn{a.save_hard_neg}.tsv", rank, nrank, self.barrier) if a.save_hard_neg else None
 
     def tokenize(self, queries):
-        out = self.tokenizer.batch_encode_plus(list(queries), max_length=32, padding="max_length", truncation=True,
-                                               return_tensors="pt")
+        out = encode_batch(self.tokenizer, queries, 32)
         return out["input_ids"], out["attention_mask"]
 
     def query_embedding(self, texts, ids, mask, rows=None):
@@ -354,8 +353,7 @@ class EvalRun:
             return torch.from_numpy(np.ascontiguousarray(self.query_table[np.asarray(rows)])).to(self.dev)
         if self.tower_tokenizer is None:      # T5-ANCE: the tower reads the NCI input ids (main_models.py:3797-3799)
             return self.tower.encode_query({"input_ids": ids, "attention_mask": mask})
-        tok = self.tower_tokenizer.batch_encode_plus(list(texts), max_length=32, truncation=True, padding="max_length",
-                                                     add_special_tokens=self.tower_special_tokens, return_tensors="pt")
+        tok = encode_batch(self.tower_tokenizer, texts, 32, add_special_tokens=self.tower_special_tokens)
         return self.tower.encode_query({"input_ids": tok["input_ids"], "attention_mask": tok["attention_mask"]})
 
     @torch.no_grad()

@@ -78,8 +78,9 @@ def load_passage_tokens(args, tokenizer=None):
         text = ("Title: " + docs["title"] + " Text: " + docs["content"]).tolist()
     else:
         text = (docs["title"] + tokenizer.sep_token + docs["content"]).tolist()
-    out = tokenizer.batch_encode_plus(text, max_length=length, truncation=True, padding="max_length",
-                                      add_special_tokens=args.document_encoder in ("ance", "ar2"), return_tensors="pt")
+    from .io import encode_batch
+
+    out = encode_batch(tokenizer, text, length, add_special_tokens=args.document_encoder in ("ance", "ar2"))
     return out["input_ids"].numpy(), out["attention_mask"].numpy()
 
 

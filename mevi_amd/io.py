@@ -73,6 +73,17 @@ def flush_rows(a):
         a.flush()
 
 
+def encode_batch(tokenizer, texts, max_length, **kw):
+    """`tokenizer.batch_encode_plus(texts, max_length=..., padding="max_length", truncation=True, return_tensors="pt")`
+    as the reference calls its vendored transformers 3.4 tokenizers (main_models.py:445-455, generate.py:85-87).
+    Current `transformers` releases removed `batch_encode_plus` in favour of `__call__` (same arguments, same result);
+    either spelling is used, whichever the tokenizer object has."""
+    fn = getattr(tokenizer, "batch_encode_plus", None)
+    if fn is None:
+        fn = tokenizer.__call__
+    return fn(list(texts), max_length=max_length, padding="max_length", truncation=True, return_tensors="pt", **kw)
+
+
 def read(path, dim):
     """Raw f32 file -> [rows, dim] (raises like numpy if the size does not divide).  Large files (the 27 GB corpus) come
     back as a read-only memory map -- an ndarray too -- so that the only copy made is the one into the upload's staging

@@ -566,6 +566,52 @@ def test_dense_cli_and_ensemble_chain(cuda, mini, tmp_path):
     assert "ANCE Pred" in r.stdout and "Fine Pred" in r.stdout and "score + 0.6 / (0.03 * crank + 1)" in r.stdout
 
 
+def test_command_lines_with_a_real_sentencepiece_tokenizer(cuda, mini, tmp_path):
+    """generate.py --gen_query and main.py --mode eval through their REAL command lines with no injected tokenizer: both load
+    `AutoTokenizer.from_pretrained(<ckpt>/t5-ance)` (a SentencePiece model trained for the test, tests/spm_fixture.py) from
+    the installed `transformers` -- whose tokenizers no longer have the reference's `batch_encode_plus`.  Embeddings equal
+    the oracle tower on the tokenizer's own ids; the eval run's coarse log carries the oracle's beams for those ids."""
+    pytest.importorskip("sentencepiece")
+    from transformers import AutoTokenizer
+
+    from spm_fixture import build_t5_tokenizer_dir
+
+    a0 = mini["args"]
+    ck = tmp_path / "ckpts"
+    shutil.copytree(a0.ckpt_dir, ck)
+    build_t5_tokenizer_dir(str(ck / "t5-ance"))
+    tok = AutoTokenizer.from_pretrained(str(ck / "t5-ance"))
+    enc = tok(mini["queries"], max_length=32, padding="max_length", truncation=True, return_tensors="pt")
+    assert int(enc["input_ids"].max()) < 512                              # inside the miniature models' vocabulary
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    qfile = os.path.join(a0.data_dir, "dev_mevi_dedup.tsv")
+    out = str(tmp_path / "query_emb.bin")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "generate.py"), "--query_file", qfile, "--model_path", str(ck / "t5-ance"),
+                        "--tokenizer_path", str(ck / "t5-ance"), "--query_embedding_path", out, "--dim", "32", "--gpus", "0",
+                        "--gen_query"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.fromfile(out, dtype=np.float32).reshape(-1, 32)
+    want = ot5.tower_encode(mini["TW"], mini["tcfg"], enc["input_ids"], enc["attention_mask"]).numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() <= 5e-5
+    save = str(tmp_path / "res" / "nci_result.tsv")
+    os.makedirs(tmp_path / "res")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--mode", "eval", "--n_gpu", "1", "--codebook", "1", "--pq_type", "rq",
+                        "--subvector_num", "4", "--subvector_bits", "5", "--query_encoder", "twin", "--document_encoder", "ance",
+                        "--recall_level", "both", "--num_return_sequences", "10", "--adaptor_layer_num", "2", "--eval_batch_size", "2",
+                        "--nci_ckpt", a0.nci_ckpt, "--ckpt_dir", str(ck), "--data_dir", a0.data_dir, "--embedding_path", a0.embedding_path,
+                        "--pq_path", a0.pq_path, "--pq_cluster_path", a0.pq_cluster_path, "--custom_save_path", save,
+                        "--save_hard_neg", str(a0.save_hard_neg), "--logs_dir", str(tmp_path / "logs"), "--learning_rate", "2e-4",
+                        "--fixnci", "--fixpq"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    coarse = [l.rstrip("\n").split("\t") for l in open(save[:-4] + "_coarse.tsv")]
+    dec, sc, _ = ot5.nci_generate(mini["W"], mini["cfg"], enc["input_ids"], enc["attention_mask"], 10)
+    codes = ot5.decode_token(dec, 32).view(len(mini["queries"]), 10, 4).numpy()
+    assert len(coarse) == len(mini["queries"])
+    for i, q in enumerate(mini["queries"]):
+        assert coarse[i][0] == q and eval(coarse[i][1]) == codes[i].tolist()
+        assert np.abs(np.array(eval(coarse[i][3])) - sc.numpy().reshape(-1, 10)[i]).max() <= 1e-5
+
+
 def test_eval_driver_with_a_bert_tower(cuda, mini, tmp_path):
     """--document_encoder cocondenser: the fine stage scores with a BERT-family tower that reads the query through its
     own tokenizer (no special tokens for 'cocondenser'), in the tower's embedding space (48-d here, NCI is 32-d)."""
@@ -658,6 +704,10 @@ def _two_rank_eval_worker(rank, world, port, args_dict, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     a = Namespace(**args_dict)
+    if rank == 1 and getattr(a, "late_rank_s", 0):
+        import time
+
+        time.sleep(a.late_rank_s)      # a rank that reaches the pickle check seconds after rank 0 (27 GB uploads skew ranks)
     out = EvalRun(a, tokenizer=FakeTokenizer(512), rank=rank, nrank=world, barrier=dist.barrier,
                   device=torch.device("cuda:0")).run(load_queries(a.data_dir))
     ret[rank] = out
@@ -665,10 +715,13 @@ def _two_rank_eval_worker(rank, world, port, args_dict, ret):
     dist.destroy_process_group()
 
 
-def test_eval_driver_with_two_ranks(cuda, mini, tmp_path):
+@pytest.mark.parametrize("first_run", [False, True])
+def test_eval_driver_with_two_ranks(cuda, mini, tmp_path, first_run):
     """main.py --n_gpu 2 in miniature (two processes sharing this GPU, gloo barrier): every rank takes its
     DistributedSampler slice, the per-rank logs are merged in rank order (the sampler's padding repeats a head sample),
-    rank 0 aggregates the metrics from all ranks' results -- same lines and same metrics as the single-rank run."""
+    rank 0 aggregates the metrics from all ranks' results -- same lines and same metrics as the single-rank run.
+    first_run: the cluster pickles do not exist yet and rank 1 arrives seconds late -- every rank must take the same
+    branch around rank 0's write (they decide before anyone writes), or the barriers pair off by one."""
     import socket
 
     import torch.multiprocessing as mp
@@ -679,6 +732,8 @@ def test_eval_driver_with_two_ranks(cuda, mini, tmp_path):
         pytest.skip("eval driver test did not run")
     a = dict(vars(a0))
     a["custom_save_path"], a["metric_path"] = str(tmp_path / "two.tsv"), str(tmp_path / "two_m.txt")
+    if first_run:
+        a["pq_cluster_path"], a["late_rank_s"] = str(tmp_path / "rqclus4_5.pkl"), 4
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -695,6 +750,8 @@ def test_eval_driver_with_two_ranks(cuda, mini, tmp_path):
         assert two[:12] == one[0::2] and two[12:23] == one[1::2] and two[23] == one[0]
     assert open(a["metric_path"]).read() == open(a0.metric_path).read()
     assert ret[0]["nqueries"] == n
+    if first_run:
+        assert pickle.load(open(a["pq_cluster_path"], "rb")) == pickle.load(open(a0.pq_cluster_path, "rb"))
 
 
 def test_generate_py_gen_doc_cli_with_two_ranks(cuda, mini, tmp_path):

@@ -363,3 +363,29 @@ def test_checkpoint_loading_rules():
     nw, tower, cb = split_whole_checkpoint(sd)
     assert bad_key[6:] not in nw and set(nw) == set(good) and list(tower) == ["shared.weight"] and cb.shape == (M, K, 8)
     assert split_whole_checkpoint(sd, not_load_document_encoder=True)[1] == {}
+
+
+def test_real_sentencepiece_tokenizer_through_autotokenizer(tmp_path):
+    """The CLIs tokenise with `AutoTokenizer.from_pretrained(dir)` of the installed `transformers`; the reference's vendored
+    3.4 spelling `batch_encode_plus` no longer exists there.  `io.encode_batch` must produce the tokenizer contract of
+    main_models.py:445-455 on a REAL SentencePiece model: ids, eos = 1, pad = 0 to max_length, mask over the real tokens."""
+    pytest.importorskip("sentencepiece")
+    from transformers import AutoTokenizer
+
+    from mevi_amd.io import encode_batch
+    from spm_fixture import build_t5_tokenizer_dir
+
+    tok = AutoTokenizer.from_pretrained(build_t5_tokenizer_dir(str(tmp_path / "t5-ance")))
+    texts = ["what is the capital of w3", "w10 w20", " ".join(f"w{i}" for i in range(60))]
+    out = encode_batch(tok, texts, 32)
+    ids, mask = out["input_ids"].numpy(), out["attention_mask"].numpy()
+    assert ids.shape == mask.shape == (3, 32) and ids.dtype.kind == "i"
+    for row, m in zip(ids, mask):
+        n = int(m.sum())
+        assert n >= 2 and m[:n].all() and not m[n:].any()            # right padding
+        assert row[n - 1] == 1 and (row[n:] == 0).all() and (row[:n - 1] > 1).all()     # ... eos, then pad
+    assert mask[2].all()                                            # truncated to the window, eos kept
+    import sentencepiece as spm
+
+    sp = spm.SentencePieceProcessor(model_file=str(tmp_path / "t5-ance" / "spiece.model"))
+    assert ids[1, :int(mask[1].sum()) - 1].tolist() == sp.encode(texts[1])
