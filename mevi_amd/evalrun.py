@@ -76,13 +76,27 @@ def split_whole_checkpoint(sd, not_load_document_encoder=False):
     return nci_w, tower, sd.get("pq.codebook")
 
 
+def load_hf_state_dict(model_dir):
+    """The weights of an HF model directory: `pytorch_model.bin` (what the reference's `from_pretrained` of 2023 reads), or
+    `model.safetensors` when a newer export of the same checkpoint ships only that."""
+    path = os.path.join(model_dir, "pytorch_model.bin")
+    if os.path.exists(path):
+        return torch.load(path, map_location="cpu")
+    st = os.path.join(model_dir, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+
+        return load_file(st, device="cpu")
+    raise FileNotFoundError(f"{model_dir}: neither pytorch_model.bin nor model.safetensors")
+
+
 def load_tower_weights(model_dir):
     """T5-ANCE directory in HF layout (config.json + pytorch_model.bin), as DocumentEncoder.build ->
     AutoModel.from_pretrained reads it (MEVI/document_encoder.py:176-188)."""
     import json
 
     cfg = json.load(open(os.path.join(model_dir, "config.json")))
-    sd = torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu")
+    sd = load_hf_state_dict(model_dir)
     if "encoder.embed_tokens.weight" in sd and "shared.weight" not in sd:
         sd["shared.weight"] = sd["encoder.embed_tokens.weight"]
     dims = T5Dims(d_model=cfg["d_model"], d_ff=cfg["d_ff"], num_heads=cfg["num_heads"], d_kv=cfg["d_kv"],
@@ -117,7 +131,7 @@ def load_bert_tower(model_path, device, batch_size=None):
         wp = strip({k[len("ctx_model."):]: v for k, v in params.items() if k.startswith("ctx_model.")})
     else:
         cfg_dir = model_path
-        wq = strip(torch.load(os.path.join(model_path, "pytorch_model.bin"), map_location="cpu"))
+        wq = strip(load_hf_state_dict(model_path))
     cfg = json.load(open(os.path.join(cfg_dir, "config.json")))
     return BertTower(wq, cfg["num_hidden_layers"], cfg["num_attention_heads"], weights_p=wp,
                      eps=cfg.get("layer_norm_eps", 1e-12), device=device, batch_size=batch_size)

@@ -389,3 +389,28 @@ def test_real_sentencepiece_tokenizer_through_autotokenizer(tmp_path):
 
     sp = spm.SentencePieceProcessor(model_file=str(tmp_path / "t5-ance" / "spiece.model"))
     assert ids[1, :int(mask[1].sum()) - 1].tolist() == sp.encode(texts[1])
+
+
+def test_tower_directory_with_safetensors_only(tmp_path):
+    """A newer export of the tower checkpoint (model.safetensors, no pytorch_model.bin) loads to the same tensors."""
+    import json
+
+    import torch
+    from safetensors.torch import save_file
+
+    from mevi_amd.evalrun import load_tower_weights
+
+    sd = {"shared.weight": torch.randn(10, 8), "encoder.final_layer_norm.weight": torch.ones(8)}
+    cfg = dict(d_model=8, d_ff=16, num_heads=2, d_kv=4, num_layers=1)
+    for name in ("bin", "st"):
+        os.makedirs(tmp_path / name)
+        json.dump(cfg, open(tmp_path / name / "config.json", "w"))
+    torch.save(sd, tmp_path / "bin" / "pytorch_model.bin")
+    save_file(sd, str(tmp_path / "st" / "model.safetensors"))
+    a, da = load_tower_weights(str(tmp_path / "bin"))
+    b, db = load_tower_weights(str(tmp_path / "st"))
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a) and da.num_decoder_layers == db.num_decoder_layers == 1
+    with pytest.raises(FileNotFoundError):
+        os.makedirs(tmp_path / "none")
+        json.dump(cfg, open(tmp_path / "none" / "config.json", "w"))
+        load_tower_weights(str(tmp_path / "none"))
