@@ -304,6 +304,9 @@ class EvalRun:
                 with open(map_path, "wb") as f:
                     pickle.dump(mapping, f)
                 del cluster, mapping
+                from .metrics import write_mapping_sidecar
+
+                write_mapping_sidecar(map_path, self.index.doc_codes(n_docs))   # the same mapping as an array (ensemble scripts)
         self.barrier()
         self.mapping = CodeMap(self.index.doc_codes(n_docs))
         print("Number of all pq document clusters:", len(self.index.keys))

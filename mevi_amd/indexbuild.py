@@ -140,6 +140,9 @@ def build_index(args, rank=0, nrank=1, barrier=None, device=None, tower=None, to
                 pickle.dump(cluster, f)
             with open(map_path, "wb") as f:
                 pickle.dump(mapping, f)
+            from .metrics import write_mapping_sidecar
+
+            write_mapping_sidecar(map_path, index.doc_codes(n_docs))
             nclus = len(cluster)
         barrier()
     if nclus is None:

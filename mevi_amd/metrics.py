@@ -78,8 +78,75 @@ def evaluate_main(dir_path, gt_file, ance_file, recall_num, ofile=None):
     return evaluate_ranked("ANCE Pred", cutoffs, gts, preds, ofile, stdout_prefix="Scoring ")
 
 
+class ArrayMapping:
+    """`rqmapping*.pkl` (dict doc id -> code tuple, main_models.py:3200-3203) held as an i32 [N, M] array (row of -1 = id
+    absent).  The pickle of 8.8 M tuples takes seconds to load; main.py / the index build write the array beside it
+    (`<same name>.npy`) and the ensemble scripts prefer it when it is not older than the pickle."""
+
+    def __init__(self, codes):
+        self.codes = codes
+
+    def __getitem__(self, doc):
+        c = self.codes[doc]
+        if c[0] < 0:
+            raise KeyError(doc)
+        return tuple(int(x) for x in c)
+
+    def __len__(self):
+        return len(self.codes)
+
+
+def mapping_sidecar(mapping_file):
+    return mapping_file[:-4] + ".npy" if mapping_file.endswith(".pkl") else mapping_file + ".npy"
+
+
+def write_mapping_sidecar(mapping_file, codes):
+    import numpy as np
+
+    np.save(mapping_sidecar(mapping_file), np.ascontiguousarray(codes, dtype=np.int32))
+
+
+def load_mapping(mapping_file):
+    import numpy as np
+
+    side = mapping_sidecar(mapping_file)
+    if os.path.exists(side) and os.path.getmtime(side) >= os.path.getmtime(mapping_file):
+        return ArrayMapping(np.load(side, mmap_mode="r"))
+    with open(mapping_file, "rb") as f:
+        return pickle.load(f)
+
+
+def _cluster_ranks_array(dense_preds, coarse_clusters, mapping):
+    """cluster_ranks for an ArrayMapping: the same ranks, one numpy comparison per query instead of a dict lookup per
+    document (a query's 1000 documents x 10 beam clusters)."""
+    import numpy as np
+
+    out, n_clusters = {}, None
+    for q, preds in dense_preds.items():
+        beam = np.asarray(coarse_clusters[q], dtype=np.int64).reshape(len(coarse_clusters[q]), -1)
+        distinct = len({tuple(c) for c in beam.tolist()})
+        if n_clusters is not None and n_clusters != distinct:
+            raise AssertionError("queries disagree on the number of beam clusters")
+        n_clusters = distinct
+        docs = np.asarray(preds, dtype=np.int64)
+        valid = docs != -1
+        dcodes = np.asarray(mapping.codes[np.where(valid, docs, 0)], dtype=np.int64)
+        if (valid & (dcodes[:, 0] < 0)).any():
+            raise KeyError(int(docs[valid & (dcodes[:, 0] < 0)][0]))
+        R = beam.shape[0]
+        if R == 0 or beam.shape[1] != dcodes.shape[1]:
+            out[q] = [n_clusters] * len(docs)
+            continue
+        eq = (dcodes[:, None, :] == beam[None, :, :]).all(-1)                  # [n, R]
+        last = R - 1 - np.argmax(eq[:, ::-1], axis=1)                          # a repeated cluster keeps its LAST index
+        out[q] = np.where(eq.any(1) & valid, last, n_clusters).tolist()
+    return out, n_clusters
+
+
 def cluster_ranks(dense_preds, coarse_clusters, mapping):
     """rank of each dense doc's RQ cluster among the query's beam clusters (else n_clusters)."""
+    if isinstance(mapping, ArrayMapping):
+        return _cluster_ranks_array(dense_preds, coarse_clusters, mapping)
     out, n_clusters = {}, None
     for q, preds in dense_preds.items():
         pos = {}
@@ -105,6 +172,9 @@ def ensemble_scores(dense_p, dense_s, cranks, fine_p, fine_s, n_clusters, alpha,
         docs = dense_p + fine_p
         scores = dense_s + fine_s
         ranks = chain(cranks, cranks)
+    fast = _ensemble_scores_numpy(docs, scores, cranks, fine_p is not None, n_clusters, alpha, beta, gamma)
+    if fast is not None:
+        return fast
     combined = {}
     for p, s, cr in zip(docs, scores, ranks):
         v = s + alpha / (beta * cr + 1)
@@ -112,6 +182,36 @@ def ensemble_scores(dense_p, dense_s, cranks, fine_p, fine_s, n_clusters, alpha,
             v *= (1 - gamma * alpha)
         combined[p] = v
     return [p for p, _ in sorted(combined.items(), key=lambda kv: -kv[1])]
+
+
+def _ensemble_scores_numpy(docs, scores, cranks, doubled, n_clusters, alpha, beta, gamma):
+    """The loop of ensemble_scores in numpy float64 -- the same IEEE operations in the same order per element
+    (s + alpha / (beta * cr + 1), then * (1 - gamma * alpha)), a document seen twice keeps its FIRST position and its LAST
+    score, ties keep first-seen order.  None when the lists are not plain numbers (the generic loop then runs)."""
+    import numpy as np
+
+    try:
+        p = np.asarray(docs)
+        s = np.asarray(scores, dtype=np.float64)
+        cr = np.asarray(cranks)
+        if p.ndim != 1 or p.dtype.kind not in "iu" or s.ndim != 1 or cr.ndim != 1 or cr.dtype.kind not in "iu":
+            return None
+    except (ValueError, TypeError):
+        return None
+    if doubled:
+        cr = np.concatenate([cr, cr])
+    n = min(len(p), len(s), len(cr))                       # zip() truncates to the shortest
+    p, s, cr = p[:n], s[:n], cr[:n]
+    if n == 0:
+        return []
+    v = s + alpha / (beta * cr + 1)
+    v = np.where(cr == n_clusters, v * (1 - gamma * alpha), v)
+    uniq, first, inv = np.unique(p, return_index=True, return_inverse=True)
+    last = np.empty(len(uniq), dtype=np.float64)
+    order_in = np.argsort(inv, kind="stable")               # occurrences of each document in list order
+    last[inv[order_in]] = v[order_in]                       # ascending position per document: the last one is written last
+    order = np.lexsort((first, -last))                      # by -score, then by first position (stable sort of the dict)
+    return uniq[order].tolist()
 
 
 def ensemble_main(dir_path, gt_file, ance_file, fine_file, coarse_file, mapping_file,
@@ -127,8 +227,7 @@ def ensemble_main(dir_path, gt_file, ance_file, fine_file, coarse_file, mapping_
     if have_fine:
         fine_p, fine_s, _ = mio.load_parsed(fine_path, RANKED_TEMPLATE)
     _, _, clusters = mio.load_parsed(resolve(coarse_file, dir_path), COARSE_TEMPLATE)
-    with open(mapping_file, "rb") as f:
-        mapping = pickle.load(f)
+    mapping = load_mapping(mapping_file)
     cranks, n_clusters = cluster_ranks(dense_p, clusters, mapping)
     if ofile is not None:
         open(ofile, "w").close()
@@ -225,8 +324,7 @@ def ensemble_nqdpr_main(dir_path, ance_file, fine_file=None, coarse_file=None, m
     if noensemble:
         return results
     _, _, clusters = parse_indexed(resolve(coarse_file, dir_path), COARSE_TEMPLATE, index_of)
-    with open(mapping_file, "rb") as f:
-        mapping = pickle.load(f)
+    mapping = load_mapping(mapping_file)
     cranks, n_clusters = cluster_ranks(dense_p, clusters, mapping)
     for a in alphas:
         for b in betas:

@@ -116,3 +116,59 @@ def test_read_raw_f32(tmp_path):
     assert np.array_equal(mio.read(str(p), 8), a)
     with pytest.raises(ValueError):
         mio.read(str(p), 7)
+
+
+@pytest.mark.parametrize("name", ["ensemble_default", "ensemble_grid", "ensemble_nofine"])
+def test_ensemble_with_the_array_form_of_the_mapping(name, g6_dir):
+    """main.py writes rqmapping*.pkl AND the same mapping as an array (rqmapping*.npy); with the array present the
+    ensemble script skips the 8.8 M-tuple unpickle and ranks clusters with numpy -- stdout and ofile stay byte-identical to
+    the UNMODIFIED reference script's (golden G6, which holds -1 ids, duplicated documents, F > len(dense))."""
+    import pickle
+
+    from mevi_amd import metrics
+
+    mp = os.path.join(g6_dir, "rqmapping.pkl")
+    mapping = pickle.load(open(mp, "rb"))
+    codes = np.full((max(mapping) + 1, len(next(iter(mapping.values())))), -1, np.int32)
+    for k, v in mapping.items():
+        codes[k] = v
+    metrics.write_mapping_sidecar(mp, codes)
+    assert isinstance(metrics.load_mapping(mp), metrics.ArrayMapping)
+    exp = json.load(open(os.path.join(G6, "expected.json")))[name]
+    argv = [a.replace("{d}", g6_dir) for a in exp["argv"]]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, argv[0])] + argv[1:], capture_output=True, text=True, cwd=g6_dir,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == exp["stdout"]
+    if exp["ofile"] is not None:
+        assert open(os.path.join(g6_dir, "ens_out.txt")).read() == exp["ofile"]
+    os.utime(mp, (os.path.getmtime(mp) + 10,) * 2)                           # a pickle newer than the array wins
+    assert isinstance(metrics.load_mapping(mp), dict)
+
+
+def test_numpy_ensemble_equals_the_reference_loop():
+    """_ensemble_scores_numpy against the literal dict loop on adversarial lists: duplicates inside and across the lists,
+    exact score ties, a fine list longer than the dense one (zip truncation), ranks equal to n_clusters."""
+    from itertools import chain
+
+    from mevi_amd import metrics
+
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        nd, nf = int(rng.integers(1, 40)), int(rng.integers(0, 90))
+        dense_p = rng.integers(-1, 25, size=nd).tolist()
+        fine_p = rng.integers(0, 25, size=nf).tolist()
+        dense_s = np.round(rng.standard_normal(nd), 1).tolist()
+        fine_s = np.round(rng.standard_normal(nf), 1).tolist()
+        cr = rng.integers(0, 6, size=nd).tolist()
+        a, b, g, ncl = 0.6, 0.03, 0.02, 5
+        for fp, fs in ((fine_p, fine_s), (None, None)):
+            docs, scores, ranks = (dense_p + fp, dense_s + fs, chain(cr, cr)) if fp is not None else (dense_p, dense_s, cr)
+            combined = {}
+            for p, s, c in zip(docs, scores, ranks):
+                v = s + a / (b * c + 1)
+                if c == ncl:
+                    v *= (1 - g * a)
+                combined[p] = v
+            want = [p for p, _ in sorted(combined.items(), key=lambda kv: -kv[1])]
+            assert metrics.ensemble_scores(dense_p, dense_s, cr, fp, fs, ncl, a, b, g) == want

@@ -92,16 +92,12 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
         fine_p[q], fine_s[q] = fd.tolist(), ranked[i][1].astype(np.float64).tolist()
         clusters[q] = bcodes[i].tolist()
 
-    class CodeMap:                                   # rqmapping: doc id -> code tuple, without an 8.8 M-entry dict
-        def __getitem__(self, p):
-            return tuple(codes_h[p].tolist())
-
     import contextlib
     import io
 
     sink = io.StringIO() if quiet else None
     with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
-        cranks, n_clusters = metrics.cluster_ranks(dense_p, clusters, CodeMap())
+        cranks, n_clusters = metrics.cluster_ranks(dense_p, clusters, metrics.ArrayMapping(codes_h))   # rqmapping as main.py's array sidecar
         res = {"dense": metrics.evaluate_ranked("ANCE Pred", [10, 50, 1000], gts, dense_p),
                "fine": metrics.evaluate_ranked("Fine Pred", [10, 50, 1000], gts, fine_p)}
         ens = {q: metrics.ensemble_scores(dense_p[q], dense_s[q], cranks[q], fine_p[q], fine_s[q], n_clusters, 0.6, 0.03, 0.02)
@@ -119,8 +115,8 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
         "queries_per_s_reusing_query_embeddings": round(nq / reuse, 1),
         "ensemble_host_ms": round(t_ens * 1e3, 1),
         "queries_per_s_incl_ensemble_host": round(nq / (total + t_ens), 1),
-        "ensemble_note": "ensemble_marco.py's combination + metrics over 6980 x (1000 dense + fine) entries: host-side "
-                         "Python dicts (the reference's algorithm), lists already in memory (no TSV parsing)",
+        "ensemble_note": "ensemble_marco.py's combination + metrics over 6980 x (1000 dense + fine) entries on the host "
+                         "(mevi_amd.metrics with the mapping in its array form; lists already in memory, no TSV parsing)",
         "setup_untimed_ms": {"rq_encode_corpus": round(t_rq * 1e3, 1), "dense_index_build": round(t_index * 1e3, 1)},
         "fine_candidates_per_query": float(ndoc.mean()), "fine_candidates_max": int(ndoc.max()),
         "mrr10": {k_: v[1][10] for k_, v in res.items()}, "recall1000": {k_: v[0][1000] for k_, v in res.items()},
