@@ -115,3 +115,30 @@ def test_strided_output_and_fused_rmsnorm(cuda):
     cache = torch.full((1500, 5, 1536), float("nan"), device=cuda)
     ops.linear(hs, w, out=cache[:, 2, :])                                   # the decoder's K|V cache slot
     assert torch.equal(cache[:, 2, :], ops.linear(hs, w)) and torch.isnan(cache[:, 1, :]).all() and torch.isnan(cache[:, 3, :]).all()
+
+
+def test_extreme_rows(cuda):
+    """Row scaling across the f32 range: all-zero rows, rows of magnitude 1e-30 and 1e+30 (exponents at the int8 clamp
+    region), one huge element beside tiny ones -- same 2e-6 bar relative to sum |a||w|; non-finite inputs stay non-finite
+    in their own rows only."""
+    g = torch.Generator(device=cuda).manual_seed(11)
+    M, N, K = 700, 256, 512
+    x = torch.randn((M, K), device=cuda, generator=g)
+    x[0] = 0
+    x[1] *= 1e-30
+    x[2] *= 1e30
+    x[3, 1:] *= 1e-6
+    x[3, 0] = 5e4
+    w = torch.randn((N, K), device=cuda, generator=g) * K ** -0.5
+    w[7] = 0
+    w[8] *= 1e-5                    # (1e-30 rows x this column stay above the f32 underflow any GEMM would hit)
+    got = ops.linear(ops.split_rows(x), ops.split_rows(w))
+    ref, den = _ref(x, w, None, None, None)
+    assert torch.isfinite(got).all() and (got[0] == 0).all() and (got[:, 7] == 0).all()
+    err = ((got.double() - ref).abs() / den.clamp_min(1e-300))
+    err[0], err[:, 7] = 0, 0
+    assert err.max().item() <= TOL
+    x[5, 9], x[6, 3] = float("inf"), float("nan")
+    got = ops.linear(ops.split_rows(x), ops.split_rows(w))
+    bad = ~torch.isfinite(got)
+    assert bad[5].any() and bad[6].any() and not bad[[0, 1, 2, 3, 4, 7, 8]].any()
