@@ -399,7 +399,11 @@ class NCIModel:
             nb = Rp
         final = ops.beam_step(logits, scores, c.K, R, final_step=True)        # [B, R]
         hyp = final.double() / (c.M + 1) ** length_penalty                    # BeamHypotheses.add: len = M+1
-        order = torch.argsort(hyp, dim=1, descending=True, stable=True)
+        # descending by score, equal scores in beam order (a stable sort of the reference's hypotheses): hyp is a monotone
+        # image of `final`, so the order comes from the tested segment-sort kernel on the f32 values (ties -> lower beam index)
+        beam_ids = torch.arange(R, dtype=torch.int64, device=self.dev).repeat(B)
+        seg = torch.arange(B + 1, dtype=torch.int64, device=self.dev) * R
+        order = ops.segment_sort_desc(final.reshape(-1), beam_ids, seg, R)[1].view(B, R)
         hyp = torch.gather(hyp, 1, order)
         codes = torch.gather(codes, 1, order[:, :, None].expand(-1, -1, c.M))
         toks = 2 + torch.arange(c.M, device=self.dev) * c.K + codes
