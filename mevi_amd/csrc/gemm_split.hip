@@ -305,32 +305,81 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
   split_tile_stream(row_bytes, kp * 2, kp / 32, lds, next, begin, emit);
 }
 
-// Few outputs: one wave per 32 x 32 outputs, fragments straight from global memory (the images of a handful of rows
-// sit in L2), the same MFMA sequence as the tile stream (W first, activations second): segments 0..2, units in order,
-// k-steps j = 0, 1, lane (row, half) supplying k = 32 u + 16 j + 8 half + [0, 8).
+// Few outputs (the latency path): one wave per 32 x 32 outputs, the same MFMA sequence as the tile stream (W first,
+// activations second; per 16 k: a_lo w_hi, a_hi w_hi, a_hi w_lo), so a row has the same bits here and there.
+// Operands are staged through LDS in chunks of 64 k with COALESCED loads: a fragment load straight from global memory
+// touches 32 rows x 32 B (32 cache lines 2 Kp bytes apart) per instruction -- tools/probes/skinny_probe.hip: 25 of the
+// kernel's 27 us at K = 768 were those loads, 6 us the dependent MFMA chain.  Here eight lanes read one row's 128 B, the
+// next chunk's loads are in flight in registers while this chunk is multiplied, LDS rows are 144 B apart (conflict-free
+// ds_read_b128 fragments).  The four waves of a workgroup share the 32 activation rows, each has its own 32 W rows.
+constexpr int SKS_LD = 36;                        // floats per staged row: 128 B + 16 B pad
+constexpr int SKS_TILE = 32 * SKS_LD;             // one (32 rows x 64 k) hi or lo tile
+constexpr int SKS_BUF = 10 * SKS_TILE;            // A hi, A lo, then W hi / W lo of the four waves
 __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
     const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
     const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
     const float *__restrict__ residual, long long ldr, int act, SplitOut so) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * SKS_BUF];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lrow = lane & 31, half = lane >> 5;
   const int n0 = (blockIdx.x * 4 + wave) * 32, m0 = blockIdx.y * 32;
-  if (n0 >= N) return;
-  const int ar = m0 + lrow < M ? m0 + lrow : M - 1;
-  const int wr = n0 + lrow < N ? n0 + lrow : N - 1;
-  const _Float16 *pa = A + (size_t)ar * 2 * kp + 8 * half;
-  const _Float16 *pw = W + (size_t)wr * 2 * kp + 8 * half;
+  // staging duty of this lane: row (lane >> 3) + 8 i of a 32-row tile, 16-byte piece lane & 7 of the chunk's 128 B
+  const int srow = lane >> 3, spc = lane & 7;
+  const _Float16 *gw[4], *ga;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gw[i] = W + (size_t)min(n0 + srow + 8 * i, N - 1) * 2 * kp + 8 * spc;
+  // the activation tile (hi and lo: 64 row-halves of 128 B) is staged by all four waves: wave w takes row-halves 16 w .. 16 w + 15
+  const int arow = 16 * wave + 2 * srow;          // two row-halves per lane-row: (row, hi) and (row, lo)
+  ga = A + (size_t)min(m0 + (arow >> 1), M - 1) * 2 * kp + 8 * spc;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 2
-  for (int k = 0; k < kp; k += 16) {   // per 16 k: a_lo w_hi, a_hi w_hi, a_hi w_lo (the tile stream's order)
-    const f16x8 ah = *reinterpret_cast<const f16x8 *>(pa + k), al = *reinterpret_cast<const f16x8 *>(pa + kp + k);
-    const f16x8 wh = *reinterpret_cast<const f16x8 *>(pw + k), wl = *reinterpret_cast<const f16x8 *>(pw + kp + k);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, acc, 0, 0, 0);
+  f16x8 rw[8], ra[2];
+  auto gload = [&](int k0) {                      // unconditional: k clamped into the row
+    const int k = min(k0, kp - 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rw[i] = *reinterpret_cast<const f16x8 *>(gw[i] + k);
+      rw[4 + i] = *reinterpret_cast<const f16x8 *>(gw[i] + kp + k);
+    }
+    ra[0] = *reinterpret_cast<const f16x8 *>(ga + k);
+    ra[1] = *reinterpret_cast<const f16x8 *>(ga + kp + k);
+  };
+  auto lstore = [&](int buf) {
+    float *b = sm + buf * SKS_BUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f16x8 *>(b + (2 + 2 * wave) * SKS_TILE + (srow + 8 * i) * SKS_LD + 4 * spc) = rw[i];
+      *reinterpret_cast<f16x8 *>(b + (3 + 2 * wave) * SKS_TILE + (srow + 8 * i) * SKS_LD + 4 * spc) = rw[4 + i];
+    }
+    *reinterpret_cast<f16x8 *>(b + 0 * SKS_TILE + (arow >> 1) * SKS_LD + 4 * spc) = ra[0];
+    *reinterpret_cast<f16x8 *>(b + 1 * SKS_TILE + (arow >> 1) * SKS_LD + 4 * spc) = ra[1];
+  };
+  // kp is a multiple of 32 and >= 64: the last chunk may start 32 k early (clamped) -- its first two k-steps were then
+  // already multiplied and are skipped
+  const int nchunk = (kp + 63) / 64;
+  gload(0);
+  for (int c = 0; c < nchunk; ++c) {
+    lstore(c & 1);
+    __syncthreads();
+    if (c + 1 < nchunk) gload(64 * (c + 1));
+    const int k0 = 64 * c;
+    const int skip = k0 > kp - 64 ? (k0 - (kp - 64)) / 16 : 0;   // k-steps of this (clamped) chunk done by the previous one
+    const float *b = sm + (c & 1) * SKS_BUF;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      if (s_ < skip) continue;
+      const int off = lrow * SKS_LD + 8 * s_ + 4 * half;
+      const f16x8 ah = *reinterpret_cast<const f16x8 *>(b + 0 * SKS_TILE + off);
+      const f16x8 al = *reinterpret_cast<const f16x8 *>(b + 1 * SKS_TILE + off);
+      const f16x8 wh = *reinterpret_cast<const f16x8 *>(b + (2 + 2 * wave) * SKS_TILE + off);
+      const f16x8 wl = *reinterpret_cast<const f16x8 *>(b + (3 + 2 * wave) * SKS_TILE + off);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, acc, 0, 0, 0);
+    }
   }
+  if (n0 >= N) return;
   const int m = m0 + lrow;
   if (m >= M) return;
   const int em = ea[m];
