@@ -145,6 +145,8 @@ __device__ __forceinline__ int out_exp(const SplitOut &so, int m) {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = (int)0x80000000;  // voffset beyond every descriptor below: the load returns 0, the store is dropped
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void *p) {
@@ -305,115 +307,141 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
   split_tile_stream(row_bytes, kp * 2, kp / 32, lds, next, begin, emit);
 }
 
-// Few outputs (the latency path): one wave per 32 x 32 outputs, the same MFMA sequence as the tile stream (W first,
+// Few outputs (the latency path): one WORKGROUP per 32 x 32 outputs, the same MFMA sequence as the tile stream (W first,
 // activations second; per 16 k: a_lo w_hi, a_hi w_hi, a_hi w_lo), so a row has the same bits here and there.
-// Operands are staged through LDS in chunks of 64 k with COALESCED loads: a fragment load straight from global memory
-// touches 32 rows x 32 B (32 cache lines 2 Kp bytes apart) per instruction -- tools/probes/skinny_probe.hip: 25 of the
-// kernel's 27 us at K = 768 were those loads, 6 us the dependent MFMA chain.  Here eight lanes read one row's 128 B, the
-// next chunk's loads are in flight in registers while this chunk is multiplied, LDS rows are 144 B apart (conflict-free
-// ds_read_b128 fragments).  The four waves of a workgroup share the 32 activation rows, each has its own 32 W rows.
-constexpr int SKS_LD = 36;                        // floats per staged row: 128 B + 16 B pad
-constexpr int SKS_TILE = 32 * SKS_LD;             // one (32 rows x 64 k) hi or lo tile
-constexpr int SKS_BUF = 10 * SKS_TILE;            // A hi, A lo, then W hi / W lo of the four waves
+// What bounds this shape is the latency of one dependent chain per output tile, so the design is: as many CUs as there are
+// tiles (a t5-base projection of one query: 48 .. 192), and per CU as many bytes in flight as LDS holds.
+//   * fragments straight from global memory touch 32 rows x 32 B per instruction (32 cache lines 2 Kp bytes apart):
+//     tools/probes/skinny_probe.hip -- 25 of 27 us at K = 768 were those loads, 6 us the MFMA chain;
+//   * here the four waves stream the tile's operands with LDS-DMA (buffer_load_dwordx4 ... lds; eight lanes per 128-B row
+//     piece, source-side swizzle) into a ring of SK_RING chunks of 64 k (16 KiB: a_hi, a_lo, w_hi, w_lo x 32 rows), seven
+//     chunks = 112 KiB in flight; wave w stages slab w, wave 0 alone reads fragments and multiplies.
+constexpr int SK_RING = 8;
+constexpr int SK_SLAB = 32 * 32;                  // floats: 32 rows x 128 B
+constexpr int SK_CHUNK = 4 * SK_SLAB;
 __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
     const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
     const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
     const float *__restrict__ residual, long long ldr, int act, SplitOut so) {
-  __shared__ __attribute__((aligned(16))) float sm[2 * SKS_BUF];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) float sm[SK_RING * SK_CHUNK];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lrow = lane & 31, half = lane >> 5;
-  const int n0 = (blockIdx.x * 4 + wave) * 32, m0 = blockIdx.y * 32;
-  // staging duty of this lane: row (lane >> 3) + 8 i of a 32-row tile, 16-byte piece lane & 7 of the chunk's 128 B
-  const int srow = lane >> 3, spc = lane & 7;
-  const _Float16 *gw[4], *ga;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  // staging: wave 0 a_hi, 1 a_lo, 2 w_hi, 3 w_lo; piece i of a slab = rows 8 i .. 8 i + 7, lane -> row 8 i + (lane >> 3),
+  // LDS slot lane & 7 of that row, which holds the row's 16-byte piece  slot ^ key(row),  key(r) = (r >> 1) & 7
+  const bool is_w = wave >= 2;
+  const int rows_left = (is_w ? N - n0 : M - m0) - 1;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      tile_rsrc((is_w ? W + (size_t)n0 * 2 * kp : A + (size_t)m0 * 2 * kp) + ((wave & 1) ? kp : 0));
+  int voff[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) gw[i] = W + (size_t)min(n0 + srow + 8 * i, N - 1) * 2 * kp + 8 * spc;
-  // the activation tile (hi and lo: 64 row-halves of 128 B) is staged by all four waves: wave w takes row-halves 16 w .. 16 w + 15
-  const int arow = 16 * wave + 2 * srow;          // two row-halves per lane-row: (row, hi) and (row, lo)
-  ga = A + (size_t)min(m0 + (arow >> 1), M - 1) * 2 * kp + 8 * spc;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  f16x8 rw[8], ra[2];
-  auto gload = [&](int k0) {                      // unconditional: k clamped into the row
-    const int k = min(k0, kp - 64);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      rw[i] = *reinterpret_cast<const f16x8 *>(gw[i] + k);
-      rw[4 + i] = *reinterpret_cast<const f16x8 *>(gw[i] + kp + k);
-    }
-    ra[0] = *reinterpret_cast<const f16x8 *>(ga + k);
-    ra[1] = *reinterpret_cast<const f16x8 *>(ga + kp + k);
-  };
-  auto lstore = [&](int buf) {
-    float *b = sm + buf * SKS_BUF;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f16x8 *>(b + (2 + 2 * wave) * SKS_TILE + (srow + 8 * i) * SKS_LD + 4 * spc) = rw[i];
-      *reinterpret_cast<f16x8 *>(b + (3 + 2 * wave) * SKS_TILE + (srow + 8 * i) * SKS_LD + 4 * spc) = rw[4 + i];
-    }
-    *reinterpret_cast<f16x8 *>(b + 0 * SKS_TILE + (arow >> 1) * SKS_LD + 4 * spc) = ra[0];
-    *reinterpret_cast<f16x8 *>(b + 1 * SKS_TILE + (arow >> 1) * SKS_LD + 4 * spc) = ra[1];
-  };
-  // kp is a multiple of 32 and >= 64: the last chunk may start 32 k early (clamped) -- its first two k-steps were then
-  // already multiplied and are skipped
-  const int nchunk = (kp + 63) / 64;
-  gload(0);
-  for (int c = 0; c < nchunk; ++c) {
-    lstore(c & 1);
-    __syncthreads();
-    if (c + 1 < nchunk) gload(64 * (c + 1));
-    const int k0 = 64 * c;
-    const int skip = k0 > kp - 64 ? (k0 - (kp - 64)) / 16 : 0;   // k-steps of this (clamped) chunk done by the previous one
-    const float *b = sm + (c & 1) * SKS_BUF;
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) {
-      if (s_ < skip) continue;
-      const int off = lrow * SKS_LD + 8 * s_ + 4 * half;
-      const f16x8 ah = *reinterpret_cast<const f16x8 *>(b + 0 * SKS_TILE + off);
-      const f16x8 al = *reinterpret_cast<const f16x8 *>(b + 1 * SKS_TILE + off);
-      const f16x8 wh = *reinterpret_cast<const f16x8 *>(b + (2 + 2 * wave) * SKS_TILE + off);
-      const f16x8 wl = *reinterpret_cast<const f16x8 *>(b + (3 + 2 * wave) * SKS_TILE + off);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, acc, 0, 0, 0);
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int r = 8 * i + (lane >> 3);
+    voff[i] = min(r, rows_left) * 4 * kp + 16 * ((lane & 7) ^ ((r >> 1) & 7));
   }
-  if (n0 >= N) return;
+  const int nchunk = (kp + 63) / 64;
+  // kp is a multiple of 32 and >= 64: the last chunk may start 32 k early (clamped) -- its first two k-steps were then
+  // already multiplied and are skipped.  Chunks past the end are issued out of bounds (no traffic, zeros into a free
+  // ring slot): every iteration issues four pieces, so one vmcnt constant tells when a chunk has landed.
+  auto issue = [&](int c) {
+    float *dst = sm + (c & (SK_RING - 1)) * SK_CHUNK + wave * SK_SLAB;
+    const int soff = 2 * min(64 * c, kp - 64);
+    const bool past = c >= nchunk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + 256 * i), 16,
+                                               past ? OOB : voff[i], soff, 0, 0);
+  };
+  // the epilogue's operands, fetched ahead of the stream (they would otherwise be a dependent round trip at the end)
   const int m = m0 + lrow;
-  if (m >= M) return;
-  const int em = ea[m];
+  const bool mok = m < M;
+  const int mc = min(m, M - 1);
+  const int em = ea[mc];
   int eo = 0;
   if (so.img) {
-    eo = out_exp(so, m);
-    if (n0 == 0 && half == 0) {
+    eo = out_exp(so, mc);
+    if (wave == 0 && mok && n0 == 0 && half == 0) {
       so.exps[m] = (signed char)eo;
       if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
     }
   }
+  int pw[4];
+  f32x4 pb[4], pr[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+  for (int q = 0; q < 4; ++q) {
+    const int n = min(n0 + 8 * q + 4 * half, N - 4);
+    pw[q] = *reinterpret_cast<const int *>(ew + n);
+    pb[q] = bias ? *reinterpret_cast<const f32x4 *>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    pr[q] = residual ? *reinterpret_cast<const f32x4 *>(residual + (size_t)mc * ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int foff[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) foff[s_] = lrow * 32 + 4 * ((2 * s_ + half) ^ ((lrow >> 1) & 7));
+#pragma unroll
+  for (int c = 0; c < SK_RING - 1; ++c) issue(c);
+  for (int c = 0; c < nchunk; ++c) {
+    // chunk c landed (this wave's pieces: all but the six chunks issued after it), then everybody's; wave 0 is done with c - 1
+    asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    issue(c + SK_RING - 1);
+    if (wave == 0) {
+      const int k0 = 64 * c;
+      const int skip = k0 > kp - 64 ? (k0 - (kp - 64)) / 16 : 0;
+      const float *b = sm + (c & (SK_RING - 1)) * SK_CHUNK;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        if (s_ < skip) continue;
+        const f16x8 ah = *reinterpret_cast<const f16x8 *>(b + 0 * SK_SLAB + foff[s_]);
+        const f16x8 al = *reinterpret_cast<const f16x8 *>(b + 1 * SK_SLAB + foff[s_]);
+        const f16x8 wh = *reinterpret_cast<const f16x8 *>(b + 2 * SK_SLAB + foff[s_]);
+        const f16x8 wl = *reinterpret_cast<const f16x8 *>(b + 3 * SK_SLAB + foff[s_]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, acc, 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the empty tail pieces: nothing may target LDS past the loop
+  if (wave != 0 || !mok) return;
+  const int a8 = act;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = n0 + 8 * q + 4 * half;       // n, N, ldc multiples of 4: a quad is whole or absent, and 16-byte aligned
     if (n < N) {
-      float v = ldexpf(acc[r], -(em + ew[n]));
-      if (bias) v += bias[n];
-      const int a8 = act;
-      v = a8 == 1 ? act_fn<1>(v) : (a8 == 2 ? act_fn<2>(v) : v);
-      if (residual) v += residual[(size_t)m * ldr + n];
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = ldexpf(acc[4 * q + j], -(em + (int)(signed char)(pw[q] >> (8 * j))));
+        if (bias) t += pb[q][j];
+        t = a8 == 1 ? act_fn<1>(t) : (a8 == 2 ? act_fn<2>(t) : t);
+        if (residual) t += pr[q][j];
+        v[j] = t;
+      }
       if (so.img) {
-        const float xs = ldexpf(v, eo);
-        const _Float16 hi = (_Float16)xs;
+        f16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xs = ldexpf(v[j], eo);
+          hi[j] = (_Float16)xs;
+          lo[j] = (_Float16)(xs - (float)hi[j]);
+        }
         _Float16 *o = so.img + (size_t)m * 2 * so.np + n;
-        o[0] = hi;
-        o[so.np] = (_Float16)(xs - (float)hi);
+        *reinterpret_cast<f16x4 *>(o) = hi;
+        *reinterpret_cast<f16x4 *>(o + so.np) = lo;
       } else {
-        C[(size_t)m * ldc + n] = v;
+        *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
       }
     }
   }
 }
 
-constexpr long long SPLIT_SKINNY_MAX_OUTPUTS = 500000;  // as gemm.hip's SK_MAX_OUTPUTS
+// crossover measured with tools/bench_skinny_crossover.py (profiles/r02_skinny_crossover.txt): the latency kernel takes
+// ~13 us (K = 768) per round of 256 workgroups, the tile stream ~50 us for any grid below one wave of tiles
+constexpr long long SPLIT_SKINNY_MAX_OUTPUTS = 1500000;
 
 }  // namespace
 }  // namespace mevi
@@ -468,9 +496,10 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
   MEVI_REQUIRE(ldc < (1LL << 20) && ldr < (1LL << 20), MEVI_ERR_UNSUPPORTED, "gemm_nt_split: row stride too large");
   const int kp = (int)mevi_split_kp(k);
   const _Float16 *A = reinterpret_cast<const _Float16 *>(a_img), *W = reinterpret_cast<const _Float16 *>(w_img);
-  static const int skinny_on = [] { const char *e = getenv("MEVI_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
-  if (m * n <= SPLIT_SKINNY_MAX_OUTPUTS && skinny_on) {
-    hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3((unsigned)((n + 127) / 128), (unsigned)((m + 31) / 32)), dim3(256), 0,
+  // MEVI_GEMM_SKINNY_MAX: the crossover in outputs (tools/bench_gemm_split.py measures it; 0 = tile stream only)
+  static const long long skinny_max = [] { const char *e = getenv("MEVI_GEMM_SKINNY_MAX"); return e ? atoll(e) : SPLIT_SKINNY_MAX_OUTPUTS; }();
+  if (m * n <= skinny_max) {
+    hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0,
                        stream, A, reinterpret_cast<const signed char *>(a_exp), (int)m, W, reinterpret_cast<const signed char *>(w_exp), (int)n, kp, c,
                        (long long)ldc, bias, residual, (long long)ldr, act, so);
     MEVI_HIP_CHECK(hipGetLastError());
