@@ -287,6 +287,43 @@ int64_t mevi_format_i64_list(const int64_t *v, int64_t n, char *out, int64_t cap
 int64_t mevi_parse_i64_list(const char *s, int64_t len, int64_t *out, int64_t cap);
 int64_t mevi_parse_f64_list(const char *s, int64_t len, double *out, int64_t cap);
 
+/* a whole ranked TSV in one call: every line's query field as (start, length) spans of `buf`, the comma lists of column
+ * col_i (integers) and col_f (floats; either -1 = absent) flat with per-line offsets seg_*[lines + 1] -- what
+ * ensemble_marco.parse / evaluate.parse build line by line with eval() (MEVI/ensemble_marco.py:92-118,
+ * MEVI/evaluate.py:91-110).  Returns the line count, or a negative status as soon as the file is not of the plain shape
+ * (the caller then parses it the reference's way). */
+int64_t mevi_parse_tsv_columns(const char *buf, int64_t len, int32_t col_q, int32_t col_i, int32_t col_f, int64_t *q_span,
+                               int64_t *seg_i, int64_t *vals_i, int64_t cap_i, int64_t *seg_f, double *vals_f,
+                               int64_t cap_f, int64_t cap_lines);
+
+/* ------------------------------------------------------------------------
+ * The consumers on the device (ensemble_marco.combine_main, MEVI/ensemble_marco.py:150-238; evaluate(), :34-82 and
+ * MEVI/evaluate.py:24-62).  Lists are flat arrays with per-query offsets seg[nq + 1].
+ *   cluster_ranks: out[e] = LAST index r with beam[q][r][:] == codes[docs[e]][:] (the dict `cr[tuple(clus)] = i` keeps the
+ *             last of a repeated cluster, :183-189), n_clusters when none matches or docs[e] == -1.  *first_bad = smallest
+ *             entry whose id has no code row (the reference raises KeyError there), ~0 when none.
+ *   ensemble_rank: per query the list dense ++ fine cut to min(n_d + n_f, 2 n_d) entries (zip with chain(cranks, cranks),
+ *             :226-232; the fine list re-uses the DENSE ranks position by position), value
+ *             v = score + term[crank], times `punish` when crank == n_clusters -- term[c] = alpha / (beta * c + 1) and
+ *             punish = 1 - gamma * alpha evaluated by the caller in host doubles, so the device does one f64 add and one
+ *             f64 multiply per entry, exactly the reference's roundings (:233-235); a document listed twice keeps its first
+ *             position and its last value (dict), ranking by descending value, ties in first-seen order (sorted() is
+ *             stable, :52-53).  out_docs[out_seg[q] ..] receives out_n[q] ids.  At most 8192 entries per query; *err != 0
+ *             when an id is outside +-2^46 or a list changed size (the caller then takes the host path).
+ *   first_hits: out[p] = first index of pair_doc[p] in list pair_row[p] (its first list_n[row] entries, or the whole
+ *             segment when list_n is NULL), -1 when absent or pair_row[p] < 0 -- the rank evaluate() looks up per gt.
+ * ---------------------------------------------------------------------- */
+int mevi_cluster_ranks_i32(const int32_t *codes, int64_t n_docs, int64_t M, const int64_t *docs, const int64_t *seg,
+                           int64_t nq, const int32_t *beam, int64_t R, int32_t n_clusters, int32_t *out_ranks,
+                           uint64_t *first_bad, void *stream);
+int mevi_ensemble_rank_f64(const int64_t *seg_dense, const int64_t *docs_dense, const double *scores_dense,
+                           const int32_t *cranks_dense, const int64_t *fine_row, const int64_t *seg_fine,
+                           const int64_t *docs_fine, const double *scores_fine, int64_t nq, int64_t max_entries,
+                           int32_t n_clusters, const double *term, double punish, const int64_t *out_seg,
+                           int64_t *out_docs, int32_t *out_n, int32_t *err, void *stream);
+int mevi_first_hits_i64(const int64_t *lists, const int64_t *seg, const int32_t *list_n, const int64_t *pair_row,
+                        const int64_t *pair_doc, int64_t n_pairs, int32_t *out_rank, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,59 @@ extern "C" int64_t mevi_parse_f64_list(const char *s, int64_t len, double *out, 
     ++p;
   }
 }
+
+// A whole ranked TSV in one call (the files evaluate.py / ensemble_marco.py read: MEVI/ensemble_marco.py:92-118 `parse`
+// eval()s one field at a time): every line's query field as a (start, length) span of `buf`, and the comma lists of up to two
+// columns -- `col_i` integers, `col_f` floats (either may be -1) -- as flat arrays with per-line offsets.  Returns the number of
+// lines, or MEVI_ERR_INVALID_ARG as soon as anything is not the plain shape (a missing column, an empty or bracketed
+// field, a token the list parsers above refuse, a carriage return, short capacities): the caller then parses that file the
+// reference's way, so odd files keep their Python meaning.
+extern "C" int64_t mevi_parse_tsv_columns(const char *buf, int64_t len, int32_t col_q, int32_t col_i, int32_t col_f,
+                                          int64_t *q_span, int64_t *seg_i, int64_t *vals_i, int64_t cap_i, int64_t *seg_f,
+                                          double *vals_f, int64_t cap_f, int64_t cap_lines) {
+  if (!buf || len < 0 || col_q < 0 || !q_span || cap_lines < 0) return MEVI_ERR_INVALID_ARG;
+  if ((col_i >= 0 && (!seg_i || !vals_i)) || (col_f >= 0 && (!seg_f || !vals_f))) return MEVI_ERR_INVALID_ARG;
+  const char *p = buf, *end = buf + len;
+  int64_t line = 0, ni = 0, nf = 0;
+  if (col_i >= 0) seg_i[0] = 0;
+  if (col_f >= 0) seg_f[0] = 0;
+  while (p < end) {
+    const char *eol = static_cast<const char *>(std::memchr(p, '\n', end - p));
+    if (!eol) eol = end;
+    if (line >= cap_lines) return MEVI_ERR_INVALID_ARG;
+    bool got_q = false, got_i = col_i < 0, got_f = col_f < 0;
+    int col = 0;
+    const char *f = p;
+    while (true) {
+      const char *tab = static_cast<const char *>(std::memchr(f, '\t', eol - f));
+      const char *fe = tab ? tab : eol;
+      if (std::memchr(f, '\r', fe - f)) return MEVI_ERR_INVALID_ARG;
+      if (col == col_q) {
+        q_span[2 * line] = f - buf;
+        q_span[2 * line + 1] = fe - f;
+        got_q = true;
+      }
+      if (col == col_i) {
+        const int64_t n = fe > f ? mevi_parse_i64_list(f, fe - f, vals_i + ni, cap_i - ni) : -1;
+        if (n < 0) return MEVI_ERR_INVALID_ARG;
+        ni += n;
+        got_i = true;
+      }
+      if (col == col_f) {
+        const int64_t n = fe > f ? mevi_parse_f64_list(f, fe - f, vals_f + nf, cap_f - nf) : -1;
+        if (n < 0) return MEVI_ERR_INVALID_ARG;
+        nf += n;
+        got_f = true;
+      }
+      ++col;
+      if (!tab) break;
+      f = tab + 1;
+    }
+    if (!got_q || !got_i || !got_f) return MEVI_ERR_INVALID_ARG;
+    ++line;
+    if (col_i >= 0) seg_i[line] = ni;
+    if (col_f >= 0) seg_f[line] = nf;
+    p = eol < end ? eol + 1 : end;
+  }
+  return line;
+}

@@ -77,6 +77,14 @@ _SIGNATURES = {
     "mevi_format_i64_list": (c_int64, [c_void_p, c_int64, c_void_p, c_int64]),
     "mevi_parse_i64_list": (c_int64, [ctypes.c_char_p, c_int64, c_void_p, c_int64]),
     "mevi_parse_f64_list": (c_int64, [ctypes.c_char_p, c_int64, c_void_p, c_int64]),
+    "mevi_parse_tsv_columns": (c_int64, [ctypes.c_char_p, c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void_p,
+                                         c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
+    "mevi_cluster_ranks_i32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                       ctypes.c_int32, c_void_p, c_void_p, c_void_p]),
+    "mevi_ensemble_rank_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_int64, ctypes.c_int32, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
+    "mevi_first_hits_i64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mevi_ip_topk_set_growth": (None, [c_double]),
     "mevi_ip_topk_set_profiling": (None, [c_int]),
     "mevi_ip_topk_get_stats": (None, [ctypes.POINTER(IpTopkStats)]),

@@ -72,6 +72,11 @@ def resolve(path, dir_path, must_exist=True):
 def evaluate_main(dir_path, gt_file, ance_file, recall_num, ofile=None):
     cutoffs = [int(r) for r in recall_num.split(",")]
     gts, _, _ = mio.load_parsed(resolve(gt_file, dir_path), GT_TEMPLATE)
+    from . import consumers
+
+    fast = consumers.evaluate_main(gts, resolve(ance_file, dir_path), cutoffs, ofile)      # flat arrays + device look-up
+    if fast is not None:
+        return fast
     preds, _, _ = mio.load_parsed(resolve(ance_file, dir_path), RANKED_TEMPLATE)
     if ofile is not None:
         open(ofile, "w").close()
@@ -221,13 +226,20 @@ def ensemble_main(dir_path, gt_file, ance_file, fine_file, coarse_file, mapping_
     alphas, betas, gammas = ([float(x) for x in v.split(",")] for v in (alphas, betas, gammas))
     cutoffs = [int(x) for x in recall_num.split(",")]
     gts, _, _ = mio.load_parsed(resolve(gt_file, dir_path), GT_TEMPLATE)
-    dense_p, dense_s, _ = mio.load_parsed(resolve(ance_file, dir_path), RANKED_TEMPLATE)
+    ance_path = resolve(ance_file, dir_path)
     fine_path = resolve(fine_file, dir_path, must_exist=False)
     have_fine = fine_path is not None and os.path.exists(fine_path)
-    if have_fine:
-        fine_p, fine_s, _ = mio.load_parsed(fine_path, RANKED_TEMPLATE)
     _, _, clusters = mio.load_parsed(resolve(coarse_file, dir_path), COARSE_TEMPLATE)
     mapping = load_mapping(mapping_file)
+    from . import consumers
+
+    fast = consumers.ensemble_main(gts, ance_path, fine_path if have_fine else None, clusters, mapping, alphas, betas, gammas,
+                                   cutoffs, ofile)            # the big lists as flat arrays, the arithmetic on the device
+    if fast is not None:
+        return fast
+    dense_p, dense_s, _ = mio.load_parsed(ance_path, RANKED_TEMPLATE)
+    if have_fine:
+        fine_p, fine_s, _ = mio.load_parsed(fine_path, RANKED_TEMPLATE)
     cranks, n_clusters = cluster_ranks(dense_p, clusters, mapping)
     if ofile is not None:
         open(ofile, "w").close()

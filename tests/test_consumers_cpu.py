@@ -172,3 +172,46 @@ def test_numpy_ensemble_equals_the_reference_loop():
                 combined[p] = v
             want = [p for p, _ in sorted(combined.items(), key=lambda kv: -kv[1])]
             assert metrics.ensemble_scores(dense_p, dense_s, cr, fp, fs, ncl, a, b, g) == want
+
+
+def test_whole_file_parser_equals_the_field_parser(tmp_path):
+    """consumers.parse_ranked (one native pass: mevi_parse_tsv_columns) gives the lists io.parse_file gives, and declines
+    (None) whatever is not the plain shape, so those files keep their Python meaning."""
+    from mevi_amd import consumers, io as mio, metrics
+
+    rng = np.random.default_rng(0)
+    p = tmp_path / "ranked.tsv"
+    lines = []
+    for i in range(50):
+        n = int(rng.integers(1, 400))
+        ids = rng.integers(-1, 10 ** 7, n)
+        sc = (rng.normal(size=n) * 10.0 ** rng.integers(-8, 8, n)).astype(np.float32).astype(np.float64)
+        if i == 3:
+            sc[:4] = [np.inf, -np.inf, -0.0, 1e-05]
+        lines.append(f"query number {i} ?\t\t{','.join(map(str, ids.tolist()))}\t{','.join(str(x) for x in sc.tolist())}")
+    p.write_text("\n".join(lines))                                   # no newline at the end
+    want_p, want_s, _ = mio.parse_file(str(p), metrics.RANKED_TEMPLATE)
+    got = consumers.parse_ranked(str(p), metrics.RANKED_TEMPLATE)
+    assert got is not None and got.queries == list(want_p)
+    for i, q in enumerate(got.queries):
+        a, b = got.seg[i], got.seg[i + 1]
+        assert got.docs[a:b].tolist() == want_p[q]
+        assert [x.hex() for x in got.scores[a:b].tolist()] == [float(x).hex() for x in want_s[q]]
+    ids_only = consumers.parse_ranked(str(p), {"query": 0, "pred": 2})
+    assert ids_only.scores is None and np.array_equal(ids_only.docs, got.docs)
+    p.write_text("\n".join(lines) + "\n")
+    assert np.array_equal(consumers.parse_ranked(str(p), metrics.RANKED_TEMPLATE).docs, got.docs)
+
+    def declined(text):
+        p.write_text(text)
+        return consumers.parse_ranked(str(p), metrics.RANKED_TEMPLATE) is None
+
+    assert declined("q\t\t[1,2]\t0.5,0.25\n")             # bracketed list
+    assert declined("q\t\t1,2\t0.5,0.25\nq\t\t3\t1.0\n")  # the same query twice
+    assert declined("q\t\t1,2\t0.5\n")                    # ids and scores differ in number
+    assert declined("q\t\t1,2\t0.5,0.25\r\n")             # carriage return
+    assert declined("q\t\t1,2\n")                         # a column short
+    assert declined("q\t\t\t\n")                          # empty fields
+    assert declined("q\t\t1,x\t0.5,0.25\n")               # not a number
+    assert declined("q\t\t1,2\t0.5,0.25\n\n")             # an empty line
+    assert declined("q\t\t1.5,2\t0.5,0.25\n")             # ids that are not integers

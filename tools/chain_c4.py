@@ -77,33 +77,40 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
     total = sum(stages.values())
     reuse = total - stages["tower_again"]
 
-    # ---- metrics as marco_ensemble.sh computes them (host side) --------------------------------------------------------
-    t0 = time.perf_counter()
-    di_h, ds_h = di.cpu().numpy(), ds.cpu().numpy()
-    gts, dense_p, dense_s, fine_p, fine_s, clusters = {}, {}, {}, {}, {}, {}
+    # ---- metrics as marco_ensemble.sh computes them: ensemble_marco.py's cluster ranks, combination, ranking and gt look-up
+    # on the device (mevi_amd/consumers.py; the lists of a live chain are already arrays), Recall / MRR accumulated by the
+    # same host code as the scripts use ------------------------------------------------------------------------------------
+    import contextlib
+    import io
+
+    from mevi_amd import consumers
+
+    di_h = di.cpu().numpy()
+    gts = {}
     for i in range(nq):
-        q = f"q{i}"
         gt = [int(planted[i])]
         fd = ranked[i][0]
         if i % 2 == 0 and len(fd):                  # a second relevant document that only the seq2seq arm can reach
             gt.append(int(fd[min(len(fd) - 1, int(rng.geometric(0.3)) - 1)]))
-        gts[q] = gt
-        dense_p[q], dense_s[q] = di_h[i].tolist(), ds_h[i].astype(np.float64).tolist()
-        fine_p[q], fine_s[q] = fd.tolist(), ranked[i][1].astype(np.float64).tolist()
-        clusters[q] = bcodes[i].tolist()
-
-    import contextlib
-    import io
-
+        gts[f"q{i}"] = gt
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    qs = list(gts)
+    fseg = np.concatenate([[0], np.cumsum([len(r[0]) for r in ranked])]).astype(np.int64)
+    fdocs = np.concatenate([np.asarray(r[0], np.int64) for r in ranked])
+    fsc = np.concatenate([np.asarray(r[1], np.float64) for r in ranked])
+    inp = consumers.EnsembleInputs(qs, torch.arange(nq + 1, device=dev) * topk, di.reshape(-1), ds.reshape(-1).double(),
+                                   bcodes, codes_h, (qs, np.arange(nq, dtype=np.int64), fseg, fdocs, fsc))
+    pairs = consumers._gt_pairs(gts, inp.row, missing_ok=False)
     sink = io.StringIO() if quiet else None
     with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
-        cranks, n_clusters = metrics.cluster_ranks(dense_p, clusters, metrics.ArrayMapping(codes_h))   # rqmapping as main.py's array sidecar
-        res = {"dense": metrics.evaluate_ranked("ANCE Pred", [10, 50, 1000], gts, dense_p),
-               "fine": metrics.evaluate_ranked("Fine Pred", [10, 50, 1000], gts, fine_p)}
-        ens = {q: metrics.ensemble_scores(dense_p[q], dense_s[q], cranks[q], fine_p[q], fine_s[q], n_clusters, 0.6, 0.03, 0.02)
-               for q in gts}
-        res["ensemble"] = metrics.evaluate_ranked("score + 0.6 / (0.03 * crank + 1); punishment (1 - 0.02 * 0.6)",
-                                                  [10, 50, 1000], gts, ens)
+        cr = inp.ranks()
+        out_docs, out_n = inp.ensemble(cr, 0.6, 0.03, 0.02)
+        res = {"dense": consumers.evaluate_lists("ANCE Pred", [10, 50, 1000], gts, pairs, inp.docs_d, inp.seg_d, None),
+               "fine": consumers.evaluate_lists("Fine Pred", [10, 50, 1000], gts, pairs, inp.fine[2], inp.fine[1], None),
+               "ensemble": consumers.evaluate_lists("score + 0.6 / (0.03 * crank + 1); punishment (1 - 0.02 * 0.6)",
+                                                    [10, 50, 1000], gts, pairs, out_docs, inp.out_seg, out_n)}
+    torch.cuda.synchronize()
     t_ens = time.perf_counter() - t0
     planted_top1 = float((di_h[:, 0] == planted).mean())
     return {
@@ -113,10 +120,11 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
         "ms": {k_: round(v * 1e3, 2) for k_, v in stages.items()},
         "chain_ms": round(total * 1e3, 2), "queries_per_s": round(nq / total, 1),
         "queries_per_s_reusing_query_embeddings": round(nq / reuse, 1),
-        "ensemble_host_ms": round(t_ens * 1e3, 1),
-        "queries_per_s_incl_ensemble_host": round(nq / (total + t_ens), 1),
-        "ensemble_note": "ensemble_marco.py's combination + metrics over 6980 x (1000 dense + fine) entries on the host "
-                         "(mevi_amd.metrics with the mapping in its array form; lists already in memory, no TSV parsing)",
+        "ensemble_ms": round(t_ens * 1e3, 1),
+        "queries_per_s_incl_ensemble": round(nq / (total + t_ens), 1),
+        "ensemble_note": "ensemble_marco.py's cluster ranks + combination + ranking + Recall/MRR of three lists over 6980 x "
+                         "(1000 dense + fine) entries: arithmetic on the device (csrc/consumers.hip), accumulation by the scripts' "
+                         "own host code; includes uploading the RQ mapping (N x M i32) and flattening the fine lists; no TSV parsing",
         "setup_untimed_ms": {"rq_encode_corpus": round(t_rq * 1e3, 1), "dense_index_build": round(t_index * 1e3, 1)},
         "fine_candidates_per_query": float(ndoc.mean()), "fine_candidates_max": int(ndoc.max()),
         "mrr10": {k_: v[1][10] for k_, v in res.items()}, "recall1000": {k_: v[0][1000] for k_, v in res.items()},
