@@ -289,7 +289,7 @@ int64_t mevi_parse_f64_list(const char *s, int64_t len, double *out, int64_t cap
 
 /* a whole ranked TSV in one call: every line's query field as (start, length) spans of `buf`, the comma lists of column
  * col_i (integers) and col_f (floats; either -1 = absent) flat with per-line offsets seg_*[lines + 1] -- what
- * ensemble_marco.parse / evaluate.parse build line by line with eval() (MEVI/ensemble_marco.py:92-118,
+ * ensemble_marco.parse / evaluate.parse build line by line with eval() (MEVI/ensemble_marco.py:92-111,
  * MEVI/evaluate.py:91-110).  Returns the line count, or a negative status as soon as the file is not of the plain shape
  * (the caller then parses it the reference's way). */
 int64_t mevi_parse_tsv_columns(const char *buf, int64_t len, int32_t col_q, int32_t col_i, int32_t col_f, int64_t *q_span,
@@ -297,8 +297,8 @@ int64_t mevi_parse_tsv_columns(const char *buf, int64_t len, int32_t col_q, int3
                                int64_t cap_f, int64_t cap_lines);
 
 /* ------------------------------------------------------------------------
- * The consumers on the device (ensemble_marco.combine_main, MEVI/ensemble_marco.py:150-238; evaluate(), :34-82 and
- * MEVI/evaluate.py:24-62).  Lists are flat arrays with per-query offsets seg[nq + 1].
+ * The consumers on the device (ensemble_marco.combine_main, MEVI/ensemble_marco.py:150-238; evaluate(), :28-73 and
+ * MEVI/evaluate.py:27-72).  Lists are flat arrays with per-query offsets seg[nq + 1].
  *   cluster_ranks: out[e] = LAST index r with beam[q][r][:] == codes[docs[e]][:] (the dict `cr[tuple(clus)] = i` keeps the
  *             last of a repeated cluster, :183-189), n_clusters when none matches or docs[e] == -1.  *first_bad = smallest
  *             entry whose id has no code row (the reference raises KeyError there), ~0 when none.
@@ -308,7 +308,7 @@ int64_t mevi_parse_tsv_columns(const char *buf, int64_t len, int32_t col_q, int3
  *             punish = 1 - gamma * alpha evaluated by the caller in host doubles, so the device does one f64 add and one
  *             f64 multiply per entry, exactly the reference's roundings (:233-235); a document listed twice keeps its first
  *             position and its last value (dict), ranking by descending value, ties in first-seen order (sorted() is
- *             stable, :52-53).  out_docs[out_seg[q] ..] receives out_n[q] ids.  At most 8192 entries per query; *err != 0
+ *             stable, :38-39).  out_docs[out_seg[q] ..] receives out_n[q] ids.  At most 8192 entries per query; *err != 0
  *             when an id is outside +-2^46 or a list changed size (the caller then takes the host path).
  *   first_hits: out[p] = first index of pair_doc[p] in list pair_row[p] (its first list_n[row] entries, or the whole
  *             segment when list_n is NULL), -1 when absent or pair_row[p] < 0 -- the rank evaluate() looks up per gt.

@@ -1,4 +1,4 @@
-"""evaluate.py / ensemble_marco.py on flat arrays and the device (MEVI/evaluate.py:24-157, MEVI/ensemble_marco.py:34-238).
+"""evaluate.py / ensemble_marco.py on flat arrays and the device (MEVI/evaluate.py:27-157, MEVI/ensemble_marco.py:28-238).
 
 The reference's consumers eval() every TSV field into dicts of Python lists and then walk them: at MS MARCO size
 (6980 queries x 1000 dense + fine entries) that is 14 M numbers and 14 M dict operations per (alpha, beta, gamma) point --

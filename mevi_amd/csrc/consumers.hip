@@ -1,6 +1,6 @@
 // The consumers' arithmetic on the device: ensemble_marco.py's cluster ranks + score combination + ranking
-// (MEVI/ensemble_marco.py:174-238) and the first-hit ranks evaluate() turns into Recall / MRR (MEVI/evaluate.py:24-62,
-// ensemble_marco.py:34-82).  The reference walks Python dicts: at MS MARCO size that is 6980 queries x (1000 dense +
+// (MEVI/ensemble_marco.py:174-238) and the first-hit ranks evaluate() turns into Recall / MRR (MEVI/evaluate.py:27-42,
+// ensemble_marco.py:28-43).  The reference walks Python dicts: at MS MARCO size that is 6980 queries x (1000 dense +
 // fine) entries = 14 M dict operations per (alpha, beta, gamma) point -- seconds, against 0.1 s for the search that
 // produced the lists.  Here one workgroup takes one query and everything stays in LDS.
 //

@@ -144,7 +144,7 @@ extern "C" int64_t mevi_parse_f64_list(const char *s, int64_t len, double *out, 
   }
 }
 
-// A whole ranked TSV in one call (the files evaluate.py / ensemble_marco.py read: MEVI/ensemble_marco.py:92-118 `parse`
+// A whole ranked TSV in one call (the files evaluate.py / ensemble_marco.py read: MEVI/ensemble_marco.py:92-111 `parse_file`
 // eval()s one field at a time): every line's query field as a (start, length) span of `buf`, and the comma lists of up to two
 // columns -- `col_i` integers, `col_f` floats (either may be -1) -- as flat arrays with per-line offsets.  Returns the number of
 // lines, or MEVI_ERR_INVALID_ARG as soon as anything is not the plain shape (a missing column, an empty or bracketed

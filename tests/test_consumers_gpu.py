@@ -95,7 +95,7 @@ def test_ensemble_on_the_device_equals_the_dict_loop(cuda, nq, k, fine_max, with
 
 
 def _dict_loop(dense_p, dense_s, cranks, fine_p, fine_s, n_clusters, alpha, beta, gamma):
-    """ensemble_marco.py:222-238 + evaluate()'s sort (:52-53), literally."""
+    """ensemble_marco.py:222-238 + evaluate()'s sort (:38-39), literally."""
     from itertools import chain
 
     docs, scores, ranks = dense_p, dense_s, cranks
