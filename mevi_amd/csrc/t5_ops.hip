@@ -561,24 +561,170 @@ __global__ __launch_bounds__(256) void attention_group_kernel(AttnArgs a) {
 
 // Whole-sequence self-attention on the f32 matrix cores, for 64 < tk = tq <= 128 and 64-wide heads (the
 // 128-token passages of gen_doc_embedding): one (batch, head) per workgroup, wave w owns query rows
-// 32w .. 32w+31.  Scores = Q.K^T and context = P.V run as v_mfma_f32_32x32x2_f32 chains (exact f32 products,
-// accumulated in k order: the same fmaf chain over d, then over the keys, as the scalar kernels above -- which
-// spent 44 % of the passage tower's time at 2.8 TFLOP/s).  The softmax works on the wave's own 32 rows in
-// LDS: two lanes per row, 64 keys each.  LDS: Q, K [128][65] and V [128][64] staged once (odd row stride:
-// conflict-free operand reads), P [128][129] re-uses the Q|K region once every wave holds its scores.
-constexpr int AM_S = 128, AM_D = 64, AM_LQ = AM_D + 1, AM_LP = AM_S + 1;
-constexpr size_t AM_LDS = (size_t)(2 * AM_S * AM_LQ + AM_S * AM_D) * sizeof(float);
-static_assert((size_t)AM_S * AM_LP <= (size_t)2 * AM_S * AM_LQ, "P must fit over Q|K");
+// 32w .. 32w+31.  Scores and context run as v_mfma_f32_32x32x2_f32 chains (exact f32 products, the scalar kernels
+// above spent 44 % of the passage tower's time at 2.8 TFLOP/s).
+//
+// Both products are computed TRANSPOSED so that the probabilities never leave the registers:
+//   S^T = K . Q^T   (A = K from LDS, B = the wave's Q rows from registers): a lane holds ONE query (lane & 31) and the
+//                    keys 32n + (r&3) + 8(r>>2) + 4*half of it -- half of the row, the other half in lane ^ 32;
+//   softmax         in registers: 64 values per lane, one cross-half exchange for the maximum, one for the sum;
+//   O^T = V^T . P^T (A = V^T from LDS, B = P^T): the B operand wants, per step, one key from the lanes of half 0 and one
+//                    from half 1 -- any pairing the A operand follows, so the step (n, r) takes exactly the two keys
+//                    the lanes already hold in sc[n][r] (keys k0 and k0 + 4) and reads V rows k0 | k0 + 4 for them.
+// The first version wrote the scores to LDS ([128][129] over Q|K), ran the softmax there and read P back as the A operand:
+// 99 KiB of LDS = one workgroup per CU, three passes over LDS per probability, 795 us per call for 512 passages x 12 heads
+// (32 TFLOP/s).  Now LDS holds K and V, [128][64] each (64 KiB: two workgroups per CU), Q passes through the V region on its
+// way to the registers (row-contiguous global loads; fragments straight from global memory are 32 rows x 16 B per
+// instruction and took half the kernel), the output goes through the K region for row-contiguous stores.
+// Summation order per output (fixed, so a passage has the same bits in any batch and in the packed / padded layouts):
+// scores over d in pairs (2j, 2j+1); row sum over the lane's registers in (n, r) order, then the other half; context over
+// the key pairs (k0, k0 + 4) in (n, r) order.
+constexpr int AM_S = 128, AM_D = 64;
+constexpr size_t AM_LDS = (size_t)(2 * AM_S * AM_D + AM_S) * sizeof(float);
 typedef float am_f32x16 __attribute__((ext_vector_type(16)));
+// K, the Q rows on their way to the registers and the output staging are [rows][64] floats with the 16-byte chunk index
+// XORed by the row (row & 15): the 16 lanes a ds_read_b128 serves per cycle read one chunk column of 16 consecutive rows
+// from 16 different chunks = all 64 banks
+__device__ __forceinline__ int am_sw4(int row, int c4) { return row * AM_D + 4 * (c4 ^ (row & 15)); }
 
-__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
+// NB = number of 32-key blocks that hold real keys (compile-time: a block test per MFMA put a branch and a full LDS wait
+// in front of every one of them)
+template <int NB>
+__device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, const float *sv, const float *smask, float *so,
+                                        const float (&qf)[AM_D / 2], int w, int h, int tk, int tq, float *og) {
+  const int lane = threadIdx.x & 63, lrow = lane & 31, half = lane >> 5;
+  const int qi = 32 * w + lrow;
+  am_f32x16 sc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[n][r] = 0.f;
+  // S^T = K . Q^T: the lanes of half 0 / 1 supply head dims [0, 32) / [32, 64), step j = dims (j, 32 + j)
+  const bool active = 32 * w < tq;    // wave-uniform
+#pragma unroll
+  for (int j4 = 0; j4 < (active ? AM_D / 8 : 0); ++j4) {
+    float4 kf[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) kf[n] = *reinterpret_cast<const float4 *>(sk + am_sw4(32 * n + lrow, 8 * half + j4));
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      sc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[n].x, qf[4 * j4], sc[n], 0, 0, 0);
+      sc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[n].y, qf[4 * j4 + 1], sc[n], 0, 0, 0);
+      sc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[n].z, qf[4 * j4 + 2], sc[n], 0, 0, 0);
+      sc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[n].w, qf[4 * j4 + 3], sc[n], 0, 0, 0);
+    }
+  }
+  __syncthreads();       // every wave is done with K: the output staging may overwrite it
+  if (!active) return;   // no workgroup barrier below
+  // scores + bias + masks (C/D map: col = lane & 31 = query, row = (r&3) + 8*(r>>2) + 4*half = key inside block n).
+  // The bias values are fetched by unconditional loads (indices clamped), all of them in flight together: a load under a
+  // per-element condition is a branch + a full wait each -- 64 dependent round trips per lane.
+  const int qpos = a.q_pos0 + qi;
+  float badd[NB][16];
+  if (a.bias) {
+    const int qrow = qpos < a.bias_rows ? qpos : a.bias_rows - 1;
+    const float *brow = a.bias + ((size_t)h * a.bias_rows + qrow) * a.bias_ld;
+    if ((a.bias_ld & 3) == 0 && a.bias_ld >= AM_S && ((uintptr_t)a.bias & 15) == 0) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 x = *reinterpret_cast<const float4 *>(brow + 32 * n + 8 * g + 4 * half);
+          badd[n][4 * g] = x.x; badd[n][4 * g + 1] = x.y; badd[n][4 * g + 2] = x.z; badd[n][4 * g + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * half;
+          badd[n][r] = brow[key < a.bias_ld ? key : a.bias_ld - 1];
+        }
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) badd[n][r] = 0.f;
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 mk = *reinterpret_cast<const float4 *>(smask + 32 * n + 8 * g + 4 * half);  // 0 | -1e9 (masked key, padded layout)
+      const float mk4[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e, key = 32 * n + 8 * g + 4 * half + e;
+        float add = mk4[e];
+        if (a.bias) add += badd[n][r];
+        add += (a.causal && key > qpos) ? -1e9f : 0.f;
+        const float v = key < tk ? sc[n][r] + add : -INFINITY;
+        sc[n][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = expf(sc[n][r] - m);
+      sc[n][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32);
+  // O^T = V^T . P^T: step (n, r) = keys (k0, k0 + 4), k0 = 32n + (r&3) + 8(r>>2) -- the two keys the lanes hold in sc[n][r]
+  am_f32x16 o[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+  const float *va = sv + 4 * half * AM_D + lrow;
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float vf[4][2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) vf[e][c] = va[(32 * n + 8 * g + e) * AM_D + 32 * c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = sc[n][4 * g + e] / sum;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e][c], p, o[c], 0, 0, 0);
+      }
+    }
+  // O^T: col = lane & 31 = query, row = head dim -> through the wave's own rows of the K region, then whole rows out
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4 *>(so + am_sw4(lrow, 8 * c + 2 * g + half)) =
+          make_float4(o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int nrow = tq - 32 * w < 32 ? tq - 32 * w : 32;
+  const int sub = lane >> 4, c4 = lane & 15;   // four rows per pass, 16 lanes x 16 B each
+  for (int r4 = 0; r4 < nrow; r4 += 4) {
+    const int rr = r4 + sub;
+    if (rr < nrow)
+      *reinterpret_cast<float4 *>(og + (size_t)(32 * w + rr) * a.o_ts + 4 * c4) = *reinterpret_cast<const float4 *>(so + am_sw4(rr, c4));
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float *sq = sm;                     // [128][65]
-  float *sk = sq + AM_S * AM_LQ;      // [128][65]
-  float *sv = sk + AM_S * AM_LQ;      // [128][64]
-  float *sp = sm;                     // [128][129], after the scores are in registers
+  float *sk = sm;                     // [128][64], chunk-swizzled
+  float *sv = sk + AM_S * AM_D;       // [128][64]; holds Q (chunk-swizzled) until the waves have their fragments
+  float *smask = sv + AM_S * AM_D;    // [128] additive key mask
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lrow = lane & 31, half = lane >> 5;
   // padded layout: sequence b = rows [b][0 .. tk) with a key mask; packed layout (seq_off): rows seq_off[b] ..
   // seq_off[b+1]-1, every key real -- only the blocks that hold real rows / keys are computed then, and since the
@@ -591,97 +737,46 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
   const float *kg = a.k + (a.seq_off ? (size_t)r0 * a.k_ts : (size_t)b * a.k_bs) + (size_t)h * AM_D;
   const float *vg = a.v + (a.seq_off ? (size_t)r0 * a.v_ts : (size_t)b * a.v_bs) + (size_t)h * AM_D;
   float *og = a.out + (a.seq_off ? (size_t)r0 * a.o_ts : (size_t)b * a.o_bs) + (size_t)h * AM_D;
-  for (int i = t; i < AM_S * (AM_D / 4); i += 256) {  // rows past tk are zero
-    const int r = i >> 4, c4 = (i & 15) * 4;
-    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
-    if (r < tk) {
-      q4 = *reinterpret_cast<const float4 *>(qg + (size_t)r * a.q_ts + c4);
-      k4 = *reinterpret_cast<const float4 *>(kg + (size_t)r * a.k_ts + c4);
-      v4 = *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + c4);
+  if (t < AM_S) smask[t] = (key_mask && t < tk && key_mask[(size_t)b * tk + t] == 0) ? -1e9f : 0.f;
+  // all three operands with row-contiguous loads (16 lanes per 256-byte row); V waits in registers while Q uses its region
+  float4 v4[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = t + 256 * it, r = i >> 4, c4 = i & 15;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4;
+    v4[it] = q4;
+    if (r < tk) {  // rows past tk are zero
+      q4 = *reinterpret_cast<const float4 *>(qg + (size_t)r * a.q_ts + 4 * c4);
+      k4 = *reinterpret_cast<const float4 *>(kg + (size_t)r * a.k_ts + 4 * c4);
+      v4[it] = *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + 4 * c4);
     }
-    float *dq = sq + r * AM_LQ + c4, *dk = sk + r * AM_LQ + c4;
-    dq[0] = q4.x * a.scale; dq[1] = q4.y * a.scale; dq[2] = q4.z * a.scale; dq[3] = q4.w * a.scale;
-    dk[0] = k4.x; dk[1] = k4.y; dk[2] = k4.z; dk[3] = k4.w;
-    *reinterpret_cast<float4 *>(sv + r * AM_D + c4) = v4;
+    *reinterpret_cast<float4 *>(sk + am_sw4(r, c4)) = k4;
+    *reinterpret_cast<float4 *>(sv + am_sw4(r, c4)) = make_float4(q4.x * a.scale, q4.y * a.scale, q4.z * a.scale, q4.w * a.scale);
   }
   __syncthreads();
-  const bool active = 32 * w < tq;  // wave-uniform
-  am_f32x16 sc[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sc[n][r] = 0.f;
-  if (active) {
-    const float *qa = sq + (32 * w + lrow) * AM_LQ + half;
-    const float *kb = sk + lrow * AM_LQ + half;
-#pragma unroll 4
-    for (int j = 0; j < AM_D / 2; ++j) {
-      const float av = qa[2 * j];
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-        if (32 * n < tk) sc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, kb[32 * n * AM_LQ + 2 * j], sc[n], 0, 0, 0);
-    }
-  }
-  __syncthreads();  // every wave is done with Q and K: P may overwrite them
-  if (!active) return;  // no workgroup barrier below
-  // scores + bias + masks -> P rows of this wave (C/D map: col = lane&31 = key, row = (r&3) + 8*(r>>2) + 4*half)
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const int key = 32 * n + lrow;
-    if (key < tk) {
-      const float madd = (key_mask && key_mask[(size_t)b * tk + key] == 0) ? -1e9f : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (qi < tq) {
-          const int qpos = a.q_pos0 + qi;
-          float add = madd;
-          if (a.bias) add += a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + key];
-          if (a.causal && key > qpos) add += -1e9f;
-          sp[qi * AM_LP + key] = sc[n][r] + add;
-        }
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();  // LDS is in order within a wave; the rows are this wave's own
-  {  // softmax: lane (row = 32w + lrow, keys [64*half, 64*half + 64))
-    float *pr = sp + (32 * w + lrow) * AM_LP + 64 * half;
-    const int nk = tk - 64 * half < 0 ? 0 : (tk - 64 * half > 64 ? 64 : tk - 64 * half);
-    float m = -INFINITY;
-    for (int j = 0; j < nk; ++j) m = fmaxf(m, pr[j]);
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float sum = 0.f;
-    for (int j = 0; j < nk; ++j) {
-      const float e = expf(pr[j] - m);
-      pr[j] = e;
-      sum += e;
-    }
-    sum += __shfl_xor(sum, 32);
-    for (int j = 0; j < 64; ++j) pr[j] = j < nk ? pr[j] / sum : 0.f;  // padded keys: p = 0 (their V rows are 0 too)
-  }
-  __builtin_amdgcn_wave_barrier();
-  am_f32x16 o[2];
-#pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+  float qf[AM_D / 2];                 // the lane's Q fragments: qf[j] = scale * Q[qi][32 half + j]
   {
-    const float *pa = sp + (32 * w + lrow) * AM_LP + half;
-    const float *vb = sv + half * AM_D + lrow;
-    const int nsteps = (tk + 1) / 2;
-    for (int j = 0; j < nsteps; ++j) {
-      const float av = pa[2 * j];
+    const int qi = 32 * w + lrow;
 #pragma unroll
-      for (int n = 0; n < 2; ++n) o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, vb[2 * j * AM_D + 32 * n], o[n], 0, 0, 0);
+    for (int j4 = 0; j4 < AM_D / 8; ++j4) {
+      const float4 x = *reinterpret_cast<const float4 *>(sv + am_sw4(qi, 8 * half + j4));
+      qf[4 * j4] = x.x; qf[4 * j4 + 1] = x.y; qf[4 * j4 + 2] = x.z; qf[4 * j4 + 3] = x.w;
     }
   }
+  __syncthreads();
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (qi < tq) og[(size_t)qi * a.o_ts + 32 * n + lrow] = o[n][r];
-    }
+  for (int it = 0; it < 8; ++it) {
+    const int i = t + 256 * it, r = i >> 4, c4 = i & 15;
+    *reinterpret_cast<float4 *>(sv + r * AM_D + 4 * c4) = v4[it];
+  }
+  __syncthreads();
+  float *so = sm + w * 32 * AM_D;
+  switch ((tk + 31) / 32) {
+    case 1: am_wave<1>(a, sk, sv, smask, so, qf, w, h, tk, tq, og); break;
+    case 2: am_wave<2>(a, sk, sv, smask, so, qf, w, h, tk, tq, og); break;
+    case 3: am_wave<3>(a, sk, sv, smask, so, qf, w, h, tk, tq, og); break;
+    default: am_wave<4>(a, sk, sv, smask, so, qf, w, h, tk, tq, og); break;
+  }
 }
 
 // logits[row, c] = sum_d s[row, d] * (T[trow, c*dim + d] + E[c, d]); one wave per (row, c); trow = row, or
