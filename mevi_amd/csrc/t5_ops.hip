@@ -375,8 +375,23 @@ __global__ __launch_bounds__(256) void attention_varlen_short_kernel(AttnArgs a,
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // the bias values of a row pair are fetched one pair ahead by unconditional loads (lane clamped to a real key): a load
+  // under `lane < tk` right before its use is a branch + a full memory wait in every iteration
+  const int blane = lane < tk ? lane : tk - 1;
+  const float *bias_h = a.bias ? a.bias + (size_t)h * a.bias_rows * a.bias_ld + blane : nullptr;
+  float nb_a = 0.f, nb_b = 0.f;
+  if (a.bias) {
+    nb_a = bias_h[0];
+    nb_b = bias_h[(size_t)(1 < tk ? 1 : 0) * a.bias_ld];
+  }
   for (int tq = 0; tq < tk; tq += 2) {
     const int t1 = tq + 1 < tk ? tq + 1 : tq;         // odd length: the last pair repeats a row
+    const float bias_a = nb_a, bias_b = nb_b;
+    if (a.bias) {
+      const int n0 = tq + 2 < tk ? tq + 2 : tk - 1, n1 = tq + 3 < tk ? tq + 3 : tk - 1;
+      nb_a = bias_h[(size_t)n0 * a.bias_ld];
+      nb_b = bias_h[(size_t)n1 * a.bias_ld];
+    }
     const float4 *qa = reinterpret_cast<const float4 *>(sq + tq * DH);
     const float4 *qb = reinterpret_cast<const float4 *>(sq + t1 * DH);
     float acc_a = 0.f, acc_b = 0.f;
@@ -393,10 +408,7 @@ __global__ __launch_bounds__(256) void attention_varlen_short_kernel(AttnArgs a,
     for (int i = 0; i < ATT_KPL; ++i) sa[i] = sb[i] = -INFINITY;
     if (lane < tk) {
       float add_a = 0.f, add_b = 0.f;
-      if (a.bias) {
-        add_a = a.bias[((size_t)h * a.bias_rows + tq) * a.bias_ld + lane];
-        add_b = a.bias[((size_t)h * a.bias_rows + t1) * a.bias_ld + lane];
-      }
+      if (a.bias) add_a = bias_a, add_b = bias_b;
       if (a.causal && lane > tq) add_a += -1e9f;
       if (a.causal && lane > t1) add_b += -1e9f;
       sa[0] = acc_a + add_a;

@@ -34,7 +34,8 @@ def _image_value(s):
 
 
 @pytest.mark.parametrize("M,N,K", [(3000, 768, 768), (517, 100, 36), (256, 96, 32), (1030, 2304, 768), (7, 3072, 768),
-                                   (70000, 256, 64), (300, 36, 64), (1, 768, 3072), (2100, 260, 2048)])
+                                   (70000, 256, 64), (300, 36, 64), (1, 768, 3072), (2100, 260, 2048),
+                                   (5, 100, 96), (300, 36, 152), (40, 64, 220), (3000, 800, 96)])   # Kp = 96, 160, 224: not whole 64-k chunks
 def test_split_gemm_matches_float64(cuda, M, N, K):
     g = torch.Generator(device=cuda).manual_seed(M + N + K)
     x = torch.randn((M, K), device=cuda, generator=g) * torch.exp(2 * torch.randn((M, 1), device=cuda, generator=g))
