@@ -527,6 +527,57 @@ __global__ __launch_bounds__(256) void attention_group_kernel(AttnArgs a) {
   }
   __syncthreads();
   const int qpos = a.q_pos0;  // tq == 1
+  if (tk <= 32) {
+    // Few keys (a query of <= 32 tokens): a wave takes 64 / G rows at once, G = 8 | 16 | 32 lanes per row, lane = (row, key).
+    // One row per wave pass left 64 - tk lanes idle in the score loop, and that loop's LDS reads -- 32 x 1 KiB per row --
+    // are what the kernel was bound by.  Same arithmetic bit for bit: the in-group butterflies (xor G/2 .. 1) are the
+    // association attn_softmax's 64-lane butterflies have when lanes >= G hold zeros (as attention_few_keys_kernel).
+    const int G = tk <= 8 ? 8 : (tk <= 16 ? 16 : 32), rpw = 64 / G;
+    const int g = lane / G, j = lane & (G - 1);
+    for (int r0 = wave * rpw; r0 < a.kv_div; r0 += 4 * rpw) {
+      const int r = r0 + g;
+      const bool ok = r < a.kv_div && bk * a.kv_div + r < a.nb && j < tk;
+      float sj = -INFINITY;
+      if (ok) {
+        const float *q = sq + r * dh;
+        const float *kr = sk + j * ldk;
+        float acc = 0.f;
+        for (int d = 0; d < dh; d += 4) {
+          const float4 kv = *reinterpret_cast<const float4 *>(kr + d);
+          const float4 qv = *reinterpret_cast<const float4 *>(q + d);
+          acc = fmaf(qv.x, kv.x, acc);
+          acc = fmaf(qv.y, kv.y, acc);
+          acc = fmaf(qv.z, kv.z, acc);
+          acc = fmaf(qv.w, kv.w, acc);
+        }
+        float add = 0.f;
+        if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + j];
+        if (a.key_mask && !a.kv_off && a.key_mask[(size_t)bk * tk + j] == 0) add += -1e9f;
+        if (a.causal && j > qpos) add += -1e9f;
+        sj = acc + add;
+      }
+      float m = sj;
+      for (int off = G >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      const float e = ok ? expf(sj - m) : 0.f;
+      float sum = e;
+      for (int off = G >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+      const float pr = e / sum;
+      for (int gg = 0; gg < rpw; ++gg) {           // the wave's 64 lanes are the output dims of one row after the other
+        const int rr = r0 + gg, b = bk * a.kv_div + rr;
+        if (rr >= a.kv_div || b >= a.nb) break;    // wave-uniform
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int jj = 0; jj < tk; ++jj) {
+          const float pj = __shfl(pr, gg * G + jj);
+          if (lane < dh) acc0 = fmaf(pj, sv[jj * dh + lane], acc0);
+          if (lane + 64 < dh) acc1 = fmaf(pj, sv[jj * dh + lane + 64], acc1);
+        }
+        float *o = a.out + (size_t)b * a.o_bs + (size_t)h * dh;
+        if (lane < dh) o[lane] = acc0;
+        if (lane + 64 < dh) o[lane + 64] = acc1;
+      }
+    }
+    return;
+  }
   for (int r = wave; r < a.kv_div; r += 4) {
     const int b = bk * a.kv_div + r;
     if (b >= a.nb) break;
