@@ -159,6 +159,7 @@ def profile_generate_query(query_file, model_path, ckpt_path, tokenizer_path, st
                            encoder=None, out_path="timer.pkl"):
     """Per-query latency of tokenise + encode at batch size 1, pickled as a list of seconds to `timer.pkl`
     (MEVI/generate.py:245-281, `--timing_infer_step N`)."""
+    import inspect
     import pickle
     from time import time
 
@@ -169,12 +170,13 @@ def profile_generate_query(query_file, model_path, ckpt_path, tokenizer_path, st
     encoder = encoder or load_document_encoder(model_path, ckpt_path, device)
     tokenizer = tokenizer or get_tokenizer(tokenizer_path)
     df = pd.read_csv(query_file, names=["query", "oldid"], encoding="utf-8", header=None, sep="\t")["query"]
+    graph = "graph" in inspect.signature(encoder.encode_query).parameters     # T5 towers: the step replays one HIP graph
     timer = []
     for start in range(0, step_num):
         batch = list(df[start:min(start + 1, step_num)])
         t0 = time()
         tok = encode_batch(tokenizer, batch, query_length)
-        encoder.encode_query(tok).cpu().numpy()
+        (encoder.encode_query(tok, graph=True) if graph else encoder.encode_query(tok)).cpu().numpy()
         timer.append(time() - t0)
     with open(out_path, "wb") as fw:
         pickle.dump(timer, fw)

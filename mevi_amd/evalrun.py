@@ -346,6 +346,10 @@ class EvalRun:
         # --eval_all_documents 1 (recall_level 'fine'): the brute-force ablation -- no beam search, the fine list is the
         # exact top-max(recall_num) of q.d over the whole corpus (main_models.py:3570,3818-3876)
         self.eval_all = bool(getattr(a, "eval_all_documents", 0))
+        # --timing_infer_step N: per-step wall clock of the beam search ('nci') and of the fine stage ('knn'), pickled to
+        # times<R>.pkl after N + 1 steps (main_models.py:1250-1252,4091-4096); the towers and the search then replay HIP graphs
+        self.timer = {"nci": [], "knn": []} if getattr(a, "timing_infer_step", 0) > 0 else None
+        self.timing_step_for_infer = 0
         # --use_topic_model 1 (topic_score_ratio 0, doc_multiclus 1): document score = NCI score of its cluster x q.d
         # (get_inference_scores, main_models.py:3539-3552) -- the beam scores on the cluster path, the scores of ALL
         # code paths (_generate_all) with --eval_all_documents
@@ -368,10 +372,11 @@ class EvalRun:
     def query_embedding(self, texts, ids, mask, rows=None):
         if self.query_table is not None:     # --query_embedding_path: generate.py already encoded these queries
             return torch.from_numpy(np.ascontiguousarray(self.query_table[np.asarray(rows)])).to(self.dev)
+        kw = {"graph": True} if self.timer is not None and isinstance(self.tower, TwinTower) else {}
         if self.tower_tokenizer is None:      # T5-ANCE: the tower reads the NCI input ids (main_models.py:3797-3799)
-            return self.tower.encode_query({"input_ids": ids, "attention_mask": mask})
+            return self.tower.encode_query({"input_ids": ids, "attention_mask": mask}, **kw)
         tok = encode_batch(self.tower_tokenizer, texts, 32, add_special_tokens=self.tower_special_tokens)
-        return self.tower.encode_query({"input_ids": tok["input_ids"], "attention_mask": tok["attention_mask"]})
+        return self.tower.encode_query({"input_ids": tok["input_ids"], "attention_mask": tok["attention_mask"]}, **kw)
 
     @torch.no_grad()
     def infer_all_documents(self, texts, doc_ids, ids, mask, rows=None):
@@ -490,11 +495,18 @@ class EvalRun:
         ids, mask = self.tokenize(texts)
         if self.eval_all:
             return self.infer_all_documents(texts, doc_ids, ids, mask, rows)
+        timing = self.timer is not None        # --timing_infer_step (main_models.py:3558,3729-3732,4057-4059,4091-4096)
+        if timing:
+            torch.cuda.synchronize()
+            t0 = time.time()
         decoded, scores, _, _ = self.nci.generate(ids, mask, num_beams=R, num_return_sequences=R,
-                                                  length_penalty=a.length_penalty, max_length=self.M + 2)
+                                                  length_penalty=a.length_penalty, max_length=self.M + 2, graph=timing)
         B = len(texts)
         codes = decode_token(decoded, self.K).view(B, R, self.M).cpu().numpy()
         scores = np.array(scores).reshape(B, R)
+        if timing:
+            t1 = time.time()
+            self.timer["nci"].append(t1 - t0)
         qemb = self.query_embedding(texts, ids, mask, rows)
         weights = torch.tensor(scores, dtype=torch.float32) if self.topic else None     # nci_scores (main_models.py:3681-3682)
         ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate, beam_weights=weights,
@@ -526,6 +538,13 @@ class EvalRun:
                 self.hn_log.add((text, mfine.f32_repr(gt_s[i]) if nq is None else "", join_i64(docs[:n]),
                                  mfine.f32_repr(sc[:n])))
             results.append((text, int(ndoc[i]), cr, fr))
+        if timing:
+            self.timer["knn"].append(time.time() - t1)
+            if self.timing_step_for_infer >= a.timing_infer_step:
+                with open(f"times{R}.pkl", "wb") as f:
+                    pickle.dump(self.timer, f)
+                raise SystemExit(0)                     # the reference exit()s here, logs unmerged
+            self.timing_step_for_infer += 1
         return results
 
     def run(self, df):
@@ -536,6 +555,8 @@ class EvalRun:
         # per query and independent of how queries are grouped (row-wise kernels, tested), so the GPU is fed
         # device_batch_size queries at a time and the logs keep the sampler's order.
         bs = max(1, a.eval_batch_size, getattr(a, "device_batch_size", None) or 1)
+        if self.timer is not None:      # latency of the script's own step: eval_batch_size queries, replayed HIP graphs
+            bs = max(1, a.eval_batch_size)
         for s in range(0, len(idx), bs):
             rows = df.iloc[idx[s:s + bs]]
             cache += self.infer(rows["query"].tolist(), rows["oldid"].tolist(), idx[s:s + bs])

@@ -610,6 +610,29 @@ def test_command_lines_with_a_real_sentencepiece_tokenizer(cuda, mini, tmp_path)
     for i, q in enumerate(mini["queries"]):
         assert coarse[i][0] == q and eval(coarse[i][1]) == codes[i].tolist()
         assert np.abs(np.array(eval(coarse[i][3])) - sc.numpy().reshape(-1, 10)[i]).max() <= 1e-5
+    # the latency hooks of the two scripts (generate.py:245-281 `--timing_infer_step N` -> timer.pkl, N entries at batch 1;
+    # main_models.py:3558,3729-3732,4057-4059,4091-4096 -> times<R>.pkl with N + 1 steps of eval_batch_size queries, then exit)
+    import pickle
+
+    wd = tmp_path / "timing"
+    os.makedirs(wd)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "generate.py"), "--query_file", qfile, "--model_path", str(ck / "t5-ance"),
+                        "--tokenizer_path", str(ck / "t5-ance"), "--dim", "32", "--gpus", "0", "--timing_infer_step", "5"],
+                       capture_output=True, text=True, env=env, cwd=wd)
+    assert r.returncode == 0, r.stderr[-2000:]
+    timer = pickle.load(open(wd / "timer.pkl", "rb"))
+    assert len(timer) == 5 and all(0 < t < 5 for t in timer)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--mode", "eval", "--n_gpu", "1", "--codebook", "1", "--pq_type", "rq",
+                        "--subvector_num", "4", "--subvector_bits", "5", "--query_encoder", "twin", "--document_encoder", "ance",
+                        "--recall_level", "both", "--num_return_sequences", "10", "--adaptor_layer_num", "2", "--eval_batch_size", "2",
+                        "--nci_ckpt", a0.nci_ckpt, "--ckpt_dir", str(ck), "--data_dir", a0.data_dir, "--embedding_path", a0.embedding_path,
+                        "--pq_path", a0.pq_path, "--pq_cluster_path", a0.pq_cluster_path, "--custom_save_path", str(wd / "t.tsv"),
+                        "--logs_dir", str(tmp_path / "logs"), "--fixnci", "--fixpq", "--timing_infer_step", "3"],
+                       capture_output=True, text=True, env=env, cwd=wd)
+    assert r.returncode == 0, r.stderr[-2000:]
+    times = pickle.load(open(wd / "times10.pkl", "rb"))
+    assert sorted(times) == ["knn", "nci"] and len(times["nci"]) == len(times["knn"]) == 4
+    assert all(0 < t < 5 for t in times["nci"] + times["knn"])
 
 
 def test_eval_driver_with_a_bert_tower(cuda, mini, tmp_path):
