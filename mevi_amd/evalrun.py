@@ -511,6 +511,9 @@ class EvalRun:
         weights = torch.tensor(scores, dtype=torch.float32) if self.topic else None     # nci_scores (main_models.py:3681-3682)
         ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate, beam_weights=weights,
                                         doc_proba=self.doc_proba if self.topic else None, ratio=self.ratio if self.topic else 0.0)
+        if getattr(a, "knn_topk_by_step", 0):       # main_models.py:3919-3995: a running torch.topk over the cluster chunks
+            pool = max(a.recall_num)                  # keeps the pool_size best of a query's candidates, best first
+            ranked = [(d[:pool], s_[:pool]) for d, s_ in ranked]
         nq = self.nq
         gt_s = self.fine.gt_scores(qemb, doc_ids) if self.hn_log is not None and nq is None else None
         results = []

@@ -166,6 +166,18 @@ def test_eval_outputs_do_not_depend_on_the_device_batch(cuda, mini, tmp_path):
         blobs.append([open(p, "rb").read() for p in (prefix + "_coarse.tsv", prefix + "_fine.tsv",
                                                      f"{prefix}_hn{a.save_hard_neg}.tsv", a.metric_path)])
     assert blobs[0] == blobs[1] == blobs[2] and all(len(b) > 0 for b in blobs[0])
+    # --knn_topk_by_step 1 outside the brute-force mode (main_models.py:3919-3995: running top-pool over the cluster
+    # chunks): the fine lists are the pool_size best of the full lists, the candidate counts stay
+    a = Namespace(**vars(mini["args"]))
+    a.knn_topk_by_step, a.recall_num = 1, [1, 3]
+    a.custom_save_path, a.metric_path = str(tmp_path / "topk" / "out.tsv"), str(tmp_path / "topk" / "m.txt")
+    os.makedirs(tmp_path / "topk")
+    EvalRun(a, tokenizer=FakeTokenizer(512), device=cuda).run(load_queries(a.data_dir))
+    full = [l.split("\t") for l in blobs[0][1].decode().splitlines()]
+    cut = [l.split("\t") for l in open(a.custom_save_path[:-4] + "_fine.tsv").read().splitlines()]
+    assert len(full) == len(cut) and any(len(eval(f[1])) > 3 for f in full)
+    for f, c in zip(full, cut):
+        assert c[0] == f[0] and eval(c[1]) == eval(f[1])[:3] and c[2:] == f[2:]
 
 
 def test_query_embeddings_of_generate_py_can_replace_the_second_tower_pass(cuda, mini, tmp_path):
