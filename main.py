@@ -153,6 +153,7 @@ EVAL_AFFECTING = {
     "rq_topk_score": ("prod",), "multiclus_label": ("top1",), "reconstruct_for_embeddings": ("0",),
     "tie_encoders": ("1",), "input_dropout": ("0", "1"), "denoising": ("0",), "load_encoder_only": ("0",),
     "pq_dist_mode": ("l2",), "use_ort": ("0",), "eval_train_data": ("0",),
+    "drop_data_rate": ("0", "0.0", "0."),      # > 0 reads dev_mevi_dedup_drop<rate>.tsv (main_utils.py:263-264)
 }
 
 
@@ -169,6 +170,8 @@ def check_supported(a):
                          "for the offline index build (training is out of scope)")
     if a.document_encoder not in ("ance", "cocondenser", "ar2"):
         raise SystemExit(f"main.py --mode eval: --document_encoder {a.document_encoder!r} is not built")
+    if a.test_set != "dev":       # load_data_infer has no other branch (main_utils.py:238: the reference dies on df = None)
+        raise SystemExit(f"main.py --mode eval: --test_set {a.test_set!r} is not built (only 'dev')")
     if a.dataset not in ("marco", "nq_dpr"):
         raise SystemExit(f"main.py --mode eval: --dataset {a.dataset!r} is not built (marco, nq_dpr)")
     need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both")

@@ -321,9 +321,12 @@ def test_main_py_rejects_what_it_does_not_build():
     assert ("--Rdrop", "0.1") in a.ignored_flags
     for argv in (["--lerning_rate", "1"], ["stray"], ["--learning_rate"], ["--fp_16", "1"],
                  ["--cat_cluster_centroid", "2"], ["--cluster_position_topk", "5"], ["--decode_embedding", "1"],
-                 ["--infer_reconstruct_vector", "1"], ["--load_encoder_only", "1"]):
+                 ["--infer_reconstruct_vector", "1"], ["--load_encoder_only", "1"], ["--drop_data_rate", "0.1"]):
         with pytest.raises(SystemExit):
             main.parsers_parser(base + argv)
+    main.parsers_parser(base + ["--drop_data_rate", "0"])
+    with pytest.raises(SystemExit):            # load_data_infer only knows the dev set (main_utils.py:238)
+        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--test_set", "test"]))
     main.parsers_parser(base + ["--use_topic_model", "0", "--fp_16", "0", "--decode_embedding", "2"])   # the built values
     main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1"]))                  # cluster score x q.d
     main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1", "--topic_score_ratio", "0.3"]))
