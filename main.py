@@ -2,7 +2,7 @@
 """`python main.py --mode eval ...` -- the argv surface of the reference's MEVI/main.py for the eval
 path that marco_eval_nci_rq.sh drives (MEVI/main.py:356-794, 267-337).  Every flag of that script is
 accepted; the ones that configure training are parsed and ignored.  Only --mode eval with
---codebook 1 --pq_type rq --document_encoder ance|cocondenser|ar2 --query_encoder twin --recall_level both is built
+--codebook 1 --pq_type rq --document_encoder ance|cocondenser|ar2 --query_encoder twin --recall_level both|coarse|fine is built
 (+ the brute-force ablation --eval_all_documents 1 --recall_level fine --knn_topk_by_step 1)
 (the configuration of every shipped eval script); anything else raises.
 
@@ -95,6 +95,8 @@ def parsers_parser(argv=None):
         ignored.append(("--" + name, value))
     args.ignored_flags = ignored
     args.recall_num = sorted(int(r) for r in args.recall_num.split(","))
+    if not args.document_encoder or args.recall_level == "coarse":      # MEVI/main.py:750-752
+        args.recall_num = [r for r in args.recall_num if r <= args.num_return_sequences]
     n = eval(args.n_gpu) if not args.n_gpu.isdigit() else int(args.n_gpu)  # int or list literal (MEVI/main.py:734-737)
     args.n_gpu = list(range(n)) if isinstance(n, int) else list(n)
     if args.ckpt_dir is None:
@@ -174,7 +176,9 @@ def check_supported(a):
         raise SystemExit(f"main.py --mode eval: --test_set {a.test_set!r} is not built (only 'dev')")
     if a.dataset not in ("marco", "nq_dpr"):
         raise SystemExit(f"main.py --mode eval: --dataset {a.dataset!r} is not built (marco, nq_dpr)")
-    need = dict(codebook=1, pq_type="rq", query_encoder="twin", recall_level="both")
+    need = dict(codebook=1, pq_type="rq", query_encoder="twin")
+    if a.recall_level not in ("both", "coarse", "fine"):
+        raise SystemExit(f"main.py --mode eval: --recall_level {a.recall_level!r} is not built (both | coarse | fine)")
     if a.doc_multiclus < 1 or (a.doc_multiclus > 1 and (a.eval_all_documents or a.knn_topk_by_step)):
         raise SystemExit("main.py --mode eval: --doc_multiclus C > 1 is built for the cluster re-ranking path only")
     if a.use_topic_model and a.doc_multiclus > 1:

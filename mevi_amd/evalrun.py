@@ -361,8 +361,11 @@ class EvalRun:
             # topic_score_ratio > 0 (`additional_reconstruct`, main_models.py:1270): doc_proba[d] = <reconstruct(codes(d)), emb[d]>
             # (gen_all_reconstruct :3272-3307 + gen_doc2index_mapping :3360-3364, bmm form of compute_similarity)
             self.doc_proba = self._doc_proba() if self.ratio else None
-        self.coarse_log = None if self.eval_all else RankLog(f"{prefix}_coarse.tsv", rank, nrank, self.barrier)
-        self.fine_log = RankLog(f"{prefix}_fine.tsv", rank, nrank, self.barrier)
+        # --recall_level: 'both' (the eval scripts), 'coarse' (beam clusters only: no tower pass, no fine stage) or 'fine'
+        # (fine list only; main_models.py:3736,3781,4103-4110)
+        self.level = "fine" if self.eval_all else getattr(a, "recall_level", "both")
+        self.coarse_log = RankLog(f"{prefix}_coarse.tsv", rank, nrank, self.barrier) if self.level in ("coarse", "both") else None
+        self.fine_log = RankLog(f"{prefix}_fine.tsv", rank, nrank, self.barrier) if self.level in ("fine", "both") else None
         self.hn_log = RankLog(f"{prefix}_hn{a.save_hard_neg}.tsv", rank, nrank, self.barrier) if a.save_hard_neg else None
 
     def tokenize(self, queries):
@@ -507,6 +510,16 @@ class EvalRun:
         if timing:
             t1 = time.time()
             self.timer["nci"].append(t1 - t0)
+        want_c, want_f = self.level in ("coarse", "both"), self.level in ("fine", "both")
+        if not want_f:      # recall_level 'coarse': cluster ranks and the candidate count only (main_models.py:3736-3780)
+            ndoc = self.fine.candidates_device(codes)[3]
+            results = []
+            for i, text in enumerate(texts):
+                d = codes[i].tolist()
+                cr, gt_codes = self._coarse_ranks(d, doc_ids[i])
+                self.coarse_log.add((text, d, gt_codes, scores[i].tolist()) if self.nq is None else (text, d, scores[i].tolist()))
+                results.append((text, int(ndoc[i]), cr))
+            return self._timed(results, t1 if timing else None)
         qemb = self.query_embedding(texts, ids, mask, rows)
         weights = torch.tensor(scores, dtype=torch.float32) if self.topic else None     # nci_scores (main_models.py:3681-3682)
         ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate, beam_weights=weights,
@@ -520,31 +533,39 @@ class EvalRun:
         for i, text in enumerate(texts):
             d = codes[i].tolist()
             docs, sc = ranked[i]
+            if want_c:
+                cr, gt_codes = self._coarse_ranks(d, doc_ids[i])
+                self.coarse_log.add((text, d, gt_codes, scores[i].tolist()) if nq is None else (text, d, scores[i].tolist()))
             if nq is None:
-                if self.C > 1:   # use_pq_topk_label (main_models.py:3761-3771): best rank over a gt doc's C paths
-                    gt_codes = [self.doc_topk[g].tolist() for g in doc_ids[i]]
-                    cr = tuple(min((d.index(g) for g in paths if g in d), default=None) for paths in gt_codes)
-                else:
-                    gt_codes = [list(self.mapping[g]) for g in doc_ids[i]]
-                    cr = tuple(d.index(g) if g in d else None for g in gt_codes)
-                self.coarse_log.add((text, d, gt_codes, scores[i].tolist()))
                 self.fine_log.add((text, docs.tolist(), doc_ids[i]))
                 fr = mfine.fine_ranks(docs, doc_ids[i])
-            else:      # main_models.py:3738-3757, 4060-4077: first beam cluster / first ranked doc answering the question
-                self.coarse_log.add((text, d, scores[i].tolist()))
-                answering = nq.docs_answering(doc_ids[i])
-                cr = [next((j for j, c in enumerate(d) if np.isin(self.index.lookup(c), answering).any()), None)]
+            else:      # main_models.py:4060-4077: first ranked doc answering the question
                 self.fine_log.add((text, docs.tolist()))
                 fr = [nq.first_hit(doc_ids[i], docs)]
             if self.hn_log is not None:
                 n = a.save_hard_neg
                 self.hn_log.add((text, mfine.f32_repr(gt_s[i]) if nq is None else "", join_i64(docs[:n]),
                                  mfine.f32_repr(sc[:n])))
-            results.append((text, int(ndoc[i]), cr, fr))
-        if timing:
+            results.append((text, int(ndoc[i]), cr, fr) if want_c else (text, int(ndoc[i]), fr))
+        return self._timed(results, t1 if timing else None)
+
+    def _coarse_ranks(self, d, gts):
+        """Ranks of a sample's gt clusters among its beam clusters `d` (+ the gt codes the coarse log prints)."""
+        if self.nq is not None:   # main_models.py:3738-3757: first beam cluster holding a document that answers the question
+            answering = self.nq.docs_answering(gts)
+            return [next((j for j, c in enumerate(d) if np.isin(self.index.lookup(c), answering).any()), None)], None
+        if self.C > 1:            # use_pq_topk_label (main_models.py:3761-3771): best rank over a gt doc's C paths
+            gt_codes = [self.doc_topk[g].tolist() for g in gts]
+            return tuple(min((d.index(g) for g in paths if g in d), default=None) for paths in gt_codes), gt_codes
+        gt_codes = [list(self.mapping[g]) for g in gts]
+        return tuple(d.index(g) if g in d else None for g in gt_codes), gt_codes
+
+    def _timed(self, results, t1):
+        """--timing_infer_step: close the step's 'knn' clock; after N + 1 steps dump and exit as the reference."""
+        if t1 is not None:
             self.timer["knn"].append(time.time() - t1)
-            if self.timing_step_for_infer >= a.timing_infer_step:
-                with open(f"times{R}.pkl", "wb") as f:
+            if self.timing_step_for_infer >= self.args.timing_infer_step:
+                with open(f"times{self.R}.pkl", "wb") as f:
                     pickle.dump(self.timer, f)
                 raise SystemExit(0)                     # the reference exit()s here, logs unmerged
             self.timing_step_for_infer += 1
@@ -570,7 +591,8 @@ class EvalRun:
         a = self.args
         if self.coarse_log is not None:
             self.coarse_log.merge()
-        self.fine_log.merge()
+        if self.fine_log is not None:
+            self.fine_log.merge()
         part = f"/tmp/{os.path.basename(a.custom_save_path)}.results_{self.rank}"
         with open(part, "wb") as f:
             pickle.dump(cache, f)
@@ -585,7 +607,7 @@ class EvalRun:
                 with open(p, "rb") as f:
                     allres += pickle.load(f)
                 os.remove(p)
-            out = summarize(allres, a.recall_num, self.R, both=not self.eval_all)
+            out = summarize(allres, a.recall_num, self.R, both=self.level == "both", at_all=self.level == "fine")
             write_metrics(out, a.metric_path, self.R, len(self.index.keys))
         self.barrier()
         return out
@@ -603,10 +625,11 @@ def _acc(v, tables):
     return found, best
 
 
-def summarize(results, recall_num, R, both=True):
-    """recall / mrr / hitrate at recall_num for the fine list and mean ndoc; with recall_level 'both' cluster_* at the
-    cut-offs <= R, with 'fine' the extra key f'cluster{R}' = found-at-all figures (handle_infer_results,
-    main_models.py:4100-4201)."""
+def summarize(results, recall_num, R, both=True, at_all=None):
+    """recall / mrr / hitrate at recall_num for the ranks the samples carry (fine ranks; cluster ranks with recall_level
+    'coarse') and mean ndoc; with recall_level 'both' cluster_* at the cut-offs <= R, with 'fine' (`at_all`) the extra key
+    f'cluster{R}' = found-at-all figures (handle_infer_results, main_models.py:4100-4201)."""
+    at_all = (not both) if at_all is None else at_all
     if both:
         queries = {q: (length, findex, cindex) for (q, length, cindex, findex) in results}
     else:
@@ -617,19 +640,19 @@ def summarize(results, recall_num, R, both=True):
         ccut.append(R)
     coarse = tuple({k: 0 for k in ccut} for _ in range(3))
     nsamples = 0
-    at_all = [0, 0, 0]
+    found_at_all = [0, 0, 0]
     for q, (length, findex, cindex) in queries.items():
         found, best = _acc(findex, fine)
         if both:
             _acc(cindex, coarse)
-        else:
-            at_all[0] += len(found) / len(findex)
-            at_all[1] += 1 / (best + 1) if best is not None else 0
-            at_all[2] += len(found) > 0
+        elif at_all:
+            found_at_all[0] += len(found) / len(findex)
+            found_at_all[1] += 1 / (best + 1) if best is not None else 0
+            found_at_all[2] += len(found) > 0
         nsamples += length
     n = len(queries)
-    if not both:
-        for t, v in zip(fine, at_all):
+    if at_all and not both:
+        for t, v in zip(fine, found_at_all):
             t[f"cluster{R}"] = v
     for t in fine + coarse:
         for k in t:

@@ -149,6 +149,50 @@ def test_eval_driver_matches_cpu_restatement(cuda, mini):
     assert os.path.exists(a.metric_path) and "ndocs@cluster10" in open(a.metric_path).read()
 
 
+def test_recall_levels_coarse_and_fine(cuda, mini, tmp_path):
+    """--recall_level coarse | fine (main_models.py:3736,3781,4103-4201): the same beams and fine lists as 'both', each with
+    its own result tuples, log files and metric keys -- cluster ranks at the cut-offs <= R and no tower pass for 'coarse',
+    fine ranks + the found-at-all `cluster<R>` key for 'fine'."""
+    import main
+    from mevi_amd.evalrun import EvalRun, load_queries, summarize
+
+    outs, files = {}, {}
+    for level in ("both", "coarse", "fine"):
+        a = Namespace(**vars(mini["args"]))
+        a.recall_level = level
+        a.recall_num = [1, 5, 10, 20, 50, 100] if level != "coarse" else [1, 5, 10]           # main.py:750-752
+        a.custom_save_path, a.metric_path = str(tmp_path / level / "out.tsv"), str(tmp_path / level / "m.txt")
+        os.makedirs(tmp_path / level)
+        run = EvalRun(a, tokenizer=FakeTokenizer(512), device=cuda)
+        if level == "coarse":
+            run.tower = None                                                                  # must not be needed
+        outs[level] = run.run(load_queries(a.data_dir))
+        files[level] = {f: open(tmp_path / level / f, "rb").read() for f in sorted(os.listdir(tmp_path / level))}
+    R = mini["args"].num_return_sequences
+    assert sorted(files["coarse"]) == ["m.txt", "out_coarse.tsv", f"out_hn{mini['args'].save_hard_neg}.tsv"]
+    assert files["coarse"]["out_coarse.tsv"] == files["both"]["out_coarse.tsv"] and files["coarse"][f"out_hn{mini['args'].save_hard_neg}.tsv"] == b""
+    assert sorted(files["fine"]) == ["m.txt", "out_fine.tsv", f"out_hn{mini['args'].save_hard_neg}.tsv"]
+    assert files["fine"]["out_fine.tsv"] == files["both"]["out_fine.tsv"]
+    assert files["fine"][f"out_hn{mini['args'].save_hard_neg}.tsv"] == files["both"][f"out_hn{mini['args'].save_hard_neg}.tsv"]
+    both, coarse, fine = outs["both"], outs["coarse"], outs["fine"]
+    assert coarse["recall"] == {k: both["cluster_recall"][k] for k in (1, 5, 10)} and "cluster_recall" not in coarse
+    assert coarse["mrr"] == {k: both["cluster_mrr"][k] for k in (1, 5, 10)} and coarse["ndoc"] == both["ndoc"]
+    assert {k: v for k, v in fine["recall"].items() if k != f"cluster{R}"} == both["recall"] and "cluster_recall" not in fine
+    assert fine["recall"][f"cluster{R}"] >= fine["recall"][100] and fine["ndoc"] == both["ndoc"]
+    assert [l.split()[0] for l in files["coarse"]["m.txt"].decode().splitlines()] == \
+        [f"{n}{k}" for n in ("recall", "mrr", "hitrate") for k in (1, 5, 10)] + [f"ndocs@cluster{R}:"]
+    # the command line: the reference's own filter of recall_num, every level accepted
+    argv = ["--mode", "eval", "--data_dir", "x", "--codebook", "1", "--pq_type", "rq", "--query_encoder", "twin",
+            "--document_encoder", "ance", "--pq_path", "p", "--pq_cluster_path", "c", "--embedding_path", "e",
+            "--custom_save_path", "o.tsv", "--nci_ckpt", "n", "--num_return_sequences", "10", "--subvector_num", "4",
+            "--subvector_bits", "5"]
+    assert main.parsers_parser(argv + ["--recall_level", "coarse"]).recall_num == [1, 5, 10]
+    for level in ("both", "coarse", "fine"):
+        main.check_supported(main.parsers_parser(argv + ["--recall_level", level]))
+    with pytest.raises(SystemExit):
+        main.check_supported(main.parsers_parser(argv + ["--recall_level", "finesampleloss"]))
+
+
 def test_eval_outputs_do_not_depend_on_the_device_batch(cuda, mini, tmp_path):
     """marco_eval_nci_rq.sh passes --eval_batch_size 2; the driver feeds the GPU --device_batch_size queries per pass.
     Every log file must be byte-identical whatever the grouping (here 1, 4 and all 23 queries per pass)."""
