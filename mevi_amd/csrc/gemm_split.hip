@@ -214,7 +214,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split_kernel(
     head_m = tail_m, head_n = tail_n;
     --n_pend;
     const int m0 = mt * 256 + 128 * wn + lrow;           // + 32 ni
-    const int n0 = nt * 256 + 128 * grp + 64 * wm + 4 * half;  // + 32 mi + 8 q (+ j)
+    // the lane's columns: nt * 256 + 128 * grp + 64 * wm + 4 * half + 32 mi + 8 q (+ j)
     const bool interior = (mt + 1) * 256 <= M && (nt + 1) * 256 <= N;
     const int ldc4 = (int)ldc * 4, ldr4 = (int)ldr * 4;
     // per-tile descriptors (64-bit origin in SGPRs) + 32-bit lane offsets
