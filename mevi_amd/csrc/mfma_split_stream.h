@@ -32,11 +32,12 @@ constexpr int SS_SLAB = 256 * H1_LD;  // floats per slab (16 KiB)
 constexpr size_t ss_lds_bytes() { return (size_t)SS_NSLAB * SS_SLAB * sizeof(float); }
 
 // next(H1Src &) / begin() / emit(acc) as h1_tile_stream.  `U` super-units per tile (>= 2), `lo_bytes` = byte offset of the
-// lo half inside an image row.
+// lo half inside an image row; `unit_bytes` = distance of consecutive 32-k units (64 for plain rows; the probe's unit-major
+// variant passes row_bytes 64, lo_bytes 16384, unit_bytes 32768).
 // ABL: ablation switches for tools/probes/stream_probe.hip, as h1_tile_stream (the product instantiates 0).
 template <class Next, class Begin, class Emit, int ABL = 0>
 __device__ __forceinline__ void split_tile_stream(int row_bytes, int lo_bytes, int U, float *lds, Next next, Begin begin,
-                                                  Emit emit) {
+                                                  Emit emit, int unit_bytes = 64) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -60,7 +61,7 @@ __device__ __forceinline__ void split_tile_stream(int row_bytes, int lo_bytes, i
     const bool spill = uu >= U;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(spill ? nxt.src : cur.src), 0, (int)(spill ? nxt.bytes : cur.bytes), 0x00020000);
-    const int soff = (spill ? uu - U : uu) * 64 + (lo ? lo_bytes : 0);
+    const int soff = (spill ? uu - U : uu) * unit_bytes + (lo ? lo_bytes : 0);
     float *base = lds + pos * SS_SLAB + (64 * (w8 & 3)) * H1_LD;
 #pragma unroll
     for (int i = 0; i < 4; ++i)

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void probe_kernel(const _Float16 *A,
 }
 
 // the split GEMM's stream (mfma_split_stream.h): image rows [hi | lo] of kp halves each
-template <int ABL>
+template <int ABL, bool BLOCKED = false>
 __global__ __launch_bounds__(PP_THREADS, 2) void probe_split_kernel(const _Float16 *A, int M, const _Float16 *W, int N, int kp,
                                                                     float *sink, int n_mtiles, int n_ntiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -87,14 +87,17 @@ __global__ __launch_bounds__(PP_THREADS, 2) void probe_split_kernel(const _Float
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) keep += acc[mi][ni][0] + acc[mi][ni][7];
   };
-  split_tile_stream<decltype(next), decltype(begin), decltype(emit), ABL>(row_bytes, kp * 2, kp / 32, lds, next, begin, emit);
+  if constexpr (BLOCKED)   // unit-major images: [tile][unit][hi | lo][256 rows][32 halves] -- every DMA piece 1 KiB contiguous
+    split_tile_stream<decltype(next), decltype(begin), decltype(emit), ABL>(64, 16384, kp / 32, lds, next, begin, emit, 32768);
+  else
+    split_tile_stream<decltype(next), decltype(begin), decltype(emit), ABL>(row_bytes, kp * 2, kp / 32, lds, next, begin, emit);
   if (keep == 12345.678f) sink[threadIdx.x] = keep;
 }
 
-template <int ABL>
+template <int ABL, bool BLOCKED = false>
 float run_split(const _Float16 *A, int M, const _Float16 *W, int N, int kp, float *sink) {
   const int n_mtiles = M / 256, n_ntiles = N / 256;
-  hipFuncSetAttribute(reinterpret_cast<const void *>(probe_split_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipFuncSetAttribute(reinterpret_cast<const void *>(probe_split_kernel<ABL, BLOCKED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)ss_lds_bytes());
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
@@ -102,7 +105,7 @@ float run_split(const _Float16 *A, int M, const _Float16 *W, int N, int kp, floa
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(probe_split_kernel<ABL>, dim3(256), dim3(PP_THREADS), ss_lds_bytes(), 0, A, M, W, N, kp, sink, n_mtiles, n_ntiles);
+    hipLaunchKernelGGL((probe_split_kernel<ABL, BLOCKED>), dim3(256), dim3(PP_THREADS), ss_lds_bytes(), 0, A, M, W, N, kp, sink, n_mtiles, n_ntiles);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -172,5 +175,7 @@ int main() {
       {"no MFMA (data movement + barriers only)", run_split<8>(A, M, W, N, kps, sink)},
       {"no MFMA, no LDS reads (DMA + barriers)", run_split<12>(A, M, W, N, kps, sink)}};
   for (auto &x : q) printf("%-48s %8.3f ms  %7.1f TFLOP/s (f16)\n", x.name, x.ms, flop / x.ms / 1e9);
+  printf("split stream on unit-major images: full loop %8.3f ms, DMA + barriers only %8.3f ms\n",
+         run_split<0, true>(A, M, W, N, kps, sink), run_split<12, true>(A, M, W, N, kps, sink));
   return 0;
 }
