@@ -191,6 +191,15 @@ int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, const float *
                        int64_t nb, int64_t tq, int64_t tk, int64_t heads, int64_t dh, int64_t kv_div,
                        const float *bias, int64_t bias_rows, int64_t bias_ld, int64_t q_pos0,
                        const int64_t *key_mask, int causal, float scale, const int64_t *kv_off, void *stream);
+/* One decode step of self-attention over beam-shared caches: row b attends to tk <= 8 cached positions, position j of
+ * row b living in cache row key_rows[b * tk + j] (k / v[row, j, h*dh + d] via (k_bs, k_ts) / (v_bs, v_ts)).  The reference
+ * re-orders every layer's K|V cache after each beam step (generation_utils.py:927-934 `_reorder_cache`: index_select of the
+ * whole cache by the surviving beams' parents); here the caches stay where each step wrote them and the rows carry their
+ * ancestors' indices -- same arithmetic as mevi_attention_f32 (tq = 1) on the re-ordered copy, bit for bit. */
+int mevi_attention_cached_f32(const float *q, int64_t q_bs, const float *k, int64_t k_bs, int64_t k_ts, const float *v,
+                              int64_t v_bs, int64_t v_ts, float *out, int64_t o_bs, int64_t nb, int64_t tk, int64_t heads,
+                              int64_t dh, const int32_t *key_rows, const float *bias, int64_t bias_rows, int64_t bias_ld,
+                              int64_t q_pos0, int causal, float scale, void *stream);
 /* The same attention over PACKED sequences (padding-free encoders): sequence b owns rows seq_off[b] .. seq_off[b+1]-1
  * (i64 [nseq + 1], device) of q / k / v / out, whose rows are `*_ts` floats apart; every key is real, bias row / column =
  * position inside the sequence, max_len = longest sequence (<= 256).  Bit-identical to mevi_attention_f32 on the padded

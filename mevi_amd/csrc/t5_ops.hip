@@ -124,6 +124,7 @@ struct AttnArgs {
   float scale;                // multiplies q before the dot product (1 for T5)
   const long long *seq_off;   // packed sequences (attention_varlen_kernel): rows seq_off[b] .. seq_off[b+1]-1, else null
   const long long *kv_off;    // packed K|V only (cross-attention): keys of kv batch bk = rows kv_off[bk] .. kv_off[bk+1]-1
+  const int *key_rows;        // attention_few_keys_kernel only: key j of row b lives in K|V batch row key_rows[b * tk + j] (else b / kv_div)
 };
 
 constexpr int ATT_KPL = 4;  // keys per lane: key j lives on lane j & 63, slot j >> 6 (tk <= 256)
@@ -449,9 +450,9 @@ __global__ __launch_bounds__(256) void attention_few_keys_kernel(AttnArgs a) {
   if (!pair_ok) pair = npair - 1;
   const int h = (int)(pair % a.H);
   const int b = (int)(pair / a.H);
-  const int bk = b / a.kv_div;
   float s = -INFINITY;
   if (j < tk) {
+    const long long bk = a.key_rows ? a.key_rows[(size_t)b * tk + j] : b / a.kv_div;   // ancestor-indexed cache: no re-ordered copy
     const float *q = a.q + (size_t)b * a.q_bs + (size_t)h * dh;
     const float *kr = a.k + (size_t)bk * a.k_bs + (size_t)j * a.k_ts + (size_t)h * dh;
     float acc = 0.f;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(256) void attention_few_keys_kernel(AttnArgs a) {
     }
     float add = 0.f;
     if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + j];
-    if (a.key_mask && a.key_mask[(size_t)bk * tk + j] == 0) add += -1e9f;
+    if (a.key_mask && a.key_mask[(size_t)(b / a.kv_div) * tk + j] == 0) add += -1e9f;
     if (a.causal && j > qpos) add += -1e9f;
     s = acc + add;
   }
@@ -483,12 +484,13 @@ __global__ __launch_bounds__(256) void attention_few_keys_kernel(AttnArgs a) {
     if (pr >= npair) break;  // wave-uniform
     const int hh = (int)(pr % a.H);
     const int bb = (int)(pr / a.H);
-    const float *vb = a.v + (size_t)(bb / a.kv_div) * a.v_bs + (size_t)hh * dh;
     float acc0 = 0.f, acc1 = 0.f;
     for (int jj = 0; jj < tk; ++jj) {
+      const long long vr = a.key_rows ? a.key_rows[(size_t)bb * tk + jj] : bb / a.kv_div;
+      const float *vb = a.v + (size_t)vr * a.v_bs + (size_t)jj * a.v_ts + (size_t)hh * dh;
       const float pj = __shfl(p, 8 * gg + jj);
-      if (lane < dh) acc0 = fmaf(pj, vb[(size_t)jj * a.v_ts + lane], acc0);
-      if (lane + 64 < dh) acc1 = fmaf(pj, vb[(size_t)jj * a.v_ts + lane + 64], acc1);
+      if (lane < dh) acc0 = fmaf(pj, vb[lane], acc0);
+      if (lane + 64 < dh) acc1 = fmaf(pj, vb[lane + 64], acc1);
     }
     float *o = a.out + (size_t)bb * a.o_bs + (size_t)hh * dh;
     if (lane < dh) o[lane] = acc0;
@@ -960,6 +962,7 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   a.key_mask = reinterpret_cast<const long long *>(key_mask); a.causal = causal; a.scale = scale;
   a.seq_off = nullptr;
   a.kv_off = reinterpret_cast<const long long *>(kv_off);
+  a.key_rows = nullptr;
   const size_t tile_lds = (size_t)tk * (3 * dh + 1) * sizeof(float);
   if (!kv_off && kv_div == 1 && tq == tk && tk > 64 && tk <= AM_S && dh == AM_D) {  // passages: f32 matrix cores
     MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
@@ -1009,6 +1012,7 @@ extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const flo
   a.key_mask = nullptr; a.causal = causal; a.scale = scale;
   a.seq_off = reinterpret_cast<const long long *>(seq_off);
   a.kv_off = nullptr;
+  a.key_rows = nullptr;
   const long long pairs = (long long)nseq * heads;
   if (max_len > 64 && max_len <= AM_S && dh == AM_D) {   // passage-length sequences: f32 matrix cores
     a.q_pos0 = 0;
@@ -1033,6 +1037,32 @@ extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const flo
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(attention_varlen_kernel, dim3((unsigned)((pairs + waves - 1) / waves)), dim3(256), lds,
                      (hipStream_t)stream, a, (int)max_len, waves);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_attention_cached_f32(const float *q, int64_t q_bs, const float *k, int64_t k_bs, int64_t k_ts, const float *v,
+                                         int64_t v_bs, int64_t v_ts, float *out, int64_t o_bs, int64_t nb, int64_t tk,
+                                         int64_t heads, int64_t dh, const int32_t *key_rows, const float *bias,
+                                         int64_t bias_rows, int64_t bias_ld, int64_t q_pos0, int causal, float scale,
+                                         void *stream) {
+  MEVI_REQUIRE(nb >= 0 && tk > 0 && tk <= 8 && heads > 0 && dh > 0 && dh <= 128 && dh % 4 == 0, MEVI_ERR_UNSUPPORTED,
+               "attention_cached: 1..8 cached positions, head width a multiple of 4 up to 128 (got tk %lld, dh %lld)",
+               (long long)tk, (long long)dh);
+  MEVI_REQUIRE(q_bs % 4 == 0 && k_bs % 4 == 0 && k_ts % 4 == 0 && v_bs % 4 == 0 && v_ts % 4 == 0, MEVI_ERR_INVALID_ARG,
+               "attention_cached: strides must be multiples of 4");
+  if (nb == 0) return MEVI_OK;
+  MEVI_REQUIRE(q && k && v && out && key_rows, MEVI_ERR_INVALID_ARG, "attention_cached: null pointer");
+  MEVI_REQUIRE(!bias || (q_pos0 < bias_rows && tk <= bias_ld), MEVI_ERR_INVALID_ARG, "attention_cached: bias table too small");
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out;
+  a.q_bs = q_bs; a.q_ts = 0; a.k_bs = k_bs; a.k_ts = k_ts; a.v_bs = v_bs; a.v_ts = v_ts; a.o_bs = o_bs; a.o_ts = 0;
+  a.nb = (int)nb; a.tq = 1; a.tk = (int)tk; a.H = (int)heads; a.dh = (int)dh; a.kv_div = 1;
+  a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = (int)q_pos0;
+  a.key_mask = nullptr; a.causal = causal; a.scale = scale;
+  a.seq_off = nullptr; a.kv_off = nullptr;
+  a.key_rows = key_rows;
+  hipLaunchKernelGGL(attention_few_keys_kernel, dim3(blocks4((nb * heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

@@ -58,6 +58,9 @@ _SIGNATURES = {
     "mevi_attention_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                    c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
                                    c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "mevi_attention_cached_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                          c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                          c_int64, c_int, c_float, c_void_p]),
     "mevi_attention_varlen_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                           c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                           c_int, c_float, c_void_p]),

@@ -250,11 +250,12 @@ class NCIModel:
         return self._tables
 
     # -- one decoding position for all live beams -----------------------------------------------
-    def _logits(self, tokens, t, dcache, acache, xkv, mask, kv_div, pidx=None):
-        """pidx: the beams' prefix indices at position t when the prefix tables cover it (acache unused then)."""
+    def _logits(self, tokens, t, dcache, acache, xkv, mask, kv_div, pidx=None, key_rows=None):
+        """pidx: the beams' prefix indices at position t when the prefix tables cover it (acache unused then).
+        key_rows: ancestor-indexed decoder caches (DecoderStack.step)."""
         c = self.cfg
         tok = ops.gather_rows(self.dec_emb, tokens)
-        seq = ops.scale(self.decoder.step(tok, t, dcache, xkv, mask, kv_div), c.d_model ** -0.5)
+        seq = ops.scale(self.decoder.step(tok, t, dcache, xkv, mask, kv_div, key_rows=key_rows), c.d_model ** -0.5)
         if pidx is not None:
             tab = self.tables()
             if tab.tmat[t] is not None:
@@ -376,20 +377,32 @@ class NCIModel:
         codes = torch.zeros((B, 1, 0), dtype=torch.int64, device=self.dev)
         levels = self.tables().levels if self.prefix_table_bytes else 0      # positions the prefix tables cover
         pidx = torch.zeros(B, dtype=torch.int64, device=self.dev)            # prefix index of every live beam
-        dcache = self.decoder.new_cache(B)
+        # The decoder's K|V caches are never re-ordered (the reference index_selects every layer's cache by the surviving
+        # beams' parents after each step, generation_utils.py:927-934): position p of step-p row r stays in cache row r and
+        # every live beam carries the cache rows of its ancestors, `anc` i32 [rows, p].  Up to 8 positions (the few-keys
+        # attention kernel); longer codes keep the copying form.
+        indexed = c.M + 1 <= 8
+        dcache = self.decoder.new_cache(B * min(R, c.K ** c.M) if indexed else B)
+        anc = torch.zeros((B, 0), dtype=torch.int32, device=self.dev)
         acache = self.adaptor.new_cache(B) if levels == 0 else None
         base = torch.arange(B, device=self.dev)[:, None]
         for p in range(c.M + 1):
             if p == levels and p > 0:       # first position beyond the tables: its cache comes from them
                 acache = self.tables().cache_rows(self.adaptor, pidx, p)
-            logits = self._logits(tokens, p, dcache, acache, xkv, mask, nb, pidx if p < levels else None)
+            key_rows = None
+            if indexed:
+                key_rows = torch.cat([anc, torch.arange(anc.shape[0], dtype=torch.int32, device=self.dev)[:, None]], 1).contiguous()
+            logits = self._logits(tokens, p, dcache, acache, xkv, mask, nb, pidx if p < levels else None, key_rows=key_rows)
             if p == c.M:
                 break
             Rp = min(R, nb * c.K)                                             # beams alive after this level
             scores, parent, code = ops.beam_step(logits, scores, c.K, Rp)
             parent, code = parent.long(), code.long()
             rows = (base * nb + parent).reshape(-1)                           # surviving parents, [B*Rp]
-            dcache = _reorder_cache(dcache, rows, p + 1)
+            if indexed:
+                anc = key_rows[rows]
+            else:
+                dcache = _reorder_cache(dcache, rows, p + 1)
             if p >= levels:
                 acache = _reorder_cache(acache, rows, p + 1)
             pidx = pidx[rows] * c.K + code.reshape(-1)

@@ -278,6 +278,31 @@ def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=
 
 
 @hip.on_device
+def attention_cached(q, k, v, key_rows, heads, bias=None, q_pos0=0, causal=True, scale=1.0, out=None):
+    """One decode step over ancestor-indexed caches: q [n, H*dh]; k / v [rows, T, H*dh] views of the caches (any row / token
+    strides); key_rows i32 [n, tk] (tk <= 8): position j of row b is cache row key_rows[b, j].  Same bits as `attention` on the
+    caches physically re-ordered by the beams' parents (generation_utils.py:927-934)."""
+    assert q.dim() == 2 and q.stride(1) == 1 and q.is_cuda and q.dtype == torch.float32
+    for t in (k, v):
+        assert t.dim() == 3 and t.stride(2) == 1 and t.is_cuda and t.dtype == torch.float32
+    n, hd = q.shape
+    assert key_rows.dtype == torch.int32 and key_rows.is_cuda and key_rows.is_contiguous() and key_rows.shape[0] == n
+    tk = key_rows.shape[1]
+    if out is None:
+        out = torch.empty((n, hd), dtype=torch.float32, device=q.device)
+    brows = bld = 0
+    if bias is not None:
+        assert bias.dim() == 3 and bias.is_contiguous() and bias.shape[0] == heads
+        brows, bld = bias.shape[1], bias.shape[2]
+    st = hip.lib().mevi_attention_cached_f32(
+        hip.ptr(q), q.stride(0), hip.ptr(k), k.stride(0), k.stride(1), hip.ptr(v), v.stride(0), v.stride(1), hip.ptr(out),
+        out.stride(0), n, tk, heads, hd // heads, hip.ptr(key_rows), hip.ptr(bias) if bias is not None else None, brows, bld,
+        q_pos0, 1 if causal else 0, scale, hip.stream_ptr())
+    hip.check(st, "mevi_attention_cached_f32")
+    return out
+
+
+@hip.on_device
 def attention_varlen(q, k, v, seq_off, max_len, heads, bias=None, causal=False, scale=1.0, out=None):
     """Self-attention over packed sequences: q / k / v [T, H*dh] row-strided views, sequence b = rows
     seq_off[b] .. seq_off[b+1]-1 (i64 [nseq+1] on the device), max_len = longest sequence (<= 256)."""

@@ -271,13 +271,19 @@ class DecoderStack:
         return [torch.empty((rows, self.max_len, 2 * self.d.inner), dtype=torch.float32, device=self.dev)
                 for _ in self.layers]
 
-    def step(self, x, t, cache, xkv, enc_mask, kv_div):
+    def step(self, x, t, cache, xkv, enc_mask, kv_div, key_rows=None):
         """x f32[n, d_model]: embeddings of the token at position t of every row; cache[l] f32[n, T, 2*inner]
         holds self-attention K|V of positions < t (position t is written here); rows r attend to the
         encoder states of query r // kv_div (`xkv`: the CrossKV of cross_kv, which carries its own mask / offsets;
-        `enc_mask` is kept for callers of the older signature).  Returns the final-normed hidden state f32[n, d_model]."""
+        `enc_mask` is kept for callers of the older signature).  Returns the final-normed hidden state f32[n, d_model].
+
+        key_rows (i32 [n, t + 1], beam search): the caches are NOT re-ordered between steps -- cache[l] has room for the
+        largest row count, position t of row r is written to cache row r, and key_rows[r, j] names the cache row that
+        holds position j of row r's prefix (its ancestor at step j; key_rows[r, t] = r)."""
         d = self.d
         n = x.shape[0]
+        if key_rows is not None:
+            cache = [kvc[:n] if t == 0 else kvc for kvc in cache]
         for L, kvc, xc in zip(self.layers, cache, xkv.layers):
             h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
             if t == 0:
@@ -290,9 +296,13 @@ class DecoderStack:
                     ctx = kvc[:, 0, d.inner:]
             else:
                 q = ops.linear(h, L["wq"])
-                ops.linear(h, L["wkv"], out=kvc[:, t, :])
-                ctx = ops.attention(q.view(n, 1, d.inner), kvc[:, :t + 1, :d.inner], kvc[:, :t + 1, d.inner:],
-                                    d.num_heads, bias=self.self_bias, q_pos0=t, causal=True).view(n, d.inner)
+                ops.linear(h, L["wkv"], out=kvc[:n, t, :])
+                if key_rows is not None:
+                    ctx = ops.attention_cached(q, kvc[:, :, :d.inner], kvc[:, :, d.inner:], key_rows, d.num_heads,
+                                               bias=self.self_bias, q_pos0=t, causal=True)
+                else:
+                    ctx = ops.attention(q.view(n, 1, d.inner), kvc[:, :t + 1, :d.inner], kvc[:, :t + 1, d.inner:],
+                                        d.num_heads, bias=self.self_bias, q_pos0=t, causal=True).view(n, d.inner)
             x = ops.linear(ctx, L["wo"], residual=x)
             h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
             q = ops.linear(h, L["xq"])

@@ -287,3 +287,22 @@ def test_few_row_gemm_gives_the_rows_of_the_large_gemm(cuda, K, N):
             if "residual" in kw_m:
                 kw_m["residual"] = r[:M]
             assert torch.equal(ops.linear(x[:M].contiguous(), w, **kw_m), full[:M]), (M, list(kw))
+
+
+@pytest.mark.parametrize("tk,H,dh", [(1, 12, 64), (5, 12, 64), (8, 4, 32), (3, 2, 128)])
+def test_attention_over_ancestor_indexed_caches_equals_the_reordered_copy(cuda, tk, H, dh):
+    """mevi_attention_cached_f32: every row reads position j of its prefix from cache row key_rows[b, j]; the reference
+    (and `attention` here) first copy the caches into beam order (generation_utils.py:927-934).  Identical bits."""
+    g = torch.Generator(device=cuda).manual_seed(tk * 7 + H)
+    rows, n, T = 37, 53, 9
+    cache = torch.randn((rows, T, 2 * H * dh), device=cuda, generator=g)
+    q = torch.randn((n, H * dh), device=cuda, generator=g)
+    bias = torch.randn((H, T, T), device=cuda, generator=g)
+    key_rows = torch.randint(0, rows, (n, tk), device=cuda, generator=g).to(torch.int32)
+    ar = torch.arange(tk, device=cuda)
+    gathered = cache[key_rows.long(), ar[None, :], :]                       # [n, tk, 2*H*dh]: the re-ordered copy
+    want = ops.attention(q.view(n, 1, -1), gathered[:, :, :H * dh], gathered[:, :, H * dh:], H, bias=bias, q_pos0=tk - 1,
+                         causal=True).view(n, -1)
+    got = ops.attention_cached(q, cache[:, :, :H * dh], cache[:, :, H * dh:], key_rows, H, bias=bias, q_pos0=tk - 1, causal=True)
+    assert torch.equal(got, want)
+
