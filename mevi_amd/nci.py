@@ -212,7 +212,7 @@ class PrefixTables:
         for q in range(p):
             idx = pidx // (K ** (p - q))
             for l, k in enumerate(cache):
-                k[:, q, :] = ops.gather_rows(self.kv[l][q], idx)
+                ops.gather_rows(self.kv[l][q], idx, out=k[:, q, :])      # straight into the cache slot (row stride T * 2d)
         return cache
 
 
