@@ -173,3 +173,45 @@ def test_scripts_on_the_device_print_the_reference_bytes(cuda, name, g6_dir):
         out = [f for f in ("eval_out.txt", "ens_out.txt") if os.path.exists(os.path.join(g6_dir, f))]
         assert open(os.path.join(g6_dir, out[0])).read() == exp["ofile"]
     assert not os.path.exists(os.path.join(g6_dir, "dense.pkl"))        # the big lists never became dicts
+
+
+def test_inputs_the_device_path_declines_fall_back_to_the_dict_path(cuda, tmp_path):
+    """More than 8192 combined entries for one query (the LDS sort's capacity), or a bracketed list: in the default mode the
+    scripts print what the dict path prints; MEVI_CONSUMERS=device refuses instead of falling back."""
+    rng = np.random.default_rng(1)
+    n_docs, M, K, R = 30000, 3, 5, 4
+    codes = rng.integers(0, K, (n_docs, M)).astype(np.int32)
+    lens = {"q0": (5000, 5000), "q1": (40, 10), "q2": (1000, 0)}
+    with open(tmp_path / "gt.tsv", "w") as fg, open(tmp_path / "dense.tsv", "w") as fd, open(tmp_path / "fine.tsv", "w") as ff, \
+            open(tmp_path / "coarse.tsv", "w") as fc:
+        for q, (nd, nf) in lens.items():
+            d = rng.choice(n_docs, nd, replace=False)
+            ds = np.sort(rng.normal(size=nd))[::-1]
+            f = rng.choice(n_docs, max(nf, 1), replace=False)
+            fs = np.sort(rng.normal(size=max(nf, 1)))[::-1]
+            beam = [tuple(int(v) for v in codes[x]) for x in d[:R - 1]]
+            while len(set(beam)) < R - 1:
+                beam.append(tuple(int(v) for v in rng.integers(0, K, M)))
+            beam = list(dict.fromkeys(beam))[:R - 1]
+            fg.write(f"{q}\t{int(d[3])},{int(f[0])}\n")
+            fd.write(f"{q}\t\t{','.join(map(str, d.tolist()))}\t{','.join(repr(float(x)) for x in ds)}\n")
+            ff.write(f"{q}\t\t{','.join(map(str, f.tolist()))}\t{','.join(repr(float(x)) for x in fs)}\n")
+            fc.write(f"{q}\t{[list(b) for b in beam] + [list(beam[0])]}\n")
+    import pickle
+
+    with open(tmp_path / "rqmapping.pkl", "wb") as f:
+        pickle.dump({i: tuple(int(v) for v in codes[i]) for i in range(n_docs)}, f)
+    metrics.write_mapping_sidecar(str(tmp_path / "rqmapping.pkl"), codes)
+    argv = [sys.executable, os.path.join(ROOT, "ensemble_marco.py"), "--dir_path", str(tmp_path), "--gt_file", "gt.tsv", "--ance_file",
+            "dense.tsv", "--fine_file", "fine.tsv", "--coarse_file", "coarse.tsv", "--mapping_file", str(tmp_path / "rqmapping.pkl"),
+            "--recall_num", "10,100"]
+    outs = {}
+    for mode in ("host", "auto", "device"):
+        for f in os.listdir(tmp_path):
+            if f.endswith(".pkl") and not f.startswith("rqmapping"):
+                os.remove(tmp_path / f)                                   # no parse caches between the runs
+        r = subprocess.run(argv, capture_output=True, text=True, cwd=tmp_path, env=dict(os.environ, PYTHONPATH=ROOT, MEVI_CONSUMERS=mode))
+        outs[mode] = (r.returncode, r.stdout, r.stderr[-600:])
+    assert outs["host"][0] == 0 and outs["auto"][:2] == outs["host"][:2], outs["auto"][2]
+    assert outs["device"][0] != 0 and "declined" in outs["device"][2]
+
