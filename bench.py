@@ -71,39 +71,13 @@ def gen_queries(nq, device, n_docs):
     return (blk0[gid] + 0.005 * torch.randn((nq, DIM), device=device, generator=g)).contiguous()
 
 
-def cpu_baseline(n_docs, nq_full, target_s=20.0):
-    """faiss-Flat-style CPU evaluation (BLAS sgemm blocks + per-query heaps = oracle.dense.ip_topk_blas)
-    on a bounded sample, scaled linearly in rows to the full corpus; sgemm and heap seconds reported apart."""
-    from oracle import dense as odense
+def cpu_baseline(n_docs, nq_full, target_s=15.0):
+    """The dense arm on the host cores (tools/bench_cpu.py): faiss itself when importable, else the faiss-Flat-style port
+    (blocked sgemm + per-query heaps) with backend / threads / block swept and the best used for a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_cpu
 
-    nd_s = min(n_docs, 500_000)
-    rng = np.random.default_rng(7)
-    d = (0.05 * rng.standard_normal((nd_s, DIM), dtype=np.float32) + 0.02).astype(np.float32)
-    q_all = (0.05 * rng.standard_normal((nq_full, DIM), dtype=np.float32) + 0.02).astype(np.float32)
-    odense.ip_topk_blas(q_all[:32], d[:50_000], TOPK)      # BLAS / OpenMP thread pools up before anything is timed
-    t = time.time()
-    odense.ip_topk_blas(q_all[:128], d, TOPK)
-    cal = time.time() - t
-    nq_s = int(min(nq_full, max(128, 128 * target_s / max(cal, 1e-3))))
-    parts = {}
-    t = time.time()
-    odense.ip_topk_blas(q_all[:nq_s], d, TOPK, timing=parts)
-    dt = time.time() - t
-    qps_sample = nq_s / dt
-    qps_full = qps_sample * nd_s / n_docs
-    try:
-        import threadpoolctl
-        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count()
-    return {
-        "value": qps_full, "unit": "queries/s", "cores": int(cores), "kind": "port",
-        "sample": f"{nq_s} queries x {nd_s} docs x {DIM} f32, top-{TOPK}, BLAS sgemm blocks + per-query heaps "
-                  f"(faiss Flat-IP algorithm) took {dt:.2f}s; scaled x{nd_s}/{n_docs} rows to the full corpus",
-        "sgemm_s": parts.get("sgemm_s"), "heap_s": parts.get("heap_s"),
-        "sgemm_tflops": 2.0 * nq_s * nd_s * DIM / max(parts.get("sgemm_s", 0.0), 1e-9) / 1e12,
-        "host_cpus": os.cpu_count(),
-    }
+    return bench_cpu.dense_baseline_subprocess(n_docs, nq_full, DIM, TOPK, target_s=target_s)
 
 
 # ---- per-query arithmetic of the seq2seq arm (SURVEY.md 8(d): KV-cached, last-position, valid-column formulation) -----
@@ -178,22 +152,133 @@ def cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs):
                     "search on the resident corpus runs at `value`"}
 
 
-def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu):
+SPLIT_DTYPE = "f16x3 split-precision MFMA GEMM, f32 accumulate (22-bit operand images, f32-equivalent); attention / norms f32"
+
+
+def dense_small_batch(device, index, query, n_docs):
+    """The reference's own timing hook for the dense arm is small batches (faiss_search.profile, MEVI/faiss_search.py:32-68:
+    search at batch 1 / 2 / 4 / 8 x 10 batches).  With few queries the filter is bound by streaming the corpus' f16 image
+    ("at query micro-batch <= 64 it flips to HBM"): ms per search on resident tensors, HBM rate of the image."""
+    image_bytes = float(n_docs) * DIM * 2
+    per = []
+    for bs in (1, 2, 4, 8, 64):
+        q = query[:bs].contiguous()
+        index.search(q, TOPK)
+        torch.cuda.synchronize()
+        reps = 10
+        t = time.perf_counter()
+        for r in range(reps):
+            index.search(query[r * bs:(r + 1) * bs].contiguous(), TOPK)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / reps * 1e3
+        per.append({"batch": bs, "ms_per_search": round(ms, 3), "queries_per_s": round(bs / ms * 1e3, 1),
+                    "image_gb_per_s": round(image_bytes / ms / 1e6, 1), "frac_of_hbm_peak": round(image_bytes / ms / 1e6 / 8000.0, 3)})
+    return {"what": "faiss_search.profile's regime: ONE index.search call of <batch> queries over the resident corpus, top-%d, mean "
+                    "of 10 calls (inputs and outputs on the device)" % TOPK,
+            "dtype": "f16 pre-filter (selection) + exact f32 chains (results)",
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                         "algorithmic_bytes_per_search": image_bytes,
+                         "note": "bytes = the corpus' f16 image (N x 768 x 2), read once per search; the f32 rows of the re-scored "
+                                 "survivors (K' x 3 KB per query) are not counted",
+                         "achieved": per[0]["image_gb_per_s"], "frac": per[0]["frac_of_hbm_peak"]},
+            "per_batch": per}
+
+
+def index_build_leg(device, docs, rn, n_docs):
+    """SURVEY 8(f).1 -- the offline index build (marco_generate_embedding_n_rq.sh): the passage tower and the RQ encode of the
+    corpus, each with its roofline.  Passage tower: 2048 synthetic passages (lengths ~ N(70, 30) in [8, 128]) through
+    TwinTower.encode_passage; RQ encode: the resident corpus at (4, 32) and (3, 256)."""
+    from mevi_amd import rq, t5
+    import synth
+
+    out = {}
+    g = torch.Generator(device=device).manual_seed(5)
+    for M_, K_ in ((4, 32), (3, 256)):
+        cb = torch.stack([torch.randn((K_, DIM), device=device, generator=g) * (0.05 / (1 + j)) for j in range(M_)])
+        rq.rq_encode(docs[:1 << 16], cb)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        codes = rq.rq_encode(docs, cb)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) * 1e3
+        byts = 4.0 * n_docs * DIM + 4.0 * n_docs * M_
+        out["rq_encode_%dx%d" % (M_, K_)] = {
+            "ms": round(ms, 2), "rows_per_s": round(n_docs / ms * 1e3), "dtype": "f32 (exact (r - c)^2 fmaf chains decide every code)",
+            "stats": rq.last_encode_stats() if hasattr(rq, "last_encode_stats") else None,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes": byts,
+                         "bytes_note": "SURVEY 8(d): 4 N d (corpus once) + 4 N M (codes)",
+                         "achieved": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / 8000.0, 4)}}
+        del codes, cb
+    TW = synth.tower_weights(device) if hasattr(synth, "tower_weights") else None
+    if TW is not None:
+        tower = t5.TwinTower(TW, device=device, num_layers=12, num_decoder_layers=12, batch_size=512)
+        rng = np.random.default_rng(0)
+        n = 2048
+        ids = np.zeros((n, 128), np.int64)
+        mask = np.zeros((n, 128), np.int64)
+        for i in range(n):
+            L = int(np.clip(rng.normal(70, 30), 8, 128))
+            ids[i, :L - 1] = rng.integers(3, 32100, size=L - 1)
+            ids[i, L - 1] = 1
+            mask[i, :L] = 1
+        psg = {"input_ids": torch.from_numpy(ids).to(device), "attention_mask": torch.from_numpy(mask).to(device)}
+        tower.encode_passage(psg)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        tower.encode_passage(psg)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        real = int(mask.sum())
+        d, ff = DIM, 3072
+        lin = 2 * (4 * d * d + 2 * d * ff)
+        lens = mask.sum(1)
+        exe = 12 * (real * lin + 4 * d * float((lens.astype(np.float64) ** 2).sum())) + 12 * n * (lin + 2 * 2 * d * d) \
+            + 12 * real * 4 * d * d + 12 * 4 * d * float(lens.sum())
+        peak3 = PEAK_F16_MFMA_TFLOPS / 3
+        out["passage_tower"] = {
+            "passages": n, "tokens": 128, "real_tokens": real, "ms": round(dt * 1e3, 1), "passages_per_s": round(n / dt, 1),
+            "corpus_hours_on_one_gpu": round(n_docs / (n / dt) / 3600, 2), "dtype": SPLIT_DTYPE,
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "flop_executed": exe, "achieved": round(exe / dt / 1e12, 1),
+                         "peak": peak3, "frac": round(exe / dt / 1e12 / peak3, 4),
+                         "peak_note": "f16 MFMA dense peak / 3 (three f16 MFMAs per f32 product); executed = real tokens only "
+                                      "(12 encoder layers incl. attention, 12 one-token decoder layers, cross K|V of real tokens)"}}
+        del tower, TW
+    return out
+
+
+def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=None, dense_index=None):
     """Untimed extras (N = 1), measured after the timed region and not part of `value`: the path around the dense search at
     t5-base shapes (synthetic weights, MS MARCO-like query lengths, tools/synth.py) --
+      * dense_small_batch: the reference's own profile() regime (batch 1..64), HBM roofline of the f16 image,
       * query tower and NCI generate alone, with the arm's roofline entries (GEMM kernel, per-query FLOP budget),
-      * config C4 timed directly: tower -> dense search -> beam search -> tower again -> fine stage (+ the ensemble's host time),
-      * NCI generate at BASELINE.json's configs[2] code shape (3 levels x 256 codes),
-      * the CLI-inclusive rate of faiss_search.py (upload + index build + search),
-      * the oracle's torch-fp32 restatement of tower / generate on the host cores for a small sample, with the agreement of
-        the two paths on that sample."""
+      * config C4 timed directly: tower -> dense search -> beam search -> tower again -> fine stage (+ the ensemble),
+      * mrr10_match: CPU oracle vs HIP path on the same inputs (dense slice of the bench's own data; 8 queries of the chain),
+      * NCI generate at BASELINE.json's configs[2] code shape (3 levels x 256 codes), with its own oracle agreement,
+      * index_build: passage tower + RQ encode rooflines,
+      * the CLI-inclusive rate of faiss_search.py (upload + index build + search)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_certify
     import chain_c4
     import synth
     from mevi_amd import nci, ops, t5
 
     M, K, R, gen_batch = 4, 32, 10, 8192
     out = {"gemm_mode": ops.GEMM_MODE}
+
+    def guarded(name, fn):                      # one failing leg must not cost the others (nor the headline line)
+        try:
+            out[name] = fn()
+        except Exception as e:
+            import traceback
+
+            out[name + "_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc()[-500:]}"
+
+    if dense_index is not None and query is not None:
+        guarded("dense_small_batch", lambda: dense_small_batch(device, dense_index, query, n_docs))
+        guarded("mrr10_match", lambda: {"dense": bench_certify.dense_certificate(query, docs, planted_ids(nq, n_docs), TOPK)})
+    del dense_index
+    torch.cuda.empty_cache()
+
     W, TW, _, rn = synth.weights(device, M, K)
     cpu_w = ({k: v.cpu() for k, v in W.items()}, {k: v.cpu() for k, v in TW.items()}) if with_cpu else None
     model = nci.NCIModel(W, device=device, M=M, K=K, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
@@ -222,10 +307,11 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu):
     out["dense_arm_with_tower"] = {
         "tower_ms": tower_ms, "tower_queries_per_s": nq / tower_ms * 1e3, "search_ms": search_ms,
         "queries_per_s": nq / (tower_ms + search_ms) * 1e3, "pass_tokens": t5.DEVICE_PASS_TOKENS,
+        "dtype": "tower: " + SPLIT_DTYPE + "; search: f16 pre-filter + exact f32 chains",
         "note": "generate.py --gen_query (T5-ANCE tower, t5-base shapes, synthetic weights) + faiss_search.py"}
     out["seq2seq_arm"] = {
         "nci_generate_ms": nci_ms, "nci_generate_queries_per_s": nq / nci_ms * 1e3, "beams": R, "rq": [M, K],
-        "queries_per_pass": gen_batch,
+        "queries_per_pass": gen_batch, "dtype": SPLIT_DTYPE,
         "roofline": {
             "bound": "mfma", "unit": "TFLOP/s", "flop_per_query_survey_8d_padded": pad, "flop_per_query_executed": exe,
             "achieved": exe * nq / nci_ms / 1e9, "achieved_padded_equivalent": pad * nq / nci_ms / 1e9,
@@ -233,12 +319,13 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu):
             "peak_note": "f16 MFMA dense peak / 3 (three f16 MFMAs per f32 product in the split-precision GEMM); `achieved` "
                          "counts the arithmetic executed (real tokens, per-prefix adaptor tables), not the padded budget"},
         "note": "main.py --mode eval beam search (t5-base NCI model, synthetic weights), all queries resident"}
-    out["gemm_roofline"] = gemm_roofline(device, real_tokens)
+    guarded("gemm_roofline", lambda: dict(gemm_roofline(device, real_tokens), dtype=SPLIT_DTYPE))
 
     # ---- C4, timed directly on the resident corpus ---------------------------------------------------------------------
     chain, dindex = chain_c4.run(model, tower, docs, ids, mask, planted_ids(nq, n_docs), rn, M, K, R, TOPK, gen_batch, rng)
+    chain["dtype"] = "tower / NCI: " + SPLIT_DTYPE + "; dense: f16 pre-filter + exact f32 chains; fine stage: f32 chains; ensemble: f64"
     out["chain_c4"] = chain
-    out["faiss_search_cli_inclusive"] = cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs)
+    guarded("faiss_search_cli_inclusive", lambda: cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs))
     del dindex
 
     if with_cpu:
@@ -266,28 +353,90 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu):
                 "beams_identical": bool(torch.equal(dec, ref_dec)),
                 "beam_score_max_abs_diff": float(np.abs(sc - ref_sc.numpy()).max())},
         }
+        # the chain on the same inputs, CPU vs GPU (codebook / codes: the chain's own, re-derived with its generator state)
+        def chain_cert():
+            cb = chain_c4.LAST.get("codebook")
+            return bench_certify.chain_certificate(model, tower, cpu_w, (ncfg, tcfg), docs, chain_c4.LAST["codes_h"], cb, ids, mask,
+                                                   planted_ids(nq, n_docs), M, K, R, TOPK, n_q=n_g, oracle_generate=(ref_dec, ref_sc))
+
+        try:
+            out.setdefault("mrr10_match", {})["chain"] = chain_cert()
+        except Exception as e:
+            import traceback
+
+            out.setdefault("mrr10_match", {})["chain_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc()[-500:]}"
         del cpu_w
+    chain_c4.LAST.clear()
 
     # ---- BASELINE.json configs[2]: 3 levels x 256 codes ------------------------------------------------------------------
     del model, gen
     torch.cuda.empty_cache()
     M2, K2 = 3, 256
     W2, _, _, _ = synth.weights(device, M2, K2, tower=False)
+    cpu_w2 = {k: v.cpu() for k, v in W2.items()} if with_cpu else None
     model2 = nci.NCIModel(W2, device=device, M=M2, K=K2, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
     del W2
-    nci2_ms, _ = timed(lambda: gen_all(model2), 1)
+    nci2_ms, gen2 = timed(lambda: gen_all(model2), 1)
     pad2, exe2 = seq2seq_flops(M2, K2, R, real_tokens / nq)
     tab = model2.tables()
     out["seq2seq_arm_rq_3x256"] = {
         "nci_generate_ms": nci2_ms, "nci_generate_queries_per_s": nq / nci2_ms * 1e3, "beams": R, "rq": [M2, K2],
-        "queries_per_pass": gen_batch,
+        "queries_per_pass": gen_batch, "dtype": SPLIT_DTYPE,
         "prefix_tables": {"levels": tab.levels, "head_matrices_at": [p for p in range(tab.levels) if tab.tmat[p] is not None],
                           "adaptor_vectors_only_at": [p for p in range(tab.levels) if tab.tmat[p] is None],
                           "bytes": tab.bytes},
         "flop_per_query_survey_8d_padded": pad2,
         "note": "BASELINE.json configs[2] code shape (3-level RQ-256): the 257-column head GEMM runs per beam from "
                 "position 2 on (65 536 prefixes: adaptor vectors tabled, head matrices not)"}
+    if with_cpu:
+        def agree2():
+            from oracle import t5 as ot5
+
+            ncfg2, _ = synth.oracle_cfgs(M2, K2)
+            n2 = min(nq, 4)
+            with torch.no_grad():
+                t = time.time()
+                rd, rs, _ = ot5.nci_generate(cpu_w2, ncfg2, ids[:n2].cpu(), mask[:n2].cpu(), R)
+                dt = time.time() - t
+            return {"queries": n2, "oracle_seconds": round(dt, 1),
+                    "beams_identical": bool(torch.equal(gen2[0][0][:n2 * R].cpu(), rd)),
+                    "beam_score_max_abs_diff": float(np.abs(np.asarray(gen2[0][1][:n2 * R]) - rs.numpy()).max())}
+
+        try:
+            out["seq2seq_arm_rq_3x256"]["agreement_on_sample"] = agree2()
+        except Exception as e:
+            out["seq2seq_arm_rq_3x256"]["agreement_error"] = f"{type(e).__name__}: {e}"
+    del model2, gen2, cpu_w2, tower
+    torch.cuda.empty_cache()
+    guarded("index_build", lambda: index_build_leg(device, docs, rn, n_docs))
     return out
+
+
+def chain_c5(device, rank, world, backend, n_docs, nq, start, end, limit_s):
+    """N > 1: BASELINE.json configs[4] is the FULL ensemble on the sharded corpus, so after the timed dense
+    steps every rank runs the C5 chain (tools/chain_c4.run_sharded) -- full f32 corpus per rank, dense arm sharded, seq2seq
+    arm as replicas over the rank's query slice -- and rank 0 reports `chain_c5`.  A watchdog bounds the leg: should a
+    collective hang on the 8-GPU node, rank 0 still prints the headline line (the caller passes `emit`)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import chain_c4
+    import synth
+    from mevi_amd import nci, t5
+
+    M, K, R, gen_batch = 4, 32, 10, 8192
+    docs = gen_shard(0, n_docs, device, n_docs)                  # the whole corpus on every rank (27 GB of 288 GB)
+    W, TW, _, rn = synth.weights(device, M, K)
+    model = nci.NCIModel(W, device=device, M=M, K=K, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
+    tower = t5.TwinTower(TW, device=device, num_layers=12, num_decoder_layers=12)
+    del W, TW
+    rng = np.random.default_rng(0)
+    ids, mask = synth.query_ids(nq, device, rng)
+    rec = chain_c4.run_sharded(model, tower, docs, start, end, ids, mask, planted_ids(nq, n_docs), rn, M, K, R, TOPK, gen_batch,
+                               rng, rank, world, backend)
+    allr = [None] * world
+    dist.all_gather_object(allr, rec)
+    if rank == 0:
+        return chain_c4.aggregate_sharded(allr, nq, world, TOPK, R, M, K, backend)
+    return None
 
 
 def main():
@@ -299,6 +448,7 @@ def main():
     ap.add_argument("--queries", type=int, default=N_QUERIES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seq2seq-legs", action="store_true", help="skip the untimed tower / beam-search extras")
+    ap.add_argument("--chain-limit-s", type=float, default=420.0, help="N > 1: watchdog of the untimed C5 chain leg")
     ap.add_argument("--exact-f32-path", action="store_true",
                     help="search with the f32-MFMA kernel only (no f16 pre-filter); same results")
     args = ap.parse_args()
@@ -404,9 +554,10 @@ def main():
         # HBM-side bytes per filter launch: PMC (FETCH_SIZE x 2 on gfx950) of THIS command, recorded by
         # tools/prof_traffic.sh + tools/traffic_summary.py; PMC passes cannot run inside the timed bench.
         traffic, traffic_note = None, "PMC not collected for this configuration"
-        tfile = os.path.join(ROOT, "profiles", "r02_filter_h1_traffic.json")
-        if not os.path.exists(tfile):
-            tfile = os.path.join(ROOT, "profiles", "r01_filter_h1_traffic.json")
+        import glob
+
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_filter_h1_traffic.json")))
+        tfile = tfiles[-1] if tfiles else ""
         if (not args.exact_f32_path and world == 1 and n_docs == N_DOCS and nq == N_QUERIES and os.path.exists(tfile)):
             with open(tfile) as f:
                 tj = json.load(f)
@@ -459,20 +610,63 @@ def main():
         if multi_gpu is not None:
             out["multi_gpu"] = multi_gpu
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n_docs, nq)
-        if not args.no_seq2seq_legs and world == 1:
-            del index
-            torch.cuda.empty_cache()
             try:
-                out.update(extras(device, docs, nq, n_docs, ms_per_step, index_build_s, with_cpu=not args.no_cpu_baseline))
+                out["cpu_baseline"] = cpu_baseline(n_docs, nq)
+            except Exception as e:
+                out["cpu_baseline_error"] = f"{type(e).__name__}: {e}"
+        if not args.no_seq2seq_legs and world == 1:
+            try:
+                out.update(extras(device, docs, nq, n_docs, ms_per_step, index_build_s, with_cpu=not args.no_cpu_baseline,
+                                  query=query, dense_index=None if args.exact_f32_path else index))
             except Exception as e:      # the extras must never cost the headline line
                 import traceback
 
                 out["extras_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc()[-600:]}"
+    else:
+        out = None
+
+    # ---- N > 1: the C5 chain on every rank (untimed extra; `value` stays the sharded dense search) ---------------------------
+    if world > 1 and not args.no_seq2seq_legs:
+        import threading
+
+        printed = threading.Event()
+
+        def emit(extra):
+            if printed.is_set():
+                return
+            printed.set()
+            if rank == 0:
+                out.update(extra)
+                print(json.dumps(out), flush=True)
+
+        def give_up():      # a hung collective / a dead rank: rank 0 still prints the headline, everybody leaves
+            emit({"chain_c5_error": f"not finished within {args.chain_limit_s}s (watchdog)"})
+            os._exit(0)
+
+        dog = threading.Timer(args.chain_limit_s, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            del index, docs
+            torch.cuda.empty_cache()
+            c5 = chain_c5(device, rank, world, backend, n_docs, nq, start, end, args.chain_limit_s)
+            extra = {"chain_c5": c5} if rank == 0 else {}
+        except Exception as e:
+            import traceback
+
+            extra = {"chain_c5_error": f"rank {rank}: {type(e).__name__}: {e} | {traceback.format_exc()[-600:]}"}
+            if rank != 0:       # rank 0 may be waiting in a collective this rank will never join: let its watchdog end the wait
+                print(json.dumps({"rank": rank, **extra}), file=sys.stderr, flush=True)
+        dog.cancel()
+        emit(extra)
+    elif rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-from mevi_amd.dense import is_trained_before_train, search, shard_range, sharded_ip_topk  # noqa: F401  (API parity: search)
+from mevi_amd.dense import is_trained_before_train, profile, search, shard_range, sharded_ip_topk  # noqa: F401  (API parity: search, profile)
 from mevi_amd.io import map_rows, read, to_file  # noqa: F401
 
 

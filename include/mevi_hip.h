@@ -95,6 +95,17 @@ int mevi_topk_merge_f32(const float *scores, const int64_t *ids, int64_t nlists,
                         float *out_score, int64_t *out_id, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* The exchange of dense.sharded_ip_topk in its wire format.  mevi_pack_lists_i64: (score, id) pairs -> one i64 per entry,
+ * score bits << 32 | id as u32 (id -1 = padding travels as 0xFFFFFFFF): 8 bytes per entry on xGMI instead of 12.
+ * mevi_topk_merge_packed_f32: the all-gathered buffer packed i64 [nlists, nq, k_in] -- every list sorted (score desc,
+ * id asc) as mevi_ip_topk_*_f32 returns them -- merged to out f32 / i64 [nq, k_out] with the ordering rule above (only
+ * the merge stages of the sorting network run), and, with `truncated` != 0 (k_in < k: first round of the two-round
+ * exchange), unproven[q] = 1 when some list's LAST entry ranks inside the merged top-k_out (deeper rows of that shard
+ * may belong to it).  nlists <= 64, nlists * next_pow2(k_in) <= 16384. */
+int mevi_pack_lists_i64(const float *scores, const int64_t *ids, int64_t n, int64_t *packed, void *stream);
+int mevi_topk_merge_packed_f32(const int64_t *packed, int64_t nlists, int64_t nq, int64_t k_in, int64_t k_out,
+                               int truncated, float *out_score, int64_t *out_id, uint8_t *unproven, void *stream);
+
 /* ------------------------------------------------------------------------
  * Residual-quantisation encode: codes[n, M] (int32, values in [0, K)).
  * Replaces pq.get_rq_document_cluster / the index path of forward_rq with
@@ -108,6 +119,22 @@ int mevi_topk_merge_f32(const float *scores, const int64_t *ids, int64_t nlists,
  * ---------------------------------------------------------------------- */
 int mevi_rq_encode_f32(const float *x, int64_t n, int64_t dim, const float *codebook, int64_t M,
                        int64_t K, int32_t *codes, void *stream);
+
+/* The same codes, bit for bit, at the HBM rate (csrc/rq_fast.hip): one f16-MFMA product of the rows against ALL
+ * M*K centroids (x centred on the level-0 mean, converted on the fly) + inter-centroid tables approximate every level's
+ * distances; a rigorous error bound leaves, per row and level, either ONE possible argmin (taken) or a short candidate
+ * list whose exact reference-order chains (the arithmetic above) decide; rows the speculation got wrong, rows with
+ * more than 8 candidates or f16 overflow are re-encoded by the exact kernel.  Same call site as mevi_rq_encode_f32
+ * (MEVI/pq.py:124-131, 281-305; MEVI/main_models.py:3182-3220).
+ *   Requirements: dim % 32 == 0, 96 <= dim <= 8192, M <= 8, K <= 256 (else MEVI_ERR_UNSUPPORTED: call
+ *   mevi_rq_encode_f32); workspace of mevi_rq_encode_fast_workspace_bytes (256-byte aligned; 0 = shape unsupported).
+ * Stream-ordered, no host synchronisation.  mevi_rq_encode_fast_stats (tests / bench only; synchronises) reads
+ * {ambiguity records, rows re-encoded exactly, ambiguous row-levels} of the last call that used `workspace`. */
+size_t mevi_rq_encode_fast_workspace_bytes(int64_t n, int64_t dim, int64_t M, int64_t K);
+int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, const float *codebook, int64_t M, int64_t K,
+                            int32_t *codes, void *workspace, size_t workspace_bytes, void *stream);
+int mevi_rq_encode_fast_stats(const void *workspace, int64_t n, int64_t dim, int64_t M, int64_t K, int64_t *out3,
+                              void *stream);
 
 /* ------------------------------------------------------------------------
  * Linear layer:  C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]
@@ -232,6 +259,13 @@ int mevi_beam_step_f32(const float *logits, const float *beam_scores, int64_t nq
                        int64_t R, int final_step, float *out_scores, int32_t *out_parent,
                        int32_t *out_code, void *stream);
 
+/* Row-wise (log-)softmax with the beam step's arithmetic (max, sum of expf(x - max), logf), for the branches that keep
+ * EVERY candidate instead of a top-R: mode 0 = log_softmax of x f32 [rows, cols] (the all-paths walk `_generate_all`,
+ * MEVI/transformers/generation_utils.py:1013-1136); mode 1 = scale[row] * softmax(x) (pq.beam_search while beams * K <= R,
+ * MEVI/pq.py:660-676; scale may be null = 1).  out f32 [rows, cols] (may alias x). */
+int mevi_row_softmax_f32(const float *x, int64_t rows, int64_t cols, int mode, const float *scale, float *out,
+                         void *stream);
+
 /* ------------------------------------------------------------------------
  * Fine stage: in-cluster re-ranking (MEVI/main_models.py:3915-4014).
  *   pair_dot: out[i] = <a[ia[i]], b[ib[i]]>, sequential f32 fmaf chain (same chain as
@@ -244,6 +278,13 @@ int mevi_pair_dot_f32(const float *a, int64_t lda, const int64_t *ia, const floa
 int mevi_segment_sort_desc_f32(const float *scores, const int64_t *ids, const int64_t *seg_offsets,
                                int64_t nseg, int64_t max_seg_len, float *out_scores, int64_t *out_ids,
                                void *stream);
+/* --doc_multiclus > 1 (MEVI/main_models.py:3997-4011: np.unique + the `uscores[ui] += s` / torch.max loop + torch.sort):
+ * per segment the entries of one id are merged -- mode 0 'add': 0 + s + s ... in list order (sequential f32 adds),
+ * mode 1 'max' -- and the unique entries sorted by (score desc, id asc) into out[seg_offsets[s] ...], out_counts[s] of
+ * them.  ids in [0, 2^32), segments of at most 16384 entries. */
+int mevi_segment_aggregate_sort_f32(const float *scores, const int64_t *ids, const int64_t *seg_offsets, int64_t nseg,
+                                    int64_t max_seg_len, int mode, float *out_scores, int64_t *out_ids,
+                                    int32_t *out_counts, void *stream);
 
 /* Pieces of pq.beam_search (MEVI/pq.py:613-713; only reached with doc_multiclus > 1): the score row
  * -sum_k (x_k - c_k)^2 of every row against the K centroids of one level, and the residual hand-down

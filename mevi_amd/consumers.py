@@ -127,7 +127,7 @@ def cluster_ranks(codes_t, docs_t, seg_t, beam_t, n_clusters):
     return out
 
 
-def ensemble_rank(seg_d, docs_d, sc_d, cr_d, fine, n_clusters, alpha, beta, gamma, max_entries, out_seg):
+def ensemble_rank(seg_d, docs_d, sc_d, cr_d, fine, n_clusters, alpha, beta, gamma, max_entries, out_seg, n_ranks=None):
     """Ranked ids of every query's ensemble: (out_docs i64[out_seg[-1]], out_n i32[nq]) on the device, or None when the
     kernel declined.  fine = (fine_row, seg_f, docs_f, sc_f) or None."""
     import torch
@@ -135,7 +135,15 @@ def ensemble_rank(seg_d, docs_d, sc_d, cr_d, fine, n_clusters, alpha, beta, gamm
     from . import hip
 
     nq = seg_d.numel() - 1
-    term = torch.tensor([alpha / (beta * c + 1) for c in range(int(n_clusters) + 1)], dtype=torch.float64).to(seg_d.device)
+    # cluster_ranks_kernel returns the LAST matching beam index (0..R-1) or n_clusters; with repeated beam clusters
+    # R - 1 > n_clusters, so the table spans both.  A rank whose denominator is zero raises only if some entry has it
+    # (the reference divides per entry, ensemble_marco.py:203).
+    n_terms = max(int(n_ranks or 0), int(n_clusters) + 1)
+    zero_den = [c for c in range(n_terms) if beta * c + 1 == 0]
+    if zero_den and bool(torch.isin(cr_d, torch.tensor(zero_den, dtype=cr_d.dtype, device=cr_d.device)).any()):
+        raise ZeroDivisionError("float division by zero")
+    term = torch.tensor([float("nan") if beta * c + 1 == 0 else alpha / (beta * c + 1) for c in range(n_terms)],
+                        dtype=torch.float64).to(seg_d.device)
     punish = 1 - gamma * alpha
     total = int(out_seg[-1].item()) if nq else 0
     out_docs = torch.empty(total, dtype=torch.int64, device=seg_d.device)
@@ -275,7 +283,7 @@ class EnsembleInputs:
 
     def ensemble(self, cr, alpha, beta, gamma):
         return ensemble_rank(self.seg_d, self.docs_d, self.sc_d, cr, self.fine, self.n_clusters, alpha, beta, gamma,
-                             self.max_entries, self.out_seg)
+                             self.max_entries, self.out_seg, n_ranks=self.beam.shape[1])
 
 
 @_or_refuse

@@ -79,10 +79,48 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float *__restrict_
   }
 }
 
+// Row-wise (log-)softmax with the arithmetic of the beam step above (max, sum of expf(x - max), logf): one wave per row.
+// mode 0: out = (x - max) - log(sum)                       (the all-paths walk of _generate_all, generation_utils.py:1013-1136)
+// mode 1: out = scale[row] * expf(x - max) / expf(log sum)  (pq.beam_search keeping every candidate, pq.py:660-676)
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float *__restrict__ x, long long rows, int cols, int mode,
+                                                         const float *__restrict__ scale, float *__restrict__ out) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float *row = x + (size_t)r * cols;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, row[c]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += expf(row[c] - m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float ls = logf(s);
+  float *o = out + (size_t)r * cols;
+  if (mode == 0) {
+    for (int c = lane; c < cols; c += 64) o[c] = (row[c] - m) - ls;
+  } else {
+    const float w = scale ? scale[r] : 1.f, den = expf(ls);
+    for (int c = lane; c < cols; c += 64) o[c] = w * (expf(row[c] - m) / den);
+  }
+}
+
 }  // namespace
 }  // namespace mevi
 
 using namespace mevi;
+
+extern "C" int mevi_row_softmax_f32(const float *x, int64_t rows, int64_t cols, int mode, const float *scale, float *out,
+                                    void *stream) {
+  MEVI_REQUIRE(rows >= 0 && cols > 0 && cols < (1LL << 30) && (mode == 0 || mode == 1), MEVI_ERR_INVALID_ARG, "row_softmax: bad arguments");
+  if (rows == 0) return MEVI_OK;
+  MEVI_REQUIRE(x && out, MEVI_ERR_INVALID_ARG, "row_softmax: null pointer");
+  hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows,
+                     (int)cols, mode, scale, out);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
 
 extern "C" int mevi_beam_step_f32(const float *logits, const float *beam_scores, int64_t nq, int64_t nb, int64_t K,
                                   int64_t R, int final_step, float *out_scores, int32_t *out_parent,

@@ -47,11 +47,20 @@ static inline int next_pow2(int x) {
   return p;
 }
 
+// tuning hook (tools/bench_shard_sim.py sweeps it; unset in production): smallest per-query slot count
+static inline int min_slots() {
+  const char *e = getenv("MEVI_IP_TOPK_MIN_SLOTS");
+  const int v = e ? atoi(e) : 0;
+  return (v >= 256 && v <= MAX_SORT && (v & (v - 1)) == 0) ? v : 2048;
+}
+
 static inline TopkGeom make_geom(int k) {
   TopkGeom g;
   g.k = k;
   int S = next_pow2(k) * 4;
-  if (S < 1024) S = 1024;
+  // short lists (the first round of a sharded search keeps ~k/W entries) still get 2048 slots: the chunk schedule grows
+  // with cap / k, and every chunk costs a compaction launch whose time does not shrink with the shard
+  if (S < min_slots()) S = min_slots();
   if (S > MAX_SORT) S = MAX_SORT;
   g.S = S;
   g.cap = S - k;
@@ -485,6 +494,66 @@ __global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ sc
   }
 }
 
+// (score, id) pairs <-> the 8-byte entries of the sharded search's all-gather: score bits << 32 | id as u32 (id -1 = padding
+// travels as 0xFFFFFFFF)
+__global__ __launch_bounds__(256) void pack_lists_kernel(const float *__restrict__ scores, const long long *__restrict__ ids,
+                                                        long long n, unsigned long long *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = ((unsigned long long)__float_as_uint(scores[i]) << 32) | (unsigned long long)(unsigned int)ids[i];
+}
+
+// Merge of the all-gathered, PACKED shard lists with the proof of dense.merge_truncated, one workgroup per query.
+// Every shard list arrives sorted (score desc, id asc), so the lists are loaded into LDS with alternating directions
+// and only the LAST stages of the bitonic network run (sizes 2 Lp .. P: 30 compare-exchange stages for 8 lists of <= 256
+// instead of the 66 of a full sort of 2048 keys).  unproven[q] = 1 when some shard's last entry reached the merged top-k
+// (then deeper rows of that shard could belong to it: the caller repeats the query with full lists).
+__global__ __launch_bounds__(256) void merge_packed_kernel(const unsigned long long *__restrict__ packed, int nlists, long long nq,
+                                                          int k_in, int Lp, int k_out, int truncated,
+                                                          float *__restrict__ out_score, long long *__restrict__ out_id,
+                                                          unsigned char *__restrict__ unproven) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  __shared__ unsigned long long last_key[64];
+  const long long q = blockIdx.x;
+  const int t = threadIdx.x;
+  int P = 2 * Lp;
+  while (P < nlists * Lp) P <<= 1;
+  for (int i = t; i < P; i += 256) {
+    const int l = i / Lp, j0 = i - l * Lp;
+    const int j = (l & 1) ? Lp - 1 - j0 : j0;  // odd lists ascending: every 2 Lp block is bitonic
+    unsigned long long key = 0ull;
+    if (l < nlists && j < k_in) {
+      const unsigned long long e = packed[((size_t)l * nq + q) * k_in + j];
+      const unsigned int id = (unsigned int)e;
+      if (id != 0xFFFFFFFFu) key = make_key(__uint_as_float((unsigned int)(e >> 32)), id);
+      if (j == k_in - 1 && l < 64) last_key[l] = key;
+    }
+    skeys[i] = key;
+  }
+  __syncthreads();
+  for (int size = 2 * Lp; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) bitonic_stage<256, false>(skeys, P, size, stride, t);
+  for (int i = t; i < k_out; i += 256) {
+    const unsigned long long key = (i < P) ? skeys[i] : 0ull;
+    const size_t off = (size_t)q * k_out + i;
+    if (key == 0ull) {
+      out_score[off] = -FLT_MAX;
+      out_id[off] = -1;
+    } else {
+      out_score[off] = key_score(key);
+      out_id[off] = (long long)key_id(key);
+    }
+  }
+  if (t == 0) {
+    // kth == 0: fewer than k rows exist in total -> every returned row is already in the list
+    const unsigned long long kth = (k_out - 1 < P) ? skeys[k_out - 1] : 0ull;
+    unsigned char u = 0;
+    if (truncated && kth != 0ull)
+      for (int l = 0; l < nlists && l < 64; ++l)
+        if (last_key[l] != 0ull && last_key[l] >= kth) u = 1;
+    unproven[q] = u;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // f16 pre-filter (see mfma_pp_f16.h): centred + scaled f16 images, approximate filter, exact re-score + proof.
 
@@ -725,6 +794,104 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
   stash_flush(stash, buf, count, S, k, cap);
 }
 
+// ---------------------------------------------------------------------------
+// Few queries (nq <= 32: faiss_search.profile's batch sizes, MEVI/faiss_search.py:32-68).  With one MFMA tile of query
+// columns the filter is bound by streaming the corpus image from HBM, and the tile stream above keeps only three 16 KiB
+// units of it in flight per CU (the other half of its LDS ring stages the query tile again and again).  Here the query
+// tile is STATIONARY in LDS (32 rows x dimp halves, 48 KiB at dim 768, loaded once per workgroup) and every wave streams
+// its own 32 corpus rows of a 256-row block through a private ring of SM_NB units (2 KiB each; no workgroup barrier in
+// the loop): 8 waves x 4 units = 64 KiB of the image in flight per CU (the stash and the query tile take the rest of LDS).  Same keys, same epilogue (emit_tile), same
+// compaction as the large-batch kernel -- the returned bits cannot differ.
+constexpr int SM_NB = 5;                       // units in a wave's ring (one being read, four landing)
+constexpr size_t sm_lds_bytes(int dimp) { return (size_t)dimp * 64 + (size_t)8 * SM_NB * 2048; }
+
+__global__ __launch_bounds__(512, 2) void ip_filter_h1_small_kernel(
+    const float *__restrict__ Qh, int nq, const float *__restrict__ Dh, long long doc_begin, long long doc_end, int dimp,
+    const float *__restrict__ tau, unsigned long long *__restrict__ buf, unsigned int *__restrict__ count, int S, int k,
+    int cap, unsigned int id_base) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lrow = lane & 31, half = lane >> 5;
+  const int U = dimp >> 5;
+  float *qst = lds;                                       // [U][32 rows][16 floats]: the query tile, piece-swizzled
+  float *ring = lds + (size_t)U * 512 + (size_t)w8 * SM_NB * 512;  // this wave's units: [SM_NB][32 rows][16 floats]
+  // lane (r16 = lane >> 2, slot = lane & 3) of a 16-row piece fetches logical piece slot ^ ((row >> 2) & 3)
+  const int voff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  {  // query tile: unit u of block 0 of the query image, rows 0..31 = its first 2 KiB; units spread over the waves
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Qh), 0, (int)((size_t)U * 16384), 0x00020000);
+    for (int u = w8; u < U; u += 8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)(qst + u * 512 + i * 256), 16,
+                                                 voff + i * 1024, u * 16384, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const long long n_blocks = (doc_end - doc_begin + 255) >> 8;
+  long long blk = blockIdx.x;
+  if (blk >= n_blocks) return;
+  const size_t block_bytes = (size_t)256 * dimp * 2;
+  auto src_of = [&](long long b) { return reinterpret_cast<const char *>(Dh) + (size_t)((doc_begin >> 8) + b) * block_bytes + (size_t)w8 * 2048; };
+  const char *cur = src_of(blk);
+  long long blk_n = blk + gridDim.x;
+  bool have_nxt = blk_n < n_blocks;
+  const char *nxt = have_nxt ? src_of(blk_n) : cur;
+  // unit u of a block: this wave's 32 rows = 2 KiB at byte u * 16 KiB of the block (rows 32 w8 .. 32 w8 + 31)
+  auto dma = [&](const char *base, bool live, int u, int slot) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, live ? (int)(block_bytes - (size_t)w8 * 2048) : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(ring + slot * 512 + i * 256), 16,
+                                               voff + i * 1024, u * 16384, 0, 0);
+  };
+  const int sw = (lrow >> 2) & 3;
+  const int off0 = lrow * 16 + (((0 + half) ^ sw) << 2), off1 = lrow * 16 + (((2 + half) ^ sw) << 2);  // k-steps j = 0, 1
+  float tq[1];
+  Stash stash;
+  {
+    char *sb = reinterpret_cast<char *>(lds) + sm_lds_bytes(dimp) + (size_t)w8 * STASH_BYTES_PER_WAVE;
+    stash.keys = reinterpret_cast<unsigned long long *>(sb);
+    stash.qs = reinterpret_cast<unsigned int *>(sb + (size_t)STASH_N * 8);
+    stash.n = 0;
+  }
+  load_tq<1>(tq, tau, 0, nq);
+  int rs = 0;  // ring slot of the unit being computed
+#pragma unroll
+  for (int u = 0; u < SM_NB - 1; ++u) dma(cur, true, u, u);   // U >= SM_NB - 1 is guaranteed by the host (dimp >= 160)
+  while (true) {
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f, acc[1][0][r] = -INFINITY;   // rows 32..63 of emit_tile's tile: none
+    for (int u = 0; u < U; ++u) {
+      // request stream unit g + SM_NB - 1 (slot before rs in the ring: its reads finished an iteration ago), then wait
+      // for unit g: at most the 2 * (SM_NB - 1) pieces behind it stay outstanding
+      const int un = u + SM_NB - 1;
+      const bool spill = un >= U;
+      dma(spill ? nxt : cur, spill ? have_nxt : true, spill ? un - U : un, rs == 0 ? SM_NB - 1 : rs - 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      static_assert(SM_NB == 5, "vmcnt immediate above = 2 * (SM_NB - 1)");
+      const float *ub = ring + rs * 512;
+      const f16x8 a0 = *reinterpret_cast<const f16x8 *>(ub + off0), a1 = *reinterpret_cast<const f16x8 *>(ub + off1);
+      const f16x8 b0 = *reinterpret_cast<const f16x8 *>(qst + u * 512 + off0), b1 = *reinterpret_cast<const f16x8 *>(qst + u * 512 + off1);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[0][0], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is re-filled by the next iteration's request
+      rs = rs == SM_NB - 1 ? 0 : rs + 1;
+    }
+    emit_tile<1>(acc, tq, 0, doc_begin + blk * 256 + 32 * w8, doc_end, buf, count, S, k, cap, id_base, &stash);
+    if (!have_nxt) break;
+    blk = blk_n;
+    cur = nxt;
+    blk_n += gridDim.x;
+    have_nxt = blk_n < n_blocks;
+    if (have_nxt) nxt = src_of(blk_n);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stash_flush(stash, buf, count, S, k, cap);
+}
+
 // Exact re-scoring of the kp approximate survivors of every query, exact top-k, and the proof that nothing
 // outside the survivors can belong to it.  With a = acc * qinv (the centred approximate score),
 //   chain(q, d) <= a + q.mu + eps_q,   eps_q = ||q|| * (c1 * max||d - mu|| + c2 * max||d||)
@@ -914,17 +1081,29 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   const int ni = 2;
   const int qt = h1 ? H1_QT : 64 * ni;
   const int n_qtiles = (int)((nq + qt - 1) / qt);
-  double growth = g_growth > 0.0 ? g_growth : (double)g.cap / (3.0 * g.k);  // expected survivors per chunk ~ cap/3
+  // expected survivors per chunk = k * growth = cap / growth_div (default 3: 3x head-room over the mean, tens of standard
+  // deviations for exchangeable row order; a query that still overflows takes the guaranteed path)
+  double growth_div = 3.0;
+  if (const char *e = getenv("MEVI_IP_TOPK_GROWTH_DIV")) {  // tuning hook, unset in production
+    const double v = atof(e);
+    if (v >= 1.05 && v <= 64.0) growth_div = v;
+  }
+  double growth = g_growth > 0.0 ? g_growth : (double)g.cap / (growth_div * g.k);
   if (growth < 1.0) growth = 1.0;
   const int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
-  const size_t pp_lds = h1 ? h1_lds_bytes() + 8 * STASH_BYTES_PER_WAVE : pp_lds_bytes<2>();
+  size_t pp_lds = h1 ? h1_lds_bytes() + 8 * STASH_BYTES_PER_WAVE : pp_lds_bytes<2>();
   const bool ktail = (dim % BK) != 0;
   const void *fn = nullptr;
 #define MEVI_PICK(NI_, T_) fn = reinterpret_cast<const void *>(ip_filter_kernel<NI_, T_>)
-  if (h1) fn = reinterpret_cast<const void *>(ip_filter_h1_kernel);  // Q, D = f16 images, dim = padded dim
+  // stationary-query streaming kernel: few queries, and the query tile + rings + stash fit the 160 KiB of LDS
+  const bool small = h1 && nq <= 32 && dim >= 160 && sm_lds_bytes(dim) + 8 * STASH_BYTES_PER_WAVE <= 160 * 1024 &&
+                     !getenv("MEVI_IP_TOPK_NO_SMALL");
+  if (small) fn = reinterpret_cast<const void *>(ip_filter_h1_small_kernel);
+  else if (h1) fn = reinterpret_cast<const void *>(ip_filter_h1_kernel);  // Q, D = f16 images, dim = padded dim
   else if (ktail) MEVI_PICK(2, true);
   else MEVI_PICK(2, false);
 #undef MEVI_PICK
+  if (small) pp_lds = sm_lds_bytes(dim) + 8 * STASH_BYTES_PER_WAVE;
   // opt in to > 64 KiB dynamic LDS (per device; cheap, so done on every call)
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds) != hipSuccess) {
     set_error("ip_topk: cannot raise dynamic LDS to %zu bytes", pp_lds);
@@ -964,7 +1143,13 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
         const int64_t per_xcd = (nwg + 7) / 8 < n_cu / 8 ? (nwg + 7) / 8 : n_cu / 8;
         grid = (unsigned)(8 * per_xcd);
       }
-      if (hipLaunchKernel(fn, dim3(grid), dim3(PP_THREADS), args, pp_lds, stream) != hipSuccess) {
+      void *args_small[] = {(void *)&Q, &nq_i, (void *)&D, &d0, &d1, &dim, (void *)&tau_c, (void *)&st.buf,
+                            (void *)&st.count, (void *)&g.S, (void *)&g.k, (void *)&g.cap, &id_base};
+      if (small) {  // one workgroup per CU, each walking 256-row blocks of the chunk
+        const int64_t nb = (chunk + 255) / 256;
+        grid = (unsigned)(nb < n_cu ? nb : n_cu);
+      }
+      if (hipLaunchKernel(fn, dim3(grid), dim3(PP_THREADS), small ? args_small : args, pp_lds, stream) != hipSuccess) {
         set_error("ip_topk: filter kernel launch failed");
         return -1;
       }
@@ -1106,8 +1291,12 @@ inline IndexView view_index(const void *index, int64_t nd, int64_t dim) {
   v.colsum = reinterpret_cast<double *>(const_cast<char *>(p));
   return v;
 }
-inline int h1_kprime(int k) {  // survivors kept per query: k plus a margin for the approximation error
-  int extra = k / 4 < 128 ? 128 : k / 4;
+// survivors kept per query: k plus a margin for the approximation error.  The margin has to cover the documents whose
+// approximate score lies within the error bound of the k-th one; their number grows with the density of scores at rank
+// k, i.e. with k -- a fixed floor of 128 made the re-scoring of a sharded search's short first-round lists (k/W + slack)
+// the largest per-rank cost that does not shrink with the shard.  Unproven queries get the second pass (2 K').
+inline int h1_kprime(int k) {
+  int extra = k / 4 < 48 ? 48 : k / 4;
   return (k + extra + 63) / 64 * 64;
 }
 }  // namespace
@@ -1236,6 +1425,11 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
     hipLaunchKernelGGL(rescore_finish_kernel, dim3((unsigned)nq), dim3(256), (size_t)P * 8, stream, st.buf, gp.S, (int)k, kp,
                        st.tau, qnorm, qinv, qshift, c1, c2, iv.bits, st.failed, top, (int)k);
   }
+  // the results are finalised BEFORE the host looks at the proof flags (the common case: every query proven); a repaired
+  // list is finalised again below
+  const long long total = nq * (long long)k;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, top, (int)k, (int)k,
+                     (long long)nq, out_score, reinterpret_cast<long long *>(out_id));
   unsigned int err_host = 0;
   MEVI_HIP_CHECK(hipMemcpyAsync(&err_host, err_bits, 4, hipMemcpyDeviceToHost, stream));
   MEVI_HIP_CHECK(hipGetLastError());
@@ -1257,6 +1451,7 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
   std::vector<int> idx;
   for (int64_t i = 0; i < nq; ++i)
     if (failed[(size_t)i] || bound_suspect) idx.push_back((int)i);
+  const bool repaired = !idx.empty();
   const int kp2 = h1_kprime2((int)k);
   if (!idx.empty() && !bound_suspect && kp2 != 0 && (int64_t)idx.size() <= h1_second_pass_max(nq)) {
     // Second chance before the 7x slower exact path: the same f16 search for the unproven queries only, with twice
@@ -1329,9 +1524,9 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
     MEVI_HIP_CHECK(hipStreamSynchronize(stream));
     profile_collect();
   }
-  const long long total = nq * (long long)k;
-  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, top, (int)k, (int)k,
-                     (long long)nq, out_score, reinterpret_cast<long long *>(out_id));
+  if (repaired)
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, top, (int)k, (int)k,
+                       (long long)nq, out_score, reinterpret_cast<long long *>(out_id));
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }
@@ -1357,6 +1552,37 @@ extern "C" int mevi_topk_merge_f32(const float *scores, const int64_t *ids, int6
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), (size_t)P * 8, stream, scores,
                      reinterpret_cast<const long long *>(ids), (int)nlists, (long long)nq, (int)k_in, (int)k_out,
                      out_score, reinterpret_cast<long long *>(out_id));
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_pack_lists_i64(const float *scores, const int64_t *ids, int64_t n, int64_t *packed, void *stream_) {
+  MEVI_REQUIRE(n >= 0, MEVI_ERR_INVALID_ARG, "pack_lists: bad size");
+  if (n == 0) return MEVI_OK;
+  MEVI_REQUIRE(scores && ids && packed, MEVI_ERR_INVALID_ARG, "pack_lists: null pointer");
+  hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), scores,
+                     reinterpret_cast<const long long *>(ids), (long long)n, reinterpret_cast<unsigned long long *>(packed));
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_topk_merge_packed_f32(const int64_t *packed, int64_t nlists, int64_t nq, int64_t k_in, int64_t k_out,
+                                          int truncated, float *out_score, int64_t *out_id, uint8_t *unproven, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(nlists > 0 && nlists <= 64 && nq >= 0 && k_in > 0 && k_out > 0, MEVI_ERR_INVALID_ARG, "topk_merge_packed: bad shape");
+  if (nq == 0) return MEVI_OK;
+  MEVI_REQUIRE(packed && out_score && out_id && unproven, MEVI_ERR_INVALID_ARG, "topk_merge_packed: null pointer");
+  int Lp = 32;
+  while (Lp < k_in) Lp <<= 1;
+  int P = 2 * Lp;
+  while (P < nlists * Lp) P <<= 1;
+  MEVI_REQUIRE(P <= MAX_SORT && k_out <= MAX_SORT, MEVI_ERR_UNSUPPORTED, "topk_merge_packed: %lld lists of %lld entries exceed the LDS sort",
+               (long long)nlists, (long long)k_in);
+  if ((size_t)P * 8 > 65536)
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
+  hipLaunchKernelGGL(merge_packed_kernel, dim3((unsigned)nq), dim3(256), (size_t)P * 8, stream,
+                     reinterpret_cast<const unsigned long long *>(packed), (int)nlists, (long long)nq, (int)k_in, Lp, (int)k_out,
+                     truncated, out_score, reinterpret_cast<long long *>(out_id), unproven);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

@@ -91,10 +91,92 @@ __global__ __launch_bounds__(256) void segment_sort_kernel(const float *__restri
   }
 }
 
+// --doc_multiclus > 1 (MEVI/main_models.py:3997-4011): a document reached through several beam clusters is listed once, its
+// per-cluster scores aggregated -- 'add': uscores = 0, then += s in candidate order (sequential f32 adds); 'max': the maximum
+// (from -inf) -- and the unique list is sorted by (score desc, id asc).  One workgroup per segment, everything in LDS:
+// sort by (id, position), run heads aggregate their run in position order, second sort by the aggregated score.
+__global__ __launch_bounds__(256) void segment_aggregate_sort_kernel(const float *__restrict__ scores,
+                                                                    const long long *__restrict__ ids,
+                                                                    const long long *__restrict__ seg, int mode,
+                                                                    float *__restrict__ out_s, long long *__restrict__ out_i,
+                                                                    int *__restrict__ out_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  const long long s0 = seg[blockIdx.x], s1 = seg[blockIdx.x + 1];
+  const int n = (int)(s1 - s0);
+  const int t = threadIdx.x;
+  if (n <= 0) {
+    if (t == 0) out_n[blockIdx.x] = 0;
+    return;
+  }
+  int P = 64;
+  while (P < n) P <<= 1;
+  // descending sort of ~(id, pos): ascending (id, pos) order; padding = 0 sorts last
+  for (int i = t; i < P; i += 256)
+    skeys[i] = (i < n) ? ~(((unsigned long long)(unsigned int)ids[s0 + i] << 32) | (unsigned long long)(unsigned int)i) : 0ull;
+  __syncthreads();
+  bitonic_sort_desc<256>(skeys, P, t);
+  __shared__ int n_unique;
+  if (t == 0) n_unique = 0;
+  __syncthreads();
+  for (int i = t; i < n; i += 256) {
+    const unsigned long long key = ~skeys[i];
+    const unsigned int id = (unsigned int)(key >> 32);
+    const bool head = i == 0 || (unsigned int)((~skeys[i - 1]) >> 32) != id;
+    float agg = 0.f;
+    long long oid = -1;
+    if (head) {
+      agg = mode == 0 ? 0.f : -INFINITY;
+      for (int r = i; r < n; ++r) {
+        const unsigned long long kr = ~skeys[r];
+        if ((unsigned int)(kr >> 32) != id) break;
+        const float sc = scores[s0 + (unsigned int)kr];
+        agg = mode == 0 ? agg + sc : fmaxf(agg, sc);
+      }
+      oid = (long long)id;
+      atomicAdd(&n_unique, 1);
+    }
+    out_s[s0 + i] = agg;      // scratch use of the output range: re-read below
+    out_i[s0 + i] = oid;
+  }
+  __syncthreads();
+  for (int i = t; i < P; i += 256) {
+    unsigned long long key = 0ull;
+    if (i < n && out_i[s0 + i] >= 0) key = make_key(out_s[s0 + i], (unsigned int)out_i[s0 + i]);
+    skeys[i] = key;
+  }
+  __syncthreads();
+  bitonic_sort_desc<256>(skeys, P, t);
+  const int nu = n_unique;
+  for (int i = t; i < nu; i += 256) {
+    out_s[s0 + i] = key_score(skeys[i]);
+    out_i[s0 + i] = (long long)key_id(skeys[i]);
+  }
+  if (t == 0) out_n[blockIdx.x] = nu;
+}
+
 }  // namespace
 }  // namespace mevi
 
 using namespace mevi;
+
+extern "C" int mevi_segment_aggregate_sort_f32(const float *scores, const int64_t *ids, const int64_t *seg_offsets, int64_t nseg,
+                                               int64_t max_seg_len, int mode, float *out_scores, int64_t *out_ids,
+                                               int32_t *out_counts, void *stream) {
+  MEVI_REQUIRE(nseg >= 0 && max_seg_len >= 0 && (mode == 0 || mode == 1), MEVI_ERR_INVALID_ARG, "segment_aggregate_sort: bad arguments");
+  if (nseg == 0) return MEVI_OK;
+  MEVI_REQUIRE(scores && ids && seg_offsets && out_scores && out_ids && out_counts, MEVI_ERR_INVALID_ARG, "segment_aggregate_sort: null pointer");
+  MEVI_REQUIRE(max_seg_len <= 16384, MEVI_ERR_UNSUPPORTED, "segment_aggregate_sort: segment of %lld > 16384 entries", (long long)max_seg_len);
+  int P = 64;
+  while (P < max_seg_len) P <<= 1;
+  if ((size_t)P * 8 > 65536)
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(segment_aggregate_sort_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
+  hipLaunchKernelGGL(segment_aggregate_sort_kernel, dim3((unsigned)nseg), dim3(256), (size_t)P * 8, (hipStream_t)stream, scores,
+                     reinterpret_cast<const long long *>(ids), reinterpret_cast<const long long *>(seg_offsets), mode, out_scores,
+                     reinterpret_cast<long long *>(out_ids), out_counts);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
 
 extern "C" int mevi_pair_dot_f32(const float *a, int64_t lda, const int64_t *ia, const float *b, int64_t ldb,
                                  const int64_t *ib, int64_t n, int64_t dim, float *out, void *stream) {

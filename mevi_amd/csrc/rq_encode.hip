@@ -35,11 +35,19 @@ constexpr int RQ_MAXM = 8;    // levels supported by the in-register code histor
 // (a runtime-indexed history array lands in scratch: 20x slower).
 // STORE = true: write -distance to neg_dist[row, c] instead of taking the argmin (pq.beam_search needs
 // the whole score row: compute_scores, pq.py:124-131); X is then an explicit residual matrix (LEVEL 0).
+// `rows` (optional): the kernel encodes X[rows[i]] for i < *nrows instead of rows 0..n-1 (the exact re-encode of the rows the
+// matrix-core encoder could not decide, rq_fast.hip); codes are read and written at the rows' own positions.
 template <int LEVEL, bool STORE>
 __global__ __launch_bounds__(256, 2) void rq_level_kernel(const float *__restrict__ X, long long n, int dim,
                                                          const float *__restrict__ C, int M, int K,
-                                                         int *__restrict__ codes, float *__restrict__ neg_dist) {
+                                                         int *__restrict__ codes, float *__restrict__ neg_dist,
+                                                         const long long *__restrict__ rows = nullptr,
+                                                         const unsigned int *__restrict__ nrows = nullptr) {
   constexpr int level = LEVEL;
+  if (rows) {
+    n = (long long)*nrows;
+    if ((long long)blockIdx.x * RQ_ROWS >= n) return;
+  }
   __shared__ __attribute__((aligned(16))) float xs[2][RQ_ROWS * RQ_LD];
   __shared__ __attribute__((aligned(16))) float cs[2][RQ_CENTS * RQ_LD];
 
@@ -59,6 +67,7 @@ __global__ __launch_bounds__(256, 2) void rq_level_kernel(const float *__restric
   for (int i = 0; i < 4; ++i) {
     long long r = row0 + srow + 32 * i;
     if (r > n - 1) r = n - 1;
+    if (rows) r = rows[r];
     xptr[i] = X + (size_t)r * dim + skq;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) prev[i][j] = codes[(size_t)r * M + j];
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void rq_level_kernel(const float *__restric
       }
     }
     const long long r = row0 + 32 * wave + ld + 8 * i;
-    if (lc == 0 && r < n) codes[(size_t)r * M + level] = best_c[i];
+    if (lc == 0 && r < n) codes[(size_t)(rows ? rows[r] : r) * M + level] = best_c[i];
   }
 }
 
@@ -199,6 +208,29 @@ __global__ __launch_bounds__(256) void gather_sub_kernel(const float *__restrict
 }
 
 }  // namespace
+
+// exact encode of the rows listed in `rows[0, *nrows)` (device-side count; the grid covers max_rows): rq_fast.hip's fallback
+int rq_encode_exact_rows(const float *x, int64_t dim, const float *codebook, int64_t M, int64_t K, int32_t *codes,
+                         const long long *rows, const unsigned int *nrows, int64_t max_rows, hipStream_t stream) {
+  const int64_t nblk = (max_rows + RQ_ROWS - 1) / RQ_ROWS;
+  MEVI_REQUIRE(nblk <= 0x7fffffffLL && M <= RQ_MAXM && dim % 4 == 0, MEVI_ERR_UNSUPPORTED, "rq_encode_exact_rows: shape");
+  for (int level = 0; level < (int)M; ++level) {
+#define MEVI_RQ_LEVEL(L)                                                                                   \
+  case L:                                                                                                  \
+    hipLaunchKernelGGL((rq_level_kernel<L, false>), dim3((unsigned)nblk), dim3(256), 0, stream, x,         \
+                       (long long)max_rows, (int)dim, codebook, (int)M, (int)K, codes, (float *)nullptr,   \
+                       rows, nrows);                                                                       \
+    break;
+    switch (level) {
+      MEVI_RQ_LEVEL(0) MEVI_RQ_LEVEL(1) MEVI_RQ_LEVEL(2) MEVI_RQ_LEVEL(3)
+      MEVI_RQ_LEVEL(4) MEVI_RQ_LEVEL(5) MEVI_RQ_LEVEL(6) MEVI_RQ_LEVEL(7)
+    }
+#undef MEVI_RQ_LEVEL
+  }
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
 }  // namespace mevi
 
 using namespace mevi;

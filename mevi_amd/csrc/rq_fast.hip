@@ -1,0 +1,769 @@
+// Residual-quantisation encode on the matrix cores with an exact re-check (round 3).
+//
+// Replaces pq.get_rq_document_cluster / forward_rq with dist_mode 'l2' (MEVI/pq.py:124-131, 281-305, 337-369) -- the same
+// codes, bit for bit, as rq_encode.hip / oracle/mevi_oracle.c (sequential f32 fmaf chains of (r - c)^2, ties to the lowest
+// centroid), at the HBM rate instead of the f32 VALU rate.
+//
+// Idea.  ||r_j - c||^2 = ||r_j||^2 - 2 r_j.c + ||c||^2 and r_j = x - sum_{i<j} C_i[code_i], so
+//     r_j.c = x.c - sum_{i<j} C_i[code_i].C_j[c]:
+// ONE product x.C^T against ALL M*K centroids (f16 MFMA, f32 accumulate) plus table look-ups
+// G[i][a][j][c] = C_i[a].C_j[c] gives an approximation F_j(c) of  dist_j(c) - ||r_j||^2  for every level; the residual is
+// never formed and x crosses HBM once (K = 256: once per level -- the accumulators of 768 columns do not fit a wave).
+// Only x and C are rounded to f16; x is centred first (x' = x - mu, mu = mean of the level-0 centroids; level-0 centroids
+// are centred the same way, which changes no distance) so the rounding error scales with ||x - mu|| ||c - mu||, not with
+// the common component of dense-retriever embeddings.
+//
+// Exactness.  Per row and level, with m = min_c F(c) at c*:  every c with F(c) - m > Delta provably has a LARGER chain
+// distance than c* (Delta: rigorous bound, see rf_delta), so the oracle's argmin is among the candidates {F(c) <= m + Delta}.
+//   * one candidate  -> code = c* (no exact distance needed);
+//   * several        -> the kernel speculates c*, appends a RECORD (row, level, premise codes, candidates); the fix-up
+//                       kernel evaluates the candidates' exact chains (the reference arithmetic: residual in f32 in the
+//                       reference's operation order, d = fma(r - c, r - c, d) over k) and takes (distance, index) min;
+//   * speculation wrong, > 8 candidates, f16 overflow, record buffer full -> the row is flagged and re-encoded from scratch
+//     by the exact VALU kernel (rq_encode.hip) through an index list.
+// No host synchronisation: record / flag counts stay on the device.
+//
+// Kernel.  Persistent 512-thread workgroups, tile = 256 x rows x TA*32 centroid columns (TA = 4 | 8 MFMA tiles: all levels of
+// (4, 32) in one tile, one level of K = 256 per tile).  Wave w owns x rows 32w..32w+31 against ALL columns: acc[TA] of
+// v_mfma_f32_32x32x16_f16 with A = centroids, B = x, so a lane holds 16 TA/2.. distances of ONE row and the per-level argmin
+// is in-lane + one cross-half shuffle.  Operands are staged by LDS-DMA (buffer_load ... lds) in units of 32 k: the f16
+// centroid image (unit-major, L2 resident) and the f32 x rows straight from the caller's matrix -- converted to f16 between
+// the LDS read and the MFMA (fma with the scale and -mu, v_cvt_pk), so there is no f16 copy of the corpus.  Three unit
+// buffers (48 KiB each at TA = 8), two units = 64 KiB of x in flight per CU.
+// Bound: HBM for (4, 32) (MFMA ~25 % busy); MFMA / LDS for K = 256.
+
+#include "mfma_pp_f16.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace mevi {
+namespace {
+
+constexpr int RF_ROWS = 256;  // x rows per tile
+constexpr int RF_NBUF = 3;
+constexpr int RF_MAXC = 8;    // candidates a record can hold
+
+struct __attribute__((aligned(16))) RfRecord {
+  long long row;
+  unsigned long long prev;  // premise: codes of levels < level, one byte each
+  unsigned char level, ncand, spec, pad;
+  unsigned char cand[RF_MAXC];
+  unsigned int pad2;
+};
+static_assert(sizeof(RfRecord) == 32, "record layout");
+
+// per-level constants written by the prep kernels (device memory; the main kernel reads them with scalar loads)
+struct RfLevel {
+  float inv2;    // -2 / (S_x S_c,j)
+  float cnmax;   // max_c ||c'_j||  (rounded up)
+  float qpre;    // sum_{i<j} cnmax_i
+  float und_c;   // 2 * 2^-25 sqrt(dim) / S_c,j   (x ||x'||: products lost to f16 underflow of the centroids)
+  float und_x;   // 2 * 2^-25 sqrt(dim) cnmax_j / S_x
+  float sc;      // S_c,j
+  float pad[2];
+};
+
+struct RfParams {
+  const float *X;
+  long long n;
+  int dim;
+  const _Float16 *img;  // [ngroups][U][TA*32][32] halves: unit-major centroid image, centred (level 0) and scaled
+  const float *mus;     // [dim]  mu * S_x
+  const float *A;       // [M][Kp]  ||c'||^2 (+inf for padding columns)
+  const float *G2;      // [(i*K + a)][M][Kp]  2 * c'_i[a] . c'_j[c]  (i < j)
+  const RfLevel *lev;   // [M]
+  const float *scal;    // [0] S_x  [1] 1 / S_x^2
+  int M, K, Kp, LPG, ngroups;
+  int *codes;
+  unsigned char *row_flag;
+  RfRecord *rec;
+  unsigned int *counters;  // [0] records appended (may exceed rec_cap)  [1] bad rows  [2] ambiguous row-levels
+  unsigned int rec_cap;
+  float e16, gam;
+  long long n_tiles;
+};
+
+template <int TA>
+constexpr int rf_unit_floats() { return (TA * 32 * 64 + RF_ROWS * 128) / 4; }
+template <int TA>
+constexpr size_t rf_lds_bytes(int dim) { return (size_t)RF_NBUF * rf_unit_floats<TA>() * 4 + (size_t)dim * 4; }
+
+// Delta of the header: candidates are the c with F(c) - m <= Delta.
+//   F*(c)  = D*(c) - rho  (real arithmetic; D* the distance to the real-number residual, rho = ||r*_j||^2),  |F - F*| <= E1
+//   chain  = the oracle's f32 value:  |chain(c) - ||r_f32 - c||^2| <= gam * itself,   ||r_f32 - r*|| <= dl
+// c is excluded when D*(c) > D*(c*) (1 + 2.1 gam) + 2.1 e2, with e2 = 2 sqrt(Dh) dl + dl^2 covering the residual's own
+// rounding for distances up to Dh.  Returns Delta (+inf when the premises of the bound do not hold -> everything is a candidate).
+__device__ __forceinline__ float rf_delta(float m, float rho_hat, float E1, float gam, float dl, float &dpos_out) {
+  const float dpos = fmaxf(rho_hat + m + E1, 0.f);  // upper bound of D*(c*)
+  const float dh = 2.f * dpos + 8.f * E1 + 1e-30f;
+  const float e2 = (2.f * sqrtf(dh) * dl + dl * dl) * 1.01f;
+  dpos_out = dpos;
+  if (!(2.1f * e2 <= 6.f * E1 + dpos)) return INFINITY;
+  return (2.f * E1 + 2.1f * gam * dpos + 2.1f * e2) * 1.01f;
+}
+
+template <int TA, int KT>
+__device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
+  constexpr int UNIT = rf_unit_floats<TA>();       // floats per unit buffer: A image then x rows
+  constexpr int AFL = TA * 32 * 16;                // floats of the A part (64 B per row)
+  constexpr int PA_PER_WAVE = TA / 4;              // A pieces (16 rows x 64 B) per wave and unit
+  constexpr int P = 4 + PA_PER_WAVE;               // DMA pieces per wave and unit
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lrow = lane & 31, half = lane >> 5;
+  const int U = p.dim >> 5;
+  float *mus_l = lds + RF_NBUF * UNIT;
+  for (int i = t; i < p.dim; i += 512) mus_l[i] = p.mus[i];
+  __syncthreads();
+
+  // ---- DMA duties ---------------------------------------------------------------------------------------------------
+  // x: piece q (8 rows x 128 B) of this wave's own 32 rows; lane (r8 = lane >> 3, slot = lane & 7) fetches logical piece
+  // slot ^ g(row), g(row) = (row >> 1) & 7, so that the b128 fragment reads below are bank-conflict free
+  int voff_x[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r8 = lane >> 3, row = 32 * w8 + 8 * q + r8;
+    voff_x[q] = row * p.dim * 4 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+  }
+  // centroid image: piece (16 rows x 64 B); lane (r16 = lane >> 2, slot = lane & 3) fetches piece slot ^ ((row >> 2) & 3)
+  int voff_a[PA_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < PA_PER_WAVE; ++i) {
+    const int row = 16 * (w8 * PA_PER_WAVE + i) + (lane >> 2);
+    voff_a[i] = row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+  }
+  const unsigned int a_block_bytes = (unsigned int)(TA * 32 * 64);  // one unit of one group's image
+
+  // work list of this workgroup: row tiles blockIdx.x, + gridDim.x, ...; inside a row tile the groups in order
+  long long rt = blockIdx.x;
+  int grp = 0;
+  struct Src {
+    const void *x;
+    unsigned int xbytes;
+    const void *a;
+  };
+  auto src_of = [&](long long rt_, int g_, Src &s) {
+    const long long r0 = rt_ * RF_ROWS;
+    long long rows = p.n - r0;
+    rows = rows > RF_ROWS ? RF_ROWS : (rows < 0 ? 0 : rows);
+    s.x = p.X + (size_t)r0 * p.dim;
+    s.xbytes = (unsigned int)(rows * p.dim * 4);
+    s.a = reinterpret_cast<const char *>(p.img) + (size_t)g_ * U * a_block_bytes;
+  };
+  auto advance = [&](long long &rt_, int &g_) -> bool {  // next (row tile, group) of this workgroup
+    if (++g_ < p.ngroups) return true;
+    g_ = 0;
+    rt_ += gridDim.x;
+    return rt_ < p.n_tiles;
+  };
+  if (rt >= p.n_tiles) return;
+  Src cur, nxt;
+  src_of(rt, grp, cur);
+  long long rt_n = rt;
+  int grp_n = grp;
+  bool have_nxt = advance(rt_n, grp_n);
+  if (have_nxt) src_of(rt_n, grp_n, nxt);
+  else nxt = cur, nxt.xbytes = 0u;
+
+  auto dma = [&](const Src &s, bool live, int u, int gb, int first, int count) {  // pieces [first, first+count) of the wave's P
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.x), 0, (int)s.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.a), 0, live ? (int)(U * a_block_bytes) : 0, 0x00020000);
+    float *ub = lds + gb * UNIT;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      if (i < first || i >= first + count) continue;
+      if (i < 4) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(ub + AFL + (32 * w8 + 8 * i) * 32), 16,
+                                                 voff_x[i], u * 128, 0, 0);
+      } else {
+        const int ia = i - 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void *)(ub + (16 * (w8 * PA_PER_WAVE + ia)) * 16), 16,
+                                                 voff_a[ia], u * (int)a_block_bytes, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment addresses ---------------------------------------------------------------------------------------------
+  const int a_sw = (lrow >> 2) & 3;
+  const int offa = lrow * 16;                                  // floats; + 32 t * 16 per MFMA tile
+  const int offb = AFL + (32 * w8 + lrow) * 32;                // floats
+  const int b_sw = (lrow >> 1) & 7;
+  f32x16 acc[TA];
+  // Fragments.  A k-step (16 k) is issued as two HALF-STEPS of H = TA/2 MFMAs (centroid tiles [0, H) then [H, TA)); the
+  // A fragments of a half-step are read while the previous half-step's MFMAs run, so 2 x H fragments are live instead of the
+  // 2 x TA of a whole-k-step double buffer (at TA = 8 that version spilled 124 registers, some inside the loop).
+  constexpr int H = TA / 2;
+  f16x8 alo[H], ahi[H], bq0, bq1;
+  const float sx = p.scal[0];
+  float rho_s = 0.f;  // sum of (x' S_x)^2 over this lane's k (the other half holds the rest)
+  auto read_a = [&](int gb, int j, int h0, f16x8 (&dst)[H]) {
+    const float *ub = lds + gb * UNIT + offa + (((2 * j + half) ^ a_sw) << 2);
+#pragma unroll
+    for (int ti = 0; ti < H; ++ti) dst[ti] = *reinterpret_cast<const f16x8 *>(ub + 32 * (h0 + ti) * 16);
+  };
+  // this lane's 8 x values of k-step (u, j): centred, scaled, rounded to f16 (and added to the row norm)
+  auto read_x = [&](int gb, int u, int j, f16x8 &b) {
+    const float *ub = lds + gb * UNIT;
+    const int c0 = 4 * j + 2 * half;
+    const float4 x0 = *reinterpret_cast<const float4 *>(ub + offb + ((c0 ^ b_sw) << 2));
+    const float4 x1 = *reinterpret_cast<const float4 *>(ub + offb + (((c0 + 1) ^ b_sw) << 2));
+    const float4 m0 = *reinterpret_cast<const float4 *>(mus_l + 32 * u + 16 * j + 8 * half);
+    const float4 m1 = *reinterpret_cast<const float4 *>(mus_l + 32 * u + 16 * j + 8 * half + 4);
+    float v[8];
+    v[0] = fmaf(x0.x, sx, -m0.x); v[1] = fmaf(x0.y, sx, -m0.y); v[2] = fmaf(x0.z, sx, -m0.z); v[3] = fmaf(x0.w, sx, -m0.w);
+    v[4] = fmaf(x1.x, sx, -m1.x); v[5] = fmaf(x1.y, sx, -m1.y); v[6] = fmaf(x1.z, sx, -m1.z); v[7] = fmaf(x1.w, sx, -m1.w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      rho_s = fmaf(v[i], v[i], rho_s);
+      b[i] = (_Float16)v[i];
+    }
+  };
+  auto mma_lo = [&](const f16x8 &b) {
+#pragma unroll
+    for (int ti = 0; ti < H; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ti], b, acc[ti], 0, 0, 0);
+  };
+  auto mma_hi = [&](const f16x8 &b) {
+#pragma unroll
+    for (int ti = 0; ti < H; ++ti) acc[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ti], b, acc[H + ti], 0, 0, 0);
+  };
+
+  // per-row state carried across the groups of a row tile (this lane's row = 32 w8 + lrow of the tile; both halves agree)
+  unsigned long long prev = 0ull;
+  float rho_hat = 0.f, xn = 0.f;
+  bool row_bad = false;
+
+  int rb = 0;
+  constexpr int P_A = P / 2, P_B = P - P / 2;
+  // One unit (32 k) of the current tile.  On entry alo / bq0 hold k-step (u, 0).  Unit u+2 of the stream is requested at
+  // the start (its buffer was released by the previous cycle's barrier); the barrier sits before the LAST half-step: by
+  // then every read of unit u has been issued (and, with lgkmcnt(0), completed) and unit u+1 must have landed for the
+  // reads of k-step (u+1, 0) that the last half-step issues.
+  auto cycle = [&](int u, bool last) {
+    const bool spill = u + 2 >= U;
+    const Src &tg = spill ? nxt : cur;
+    const bool live = spill ? have_nxt : true;
+    const int tu = spill ? u + 2 - U : u + 2;
+    const int wb = rb == 0 ? RF_NBUF - 1 : rb - 1;
+    read_a(rb, 0, H, ahi);
+    mma_lo(bq0);
+    dma(tg, live, tu, wb, 0, P_A);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(rb, 1, 0, alo);
+    read_x(rb, u, 1, bq1);
+    mma_hi(bq0);
+    dma(tg, live, tu, wb, P_A, P_B);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(rb, 1, H, ahi);
+    mma_lo(bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (P == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    rb = rb == RF_NBUF - 1 ? 0 : rb + 1;
+    if (!last) {
+      read_a(rb, 0, 0, alo);
+      read_x(rb, u + 1, 0, bq0);
+    }
+    mma_hi(bq1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  dma(cur, true, 0, 0, 0, P);
+  dma(cur, true, 1, 1, 0, P);
+  if constexpr (P == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  while (true) {
+#pragma unroll
+    for (int ti = 0; ti < TA; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+    rho_s = 0.f;
+    read_a(rb, 0, 0, alo);      // k-step (0, 0) of the tile: its unit has landed (prologue / the previous tile's last barrier)
+    read_x(rb, 0, 0, bq0);
+    for (int u = 0; u < U - 1; ++u) cycle(u, false);
+    cycle(U - 1, true);
+
+    // ---- epilogue of (row tile rt, group grp): per level argmin of F, candidate test, record ---------------------------------
+    const long long row = rt * RF_ROWS + 32 * w8 + lrow;
+    if (grp == 0) {
+      const float tot = rho_s + __shfl_xor(rho_s, 32);
+      rho_hat = tot * p.scal[1] * 1.0001f;  // ||x'||^2, rounded up
+      xn = sqrtf(rho_hat) * 1.0001f;
+      prev = 0ull;
+      row_bad = false;
+    }
+    const int lev0 = grp * p.LPG;
+#pragma unroll
+    for (int l = 0; l < TA / KT; ++l) {
+      const int j = lev0 + l;
+      if (l >= p.LPG || j >= p.M) break;  // uniform
+      const RfLevel L = p.lev[j];
+      const float *Aj = p.A + (size_t)j * p.Kp;
+      // F in place: acc <- acc * (-2 / (S_x S_c)) + A[c], then += 2 G[i][code_i][j][c] level by level (no second copy of the
+      // tile: 128 accumulators + one tile's table values is what fits the 256-register budget at K = 256)
+#pragma unroll
+      for (int tk = 0; tk < KT; ++tk) {
+        f32x16 &a = acc[l * KT + tk];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 av = *reinterpret_cast<const float4 *>(Aj + 32 * tk + 8 * g4 + 4 * half);
+          a[4 * g4] = fmaf(a[4 * g4], L.inv2, av.x), a[4 * g4 + 1] = fmaf(a[4 * g4 + 1], L.inv2, av.y);
+          a[4 * g4 + 2] = fmaf(a[4 * g4 + 2], L.inv2, av.z), a[4 * g4 + 3] = fmaf(a[4 * g4 + 3], L.inv2, av.w);
+        }
+        if constexpr (KT > 2) __builtin_amdgcn_sched_barrier(0);
+      }
+      for (int i = 0; i < j; ++i) {
+        const unsigned int ci = (unsigned int)(prev >> (8 * i)) & 255u;
+        const float *Gi = p.G2 + ((size_t)(i * p.K + (int)ci) * p.M + j) * p.Kp + 4 * half;
+#pragma unroll
+        for (int tk = 0; tk < KT; ++tk) {
+          f32x16 &a = acc[l * KT + tk];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 gv = *reinterpret_cast<const float4 *>(Gi + 32 * tk + 8 * g4);
+            a[4 * g4] += gv.x, a[4 * g4 + 1] += gv.y, a[4 * g4 + 2] += gv.z, a[4 * g4 + 3] += gv.w;
+          }
+          if constexpr (KT > 2) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      float m = INFINITY;
+      int mi = 0;
+#pragma unroll
+      for (int tk = 0; tk < KT; ++tk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float f = acc[l * KT + tk][r];
+          if (f < m) {  // ascending c inside a lane: strict < keeps the lowest index
+            m = f;
+            mi = 32 * tk + (r & 3) + 8 * (r >> 2) + 4 * half;
+          }
+        }
+      }
+      {
+        const float om = __shfl_xor(m, 32);
+        const int oi = __shfl_xor(mi, 32);
+        if (om < m || (om == m && oi < mi)) m = om, mi = oi;
+      }
+      // bound (rf_delta): E1 = everything between F and F*
+      const float q = xn + L.qpre;
+      // roundings between F and F*: the table entries (A, j of G), the j adds and the fma, each relative to <= cnmax^2 + 2 q cnmax
+      const float e24 = (2.f * (float)j + 3.f) * 5.97e-8f;
+      const float E1 = (p.e16 * xn * L.cnmax + e24 * (L.cnmax * L.cnmax + 2.f * q * L.cnmax) + L.und_c * xn + L.und_x) * 1.01f;
+      const float dl = (float)j * 5.97e-8f * q * 1.01f;
+      float dpos;
+      float delta = rf_delta(m, rho_hat, E1, p.gam, dl, dpos);
+      const bool finite = (m > -3.0e38f) && (m < 3.0e38f);  // f16 overflow / NaN inputs end here
+      if (!finite) delta = INFINITY;
+      const float thr = m + delta;
+      int cnt = 0;
+#pragma unroll
+      for (int tk = 0; tk < KT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cnt += (acc[l * KT + tk][r] <= thr) ? 1 : 0;
+      const int ocnt = __shfl_xor(cnt, 32);
+      const int total = cnt + ocnt;
+      if (total != 1 && !row_bad && row < p.n) {  // ambiguous (or nothing finite): record, or give the row to the exact kernel
+        bool overflow = !finite || total > RF_MAXC || total < 1;
+        unsigned int slot = 0u;
+        if (!overflow) {
+          if (half == 0) {
+            slot = atomicAdd(&p.counters[0], 1u);
+            atomicAdd(&p.counters[2], 1u);
+          }
+          slot = __shfl(slot, lrow);
+          overflow = slot >= p.rec_cap;
+        }
+        if (overflow) {
+          row_bad = true;
+        } else {
+          RfRecord *rec = p.rec + slot;
+          if (half == 0) {
+            rec->row = row;
+            rec->prev = prev;
+            rec->level = (unsigned char)j;
+            rec->ncand = (unsigned char)total;
+            rec->spec = (unsigned char)mi;
+          }
+          int pos = half == 0 ? 0 : ocnt;  // lower half's candidates first
+#pragma unroll
+          for (int tk = 0; tk < KT; ++tk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (acc[l * KT + tk][r] <= thr) rec->cand[pos++] = (unsigned char)(32 * tk + (r & 3) + 8 * (r >> 2) + 4 * half);
+        }
+      }
+      prev |= (unsigned long long)(unsigned int)mi << (8 * j);
+      rho_hat = (dpos + (delta < INFINITY ? delta : 0.f)) * 1.0001f;  // upper bound of ||r*_{j+1}||^2 for any candidate
+      if (half == 0 && row < p.n) p.codes[(size_t)row * p.M + j] = mi;
+    }
+    if (grp == p.ngroups - 1 && row_bad && half == 0 && row < p.n) p.row_flag[row] = 1;
+
+    if (!have_nxt) break;
+    cur = nxt;
+    rt = rt_n, grp = grp_n;
+    have_nxt = advance(rt_n, grp_n);
+    if (have_nxt) src_of(rt_n, grp_n, nxt);
+    else nxt.xbytes = 0u;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// (the body lives in a __device__ function: the host pass instantiates a kernel template's own body, and the buffer / LDS
+// builtins above do not exist there)
+template <int TA, int KT>
+__global__ __launch_bounds__(512, 2) void rq_fast_kernel(const RfParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  rq_fast_body<TA, KT>(p, lds);
+}
+
+// ---- prep kernels (codebook only: a few hundred KB) -------------------------------------------------------------------------
+// mu = mean of the level-0 centroids (f32); one thread per column
+__global__ __launch_bounds__(256) void rf_mu_kernel(const float *__restrict__ C, int K, int dim, float *__restrict__ mu) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= dim) return;
+  double s = 0.0;
+  for (int c = 0; c < K; ++c) s += (double)C[(size_t)c * dim + k];
+  mu[k] = (float)(s / (double)K);
+}
+
+// per level: max |c'_k| and max ||c'|| over its centroids (c' = c - mu on level 0); one workgroup per level
+__global__ __launch_bounds__(256) void rf_level_stats_kernel(const float *__restrict__ C, int M, int K, int dim,
+                                                            const float *__restrict__ mu, float *__restrict__ stat) {
+  __shared__ float smax[256], snorm[256];
+  const int j = blockIdx.x, t = threadIdx.x;
+  float mx = 0.f, mn = 0.f;
+  for (int c = t; c < K; c += 256) {
+    const float *row = C + ((size_t)j * K + c) * dim;
+    double ss = 0.0;
+    for (int k = 0; k < dim; ++k) {
+      const double v = (double)row[k] - (j == 0 ? (double)mu[k] : 0.0);
+      ss += v * v;
+      mx = fmaxf(mx, (float)fabs(v));
+    }
+    mn = fmaxf(mn, (float)sqrt(ss) * 1.00001f);
+  }
+  smax[t] = mx, snorm[t] = mn;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) smax[t] = fmaxf(smax[t], smax[t + s]), snorm[t] = fmaxf(snorm[t], snorm[t + s]);
+    __syncthreads();
+  }
+  if (t == 0) stat[2 * j] = smax[0] * 1.00001f, stat[2 * j + 1] = snorm[0];
+}
+
+__device__ __forceinline__ float rf_pow2_scale(float m, int target_exp) {  // power of two S with m S in [2^(t-1), 2^t)
+  if (!(m > 0.f)) return 1.f;
+  int e;
+  (void)frexpf(m, &e);
+  int s = target_exp - e;
+  s = s > 100 ? 100 : (s < -100 ? -100 : s);
+  return ldexpf(1.f, s);
+}
+
+// scales and the per-level constants; one thread
+__global__ void rf_levels_kernel(const float *__restrict__ stat, int M, int dim, RfLevel *__restrict__ lev, float *__restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float sx = rf_pow2_scale(stat[0], 11);  // x' = c'_0 + residual: 32x head-room to the f16 maximum
+  scal[0] = sx;
+  scal[1] = (1.f / sx) * (1.f / sx);
+  float qpre = 0.f;
+  const float sq = sqrtf((float)dim) * 1.001f;
+  for (int j = 0; j < M; ++j) {
+    const float sc = rf_pow2_scale(stat[2 * j], 13);
+    RfLevel L;
+    L.sc = sc;
+    L.inv2 = -2.f * (1.f / sx) * (1.f / sc);
+    L.cnmax = stat[2 * j + 1];
+    L.qpre = qpre;
+    L.und_c = 2.f * 2.98e-8f * 1.01f * sq / sc;
+    L.und_x = 2.f * 2.98e-8f * 1.01f * sq * L.cnmax / sx;
+    L.pad[0] = L.pad[1] = 0.f;
+    lev[j] = L;
+    qpre += L.cnmax * 1.00001f;
+  }
+}
+
+__global__ __launch_bounds__(256) void rf_mus_kernel(const float *__restrict__ mu, const float *__restrict__ scal, int dim,
+                                                    float *__restrict__ mus) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < dim) mus[k] = mu[k] * scal[0];
+}
+
+// image + A: one wave per (level, centroid incl. padding)
+__global__ __launch_bounds__(256) void rf_image_kernel(const float *__restrict__ C, int M, int K, int Kp, int dim, int LPG, int TA,
+                                                      const float *__restrict__ mu, const RfLevel *__restrict__ lev,
+                                                      _Float16 *__restrict__ img, float *__restrict__ A) {
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wv >= M * Kp) return;
+  const int j = wv / Kp, c = wv - j * Kp;
+  const int g = j / LPG, rowi = (j - g * LPG) * Kp + c;  // row inside the group's TA*32-row block
+  const int U = dim >> 5;
+  const bool real = c < K;
+  const float sc = lev[j].sc;
+  double ss = 0.0;
+  for (int k = lane; k < dim; k += 64) {
+    float v = 0.f;
+    if (real) {
+      v = C[((size_t)j * K + c) * dim + k];
+      if (j == 0) v = (float)((double)v - (double)mu[k]);
+      ss += (double)v * (double)v;
+    }
+    img[(((size_t)g * U + (k >> 5)) * (TA * 32) + rowi) * 32 + (k & 31)] = (_Float16)(v * sc);
+  }
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  if (lane == 0) A[(size_t)j * Kp + c] = real ? (float)ss : INFINITY;
+}
+
+// G2[(i K + a)][j][c] = 2 c'_i[a] . c'_j[c] for i < j (f64 accumulation); one thread per entry
+__global__ __launch_bounds__(256) void rf_g_kernel(const float *__restrict__ C, int M, int K, int Kp, int dim,
+                                                  const float *__restrict__ mu, float *__restrict__ G2) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)M * K * M * Kp;
+  if (e >= total) return;
+  const int c = (int)(e % Kp);
+  const int j = (int)((e / Kp) % M);
+  const int a = (int)((e / ((long long)Kp * M)) % K);
+  const int i = (int)(e / ((long long)Kp * M * K));
+  float out = 0.f;
+  if (i < j && c < K) {
+    const float *ci = C + ((size_t)i * K + a) * dim, *cj = C + ((size_t)j * K + c) * dim;
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) s += ((double)ci[k] - (i == 0 ? (double)mu[k] : 0.0)) * (double)cj[k];
+    out = (float)(2.0 * s);
+  }
+  G2[e] = out;
+}
+
+// ---- fix-up: exact chains of a record's candidates -----------------------------------------------------------------------------
+// 8 lanes per record (one per candidate slot), 8 records per wave.  The chain is the oracle's: r = ((x - c_0) - c_1) - ...
+// in f32 in that order, d = fma(r - c, r - c, d) over k = 0..dim-1.
+__global__ __launch_bounds__(256) void rf_fixup_kernel(const float *__restrict__ X, int dim, const float *__restrict__ C, int M, int K,
+                                                      const RfRecord *__restrict__ rec, const unsigned int *__restrict__ counters,
+                                                      unsigned int rec_cap, unsigned char *__restrict__ row_flag) {
+  unsigned int nrec = counters[0];
+  nrec = nrec < rec_cap ? nrec : rec_cap;
+  const unsigned int ri = (blockIdx.x * 256 + threadIdx.x) >> 3;
+  const int slot = threadIdx.x & 7;
+  const bool live = ri < nrec;
+  RfRecord R;
+  if (live) R = rec[ri];
+  const int level = live ? R.level : 0;
+  const bool has = live && slot < (int)R.ncand;
+  const int cand = has ? R.cand[slot] : 0;
+  const float *xr = X + (size_t)(live ? R.row : 0) * dim;
+  const float *cc = C + ((size_t)level * K + cand) * dim;
+  float d = 0.f;
+  if (has) {
+    const float *pc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pc[i] = C + ((size_t)i * K + (int)((R.prev >> (8 * i)) & 255ull)) * dim;
+    for (int k = 0; k < dim; k += 4) {
+      float4 r = *reinterpret_cast<const float4 *>(xr + k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < level) {
+          const float4 c = *reinterpret_cast<const float4 *>(pc[i] + k);
+          r.x -= c.x, r.y -= c.y, r.z -= c.z, r.w -= c.w;
+        }
+      }
+      const float4 c = *reinterpret_cast<const float4 *>(cc + k);
+      float e;
+      e = r.x - c.x; d = fmaf(e, e, d);
+      e = r.y - c.y; d = fmaf(e, e, d);
+      e = r.z - c.z; d = fmaf(e, e, d);
+      e = r.w - c.w; d = fmaf(e, e, d);
+    }
+  } else {
+    d = INFINITY;
+  }
+  int best = has ? cand : 0x7fffffff;
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    const float od = __shfl_xor(d, off);
+    const int oc = __shfl_xor(best, off);
+    if (od < d || (od == d && oc < best)) d = od, best = oc;
+  }
+  if (live && slot == 0 && best != (int)R.spec) row_flag[R.row] = 1;  // speculation wrong (or NaN distances): exact re-encode
+}
+
+// flagged rows -> index list (order irrelevant)
+__global__ __launch_bounds__(256) void rf_badlist_kernel(const unsigned char *__restrict__ row_flag, long long n,
+                                                        long long *__restrict__ list, unsigned int *__restrict__ counters) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r < n && row_flag[r]) list[atomicAdd(&counters[1], 1u)] = r;
+}
+
+}  // namespace
+
+// exact VALU encoder over an index list (rq_encode.hip)
+int rq_encode_exact_rows(const float *x, int64_t dim, const float *codebook, int64_t M, int64_t K, int32_t *codes,
+                         const long long *rows, const unsigned int *nrows, int64_t max_rows, hipStream_t stream);
+
+}  // namespace mevi
+
+using namespace mevi;
+
+namespace {
+struct RfPlan {
+  int Kp, KT, LPG, ngroups, TA;
+  bool ok;
+};
+RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
+  RfPlan pl = {0, 0, 0, 0, 0, false};
+  if (dim % 32 != 0 || dim < 96 || dim > 8192 || M < 1 || M > 8 || K < 1 || K > 256) return pl;
+  int Kp = 32;
+  while (Kp < K) Kp <<= 1;
+  pl.Kp = Kp;
+  pl.KT = Kp / 32;
+  pl.LPG = 256 / Kp;
+  pl.ngroups = (int)((M + pl.LPG - 1) / pl.LPG);
+  const int tiles = (int)(M < pl.LPG ? M : pl.LPG) * pl.KT;  // MFMA tiles of the fullest group
+  pl.TA = (tiles <= 4 && pl.KT == 1) ? 4 : 8;
+  pl.ok = true;
+  return pl;
+}
+struct RfWs {
+  _Float16 *img;
+  float *mu, *mus, *A, *G2, *stat, *scal;
+  RfLevel *lev;
+  unsigned int *counters;
+  unsigned char *row_flag;
+  long long *badlist;
+  RfRecord *rec;
+  unsigned int rec_cap;
+};
+size_t rf_carve(char *base, size_t avail, int64_t n, int64_t dim, int64_t M, int64_t K, const RfPlan &pl, RfWs *ws) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char *q = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return q;
+  };
+  char *img = take((size_t)pl.ngroups * (dim / 32) * pl.TA * 32 * 32 * 2);
+  char *mu = take((size_t)dim * 4), *mus = take((size_t)dim * 4);
+  char *A = take((size_t)M * pl.Kp * 4);
+  char *G2 = take((size_t)M * K * M * pl.Kp * 4);
+  char *stat = take(64 * 4), *scal = take(256), *lev = take(sizeof(RfLevel) * 8), *counters = take(256);
+  char *row_flag = take((size_t)n);
+  char *badlist = take((size_t)n * 8);
+  size_t cap = (size_t)n / 2 + 4096;  // records: every second row may be ambiguous once before rows fall back
+  if (base) {
+    const size_t room = avail > off ? (avail - off) / sizeof(RfRecord) : 0;
+    cap = cap < room ? cap : room;
+  }
+  char *rec = take(cap * sizeof(RfRecord));
+  if (ws) {
+    ws->img = reinterpret_cast<_Float16 *>(img);
+    ws->mu = reinterpret_cast<float *>(mu), ws->mus = reinterpret_cast<float *>(mus);
+    ws->A = reinterpret_cast<float *>(A), ws->G2 = reinterpret_cast<float *>(G2);
+    ws->stat = reinterpret_cast<float *>(stat), ws->scal = reinterpret_cast<float *>(scal);
+    ws->lev = reinterpret_cast<RfLevel *>(lev);
+    ws->counters = reinterpret_cast<unsigned int *>(counters);
+    ws->row_flag = reinterpret_cast<unsigned char *>(row_flag);
+    ws->badlist = reinterpret_cast<long long *>(badlist);
+    ws->rec = reinterpret_cast<RfRecord *>(rec);
+    ws->rec_cap = (unsigned int)(cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : cap);
+  }
+  return off;
+}
+}  // namespace
+
+extern "C" size_t mevi_rq_encode_fast_workspace_bytes(int64_t n, int64_t dim, int64_t M, int64_t K) {
+  const RfPlan pl = rf_plan(dim, M, K);
+  if (!pl.ok || n <= 0) return 0;
+  return rf_carve(nullptr, 0, n, dim, M, K, pl, nullptr) + 256;
+}
+
+extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, const float *codebook, int64_t M, int64_t K,
+                                       int32_t *codes, void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(n >= 0 && dim > 0 && M > 0 && K > 0, MEVI_ERR_INVALID_ARG, "rq_encode_fast: bad shape");
+  if (n == 0) return MEVI_OK;
+  const RfPlan pl = rf_plan(dim, M, K);
+  MEVI_REQUIRE(pl.ok, MEVI_ERR_UNSUPPORTED, "rq_encode_fast: needs dim %% 32 == 0, 96 <= dim <= 8192, M <= 8, K <= 256 (use mevi_rq_encode_f32)");
+  MEVI_REQUIRE(x && codebook && codes && workspace, MEVI_ERR_INVALID_ARG, "rq_encode_fast: null pointer");
+  MEVI_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)codebook % 16) == 0 && ((uintptr_t)workspace % 256) == 0,
+               MEVI_ERR_INVALID_ARG, "rq_encode_fast: x / codebook must be 16-byte, the workspace 256-byte aligned");
+  MEVI_REQUIRE(n < (1LL << 40), MEVI_ERR_UNSUPPORTED, "rq_encode_fast: too many rows");
+  RfWs ws;
+  const size_t fixed = rf_carve(nullptr, 0, n, dim, M, K, pl, nullptr) - align_up(((size_t)n / 2 + 4096) * sizeof(RfRecord), 256);
+  MEVI_REQUIRE(workspace_bytes >= fixed + 4096 * sizeof(RfRecord), MEVI_ERR_WORKSPACE, "rq_encode_fast: workspace %zu bytes too small",
+               workspace_bytes);
+  (void)rf_carve(reinterpret_cast<char *>(workspace), workspace_bytes, n, dim, M, K, pl, &ws);
+
+  const int d = (int)dim, Mi = (int)M, Ki = (int)K;
+  MEVI_HIP_CHECK(hipMemsetAsync(ws.counters, 0, 256, stream));
+  MEVI_HIP_CHECK(hipMemsetAsync(ws.row_flag, 0, (size_t)n, stream));
+  MEVI_HIP_CHECK(hipMemsetAsync(ws.img, 0, (size_t)pl.ngroups * (dim / 32) * pl.TA * 32 * 32 * 2, stream));
+  hipLaunchKernelGGL(rf_mu_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, stream, codebook, Ki, d, ws.mu);
+  hipLaunchKernelGGL(rf_level_stats_kernel, dim3((unsigned)Mi), dim3(256), 0, stream, codebook, Mi, Ki, d, ws.mu, ws.stat);
+  hipLaunchKernelGGL(rf_levels_kernel, dim3(1), dim3(64), 0, stream, ws.stat, Mi, d, ws.lev, ws.scal);
+  hipLaunchKernelGGL(rf_mus_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, stream, ws.mu, ws.scal, d, ws.mus);
+  hipLaunchKernelGGL(rf_image_kernel, dim3((unsigned)((Mi * pl.Kp + 3) / 4)), dim3(256), 0, stream, codebook, Mi, Ki, pl.Kp, d, pl.LPG,
+                     pl.TA, ws.mu, ws.lev, ws.img, ws.A);
+  {
+    const long long total = (long long)Mi * Ki * Mi * pl.Kp;
+    hipLaunchKernelGGL(rf_g_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, codebook, Mi, Ki, pl.Kp, d, ws.mu, ws.G2);
+  }
+
+  RfParams p;
+  p.X = x, p.n = n, p.dim = d;
+  p.img = ws.img, p.mus = ws.mus, p.A = ws.A, p.G2 = ws.G2, p.lev = ws.lev, p.scal = ws.scal;
+  p.M = Mi, p.K = Ki, p.Kp = pl.Kp, p.LPG = pl.LPG, p.ngroups = pl.ngroups;
+  p.codes = codes, p.row_flag = ws.row_flag, p.rec = ws.rec, p.counters = ws.counters, p.rec_cap = ws.rec_cap;
+  // |x~.c~ / (S_x S_c) - x'.c'| <= ((2u + u^2) + 4 dim 2^-24 + 2^-22) ||x'|| ||c'||  (both operands rounded once to f16, u = 2^-11;
+  // f16 x f16 products exact in f32; 4 x 2^-24 per accumulation step lets the matrix core truncate; 2^-22 covers the f32
+  // roundings of x S_x - mu S_x and c' S_c); it enters F twice
+  p.e16 = (float)(2.0 * ((2.0 / 2048.0 + 1.0 / (2048.0 * 2048.0)) + 4.0 * (double)dim / 16777216.0 + 1.0 / 4194304.0) * 1.001);
+  p.gam = (float)((double)(dim + 2) / 16777216.0 * 1.01);   // the oracle's chain: dim fma + the subtraction, relative
+  p.n_tiles = (n + RF_ROWS - 1) / RF_ROWS;
+  int n_cu = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n_cu = v;
+  }
+  const unsigned grid = (unsigned)(p.n_tiles < n_cu ? p.n_tiles : n_cu);
+  const void *fn = nullptr;
+  size_t lds_bytes = 0;
+#define MEVI_RF_PICK(TA_, KT_)                                             \
+  if (pl.TA == TA_ && pl.KT == KT_) {                                      \
+    fn = reinterpret_cast<const void *>(rq_fast_kernel<TA_, KT_>);         \
+    lds_bytes = rf_lds_bytes<TA_>(d);                                      \
+  }
+  MEVI_RF_PICK(4, 1) MEVI_RF_PICK(8, 1) MEVI_RF_PICK(8, 2) MEVI_RF_PICK(8, 4) MEVI_RF_PICK(8, 8)
+#undef MEVI_RF_PICK
+  MEVI_REQUIRE(fn != nullptr, MEVI_ERR_UNSUPPORTED, "rq_encode_fast: no kernel for TA=%d KT=%d", pl.TA, pl.KT);
+  MEVI_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  {
+    void *args[] = {(void *)&p};
+    MEVI_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, lds_bytes, stream));
+  }
+  hipLaunchKernelGGL(rf_fixup_kernel, dim3((unsigned)(((size_t)ws.rec_cap * 8 + 255) / 256)), dim3(256), 0, stream, x, d, codebook, Mi, Ki,
+                     ws.rec, ws.counters, ws.rec_cap, ws.row_flag);
+  hipLaunchKernelGGL(rf_badlist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws.row_flag, (long long)n, ws.badlist,
+                     ws.counters);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return rq_encode_exact_rows(x, dim, codebook, M, K, codes, ws.badlist, ws.counters + 1, n, stream);
+}
+
+// {records appended, rows re-encoded exactly, ambiguous row-levels} of the last fast encode that used `workspace`
+// (synchronises the stream: for tests and the bench's report, not for the product path)
+extern "C" int mevi_rq_encode_fast_stats(const void *workspace, int64_t n, int64_t dim, int64_t M, int64_t K, int64_t *out3,
+                                         void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const RfPlan pl = rf_plan(dim, M, K);
+  MEVI_REQUIRE(pl.ok && workspace && out3, MEVI_ERR_INVALID_ARG, "rq_encode_fast_stats: bad arguments");
+  RfWs ws;
+  (void)rf_carve(reinterpret_cast<char *>(const_cast<void *>(workspace)), (size_t)1 << 62, n, dim, M, K, pl, &ws);
+  unsigned int h[3] = {0, 0, 0};
+  MEVI_HIP_CHECK(hipMemcpyAsync(h, ws.counters, 12, hipMemcpyDeviceToHost, stream));
+  MEVI_HIP_CHECK(hipStreamSynchronize(stream));
+  out3[0] = h[0], out3[1] = h[1], out3[2] = h[2];
+  return MEVI_OK;
+}

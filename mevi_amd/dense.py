@@ -5,6 +5,8 @@ Mirrors the reference's `faiss_search.search(query, doc, dim, topk, param)`
 the north star: every rank searches its contiguous shard with
 global ids, one RCCL all-gather of the per-shard top-k, then a device-side merge.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -128,12 +130,15 @@ def shard_range(n_rows, rank, world_size):
 
 def truncated_list_len(k, world):
     """Entries each shard contributes in the first round of a sharded search.  With rows spread evenly a
-    shard holds Binomial(k, 1/world) of the global top-k: mean k/world, deviation < sqrt(k/world); eight
-    deviations of head-room make a second round rare, and the proof in merge_truncated catches the rest."""
+    shard holds Binomial(k, 1/world) of the global top-k: mean k/world, deviation < sqrt(k/world); five
+    deviations + 8 of head-room (W = 8, k = 1000: 193 entries, 6.5 actual deviations: < 1e-9 per query and
+    shard) make a second round rare, and the proof in merge_truncated catches the rest.  The per-rank costs
+    that do not shrink with the shard (re-scoring K' = k_local + slack survivors, compaction, the all-gather
+    payload, the merge) are all proportional to this length."""
     if world <= 1:
         return k
     share = (k + world - 1) // world
-    return min(k, share + 8 * int(np.ceil(np.sqrt(share))) + 16)
+    return min(k, share + 5 * int(np.ceil(np.sqrt(share))) + 8)
 
 
 def merge_truncated(all_s, all_i, k, merge=None):
@@ -155,6 +160,45 @@ def merge_truncated(all_s, all_i, k, merge=None):
     truncated = kl < k
     unproven = in_topk.any(0) if truncated else torch.zeros(nq, dtype=torch.bool, device=ms.device)
     return ms, mi, unproven
+
+
+def pack_lists(scores, ids):
+    """(scores f32 [..], ids i64 [..]) -> i64 [..]: score bits << 32 | id as u32 -- the 8-byte wire format of the exchange."""
+    scores, ids = scores.contiguous(), ids.contiguous()
+    if not scores.is_cuda:       # the gloo CPU tests inject their own search / merge; same format
+        return (scores.view(torch.int32).to(torch.int64) << 32) | (ids & 0xFFFFFFFF)
+    out = torch.empty(scores.shape, dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        hip.check(hip.lib().mevi_pack_lists_i64(hip.ptr(scores), hip.ptr(ids), scores.numel(), hip.ptr(out), hip.stream_ptr()),
+                  "mevi_pack_lists_i64")
+    return out
+
+
+def unpack_lists(packed):
+    all_s = (packed >> 32).to(torch.int32).view(torch.float32)
+    all_i = packed & 0xFFFFFFFF
+    return all_s, torch.where(all_i == 0xFFFFFFFF, torch.full_like(all_i, -1), all_i)
+
+
+def merge_packed(gathered, k):
+    """merge_truncated on the all-gathered wire format, in ONE kernel (mevi_topk_merge_packed_f32): gathered i64
+    [world, nq, k_local], every list sorted as the local searches return them.  Returns (scores, ids, unproven bool[nq])."""
+    world, nq, kl = gathered.shape
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
+    unproven = torch.zeros(nq, dtype=torch.uint8, device=gathered.device)
+    with torch.cuda.device(gathered.device):
+        st = hip.lib().mevi_topk_merge_packed_f32(hip.ptr(gathered), world, nq, kl, k, 1 if kl < k else 0, hip.ptr(out_s),
+                                                  hip.ptr(out_i), hip.ptr(unproven), hip.stream_ptr())
+    hip.check(st, "mevi_topk_merge_packed_f32")
+    return out_s, out_i, unproven.bool()
+
+
+def _packed_merge_fits(world, kl, k):
+    lp = 32
+    while lp < kl:
+        lp <<= 1
+    return world <= 64 and world * lp <= 16384 and k <= 16384
 
 
 class SearchTrace:
@@ -231,7 +275,7 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
             t0 = trace.lap("local_search", t0)
             trace.rounds += 1
         n = s.shape[0]
-        packed = (s.contiguous().view(torch.int32).to(torch.int64) << 32) | (i & 0xFFFFFFFF)
+        packed = pack_lists(s, i)
         if packed.is_cuda and dist.get_backend(group) == "gloo":     # rehearsal backend: collectives through host memory
             host = torch.empty((world * n, kk), dtype=torch.int64)
             dist.all_gather_into_tensor(host, packed.cpu().contiguous(), group=group)
@@ -241,15 +285,16 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
             dist.all_gather_into_tensor(gathered, packed.contiguous(), group=group)
         if trace is not None:
             trace.lap("all_gather", t0)
-        all_s = (gathered >> 32).to(torch.int32).view(torch.float32)
-        all_i = gathered & 0xFFFFFFFF
-        all_i = torch.where(all_i == 0xFFFFFFFF, torch.full_like(all_i, -1), all_i)
-        return all_s.view(world, n, kk), all_i.view(world, n, kk)
+        return gathered.view(world, n, kk)
 
     def merged(q, kk):
-        lists = exchange(q, kk)
+        gathered = exchange(q, kk)
         t0 = time.perf_counter() if trace is not None else 0.0
-        out = merge_truncated(*lists, k, merge=merge)
+        if merge is None and gathered.is_cuda and _packed_merge_fits(world, kk, k):
+            out = merge_packed(gathered, k)                          # unpack + merge + proof in one kernel
+        else:
+            all_s, all_i = unpack_lists(gathered)
+            out = merge_truncated(all_s, all_i, k, merge=merge)
         if trace is not None:
             trace.lap("merge", t0)
         return out
@@ -303,6 +348,71 @@ def search(query, doc, dim, topk, param="Flat", device=None):
     else:
         s, i = DenseIndex(d).search(q, topk)  # index.add(doc); index.search(query, topk)
     return s.cpu().numpy(), i.cpu().numpy()
+
+
+def profile(query, doc, dim, topk, param, bs=[1, 2, 4, 8], device=None):
+    """Drop-in for faiss_search.profile (MEVI/faiss_search.py:32-68), the reference authors' timing hook of the dense arm:
+    seconds of `train`, `add` (= upload + index build here) and the MEAN seconds of one `index.search` call at each batch size
+    over the first ten batches of `query` (a ragged last batch is filled with random other queries, as the reference does).
+    Every search takes the batch from host memory and returns numpy arrays, like faiss's API.  Returns the `all_time` dict."""
+    import time
+
+    from . import ivf
+
+    hip.require_gpu()
+    device = torch.device(device if device is not None else "cuda")
+    all_time = {"train": 0, "add": 0}
+    for b in bs:
+        all_time[f"search_bs{b}"] = 0
+    print(f"Param {param} trained: {is_trained_before_train(param)}.")
+    query = np.asarray(query, dtype=np.float32).reshape(-1, dim)
+    nlist = ivf.parse_factory(param)
+    with torch.cuda.device(device):
+        t = time.time()
+        d = _as_device_f32(np.asarray(doc).reshape(-1, dim) if isinstance(doc, np.ndarray) else doc, device)
+        torch.cuda.synchronize()
+        upload = time.time() - t
+        use_ivf = nlist is not None and 0 < nlist <= d.shape[0] and topk <= MAX_K
+        t = time.time()
+        cent = ivf.train_centroids(d, nlist) if use_ivf else None      # index.train(doc)
+        torch.cuda.synchronize()
+        all_time["train"] += time.time() - t
+        t = time.time()
+        index = ivf.IVFFlatIndex(d, nlist, centroids=cent) if use_ivf else (DenseIndex(d) if topk <= MAX_K else None)
+        torch.cuda.synchronize()
+        all_time["add"] += upload + time.time() - t
+
+        def one(bq):
+            q = torch.from_numpy(np.ascontiguousarray(bq)).to(device)
+            if use_ivf:
+                s, i = index.search(q, topk, int(os.environ.get("MEVI_IVF_NPROBE", "1")))
+            elif index is None:
+                s, i = _search_large_k(q, d, topk)
+            else:
+                s, i = index.search(q, topk)
+            return s.cpu().numpy(), i.cpu().numpy()
+
+        nquery = len(query)
+        for b in bs:
+            print(f"Profile batch size {b}...")
+            batched = []
+            for start in range(0, nquery, b):
+                cur = query[start:start + b]
+                if len(cur) < b:
+                    rest = np.random.choice(np.arange(nquery), size=b - len(cur), replace=False)
+                    cur = np.concatenate((cur, query[rest]), axis=0)
+                batched.append(cur)
+                if len(batched) >= 10:
+                    break
+            if not batched:
+                continue
+            one(batched[0])                                     # first-call set-up (module load, LDS opt-in) is not a search cost
+            torch.cuda.synchronize()
+            t = time.time()
+            for bq in batched:
+                one(bq)
+            all_time[f"search_bs{b}"] += (time.time() - t) / len(batched)
+    return all_time
 
 
 MAX_K = 4096     # list length the threshold-filter kernels keep per query (include/mevi_hip.h)

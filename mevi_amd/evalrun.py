@@ -521,7 +521,9 @@ class EvalRun:
                 results.append((text, int(ndoc[i]), cr))
             return self._timed(results, t1 if timing else None)
         qemb = self.query_embedding(texts, ids, mask, rows)
-        weights = torch.tensor(scores, dtype=torch.float32) if self.topic else None     # nci_scores (main_models.py:3681-3682)
+        weights = None
+        if self.topic:      # nci_scores: the beam scores, or ones for a single returned sequence (main_models.py:3678-3682)
+            weights = torch.ones((B, 1), dtype=torch.float32) if R == 1 else torch.tensor(scores, dtype=torch.float32)
         ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate, beam_weights=weights,
                                         doc_proba=self.doc_proba if self.topic else None, ratio=self.ratio if self.topic else 0.0)
         if getattr(a, "knn_topk_by_step", 0):       # main_models.py:3919-3995: a running torch.topk over the cluster chunks

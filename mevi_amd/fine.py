@@ -115,6 +115,13 @@ class FineStage:
             sc = w[cand_q, cand_beam] * sc
         seg_len = ndoc
         if aggregate is not None:
+            if aggregate not in ("add", "max"):
+                raise ValueError(aggregate)
+            if int(ndoc.max()) <= MAX_SEGMENT:          # unique + aggregate + final sort in one kernel (csrc/rerank.hip)
+                s_u, i_u, cnt = ops.segment_aggregate_sort(sc, cand_t, torch.from_numpy(seg), int(ndoc.max()), aggregate)
+                s_u, i_u, cnt = s_u.cpu().numpy(), i_u.cpu().numpy(), cnt.cpu().numpy()
+                return [(i_u[a:a + c], s_u[a:a + c]) for a, c in zip(seg[:-1], cnt)], ndoc
+            # a query with more candidates than the LDS sort holds (rare): the same merge with device-wide sorts
             n = self.emb.shape[0]
             key, inverse, count = torch.unique(cand_q * n + cand_t, sorted=True, return_inverse=True, return_counts=True)
             one = torch.empty(key.shape, dtype=torch.float32, device=self.dev)
@@ -124,8 +131,6 @@ class FineStage:
                 for t in range(1, int(count.max().item())):
                     acc = torch.where(count > t, acc + one, acc)
                 one = acc
-            elif aggregate != "max":
-                raise ValueError(aggregate)
             sc, cand_t = one, key % n
             seg_len = torch.bincount(key // n, minlength=B).cpu().numpy()
             seg = np.concatenate([[0], np.cumsum(seg_len)]).astype(np.int64)

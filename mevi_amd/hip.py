@@ -38,7 +38,14 @@ _SIGNATURES = {
     "mevi_topk_merge_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "mevi_topk_merge_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mevi_pack_lists_i64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mevi_topk_merge_packed_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     "mevi_rq_encode_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "mevi_rq_encode_fast_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "mevi_rq_encode_fast_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t,
+                                        c_void_p]),
+    "mevi_rq_encode_fast_stats": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "mevi_gemm_nt_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                  c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mevi_split_kp": (c_int64, [c_int64]),
@@ -68,9 +75,12 @@ _SIGNATURES = {
                                          c_int64, c_void_p, c_void_p]),
     "mevi_beam_step_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
+    "mevi_row_softmax_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "mevi_pair_dot_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                   c_void_p, c_void_p]),
     "mevi_segment_sort_desc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mevi_segment_aggregate_sort_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p,
+                                                c_void_p, c_void_p]),
     "mevi_rq_neg_dist_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "mevi_gather_sub_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "mevi_cluster_means_workspace_bytes": (ctypes.c_size_t, [c_int64, c_int64, c_int64]),

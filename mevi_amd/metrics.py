@@ -92,6 +92,8 @@ class ArrayMapping:
         self.codes = codes
 
     def __getitem__(self, doc):
+        if not 0 <= doc < len(self.codes):         # a negative id would wrap to a row from the end; the dict raises KeyError
+            raise KeyError(doc)
         c = self.codes[doc]
         if c[0] < 0:
             raise KeyError(doc)
@@ -105,18 +107,39 @@ def mapping_sidecar(mapping_file):
     return mapping_file[:-4] + ".npy" if mapping_file.endswith(".pkl") else mapping_file + ".npy"
 
 
+def _pickle_fingerprint(mapping_file):
+    st = os.stat(mapping_file)
+    return {"size": int(st.st_size), "mtime_ns": int(st.st_mtime_ns)}
+
+
 def write_mapping_sidecar(mapping_file, codes):
-    import numpy as np
+    """The mapping as an array beside its pickle, plus the pickle's fingerprint (size, mtime_ns) the array was made for:
+    load_mapping trusts the array only while the pickle still carries it (comparing mtimes with >= kept a stale array when
+    the pickle was regenerated within the timestamp granularity)."""
+    import json
 
-    np.save(mapping_sidecar(mapping_file), np.ascontiguousarray(codes, dtype=np.int32))
-
-
-def load_mapping(mapping_file):
     import numpy as np
 
     side = mapping_sidecar(mapping_file)
-    if os.path.exists(side) and os.path.getmtime(side) >= os.path.getmtime(mapping_file):
-        return ArrayMapping(np.load(side, mmap_mode="r"))
+    np.save(side, np.ascontiguousarray(codes, dtype=np.int32))
+    with open(side + ".json", "w") as f:
+        json.dump(_pickle_fingerprint(mapping_file) if os.path.exists(mapping_file) else {}, f)
+
+
+def load_mapping(mapping_file):
+    import json
+
+    import numpy as np
+
+    side = mapping_sidecar(mapping_file)
+    if os.path.exists(side) and os.path.exists(side + ".json"):
+        try:
+            with open(side + ".json") as f:
+                made_for = json.load(f)
+        except ValueError:
+            made_for = None
+        if made_for and made_for == _pickle_fingerprint(mapping_file):
+            return ArrayMapping(np.load(side, mmap_mode="r"))
     with open(mapping_file, "rb") as f:
         return pickle.load(f)
 
@@ -135,9 +158,11 @@ def _cluster_ranks_array(dense_preds, coarse_clusters, mapping):
         n_clusters = distinct
         docs = np.asarray(preds, dtype=np.int64)
         valid = docs != -1
-        dcodes = np.asarray(mapping.codes[np.where(valid, docs, 0)], dtype=np.int64)
-        if (valid & (dcodes[:, 0] < 0)).any():
-            raise KeyError(int(docs[valid & (dcodes[:, 0] < 0)][0]))
+        inside = (docs >= 0) & (docs < len(mapping.codes))
+        dcodes = np.asarray(mapping.codes[np.where(inside, docs, 0)], dtype=np.int64)
+        bad = valid & (~inside | (dcodes[:, 0] < 0))       # ids outside the table or without a code row: KeyError, as the dict
+        if bad.any():
+            raise KeyError(int(docs[bad][0]))
         R = beam.shape[0]
         if R == 0 or beam.shape[1] != dcodes.shape[1]:
             out[q] = [n_clusters] * len(docs)

@@ -333,7 +333,7 @@ class NCIModel:
             if p >= levels and acache is None:               # the adaptor runs per row from here on
                 acache = self.adaptor.new_cache(n) if p == 0 else self.tables().cache_rows(self.adaptor, pidx, p)
             logits = self._logits(tokens, p, dcache, acache, xkv, None, kv_div, pidx if p < levels else None)
-            lsm = torch.log_softmax(logits, dim=-1)          # columns: eos, then the K codes of position p
+            lsm = ops.row_softmax(logits, log=True)          # columns: eos, then the K codes of position p
             qrow = q0 + torch.arange(n, device=self.dev) // kv_div
             if p == M:
                 out[qrow, pidx] = (lsm[:, 0] + score) / scale

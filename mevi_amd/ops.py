@@ -74,15 +74,14 @@ def prepare_weights(layers, keys):
             L[k] = weight(L[k])
 
 
-_ABS_MAX = {}
-
-
 def _abs_max(t):
-    """max |t| of a static tensor (a bias), computed once (keyed by storage: no host synchronisation per call)."""
-    key = (t.data_ptr(), t.numel())
-    if key not in _ABS_MAX:
-        _ABS_MAX[key] = float(t.abs().max().item())
-    return _ABS_MAX[key]
+    """max |t| of a static tensor (a bias), computed once and kept ON the tensor (no host synchronisation per call; a
+    cache keyed by address could hand a new model's bias the value of a freed one that lived at the same address)."""
+    v = getattr(t, "_mevi_abs_max", None)
+    if v is None:
+        v = float(t.abs().max().item())
+        t._mevi_abs_max = v
+    return v
 
 
 def gemm_input(x):
@@ -367,6 +366,21 @@ def beam_step(logits, beam_scores, K, R, final_step=False):
 
 
 @hip.on_device
+def row_softmax(x, log=True, scale=None):
+    """Row-wise log-softmax (log=True) or scale[row] * softmax of x f32 [rows, cols], with the beam step's arithmetic
+    (mevi_row_softmax_f32): for the branches that keep every candidate (_generate_all, pq.beam_search below R candidates)."""
+    x = _f32(x).contiguous()
+    rows, cols = x.shape
+    out = torch.empty_like(x)
+    sc = None if scale is None else _f32(scale).contiguous().view(-1)
+    assert sc is None or sc.numel() == rows
+    st = hip.lib().mevi_row_softmax_f32(hip.ptr(x), rows, cols, 0 if log else 1, None if sc is None else hip.ptr(sc), hip.ptr(out),
+                                        hip.stream_ptr())
+    hip.check(st, "mevi_row_softmax_f32")
+    return out
+
+
+@hip.on_device
 def pair_dot(a, ia, b, ib):
     a, _, dim, lda = _rows2d(_f32(a))
     b, _, dim2, ldb = _rows2d(_f32(b))
@@ -393,3 +407,20 @@ def segment_sort_desc(scores, ids, seg_offsets, max_seg_len):
                                               int(max_seg_len), hip.ptr(out_s), hip.ptr(out_i), hip.stream_ptr())
     hip.check(st, "mevi_segment_sort_desc_f32")
     return out_s, out_i
+
+
+@hip.on_device
+def segment_aggregate_sort(scores, ids, seg_offsets, max_seg_len, mode):
+    """Per segment: entries of one id merged ('add': sequential f32 adds from 0 in list order, 'max'), unique entries
+    sorted by (score desc, id asc) at the segment's start; returns (scores, ids, counts i32 [nseg])."""
+    scores = _f32(scores).contiguous()
+    ids = ids.to(device=scores.device, dtype=torch.int64).contiguous()
+    seg = seg_offsets.to(device=scores.device, dtype=torch.int64).contiguous()
+    out_s = torch.empty_like(scores)
+    out_i = torch.empty_like(ids)
+    counts = torch.empty(seg.numel() - 1, dtype=torch.int32, device=scores.device)
+    st = hip.lib().mevi_segment_aggregate_sort_f32(hip.ptr(scores), hip.ptr(ids), hip.ptr(seg), seg.numel() - 1, int(max_seg_len),
+                                                   {"add": 0, "max": 1}[mode], hip.ptr(out_s), hip.ptr(out_i), hip.ptr(counts),
+                                                   hip.stream_ptr())
+    hip.check(st, "mevi_segment_aggregate_sort_f32")
+    return out_s, out_i, counts

@@ -20,19 +20,56 @@ import torch
 from . import hip
 
 
-def rq_encode(x, codebook):
-    """codes i32[n, M] of x f32[n, dim] against codebook f32[M, K, dim] (CUDA tensors)."""
+_LAST_ENCODE = {}
+
+
+def last_encode_stats():
+    """What the last rq_encode call did: path taken and, for the matrix-core path, {ambiguity records, rows re-encoded by
+    the exact kernel, ambiguous row-levels} (read back with a stream synchronisation: bench / tests only)."""
+    st = dict(_LAST_ENCODE)
+    ws = st.pop("_ws", None)
+    if ws is not None:
+        import ctypes
+
+        out = (ctypes.c_int64 * 3)()
+        with torch.cuda.device(ws.device):
+            hip.check(hip.lib().mevi_rq_encode_fast_stats(hip.ptr(ws), st["n"], st["dim"], st["M"], st["K"], out, hip.stream_ptr()),
+                      "mevi_rq_encode_fast_stats")
+        st.update(records=int(out[0]), rows_reencoded_exactly=int(out[1]), ambiguous_row_levels=int(out[2]))
+    return st
+
+
+def rq_encode(x, codebook, mode=None):
+    """codes i32[n, M] of x f32[n, dim] against codebook f32[M, K, dim] (CUDA tensors).
+
+    mode (default MEVI_RQ or 'fast'): 'fast' = the matrix-core encoder with exact re-check (csrc/rq_fast.hip) wherever its
+    shape constraints hold, 'exact' = the f32 VALU kernel (csrc/rq_encode.hip).  Both return the oracle's codes bit for bit."""
+    import os
+
     hip.require_gpu()
     assert x.is_cuda and codebook.is_cuda and x.dtype == torch.float32 and codebook.dtype == torch.float32
     x = x.contiguous()
     codebook = codebook.contiguous()
     M, K, dim = codebook.shape
     assert x.dim() == 2 and x.shape[1] == dim
-    codes = torch.empty((x.shape[0], M), dtype=torch.int32, device=x.device)
+    n = x.shape[0]
+    mode = mode or os.environ.get("MEVI_RQ", "fast")
+    assert mode in ("fast", "exact"), mode
+    codes = torch.empty((n, M), dtype=torch.int32, device=x.device)
+    L = hip.lib()
+    _LAST_ENCODE.clear()
     with torch.cuda.device(x.device):
-        st = hip.lib().mevi_rq_encode_f32(hip.ptr(x), x.shape[0], dim, hip.ptr(codebook), M, K,
-                                          hip.ptr(codes), hip.stream_ptr())
-    hip.check(st, "mevi_rq_encode_f32")
+        nbytes = L.mevi_rq_encode_fast_workspace_bytes(n, dim, M, K) if mode == "fast" and n > 0 else 0
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            st = L.mevi_rq_encode_fast_f32(hip.ptr(x), n, dim, hip.ptr(codebook), M, K, hip.ptr(codes), hip.ptr(ws), nbytes,
+                                           hip.stream_ptr())
+            hip.check(st, "mevi_rq_encode_fast_f32")
+            _LAST_ENCODE.update(path="fast", n=n, dim=dim, M=M, K=K, _ws=ws)
+        else:
+            st = L.mevi_rq_encode_f32(hip.ptr(x), n, dim, hip.ptr(codebook), M, K, hip.ptr(codes), hip.stream_ptr())
+            hip.check(st, "mevi_rq_encode_f32")
+            _LAST_ENCODE.update(path="exact", n=n, dim=dim, M=M, K=K)
     return codes
 
 
@@ -347,7 +384,9 @@ class ProductQuantization:
                                                hip.ptr(parent), hip.ptr(code), hip.stream_ptr()), "mevi_beam_step_f32")
                 nb_new = R
             else:  # fewer candidates than beams: keep them all, in (beam, code) order
-                sc = (scores[:, :, None] * torch.softmax(nd.view(bs, nb, K), -1)).reshape(bs, nb * K)
+                from . import ops
+
+                sc = ops.row_softmax(nd, log=False, scale=scores.reshape(-1)).reshape(bs, nb * K)
                 parent = torch.arange(nb, device=self.device, dtype=torch.int32).repeat_interleave(K)[None].expand(bs, -1).contiguous()
                 code = torch.arange(K, device=self.device, dtype=torch.int32).repeat(nb)[None].expand(bs, -1).contiguous()
                 nb_new = nb * K

@@ -215,3 +215,34 @@ def test_whole_file_parser_equals_the_field_parser(tmp_path):
     assert declined("q\t\t1,x\t0.5,0.25\n")               # not a number
     assert declined("q\t\t1,2\t0.5,0.25\n\n")             # an empty line
     assert declined("q\t\t1.5,2\t0.5,0.25\n")             # ids that are not integers
+
+
+def test_array_mapping_raises_keyerror_outside_the_table_and_stale_sidecars_are_ignored(tmp_path):
+    """a negative id other than -1 must not wrap to a row from the end, an id >= N raises KeyError like the
+    reference's dict (both ArrayMapping paths); a pickle regenerated within the same timestamp is recognised by its
+    fingerprint (size + mtime_ns), not by mtime >=."""
+    import pickle
+
+    from mevi_amd import metrics
+
+    codes = np.arange(12, dtype=np.int32).reshape(6, 2)
+    m = metrics.ArrayMapping(codes)
+    assert m[5] == (10, 11)
+    for bad in (-2, 6, 1 << 40):
+        with pytest.raises(KeyError):
+            m[bad]
+        with pytest.raises(KeyError) as e:
+            metrics.cluster_ranks({"q": [1, bad, 2]}, {"q": [[0, 1], [2, 3]]}, m)
+        assert e.value.args[0] == bad
+    ranks, n = metrics.cluster_ranks({"q": [1, -1, 0]}, {"q": [[0, 1], [2, 3]]}, m)       # -1 stays the padding id
+    assert ranks["q"] == [1, 2, 0] and n == 2
+    mp = str(tmp_path / "rqmapping.pkl")
+    with open(mp, "wb") as f:
+        pickle.dump({i: tuple(int(v) for v in codes[i]) for i in range(6)}, f)
+    metrics.write_mapping_sidecar(mp, codes)
+    assert isinstance(metrics.load_mapping(mp), metrics.ArrayMapping)
+    st = os.stat(mp)
+    with open(mp, "wb") as f:                                   # regenerated: other contents, SAME timestamps
+        pickle.dump({i: tuple(int(v) for v in codes[i]) for i in range(5)}, f)
+    os.utime(mp, ns=(st.st_atime_ns, st.st_mtime_ns))
+    assert isinstance(metrics.load_mapping(mp), dict)

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G6 = os.path.join(ROOT, "tests", "golden", "g6_consumers")
 
 
-def _lists(rng, nq, n_docs, k, fine_max, M, K, R):
+def _lists(rng, nq, n_docs, k, fine_max, M, K, R, repeats=1):
     """Dense + fine lists with everything the reference's loop is sensitive to: -1 padding, documents repeated inside and
     across the lists, equal combined scores, fine lists longer than the dense one, empty lists."""
     codes = rng.integers(0, K, (n_docs, M)).astype(np.int32)
@@ -46,9 +46,9 @@ def _lists(rng, nq, n_docs, k, fine_max, M, K, R):
             fs[1] = fs[2]
         b = []                                                      # R - 1 distinct clusters ...
         for c in [tuple(codes[x]) for x in d[d >= 0][:3]] + [tuple(c) for c in rng.integers(0, K, (8 * R, M)).tolist()]:
-            if c not in b and len(b) < R - 1:                       # ... some of them holding dense documents
+            if c not in b and len(b) < R - repeats:                 # ... some of them holding dense documents
                 b.append(tuple(int(v) for v in c))
-        b = np.asarray(b + [b[0]])                                  # ... and a repeated one: the LAST index counts
+        b = np.asarray(b + [b[j % len(b)] for j in range(repeats)])  # ... and repeated ones: the LAST index counts
         dense_p[q], dense_s[q] = d.tolist(), s.tolist()
         fine_p[q], fine_s[q] = f.tolist(), fs.tolist()
         beams[q] = b.tolist()
@@ -92,6 +92,32 @@ def test_ensemble_on_the_device_equals_the_dict_loop(cuda, nq, k, fine_max, with
             want = _dict_loop(dense_p[q], dense_s[q], cranks[q], fine_p[q] if with_fine else None,
                               fine_s[q] if with_fine else None, n_clusters, a, b, g)
             assert out_docs[oseg[i]:oseg[i] + out_n[i]].tolist() == want, (q, a, b, g)
+
+
+def test_several_repeated_beam_clusters_rank_past_the_number_of_distinct_ones(cuda):
+    """with two or more repeated clusters in a beam the LAST-index ranks run up to R - 1 > n_clusters; the
+    term table must cover them (it used to be n_clusters + 1 long: reads past its end, silently wrong scores)."""
+    rng = np.random.default_rng(11)
+    R = 10
+    codes, dense_p, dense_s, fine_p, fine_s, beams = _lists(rng, 24, 5000, 60, 30, 3, 6, R, repeats=3)
+    cranks, n_clusters = metrics.cluster_ranks(dense_p, beams, metrics.ArrayMapping(codes))
+    assert n_clusters == R - 3 and max(max(c) for c in cranks.values() if c) > n_clusters
+    inp = _inputs(codes, dense_p, dense_s, fine_p, fine_s, beams)
+    cr = inp.ranks()
+    seg, oseg = inp.seg_d.cpu().numpy(), inp.out_seg.cpu().numpy()
+    for i, q in enumerate(inp.queries):
+        assert cr[seg[i]:seg[i + 1]].cpu().tolist() == cranks[q]
+    for a, b, g in ((0.6, 0.03, 0.02), (1.7, 0.3, 0.4)):
+        out_docs, out_n = inp.ensemble(cr, a, b, g)
+        out_docs, out_n = out_docs.cpu().numpy(), out_n.cpu().numpy()
+        for i, q in enumerate(inp.queries):
+            want = _dict_loop(dense_p[q], dense_s[q], cranks[q], fine_p[q], fine_s[q], n_clusters, a, b, g)
+            assert out_docs[oseg[i]:oseg[i] + out_n[i]].tolist() == want, (q, a, b, g)
+    # a zero denominator raises only when some entry carries that rank (beta = -1 / rank), as the per-entry division does
+    present = next(c for c in (8, 4, 2, 1) if bool((cr == c).any()))
+    with pytest.raises(ZeroDivisionError):
+        inp.ensemble(cr, 0.6, -1.0 / present, 0.0)
+    assert inp.ensemble(cr, 0.6, -1.0 / 64, 0.0) is not None        # rank 64 does not occur: no error, as the reference
 
 
 def _dict_loop(dense_p, dense_s, cranks, fine_p, fine_s, n_clusters, alpha, beta, gamma):

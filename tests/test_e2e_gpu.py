@@ -425,6 +425,43 @@ def test_use_topic_model_ablation(cuda, mini_small, tmp_path, ratio):
         assert len(got_sc) == len(want) and np.abs(got_sc - want).max() <= 5e-4
 
 
+def test_use_topic_model_with_one_returned_sequence_weights_are_ones(cuda, mini_small, tmp_path):
+    """with --num_return_sequences 1 the reference sets nci_scores = ones((B, 1)) (main_models.py:3678-3680),
+    so --use_topic_model 1 ranks the single beam cluster by plain q.d -- not by (negative) hypothesis score x q.d, which
+    would reverse the list."""
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    mini = mini_small
+    M, K = 3, 4
+    tok = FakeTokenizer(512)
+    enc = tok.batch_encode_plus(mini["queries"])
+    ids, mask = enc["input_ids"], enc["attention_mask"]
+    qemb = ot5.tower_encode(mini["TW"], mini["tcfg"], ids, mask)
+    emb = torch.from_numpy(mini["emb"])
+    cluster, _ = orq.cluster_dict(orq.rq_encode(mini["emb"], mini["C"]))
+    a = Namespace(**vars(mini["args"]))
+    a.use_topic_model, a.topic_score_ratio, a.num_return_sequences = 1, 0.0, 1
+    a.custom_save_path, a.metric_path = str(tmp_path / "t1.tsv"), str(tmp_path / "m1.txt")
+    EvalRun(a, tokenizer=tok, device=cuda).run(load_queries(a.data_dir))
+    hn = [l.rstrip("\n").split("\t") for l in open(f"{a.custom_save_path[:-4]}_hn{a.save_hard_neg}.tsv")]
+    dec, _, _ = ot5.nci_generate(mini["W"], mini["cfg"], ids, mask, 1)
+    bcodes = ot5.decode_token(dec, K).view(len(ids), 1, M).numpy()
+    checked = 0
+    for i in range(len(ids)):
+        cur = cluster.get(tuple(bcodes[i, 0].tolist()))
+        if cur is None:
+            assert hn[i][2] == ""
+            continue
+        ref_s, order = torch.sort(1.0 * (qemb[i] @ emb[cur].T), descending=True)      # ones x q.d
+        got_d = [int(x) for x in hn[i][2].split(",")]
+        got_s = np.array([float(x) for x in hn[i][3].split(",")])
+        assert sorted(got_d) == sorted(cur) and np.abs(got_s - ref_s.numpy()).max() <= 2e-4
+        firm = _firm(ref_s.numpy(), 1e-3)
+        assert all(got_d[j] == int(np.array(cur)[order.numpy()][j]) for j in np.nonzero(firm)[0])
+        checked += int(firm.sum())
+    assert checked > 20
+
+
 def test_eval_driver_on_the_nq_dataset_path(cuda, mini, tmp_path):
     """--dataset nq_dpr: questions from nq-test.qa.csv, hits judged through test_inverse_{offsets,array}.bin; the log
     lines lose their gt columns (main_models.py:3738-3757,4060-4077).  Same model and corpus as the marco run, so

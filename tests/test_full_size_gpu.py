@@ -85,7 +85,7 @@ def test_scores_are_exact_chains_and_lists_are_complete(c2):
         assert float(full.max()) <= float(kth) + 2e-5 * max(1.0, abs(float(kth)))
 
 
-def _bench_two_ranks(backend_env):
+def _bench_two_ranks(backend_env, extra=("--docs", "700000", "--queries", "600", "--no-cpu-baseline", "--no-seq2seq-legs")):
     import json
     import os
     import socket
@@ -100,19 +100,19 @@ def _bench_two_ranks(backend_env):
     env = dict(os.environ, PYTHONPATH=root, **backend_env)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-                        "--warmup", "1", "--docs", "700000", "--queries", "600", "--no-cpu-baseline", "--no-seq2seq-legs"],
-                       capture_output=True, text=True, env=env, timeout=600)
+                        "--warmup", "1", *extra],
+                       capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE JSON line
     return json.loads(lines[0])
 
 
-def _check_two_rank_line(d):
+def _check_two_rank_line(d, rows=700000):
     assert d["n_gpus"] == 2 and d["config"]["planted_top1_ok"] == 1.0 and d["value"] > 0
     m = d["multi_gpu"]
     assert m["rounds"] >= 1 and len(m["per_rank"]) == 2 and {r["rank"] for r in m["per_rank"]} == {0, 1}
-    assert sum(r["shard_rows"] for r in m["per_rank"]) == 700000
+    assert sum(r["shard_rows"] for r in m["per_rank"]) == rows
     assert m["local_search_ms"]["max"] >= m["local_search_ms"]["min"] > 0 and m["all_gather_ms"] >= 0 and m["merge_ms"] > 0
     assert d["roofline"]["launches"] > 0 and d["roofline"]["achieved"] > 0
 
@@ -122,6 +122,26 @@ def test_bench_launch_line_with_two_ranks_sharing_the_device():
     collectives over gloo: the sharded search, its per-rank phase breakdown and the single JSON line -- a rehearsal of
     the N > 1 path, not a timing."""
     _check_two_rank_line(_bench_two_ranks({"MEVI_BENCH_BACKEND": "gloo"}))
+
+
+def test_bench_c5_chain_rehearsal_with_two_ranks_sharing_the_device():
+    """N > 1 runs C5, not C2-sharded: after the timed dense steps every rank runs the chain -- dense arm sharded,
+    NCI beam search + tower + fine stage as replicas over the rank's DistributedSampler slice, full corpus per rank -- and
+    rank 0's line carries `chain_c5`.  Two ranks on this GPU over gloo, reduced corpus, 101 queries (odd: rank 1 pads)."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip("two t5-base model replicas + prefix tables: needs ~40 GB of HBM")
+    d = _bench_two_ranks({"MEVI_BENCH_BACKEND": "gloo"}, ("--docs", "300000", "--queries", "101", "--no-cpu-baseline"))
+    _check_two_rank_line(d, rows=300000)
+    assert "chain_c5_error" not in d, d.get("chain_c5_error")
+    c = d["chain_c5"]
+    assert c["chain_ms"] > 0 and c["queries_per_s"] > 0 and len(c["per_rank"]) == 2
+    assert c["dense_lists_identical_on_all_ranks"] and c["doc_codes_identical_on_all_ranks"]
+    assert sum(r["queries"] for r in c["per_rank"]) == 101 and [r["queries_with_padding"] for r in c["per_rank"]] == [51, 51]
+    assert set(c["stage_ms_max_over_ranks"]) >= {"tower", "query_all_gather", "dense_top1000_sharded", "nci_beam_search",
+                                                 "tower_again", "fine_stage"}
+    assert set(c["mrr10"]) == {"dense", "fine", "ensemble", "ensemble_alpha20"} and 0.0 <= c["mrr10"]["ensemble"] <= 1.0
+    assert "REHEARSAL" in c["workload"]
 
 
 def test_bench_over_rccl_when_two_gpus_are_visible():

@@ -40,6 +40,85 @@ def test_codes_bit_identical_to_oracle(cuda, n, dim, M, K):
     assert np.array_equal(_codes(x, cb, cuda), orq.rq_encode(x, cb))
 
 
+def _both(x, cb, cuda):
+    xt, ct = torch.from_numpy(x).to(cuda), torch.from_numpy(cb).to(cuda)
+    fast = rq.rq_encode(xt, ct, mode="fast")
+    st = rq.last_encode_stats()
+    exact = rq.rq_encode(xt, ct, mode="exact")
+    torch.cuda.synchronize()
+    return fast.cpu().numpy(), exact.cpu().numpy(), st
+
+
+@pytest.mark.parametrize("n,dim,M,K", [
+    (5000, 768, 4, 32), (3000, 768, 3, 256), (1, 96, 2, 4), (255, 128, 1, 32), (257, 96, 8, 32), (1000, 1024, 3, 40),
+    (2049, 256, 4, 64), (700, 160, 2, 100), (513, 768, 5, 32), (900, 96, 3, 3),
+])
+def test_matrix_core_encoder_equals_exact_kernel_and_oracle(cuda, n, dim, M, K):
+    """mevi_rq_encode_fast_f32 (f16 MFMA shortlist + exact re-check, csrc/rq_fast.hip) returns the oracle's codes bit for
+    bit over tile shapes (4 / 8 MFMA tiles, 1..8 tiles per level, several levels per tile, several tiles per row block),
+    ragged row counts and padded centroid columns."""
+    rng = np.random.default_rng(n + dim + M + K)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    cb = (rng.standard_normal((M, K, dim)) / np.arange(1, M + 1)[:, None, None]).astype(np.float32)
+    fast, exact, st = _both(x, cb, cuda)
+    want = orq.rq_encode(x, cb)
+    assert st["path"] == "fast"
+    assert np.array_equal(exact, want)
+    assert np.array_equal(fast, want), (st, int((fast != want).any(1).sum()))
+    assert st["rows_reencoded_exactly"] <= max(8, 0.2 * n), st         # the bound must be useful, not only safe
+
+
+def test_matrix_core_encoder_on_adversarial_inputs(cuda):
+    """What the error bound has to survive: exact ties (duplicated centroids, small-integer data), near-ties far below
+    the f16 resolution, a large common component (dense-retriever embeddings: cosine ~0.99 between rows), rows that
+    overflow the f16 range, a trained (k-means) codebook whose cells meet exactly where the data is dense."""
+    rng = np.random.default_rng(0)
+    # -- exact ties: lowest index wins
+    cb = rng.integers(-2, 3, size=(3, 32, 96)).astype(np.float32)
+    cb[:, 7] = cb[:, 3]
+    cb[:, 30] = cb[:, 11]
+    x = rng.integers(-4, 5, size=(700, 96)).astype(np.float32)
+    fast, exact, st = _both(x, cb, cuda)
+    want = orq.rq_encode(x, cb)
+    assert np.array_equal(fast, want) and np.array_equal(exact, want) and not np.isin(fast, [7, 30]).any()
+    # -- near-ties: pairs of centroids 1e-6 apart, rows on their bisectors
+    cb = rng.standard_normal((4, 32, 768)).astype(np.float32) * 0.05
+    cb[:, 1::2] = cb[:, 0::2] + 1e-6 * rng.standard_normal((4, 16, 768)).astype(np.float32)
+    x = (cb[0][rng.integers(0, 32, 4000)] + 0.02 * rng.standard_normal((4000, 768))).astype(np.float32)
+    fast, exact, st = _both(x, cb, cuda)
+    want = orq.rq_encode(x, cb)
+    assert np.array_equal(fast, want) and np.array_equal(exact, want)
+    assert st["records"] > 1000                                          # nearly every row-level is ambiguous and still right
+    # -- common component + f16 overflow rows + NaN-free huge rows
+    base = rng.standard_normal((1, 768)).astype(np.float32) * 0.4
+    x = (base + 0.05 * rng.standard_normal((6000, 768))).astype(np.float32)
+    xt = torch.from_numpy(x).to(cuda)
+    book, codes_train = rq.train_rq_codebook(xt, 4, 32, seed=1)           # a trained codebook (cells meet in dense regions)
+    x[17] *= 3.0e4
+    x[4242] = 1.0e7
+    fast, exact, st = _both(x, book.cpu().numpy(), cuda)
+    want = orq.rq_encode(x, book.cpu().numpy())
+    assert np.array_equal(fast, want) and np.array_equal(exact, want)
+    assert 2 <= st["rows_reencoded_exactly"] <= 0.1 * len(x), st          # the two overflow rows, few others
+
+
+def test_matrix_core_encoder_large(cuda):
+    """300 k rows at both script shapes against the oracle, 2 M rows fast vs the exact kernel."""
+    g = torch.Generator(device=cuda).manual_seed(3)
+    for M, K, n in ((4, 32, 300_000), (3, 256, 120_000)):
+        x = 0.05 * torch.randn((n, 768), device=cuda, generator=g) + 0.02
+        cb = torch.stack([torch.randn((K, 768), device=cuda, generator=g) * (0.05 / (1 + j)) for j in range(M)])
+        fast = rq.rq_encode(x, cb, mode="fast")
+        st = rq.last_encode_stats()
+        assert np.array_equal(fast.cpu().numpy(), orq.rq_encode(x.cpu().numpy(), cb.cpu().numpy())), st
+    x = 0.05 * torch.randn((2_000_000, 768), device=cuda, generator=g) + 0.02
+    cb = torch.stack([torch.randn((32, 768), device=cuda, generator=g) * (0.05 / (1 + j)) for j in range(4)])
+    fast = rq.rq_encode(x, cb, mode="fast")
+    st = rq.last_encode_stats()
+    assert torch.equal(fast, rq.rq_encode(x, cb, mode="exact")), st
+    assert st["rows_reencoded_exactly"] < 0.05 * x.shape[0], st
+
+
 def test_exact_ties_pick_lowest_index(cuda):
     rng = np.random.default_rng(0)
     cb = rng.integers(-2, 3, size=(3, 32, 16)).astype(np.float32)

@@ -161,6 +161,8 @@ def _seeded_nci_weights(M, K, d, d_ff, heads, enc_layers=2, dec_layers=2, adapto
     (3, 256, 256, 1024, 4, 6 << 30, "adaptor vectors only at position 2"),
     # budget too small for position 2 at all: the adaptor continues per beam from a cache assembled by lookup
     (3, 256, 256, 1024, 4, 200 << 20, "tables end before position 2"),
+    # BASELINE.json configs[2] at its REAL width (t5-base: d 768, ff 3072, 12 x 64 heads), 2 + 2 + 2 layers
+    (3, 256, 768, 3072, 12, 6 << 30, "t5-base width: adaptor vectors only at position 2"),
 ])
 def test_base_shape_model_against_oracle(cuda, M, K, d, d_ff, heads, table_bytes, regime):
     """t5-base widths (d 768, ff 3072, 12x64 heads, adaptor heads of 96) with few layers, and the (3, 256) code shape
@@ -195,9 +197,15 @@ def test_base_shape_model_against_oracle(cuda, M, K, d, d_ff, heads, table_bytes
     sc = np.array(sc)
     assert np.abs(sc - osc.numpy()).max() <= 2e-4
     # identical beams wherever the oracle's neighbouring scores are separated by more than the tolerance
-    same = (dec.cpu().numpy() == odec.numpy()).all(1)
-    gaps = np.abs(np.diff(osc.numpy().reshape(B, R), axis=1)).min()
-    assert same.all() or gaps < 4e-4
+    # -- asserted per query, on the offending pair only: a row that differs from the oracle's at rank j must be the
+    # oracle's row of a rank j' whose score is within the tolerance of rank j's (a swap inside a near-tie), nothing else
+    got, want, oscq = dec.cpu().numpy().reshape(B, R, -1), odec.numpy().reshape(B, R, -1), osc.numpy().reshape(B, R)
+    for i in range(B):
+        for j in range(R):
+            if (got[i, j] == want[i, j]).all():
+                continue
+            twins = [jj for jj in range(R) if (got[i, j] == want[i, jj]).all()]
+            assert twins and abs(oscq[i, twins[0]] - oscq[i, j]) < 4e-4, (regime, i, j, twins, oscq[i].tolist())
     tower = t5.TwinTower(W, device=cuda, **{k: v for k, v in cfg.items() if k not in ("M", "K", "adaptor_layer_num")})
     reps = tower.encode_query({"input_ids": ids, "attention_mask": mask}).cpu()
     oreps = ot5.tower_encode(W, dict(cfg), ids, mask)

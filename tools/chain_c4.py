@@ -16,6 +16,24 @@ import torch
 from mevi_amd import dense, fine, metrics, nci, rq
 
 
+def synthetic_gt(i, planted_doc, fine_docs):
+    """Relevant documents of synthetic query i.  Three kinds, so that the three ranked lists score DIFFERENTLY and a wrong
+    ensemble changes the number (with `planted` in every gt the ensemble's MRR@10 equalled the dense arm's):
+    i % 4 == 1 -> only a document of the seq2seq arm's fine list (rank <= 2 there; the dense arm finds it only by luck),
+    even i     -> the planted dense neighbour plus such a document, else -> the planted neighbour alone."""
+    fine_docs = list(fine_docs)
+    if i % 4 == 1 and fine_docs:
+        return [int(fine_docs[min(len(fine_docs) - 1, i // 4 % 3)])]
+    gt = [int(planted_doc)]
+    if i % 2 == 0 and fine_docs:
+        gt.append(int(fine_docs[min(len(fine_docs) - 1, i // 2 % 3)]))
+    return gt
+
+
+ALPHA_STRONG = 20.0     # second ensemble point: large enough for the beam clusters to re-order the top 10 of the synthetic corpus
+LAST = {}      # codebook / corpus codes of the last run(), for bench.py's chain certificate (same index artefacts)
+
+
 def sync_time(fn):
     torch.cuda.synchronize()
     t = time.perf_counter()
@@ -45,6 +63,7 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
     codebook = torch.stack([rn(K, d, s=0.05 / (1 + j)) for j in range(M)])
     t_rq, codes = sync_time(lambda: rq.rq_encode(docs, codebook))
     codes_h = codes.cpu().numpy()
+    LAST.update(codebook=codebook, codes_h=codes_h)
     index = rq.ClusterIndex.from_codes(codes_h, K)
     fs = fine.FineStage(docs, index)
     t_index, dindex = sync_time(lambda: dense.DenseIndex(docs))
@@ -88,11 +107,7 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
     di_h = di.cpu().numpy()
     gts = {}
     for i in range(nq):
-        gt = [int(planted[i])]
-        fd = ranked[i][0]
-        if i % 2 == 0 and len(fd):                  # a second relevant document that only the seq2seq arm can reach
-            gt.append(int(fd[min(len(fd) - 1, int(rng.geometric(0.3)) - 1)]))
-        gts[f"q{i}"] = gt
+        gts[f"q{i}"] = synthetic_gt(i, planted[i], ranked[i][0])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     qs = list(gts)
@@ -110,6 +125,10 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
                "fine": consumers.evaluate_lists("Fine Pred", [10, 50, 1000], gts, pairs, inp.fine[2], inp.fine[1], None),
                "ensemble": consumers.evaluate_lists("score + 0.6 / (0.03 * crank + 1); punishment (1 - 0.02 * 0.6)",
                                                     [10, 50, 1000], gts, pairs, out_docs, inp.out_seg, out_n)}
+        # the scripts' alpha = 0.6 is tuned to real ANCE score gaps; on this synthetic corpus (q.d spread ~1.4 per sigma) it
+        # re-orders nothing inside the top 10, so the SAME code is also run at alpha = 20, where the beam clusters decide
+        out_docs2, out_n2 = inp.ensemble(cr, ALPHA_STRONG, 0.03, 0.02)
+        res["ensemble_alpha%g" % ALPHA_STRONG] = consumers.evaluate_lists("strong", [10, 50, 1000], gts, pairs, out_docs2, inp.out_seg, out_n2)
     torch.cuda.synchronize()
     t_ens = time.perf_counter() - t0
     planted_top1 = float((di_h[:, 0] == planted).mean())
@@ -133,3 +152,167 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
                       (("qemb", qemb.cpu().numpy()), ("doc_codes", codes_h), ("beam_codes", bcodes), ("dense_ids", di_h),
                        ("ndoc", ndoc))},
     }, dindex
+
+
+# ---- config C5: the same chain on W ranks (one process per GPU) ---------------------------------------------------------
+def _all_gather_rows(t, world, backend):
+    """[n, d] on every rank -> [world, n, d] (RCCL; through host memory over the gloo rehearsal backend)."""
+    import torch.distributed as dist
+
+    n = t.shape[0]
+    if backend == "nccl":
+        out = torch.empty((world * n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)    # rank-major concatenation
+        dist.all_gather_into_tensor(out, t.contiguous())
+        return out.view((world, n) + tuple(t.shape[1:]))
+    host = torch.empty((world * n,) + tuple(t.shape[1:]), dtype=t.dtype)
+    dist.all_gather_into_tensor(host, t.cpu().contiguous())
+    return host.to(t.device).view((world, n) + tuple(t.shape[1:]))
+
+
+def run_sharded(model, tower, docs, start, end, ids, mask, planted, rn, M, K, R, topk, batch, rng, rank, world, backend):
+    """C5 (BASELINE.json configs[4]: corpus row-sharded over the ranks, RCCL top-k all-gather, full ensemble).
+    Dense arm sharded (rank r searches rows [start, end) of `docs` with global ids, dense.sharded_ip_topk); the seq2seq arm
+    as REPLICAS over the rank's query slice -- DistributedSampler(shuffle=False) semantics, MEVI/main.py:318-322 -- with the
+    full f32 corpus per rank for the fine stage (27 GB of 288 GB).  `docs` is the FULL corpus on every rank
+    (modified in place with the planted neighbours, identically on all ranks).  Every rank returns its own record; rank 0
+    aggregates.  Stages are separated by barriers so that per-stage times attribute; `chain_ms` is one un-bracketed pass."""
+    import torch.distributed as dist
+
+    from mevi_amd.evalrun import rank_slice
+
+    nq, d = ids.shape[0], docs.shape[1]
+    dev = docs.device
+    mine = np.asarray(rank_slice(nq, rank, world), dtype=np.int64)           # padded by repeating the head
+    real = (np.arange(len(mine)) * world + rank) < nq                        # False: a padding duplicate
+    mine_t = torch.from_numpy(mine).to(dev)
+    my_ids, my_mask = ids[mine_t].contiguous(), mask[mine_t].contiguous()
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def encode_mine():
+        return tower.encode_query({"input_ids": my_ids, "attention_mask": my_mask})
+
+    def gather_queries(q_mine):
+        """rank-sliced embeddings -> the full [nq, d] matrix in query order on every rank (generate.py writes them to one
+        memmap, MEVI/generate.py:74-113; here one all-gather of 768 floats per query)."""
+        g = _all_gather_rows(q_mine, world, backend)                          # [world, per, d]; query j sits at (j % world, j // world)
+        return g.permute(1, 0, 2).reshape(-1, d)[:nq].contiguous()
+
+    # ---- untimed set-up (identical on every rank) ---------------------------------------------------------------------------
+    qemb = gather_queries(encode_mine())
+    c = qemb - qemb.mean(0, keepdim=True)
+    c = c / c.norm(dim=1, keepdim=True)
+    z = torch.from_numpy(rng.uniform(3.8, 6.5, nq).astype(np.float32)).to(dev)
+    strength = z * 0.05 * qemb.norm(dim=1) / (qemb * c).sum(1).clamp_min(1e-6)
+    docs[torch.from_numpy(planted).to(dev)] += strength[:, None] * c
+    codebook = torch.stack([rn(K, d, s=0.05 / (1 + j)) for j in range(M)])
+    t_rq, codes = sync_time(lambda: rq.rq_encode(docs, codebook))
+    codes_h = codes.cpu().numpy()
+    index = rq.ClusterIndex.from_codes(codes_h, K)
+    fs = fine.FineStage(docs, index)
+    t_index, dindex = sync_time(lambda: dense.DenseIndex(docs[start:end]))
+    planted_mine = planted[mine]
+
+    def chain(t=None):
+        def lap(name, fn):
+            if t is None:
+                return fn()
+            barrier()
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            t[name] = t.get(name, 0.0) + (time.perf_counter() - t0)
+            return out
+
+        q_mine = lap("tower", encode_mine)
+        q_all = lap("query_all_gather", lambda: gather_queries(q_mine))
+        ds, di = lap("dense_top%d_sharded" % topk, lambda: dense.sharded_ip_topk(q_all, dindex, topk, id_offset=start))
+        bcodes, ranked, ndoc = [], [], []
+        for a in range(0, len(mine), batch):
+            i, m = my_ids[a:a + batch], my_mask[a:a + batch]
+            o = lap("nci_beam_search", lambda: model.generate(i, m, num_beams=R))
+            bc = nci.decode_token(o[0], K).view(-1, R, M).cpu().numpy()
+            q2 = lap("tower_again", lambda: tower.encode_query({"input_ids": i, "attention_mask": m}))
+            rk, nd = lap("fine_stage", lambda: fs.rerank(q2, bc))
+            bcodes.append(bc)
+            ranked += rk
+            ndoc.append(nd)
+        return ds, di, np.concatenate(bcodes), ranked, np.concatenate(ndoc)
+
+    chain()                                                    # warm-up
+    stages = {}
+    ds, di, bcodes, ranked, ndoc = chain(stages)               # per-stage attribution (barrier before every stage)
+    barrier()
+    t0 = time.perf_counter()
+    chain()                                                    # the chain as it runs: no barriers inside
+    barrier()
+    chain_s = time.perf_counter() - t0
+
+    # ---- this rank's share of the metrics (its real queries): dense / fine / ensemble MRR@10 sums ------------------------------
+    import contextlib
+    import io
+
+    from mevi_amd import consumers
+
+    keep = np.flatnonzero(real)
+    gts = {}
+    for p in keep:
+        gts[f"q{int(mine[p])}"] = synthetic_gt(int(mine[p]), planted_mine[p], ranked[p][0])
+    qs = list(gts)
+    sel = torch.from_numpy(mine[keep]).to(dev)
+    di_m, ds_m = di[sel].contiguous(), ds[sel].contiguous()
+    fseg = np.concatenate([[0], np.cumsum([len(ranked[p][0]) for p in keep])]).astype(np.int64)
+    fdocs = np.concatenate([np.asarray(ranked[p][0], np.int64) for p in keep]) if len(keep) else np.zeros(0, np.int64)
+    fsc = np.concatenate([np.asarray(ranked[p][1], np.float64) for p in keep]) if len(keep) else np.zeros(0)
+    sums, err = {}, None
+    try:
+        inp = consumers.EnsembleInputs(qs, torch.arange(len(qs) + 1, device=dev) * topk, di_m.reshape(-1), ds_m.reshape(-1).double(),
+                                       bcodes[keep], codes_h, (qs, np.arange(len(qs), dtype=np.int64), fseg, fdocs, fsc))
+        pairs = consumers._gt_pairs(gts, inp.row, missing_ok=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cr = inp.ranks()
+            out_docs, out_n = inp.ensemble(cr, 0.6, 0.03, 0.02)
+            res = {"dense": consumers.evaluate_lists("ANCE Pred", [10], gts, pairs, inp.docs_d, inp.seg_d, None),
+                   "fine": consumers.evaluate_lists("Fine Pred", [10], gts, pairs, inp.fine[2], inp.fine[1], None),
+                   "ensemble": consumers.evaluate_lists("ensemble", [10], gts, pairs, out_docs, inp.out_seg, out_n)}
+            od2, on2 = inp.ensemble(cr, ALPHA_STRONG, 0.03, 0.02)
+            res["ensemble_alpha%g" % ALPHA_STRONG] = consumers.evaluate_lists("strong", [10], gts, pairs, od2, inp.out_seg, on2)
+        sums = {k_: v[1][10] * len(qs) for k_, v in res.items()}
+    except Exception as e:                                    # e.g. queries disagreeing on the number of distinct beam clusters
+        err = f"{type(e).__name__}: {e}"
+    top1 = float((di[sel][:, 0].cpu().numpy() == planted_mine[keep]).sum())
+    return {"rank": rank, "queries": int(len(keep)), "queries_with_padding": int(len(mine)), "shard_rows": int(end - start),
+            "stage_ms": {k_: round(v * 1e3, 2) for k_, v in stages.items()}, "chain_ms": round(chain_s * 1e3, 2),
+            "setup_untimed_ms": {"rq_encode_corpus": round(t_rq * 1e3, 1), "dense_index_build_shard": round(t_index * 1e3, 1)},
+            "fine_candidates_per_query": float(ndoc[keep].mean()) if len(keep) else 0.0,
+            "mrr10_sums": sums, "metrics_error": err, "planted_top1_hits": top1,
+            "checksums": {"dense_ids": zlib.crc32(np.ascontiguousarray(di.cpu().numpy()).tobytes()),
+                          "doc_codes": zlib.crc32(np.ascontiguousarray(codes_h).tobytes())}}
+
+
+def aggregate_sharded(records, nq, world, topk, R, M, K, backend):
+    """Rank 0: the `chain_c5` entry of the bench line from every rank's record."""
+    stage_names = list(records[0]["stage_ms"])
+    stage_max = {s: max(r["stage_ms"][s] for r in records) for s in stage_names}
+    chain_ms = max(r["chain_ms"] for r in records)
+    nreal = sum(r["queries"] for r in records)
+    mrr = {}
+    if all(r["mrr10_sums"] for r in records):
+        mrr = {k_: sum(r["mrr10_sums"][k_] for r in records) / max(nreal, 1) for k_ in records[0]["mrr10_sums"]}
+    return {
+        "workload": f"C5: {nq} queries over {world} ranks; corpus row-sharded for the dense arm (RCCL all-gather of per-shard "
+                    f"top-{topk} + merge), NCI beam search (beams {R}, RQ ({M},{K})) + query tower + fine stage as replicas over "
+                    f"each rank's query slice (DistributedSampler order, full f32 corpus per rank), inputs in HBM"
+                    + ("" if backend == "nccl" else f" [REHEARSAL over {backend}: not a timing]"),
+        "chain_ms": chain_ms, "queries_per_s": round(nq / chain_ms * 1e3, 1),
+        "chain_note": "one pass of the whole chain between two barriers (max over ranks by construction)",
+        "stage_ms_max_over_ranks": stage_max, "sum_of_stage_maxima_ms": round(sum(stage_max.values()), 2),
+        "dtype": "tower / NCI linear layers: split-precision f16x3 MFMA GEMM (f32-equivalent, 22-bit operand images); "
+                 "dense arm f16 pre-filter + exact f32 chains; fine stage f32 chains",
+        "mrr10": mrr, "planted_top1_ok": sum(r["planted_top1_hits"] for r in records) / max(nreal, 1),
+        "dense_lists_identical_on_all_ranks": len({r["checksums"]["dense_ids"] for r in records}) == 1,
+        "doc_codes_identical_on_all_ranks": len({r["checksums"]["doc_codes"] for r in records}) == 1,
+        "per_rank": records,
+    }

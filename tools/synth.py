@@ -74,8 +74,8 @@ def build(dev, M, K, batch, seed=0):
     return model, tower, g, rn
 
 
-def build_tower(dev, seed=0):
-    """The T5-ANCE-shaped tower alone (12 + 12 layers), same initialiser scales as build()."""
+def tower_weights(dev, seed=0):
+    """State dict of the T5-ANCE-shaped tower alone (12 + 12 layers), same initialiser scales as weights()."""
     g = torch.Generator(device=dev).manual_seed(seed)
 
     def rn(*shape, s=1.0):
@@ -83,7 +83,11 @@ def build_tower(dev, seed=0):
 
     TW = {"shared.weight": rn(32128, d)}
     _t5_weights(TW, 12, 12, rn, dev)
-    return t5.TwinTower(TW, device=dev, num_layers=12, num_decoder_layers=12)
+    return TW
+
+
+def build_tower(dev, seed=0):
+    return t5.TwinTower(tower_weights(dev, seed), device=dev, num_layers=12, num_decoder_layers=12)
 
 
 def query_ids(nq, dev, rng):
