@@ -181,8 +181,6 @@ def check_supported(a):
         raise SystemExit(f"main.py --mode eval: --recall_level {a.recall_level!r} is not built (both | coarse | fine)")
     if a.doc_multiclus < 1 or (a.doc_multiclus > 1 and (a.eval_all_documents or a.knn_topk_by_step)):
         raise SystemExit("main.py --mode eval: --doc_multiclus C > 1 is built for the cluster re-ranking path only")
-    if a.use_topic_model and a.doc_multiclus > 1:
-        raise SystemExit("main.py --mode eval: --use_topic_model 1 is built for --doc_multiclus 1")
     if a.eval_all_documents:   # the brute-force ablation; same preconditions as the reference (MEVI/main.py:657-658)
         need.update(recall_level="fine", knn_topk_by_step=1)
     for k, v in need.items():

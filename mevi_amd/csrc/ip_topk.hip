@@ -54,10 +54,21 @@ static inline int min_slots() {
   return (v >= 256 && v <= MAX_SORT && (v & (v - 1)) == 0) ? v : 2048;
 }
 
-static inline TopkGeom make_geom(int k) {
+static inline TopkGeom make_geom(int k, int64_t nq = (int64_t)1 << 40) {
   TopkGeom g;
   g.k = k;
   int S = next_pow2(k) * 4;
+  // a handful of queries (the streaming filter kernel): measured on a single query over 8.8 M rows (k = 100 / 1000), slots
+  // 2048: 2.61 / -, 4096: 2.56 / 2.78 ms, 8192: 2.58 / 2.80, 16384: 2.69 / 2.87 -- few large chunks save launches but their
+  // first chunk (as many rows as slots, every row a candidate) and the compaction of large areas cost more than they save
+  if (nq <= 32) {
+    S = 2 * next_pow2(k) > 4096 ? 2 * next_pow2(k) : 4096;
+    if (S > MAX_SORT) S = MAX_SORT;
+    if (const char *e = getenv("MEVI_IP_TOPK_SMALL_SLOTS")) {  // tuning hook
+      const int v = atoi(e);
+      if (v >= 1024 && v <= MAX_SORT && (v & (v - 1)) == 0 && v >= 2 * next_pow2(k)) S = v;
+    }
+  }
   // short lists (the first round of a sharded search keeps ~k/W entries) still get 2048 slots: the chunk schedule grows
   // with cap / k, and every chunk costs a compaction launch whose time does not shrink with the shard
   if (S < min_slots()) S = min_slots();
@@ -1358,7 +1369,7 @@ inline size_t h1_second_pass_bytes(int64_t nq, int64_t dim, int64_t k) {
 
 extern "C" size_t mevi_ip_topk_indexed_workspace_bytes(int64_t nq, int64_t dim, int64_t k) {
   if (nq <= 0 || k <= 0 || k > 4096 || dim <= 0) return 0;
-  const TopkGeom gp = make_geom(h1_kprime((int)k));
+  const TopkGeom gp = make_geom(h1_kprime((int)k), nq);
   // approx state (K' geometry) + exact top lists + f16 queries + per-query norm / scale / shift, the second
   // pass, then the exact-path workspace for the fallback
   return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)image_rows(nq) * pad_k(dim) * 2, 256) +
@@ -1386,7 +1397,7 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
                "ip_topk_indexed: workspace %zu bytes < required %zu (or misaligned)", workspace_bytes, need);
 
   const int kp = h1_kprime((int)k);
-  const TopkGeom gp = make_geom(kp), g = make_geom((int)k);
+  const TopkGeom gp = make_geom(kp, nq), g = make_geom((int)k);
   const int64_t dimp = pad_k(dim);
   IndexView iv = view_index(index, nd, dim);
   char *p = reinterpret_cast<char *>(workspace);

@@ -36,6 +36,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <vector>
 
 namespace mevi {
 namespace {
@@ -77,9 +78,10 @@ struct RfParams {
   int M, K, Kp, LPG, ngroups;
   int *codes;
   unsigned char *row_flag;
-  RfRecord *rec;
-  unsigned int *counters;  // [0] records appended (may exceed rec_cap)  [1] bad rows  [2] ambiguous row-levels
-  unsigned int rec_cap;
+  RfRecord *rec;           // [n_regions][region_cap]: one region per wave of the persistent grid (no atomics on the hot path)
+  unsigned int *counters;  // [0] bad rows (bad-list kernel)  [1] rows flagged by the main kernel  [2 ...] unused
+  unsigned int *region_n;  // [n_regions] records wanted by the region's wave (may exceed region_cap: the excess rows are flagged)
+  unsigned int region_cap;
   float e16, gam;
   long long n_tiles;
 };
@@ -158,7 +160,10 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     rt_ += gridDim.x;
     return rt_ < p.n_tiles;
   };
-  if (rt >= p.n_tiles) return;
+  if (rt >= p.n_tiles) {
+    if (lane == 0) p.region_n[blockIdx.x * 8 + w8] = 0u;
+    return;
+  }
   Src cur, nxt;
   src_of(rt, grp, cur);
   long long rt_n = rt;
@@ -230,6 +235,8 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     for (int ti = 0; ti < H; ++ti) acc[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ti], b, acc[H + ti], 0, 0, 0);
   };
 
+  RfRecord *rec_base = p.rec + (size_t)(blockIdx.x * 8 + w8) * p.region_cap;
+  unsigned int rec_n = 0u;  // records of this wave so far (wave-uniform)
   // per-row state carried across the groups of a row tile (this lane's row = 32 w8 + lrow of the tile; both halves agree)
   unsigned long long prev = 0ull;
   float rho_hat = 0.f, xn = 0.f;
@@ -367,21 +374,21 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
         for (int r = 0; r < 16; ++r) cnt += (acc[l * KT + tk][r] <= thr) ? 1 : 0;
       const int ocnt = __shfl_xor(cnt, 32);
       const int total = cnt + ocnt;
-      if (total != 1 && !row_bad && row < p.n) {  // ambiguous (or nothing finite): record, or give the row to the exact kernel
-        bool overflow = !finite || total > RF_MAXC || total < 1;
-        unsigned int slot = 0u;
-        if (!overflow) {
-          if (half == 0) {
-            slot = atomicAdd(&p.counters[0], 1u);
-            atomicAdd(&p.counters[2], 1u);
-          }
-          slot = __shfl(slot, lrow);
-          overflow = slot >= p.rec_cap;
-        }
+      // ambiguous (or nothing finite): a record in this wave's own region -- slots handed out by ballot, no atomics (a single
+      // global counter cost 25 ms: 4 M returning atomics on one word) -- or the row goes to the exact kernel
+      const bool amb = total != 1 && !row_bad && row < p.n;
+      bool overflow = amb && (!finite || total > RF_MAXC || total < 1);
+      const bool want = amb && !overflow;
+      const unsigned long long wmask = __ballot(want && half == 0);
+      unsigned int slot = rec_n + (unsigned int)__builtin_amdgcn_mbcnt_lo((unsigned int)wmask, 0u);   // rows are lanes 0..31
+      slot = __shfl(slot, lrow);
+      rec_n += (unsigned int)__popcll(wmask);
+      if (want && slot >= p.region_cap) overflow = true;
+      if (amb) {
         if (overflow) {
           row_bad = true;
         } else {
-          RfRecord *rec = p.rec + slot;
+          RfRecord *rec = rec_base + slot;
           if (half == 0) {
             rec->row = row;
             rec->prev = prev;
@@ -411,6 +418,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     else nxt.xbytes = 0u;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) p.region_n[blockIdx.x * 8 + w8] = rec_n;
 }
 
 // (the body lives in a __device__ function: the host pass instantiates a kernel template's own body, and the buffer / LDS
@@ -540,62 +548,108 @@ __global__ __launch_bounds__(256) void rf_g_kernel(const float *__restrict__ C, 
 }
 
 // ---- fix-up: exact chains of a record's candidates -----------------------------------------------------------------------------
-// 8 lanes per record (one per candidate slot), 8 records per wave.  The chain is the oracle's: r = ((x - c_0) - c_1) - ...
-// in f32 in that order, d = fma(r - c, r - c, d) over k = 0..dim-1.
+// SLOTS lanes per record (one per candidate), 64 / SLOTS records per wave; the <4> instance takes the records with <= 4
+// candidates (nearly all), the <8> instance the rest.  The chain is the oracle's: r = ((x - c_0) - c_1) - ... in f32 in that
+// order, d = fma(r - c, r - c, d) over k = 0..dim-1.  Per 32-wide k slab the wave first STAGES the records' residual slabs in
+// LDS -- lane (record, 16-byte piece) loads its piece of x (whole 128-byte lines per record: the 12 GB of re-read rows come
+// at the gather rate) and of the premise centroids, subtracts in the reference's order -- then every (record, candidate) lane
+// runs its 32 chain steps on the staged residual and its own centroid slab (8 x 16-byte loads from L2).
+template <int SLOTS>
 __global__ __launch_bounds__(256) void rf_fixup_kernel(const float *__restrict__ X, int dim, const float *__restrict__ C, int M, int K,
-                                                      const RfRecord *__restrict__ rec, const unsigned int *__restrict__ counters,
-                                                      unsigned int rec_cap, unsigned char *__restrict__ row_flag) {
-  unsigned int nrec = counters[0];
-  nrec = nrec < rec_cap ? nrec : rec_cap;
-  const unsigned int ri = (blockIdx.x * 256 + threadIdx.x) >> 3;
-  const int slot = threadIdx.x & 7;
-  const bool live = ri < nrec;
-  RfRecord R;
-  if (live) R = rec[ri];
-  const int level = live ? R.level : 0;
-  const bool has = live && slot < (int)R.ncand;
-  const int cand = has ? R.cand[slot] : 0;
-  const float *xr = X + (size_t)(live ? R.row : 0) * dim;
-  const float *cc = C + ((size_t)level * K + cand) * dim;
-  float d = 0.f;
-  if (has) {
-    const float *pc[8];
+                                                      const RfRecord *__restrict__ rec, const unsigned int *__restrict__ region_n,
+                                                      unsigned int region_cap, unsigned int waves_per_region,
+                                                      unsigned char *__restrict__ row_flag) {
+  constexpr int RPW = 64 / SLOTS;           // records per wave
+  constexpr int PPL = RPW * 8 / 64;         // staged 16-byte pieces per lane and slab (2 at SLOTS = 4, 1 at SLOTS = 8)
+  constexpr int LD = 36;                    // floats per staged row (32 + pad)
+  __shared__ __attribute__((aligned(16))) float stage[4][RPW * LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned int gw = blockIdx.x * 4 + wave;
+  const unsigned int region = gw / waves_per_region, chunk = gw - region * waves_per_region;
+  unsigned int nrec = region_n[region];
+  nrec = nrec < region_cap ? nrec : region_cap;
+  if (chunk * RPW >= nrec) return;  // wave-uniform
+  const RfRecord *base = rec + (size_t)region * region_cap + (size_t)chunk * RPW;
+  const int nhere = (int)(nrec - chunk * RPW < (unsigned)RPW ? nrec - chunk * RPW : RPW);
+  float *st = stage[wave];
+  // staging duty: piece (lane & 7) of records (lane >> 3) + 8 i
+  const float *sx[PPL];
+  unsigned long long sprev[PPL];
+  int slevel[PPL];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pc[i] = C + ((size_t)i * K + (int)((R.prev >> (8 * i)) & 255ull)) * dim;
-    for (int k = 0; k < dim; k += 4) {
-      float4 r = *reinterpret_cast<const float4 *>(xr + k);
+  for (int i = 0; i < PPL; ++i) {
+    const int r = (lane >> 3) + 8 * i;
+    const bool live = r < nhere;
+    const RfRecord R = base[live ? r : 0];
+    const bool mine = live && (SLOTS == 4 ? R.ncand <= 4 : R.ncand > 4);
+    sx[i] = X + (size_t)R.row * dim + (lane & 7) * 4;
+    sprev[i] = R.prev;
+    slevel[i] = mine ? (int)R.level : -1;  // -1: not this instance's record, nothing staged
+  }
+  // compute duty: candidate `slot` of record `r`
+  const int r = lane / SLOTS, slot = lane % SLOTS;
+  const bool rlive = r < nhere;
+  const RfRecord R = base[rlive ? r : 0];
+  const bool mine = rlive && (SLOTS == 4 ? R.ncand <= 4 : R.ncand > 4);
+  if (!__any(mine)) return;  // nothing of this instance's in the wave's records (nearly every wave of the <8> instance)
+  const bool has = mine && slot < (int)R.ncand;
+  const int cand = has ? (int)R.cand[slot] : 0;
+  const float *cc = C + ((size_t)R.level * K + cand) * dim;
+  float d = has ? 0.f : INFINITY;
+  const int nslab = dim >> 5;  // dim % 32 == 0 on this path
+  // Measured on 4.1 M records (C2 corpus, (4, 32); profiles/r03_rq_fixup_variants.txt): this form 5.8 ms (36 waves per CU,
+  // no prefetch); + the next slab's x / centroid pieces prefetched in registers (16 waves per CU) 6.8 ms; candidate
+  // centroids staged through LDS by whole 128-byte lines (12 waves per CU) 9.3 - 15 ms.  Occupancy beats both refinements.
+  for (int s = 0; s < nslab; ++s) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (i < level) {
-          const float4 c = *reinterpret_cast<const float4 *>(pc[i] + k);
-          r.x -= c.x, r.y -= c.y, r.z -= c.z, r.w -= c.w;
-        }
+    for (int i = 0; i < PPL; ++i) {
+      if (slevel[i] < 0) continue;
+      float4 v = *reinterpret_cast<const float4 *>(sx[i] + s * 32);
+      for (int j = 0; j < slevel[i]; ++j) {
+        const float4 c = *reinterpret_cast<const float4 *>(C + ((size_t)j * K + (int)((sprev[i] >> (8 * j)) & 255ull)) * dim + s * 32 + (lane & 7) * 4);
+        v.x -= c.x, v.y -= c.y, v.z -= c.z, v.w -= c.w;
       }
-      const float4 c = *reinterpret_cast<const float4 *>(cc + k);
-      float e;
-      e = r.x - c.x; d = fmaf(e, e, d);
-      e = r.y - c.y; d = fmaf(e, e, d);
-      e = r.z - c.z; d = fmaf(e, e, d);
-      e = r.w - c.w; d = fmaf(e, e, d);
+      *reinterpret_cast<float4 *>(st + ((lane >> 3) + 8 * i) * LD + (lane & 7) * 4) = v;
     }
-  } else {
-    d = INFINITY;
+    __builtin_amdgcn_wave_barrier();  // LDS is in order within a wave
+    if (has) {
+      float4 c[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) c[q] = *reinterpret_cast<const float4 *>(cc + s * 32 + 4 * q);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 rr = *reinterpret_cast<const float4 *>(st + r * LD + 4 * q);
+        float e;
+        e = rr.x - c[q].x; d = fmaf(e, e, d);
+        e = rr.y - c[q].y; d = fmaf(e, e, d);
+        e = rr.z - c[q].z; d = fmaf(e, e, d);
+        e = rr.w - c[q].w; d = fmaf(e, e, d);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   int best = has ? cand : 0x7fffffff;
 #pragma unroll
-  for (int off = 1; off < 8; off <<= 1) {
+  for (int off = 1; off < SLOTS; off <<= 1) {
     const float od = __shfl_xor(d, off);
     const int oc = __shfl_xor(best, off);
     if (od < d || (od == d && oc < best)) d = od, best = oc;
   }
-  if (live && slot == 0 && best != (int)R.spec) row_flag[R.row] = 1;  // speculation wrong (or NaN distances): exact re-encode
+  if (mine && slot == 0 && best != (int)R.spec) row_flag[R.row] = 1;  // speculation wrong (or NaN distances): exact re-encode
 }
 
-// flagged rows -> index list (order irrelevant)
+// flagged rows -> index list (order irrelevant); one atomic per wave
 __global__ __launch_bounds__(256) void rf_badlist_kernel(const unsigned char *__restrict__ row_flag, long long n,
                                                         long long *__restrict__ list, unsigned int *__restrict__ counters) {
   const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (r < n && row_flag[r]) list[atomicAdd(&counters[1], 1u)] = r;
+  const bool bad = r < n && row_flag[r];
+  const unsigned long long m = __ballot(bad);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  unsigned int base = 0u;
+  if (lane == 0) base = atomicAdd(&counters[0], (unsigned int)__popcll(m));
+  base = __shfl(base, 0);
+  if (bad) list[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = r;
 }
 
 }  // namespace
@@ -627,36 +681,40 @@ RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
   pl.ok = true;
   return pl;
 }
+constexpr int RF_GRID = 256;  // persistent workgroups (one per CU of the MI355X); 8 record regions each
 struct RfWs {
   _Float16 *img;
   float *mu, *mus, *A, *G2, *stat, *scal;
   RfLevel *lev;
-  unsigned int *counters;
+  unsigned int *counters, *region_n;
   unsigned char *row_flag;
   long long *badlist;
   RfRecord *rec;
-  unsigned int rec_cap;
+  unsigned int region_cap, n_regions, grid;
 };
-size_t rf_carve(char *base, size_t avail, int64_t n, int64_t dim, int64_t M, int64_t K, const RfPlan &pl, RfWs *ws) {
+size_t rf_carve(char *base, int64_t n, int64_t dim, int64_t M, int64_t K, const RfPlan &pl, RfWs *ws) {
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char *q = base ? base + off : nullptr;
     off += align_up(bytes, 256);
     return q;
   };
+  const int64_t n_tiles = (n + RF_ROWS - 1) / RF_ROWS;
+  const unsigned int grid = (unsigned int)(n_tiles < RF_GRID ? n_tiles : RF_GRID);
+  const unsigned int n_regions = grid * 8;
+  // a wave sees ceil(tiles / grid) x 32 rows x M levels; ~12 % of the row-levels are ambiguous on gaussian data with the
+  // f16 bound: room for 35 %, the excess rows fall back to the exact kernel
+  const size_t rows_per_wave = (size_t)((n_tiles + grid - 1) / grid) * 32;
+  const unsigned int region_cap = (unsigned int)((rows_per_wave * (size_t)M * 35 + 99) / 100 + 64);
   char *img = take((size_t)pl.ngroups * (dim / 32) * pl.TA * 32 * 32 * 2);
   char *mu = take((size_t)dim * 4), *mus = take((size_t)dim * 4);
   char *A = take((size_t)M * pl.Kp * 4);
   char *G2 = take((size_t)M * K * M * pl.Kp * 4);
   char *stat = take(64 * 4), *scal = take(256), *lev = take(sizeof(RfLevel) * 8), *counters = take(256);
+  char *region_n = take((size_t)n_regions * 4);
   char *row_flag = take((size_t)n);
   char *badlist = take((size_t)n * 8);
-  size_t cap = (size_t)n / 2 + 4096;  // records: every second row may be ambiguous once before rows fall back
-  if (base) {
-    const size_t room = avail > off ? (avail - off) / sizeof(RfRecord) : 0;
-    cap = cap < room ? cap : room;
-  }
-  char *rec = take(cap * sizeof(RfRecord));
+  char *rec = take((size_t)n_regions * region_cap * sizeof(RfRecord));
   if (ws) {
     ws->img = reinterpret_cast<_Float16 *>(img);
     ws->mu = reinterpret_cast<float *>(mu), ws->mus = reinterpret_cast<float *>(mus);
@@ -664,10 +722,11 @@ size_t rf_carve(char *base, size_t avail, int64_t n, int64_t dim, int64_t M, int
     ws->stat = reinterpret_cast<float *>(stat), ws->scal = reinterpret_cast<float *>(scal);
     ws->lev = reinterpret_cast<RfLevel *>(lev);
     ws->counters = reinterpret_cast<unsigned int *>(counters);
+    ws->region_n = reinterpret_cast<unsigned int *>(region_n);
     ws->row_flag = reinterpret_cast<unsigned char *>(row_flag);
     ws->badlist = reinterpret_cast<long long *>(badlist);
     ws->rec = reinterpret_cast<RfRecord *>(rec);
-    ws->rec_cap = (unsigned int)(cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : cap);
+    ws->region_cap = region_cap, ws->n_regions = n_regions, ws->grid = grid;
   }
   return off;
 }
@@ -676,7 +735,7 @@ size_t rf_carve(char *base, size_t avail, int64_t n, int64_t dim, int64_t M, int
 extern "C" size_t mevi_rq_encode_fast_workspace_bytes(int64_t n, int64_t dim, int64_t M, int64_t K) {
   const RfPlan pl = rf_plan(dim, M, K);
   if (!pl.ok || n <= 0) return 0;
-  return rf_carve(nullptr, 0, n, dim, M, K, pl, nullptr) + 256;
+  return rf_carve(nullptr, n, dim, M, K, pl, nullptr) + 256;
 }
 
 extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, const float *codebook, int64_t M, int64_t K,
@@ -691,10 +750,9 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
                MEVI_ERR_INVALID_ARG, "rq_encode_fast: x / codebook must be 16-byte, the workspace 256-byte aligned");
   MEVI_REQUIRE(n < (1LL << 40), MEVI_ERR_UNSUPPORTED, "rq_encode_fast: too many rows");
   RfWs ws;
-  const size_t fixed = rf_carve(nullptr, 0, n, dim, M, K, pl, nullptr) - align_up(((size_t)n / 2 + 4096) * sizeof(RfRecord), 256);
-  MEVI_REQUIRE(workspace_bytes >= fixed + 4096 * sizeof(RfRecord), MEVI_ERR_WORKSPACE, "rq_encode_fast: workspace %zu bytes too small",
-               workspace_bytes);
-  (void)rf_carve(reinterpret_cast<char *>(workspace), workspace_bytes, n, dim, M, K, pl, &ws);
+  MEVI_REQUIRE(workspace_bytes >= rf_carve(nullptr, n, dim, M, K, pl, nullptr), MEVI_ERR_WORKSPACE,
+               "rq_encode_fast: workspace %zu bytes too small", workspace_bytes);
+  (void)rf_carve(reinterpret_cast<char *>(workspace), n, dim, M, K, pl, &ws);
 
   const int d = (int)dim, Mi = (int)M, Ki = (int)K;
   MEVI_HIP_CHECK(hipMemsetAsync(ws.counters, 0, 256, stream));
@@ -715,20 +773,15 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   p.X = x, p.n = n, p.dim = d;
   p.img = ws.img, p.mus = ws.mus, p.A = ws.A, p.G2 = ws.G2, p.lev = ws.lev, p.scal = ws.scal;
   p.M = Mi, p.K = Ki, p.Kp = pl.Kp, p.LPG = pl.LPG, p.ngroups = pl.ngroups;
-  p.codes = codes, p.row_flag = ws.row_flag, p.rec = ws.rec, p.counters = ws.counters, p.rec_cap = ws.rec_cap;
+  p.codes = codes, p.row_flag = ws.row_flag, p.rec = ws.rec, p.counters = ws.counters, p.region_n = ws.region_n;
+  p.region_cap = ws.region_cap;
   // |x~.c~ / (S_x S_c) - x'.c'| <= ((2u + u^2) + 4 dim 2^-24 + 2^-22) ||x'|| ||c'||  (both operands rounded once to f16, u = 2^-11;
   // f16 x f16 products exact in f32; 4 x 2^-24 per accumulation step lets the matrix core truncate; 2^-22 covers the f32
   // roundings of x S_x - mu S_x and c' S_c); it enters F twice
   p.e16 = (float)(2.0 * ((2.0 / 2048.0 + 1.0 / (2048.0 * 2048.0)) + 4.0 * (double)dim / 16777216.0 + 1.0 / 4194304.0) * 1.001);
   p.gam = (float)((double)(dim + 2) / 16777216.0 * 1.01);   // the oracle's chain: dim fma + the subtraction, relative
   p.n_tiles = (n + RF_ROWS - 1) / RF_ROWS;
-  int n_cu = 256;
-  {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n_cu = v;
-  }
-  const unsigned grid = (unsigned)(p.n_tiles < n_cu ? p.n_tiles : n_cu);
+  const unsigned grid = ws.grid;
   const void *fn = nullptr;
   size_t lds_bytes = 0;
 #define MEVI_RF_PICK(TA_, KT_)                                             \
@@ -744,12 +797,17 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
     void *args[] = {(void *)&p};
     MEVI_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, lds_bytes, stream));
   }
-  hipLaunchKernelGGL(rf_fixup_kernel, dim3((unsigned)(((size_t)ws.rec_cap * 8 + 255) / 256)), dim3(256), 0, stream, x, d, codebook, Mi, Ki,
-                     ws.rec, ws.counters, ws.rec_cap, ws.row_flag);
+  {
+    const unsigned int wpr4 = (ws.region_cap + 15) / 16, wpr8 = (ws.region_cap + 7) / 8;
+    hipLaunchKernelGGL(rf_fixup_kernel<4>, dim3((unsigned)(((size_t)ws.n_regions * wpr4 + 3) / 4)), dim3(256), 0, stream, x, d, codebook, Mi,
+                       Ki, ws.rec, ws.region_n, ws.region_cap, wpr4, ws.row_flag);
+    hipLaunchKernelGGL(rf_fixup_kernel<8>, dim3((unsigned)(((size_t)ws.n_regions * wpr8 + 3) / 4)), dim3(256), 0, stream, x, d, codebook, Mi,
+                       Ki, ws.rec, ws.region_n, ws.region_cap, wpr8, ws.row_flag);
+  }
   hipLaunchKernelGGL(rf_badlist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws.row_flag, (long long)n, ws.badlist,
                      ws.counters);
   MEVI_HIP_CHECK(hipGetLastError());
-  return rq_encode_exact_rows(x, dim, codebook, M, K, codes, ws.badlist, ws.counters + 1, n, stream);
+  return rq_encode_exact_rows(x, dim, codebook, M, K, codes, ws.badlist, ws.counters, n, stream);
 }
 
 // {records appended, rows re-encoded exactly, ambiguous row-levels} of the last fast encode that used `workspace`
@@ -760,10 +818,14 @@ extern "C" int mevi_rq_encode_fast_stats(const void *workspace, int64_t n, int64
   const RfPlan pl = rf_plan(dim, M, K);
   MEVI_REQUIRE(pl.ok && workspace && out3, MEVI_ERR_INVALID_ARG, "rq_encode_fast_stats: bad arguments");
   RfWs ws;
-  (void)rf_carve(reinterpret_cast<char *>(const_cast<void *>(workspace)), (size_t)1 << 62, n, dim, M, K, pl, &ws);
-  unsigned int h[3] = {0, 0, 0};
-  MEVI_HIP_CHECK(hipMemcpyAsync(h, ws.counters, 12, hipMemcpyDeviceToHost, stream));
+  (void)rf_carve(reinterpret_cast<char *>(const_cast<void *>(workspace)), n, dim, M, K, pl, &ws);
+  unsigned int nbad = 0;
+  std::vector<unsigned int> reg(ws.n_regions);
+  MEVI_HIP_CHECK(hipMemcpyAsync(&nbad, ws.counters, 4, hipMemcpyDeviceToHost, stream));
+  MEVI_HIP_CHECK(hipMemcpyAsync(reg.data(), ws.region_n, (size_t)ws.n_regions * 4, hipMemcpyDeviceToHost, stream));
   MEVI_HIP_CHECK(hipStreamSynchronize(stream));
-  out3[0] = h[0], out3[1] = h[1], out3[2] = h[2];
+  int64_t kept = 0, wanted = 0;
+  for (unsigned int v : reg) wanted += v, kept += v < ws.region_cap ? v : ws.region_cap;
+  out3[0] = kept, out3[1] = nbad, out3[2] = wanted;
   return MEVI_OK;
 }

@@ -355,12 +355,13 @@ class EvalRun:
         # code paths (_generate_all) with --eval_all_documents
         self.topic = bool(getattr(a, "use_topic_model", 0))
         if self.topic:
-            assert self.C == 1, "use_topic_model is built for doc_multiclus 1"
+            assert self.C == 1 or not self.eval_all, "use_topic_model over multi-cluster documents is built for the cluster path"
             self.ratio = float(getattr(a, "topic_score_ratio", 0) or 0)
             self.doc_path = None
             # topic_score_ratio > 0 (`additional_reconstruct`, main_models.py:1270): doc_proba[d] = <reconstruct(codes(d)), emb[d]>
-            # (gen_all_reconstruct :3272-3307 + gen_doc2index_mapping :3360-3364, bmm form of compute_similarity)
-            self.doc_proba = self._doc_proba() if self.ratio else None
+            # (gen_all_reconstruct :3272-3307 + gen_doc2index_mapping :3360-3364, bmm form of compute_similarity); with
+            # multi-cluster documents the probability is per (document, cluster) and computed per candidate (FineStage.rerank)
+            self.doc_proba = self._doc_proba() if self.ratio and self.C == 1 else None
         # --recall_level: 'both' (the eval scripts), 'coarse' (beam clusters only: no tower pass, no fine stage) or 'fine'
         # (fine list only; main_models.py:3736,3781,4103-4110)
         self.level = "fine" if self.eval_all else getattr(a, "recall_level", "both")
@@ -524,8 +525,12 @@ class EvalRun:
         weights = None
         if self.topic:      # nci_scores: the beam scores, or ones for a single returned sequence (main_models.py:3678-3682)
             weights = torch.ones((B, 1), dtype=torch.float32) if R == 1 else torch.tensor(scores, dtype=torch.float32)
+        beam_recon = None
+        if self.topic and self.C > 1 and self.ratio:       # reconstruct vectors of the beam code paths (pq.get_reconstruct_vector)
+            beam_recon = self.pq.get_reconstruct_vector(torch.from_numpy(codes.reshape(B * R, self.M)).to(self.dev)).contiguous()
         ranked, ndoc = self.fine.rerank(qemb, codes, aggregate=self.aggregate, beam_weights=weights,
-                                        doc_proba=self.doc_proba if self.topic else None, ratio=self.ratio if self.topic else 0.0)
+                                        doc_proba=self.doc_proba if self.topic else None, ratio=self.ratio if self.topic else 0.0,
+                                        beam_recon=beam_recon)
         if getattr(a, "knn_topk_by_step", 0):       # main_models.py:3919-3995: a running torch.topk over the cluster chunks
             pool = max(a.recall_num)                  # keeps the pool_size best of a query's candidates, best first
             ranked = [(d[:pool], s_[:pool]) for d, s_ in ranked]

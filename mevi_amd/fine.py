@@ -91,7 +91,7 @@ class FineStage:
             return cand, cand_q, seg, ndoc, torch.repeat_interleave(torch.arange(R, dtype=torch.int64, device=self.dev).repeat(B), size)
         return cand, cand_q, seg, ndoc
 
-    def rerank(self, query_emb, beam_codes, aggregate=None, beam_weights=None, doc_proba=None, ratio=0.0):
+    def rerank(self, query_emb, beam_codes, aggregate=None, beam_weights=None, doc_proba=None, ratio=0.0, beam_recon=None):
         """query_emb f32[B, dim] (CUDA).  Returns per query: (doc ids i64 ndarray, scores f32 ndarray) -- views of
         one host copy of the sorted batch --, and ndoc (candidates incl. repeats).
 
@@ -102,7 +102,10 @@ class FineStage:
         beam_weights f32[B, R] (--use_topic_model 1, main_models.py:3539-3552,3952: get_inference_scores with
         topic_score_ratio 0): every document's score is its cluster's beam score times q.d (one f32 multiply); with
         `doc_proba` f32[N] and ratio > 0 the reference's full form w * (ratio * doc_proba[d] + (1 - ratio) * q.d), each
-        operation an f32 tensor operation in that order."""
+        operation an f32 tensor operation in that order.  With multi-cluster documents (--doc_multiclus > 1) the document
+        probability belongs to the (document, cluster) pair -- all_doc_proba[d].gather(inclus_index), main_models.py:3944-
+        3985,3311-3372: <reconstruct vector of THAT cluster's code path, emb[d]> -- and is computed per candidate from
+        `beam_recon` f32 [B * R, dim], the reconstruct vectors of the beam code paths (exact fmaf chains)."""
         cand_t, cand_q, seg, ndoc, cand_beam = self.candidates_device(beam_codes, with_beam=True)
         B = len(ndoc)
         if cand_t.numel() == 0:
@@ -110,7 +113,11 @@ class FineStage:
         sc = ops.pair_dot(query_emb, cand_q, self.emb, cand_t)
         if beam_weights is not None:
             w = torch.as_tensor(beam_weights, dtype=torch.float32, device=self.dev)
-            if doc_proba is not None and ratio:
+            if beam_recon is not None and ratio:
+                R = w.shape[1]
+                dp = ops.pair_dot(beam_recon, cand_q * R + cand_beam, self.emb, cand_t)
+                sc = ratio * dp + (1 - ratio) * sc
+            elif doc_proba is not None and ratio:
                 sc = ratio * doc_proba[cand_t] + (1 - ratio) * sc
             sc = w[cand_q, cand_beam] * sc
         seg_len = ndoc

@@ -623,6 +623,66 @@ def test_eval_driver_with_multi_cluster_documents(cuda, mini, tmp_path, aggr):
     assert abs(out["ndoc"] - nd / len(mini["queries"])) < 1e-9
 
 
+@pytest.mark.parametrize("aggr,ratio", [("add", 0.0), ("max", 0.3)])
+def test_topic_model_over_multi_cluster_documents(cuda, mini, tmp_path, aggr, ratio):
+    """--use_topic_model 1 --doc_multiclus 3 on the cluster path (main_models.py:3944-4011 with :3539-3552 and the per-(document,
+    cluster) probability of gen_doc2index_mapping :3311-3372): a candidate reached through beam cluster i scores
+    nci_score_i * (ratio * <reconstruct(cluster i), emb[d]> + (1 - ratio) * q.d); a document reached through several beams is
+    listed once with those scores summed in list order / maxed.  Against the reference's loop restated from oracle pieces."""
+    import shutil
+    from collections import defaultdict
+
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    a = Namespace(**vars(mini["args"]))
+    shutil.copy(a.pq_path, tmp_path / "rqcodebook4_5.pt")
+    a.pq_path, a.pq_cluster_path = str(tmp_path / "rqcodebook4_5.pt"), str(tmp_path / "rqclus4_5.pkl")
+    a.custom_save_path, a.metric_path = str(tmp_path / "tm.tsv"), str(tmp_path / "tm_m.txt")
+    a.doc_multiclus, a.multiclus_score_aggr, a.use_topic_model, a.topic_score_ratio = 3, aggr, 1, ratio
+    tok = FakeTokenizer(512)
+    EvalRun(a, tokenizer=tok, device=cuda).run(load_queries(a.data_dir))
+    got_labels = torch.load(str(tmp_path / "rqtopk34_5.pt")).numpy()
+    multi = defaultdict(list)
+    for i, paths in enumerate(got_labels.tolist()):
+        for p_ in paths:
+            multi[tuple(p_)].append(i)
+    enc = tok.batch_encode_plus(mini["queries"])
+    dec, sc, _ = ot5.nci_generate(mini["W"], mini["cfg"], enc["input_ids"], enc["attention_mask"], 10)
+    codes = ot5.decode_token(dec, 32).view(len(mini["queries"]), 10, 4).numpy()
+    nci_scores = torch.tensor(sc.tolist(), dtype=torch.float32).reshape(len(mini["queries"]), 10)
+    qemb = ot5.tower_encode(mini["TW"], mini["tcfg"], enc["input_ids"], enc["attention_mask"])
+    emb, Ct = torch.from_numpy(mini["emb"]), torch.from_numpy(mini["C"])
+    hn = [l.rstrip("\n").split("\t") for l in open(f"{a.custom_save_path[:-4]}_hn{a.save_hard_neg}.tsv")]
+    checked = merged = 0
+    for i in range(len(mini["queries"])):
+        scores, docs = [], []
+        for r in range(10):
+            cur = multi.get(tuple(codes[i, r].tolist()))
+            if cur is None:
+                continue
+            recon = sum(Ct[j][int(codes[i, r, j])] for j in range(4))
+            dp = (emb[cur] @ recon) if ratio else 0
+            scores.append(nci_scores[i][r].item() * (ratio * dp + (1 - ratio) * (qemb[i] @ emb[cur].T)))
+            docs += cur
+        if not docs:
+            assert hn[i][2] == ""
+            continue
+        scores, docs = torch.cat(scores), np.array(docs)
+        udocs, uidx = np.unique(docs, return_inverse=True)
+        us = torch.zeros(len(udocs)) if aggr == "add" else torch.full((len(udocs),), -float("inf"))
+        for ui, s_ in zip(uidx, scores):                            # main_models.py:4003-4008
+            us[ui] = us[ui] + s_ if aggr == "add" else torch.max(us[ui], s_)
+        merged += len(docs) - len(udocs)
+        ref_s, order = torch.sort(us, descending=True)
+        got_d = [int(x) for x in hn[i][2].split(",")]
+        got_s = np.array([float(x) for x in hn[i][3].split(",")])
+        assert sorted(got_d) == udocs.tolist() and np.abs(got_s - ref_s.numpy()).max() <= 5e-4 * max(1.0, float(ref_s.abs().max()))
+        firm = _firm(ref_s.numpy(), 2e-3)
+        assert all(got_d[j] == int(udocs[order.numpy()][j]) for j in np.nonzero(firm)[0])
+        checked += int(firm.sum())
+    assert checked > 50 and merged > 5
+
+
 def test_dense_cli_and_ensemble_chain(cuda, mini, tmp_path):
     """faiss_search.py (C1-style plumbing on the GPU) -> evaluate.py -> ensemble_marco.py on the files above."""
     d, a = mini["dir"], mini["args"]

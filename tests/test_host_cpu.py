@@ -330,8 +330,11 @@ def test_main_py_rejects_what_it_does_not_build():
     main.parsers_parser(base + ["--use_topic_model", "0", "--fp_16", "0", "--decode_embedding", "2"])   # the built values
     main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1"]))                  # cluster score x q.d
     main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1", "--topic_score_ratio", "0.3"]))
-    with pytest.raises(SystemExit):            # the topic model over multi-cluster documents is not built
-        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1", "--doc_multiclus", "3"]))
+    # the topic model over multi-cluster documents: built on the cluster path (round 3), not with --eval_all_documents
+    main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1", "--doc_multiclus", "3"]))
+    with pytest.raises(SystemExit):
+        main.check_supported(main.parsers_parser(EVAL_ARGV + ["--use_topic_model", "1", "--doc_multiclus", "3", "--eval_all_documents", "1",
+                                                              "--recall_level", "fine", "--knn_topk_by_step", "1"]))
     with pytest.raises(SystemExit):            # try_load_ckpt asserts a checkpoint (MEVI/main.py:201)
         main.check_supported(main.parsers_parser([t for t in EVAL_ARGV if not t.startswith("--nci_ckpt")][:0] + base + [
             "--codebook", "1", "--pq_type", "rq", "--query_encoder", "twin", "--recall_level", "both", "--document_encoder",
