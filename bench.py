@@ -162,25 +162,32 @@ def dense_small_batch(device, index, query, n_docs):
     image_bytes = float(n_docs) * DIM * 2
     per = []
     for bs in (1, 2, 4, 8, 64):
-        q = query[:bs].contiguous()
-        index.search(q, TOPK)
-        torch.cuda.synchronize()
-        reps = 10
-        t = time.perf_counter()
-        for r in range(reps):
-            index.search(query[r * bs:(r + 1) * bs].contiguous(), TOPK)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t) / reps * 1e3
-        per.append({"batch": bs, "ms_per_search": round(ms, 3), "queries_per_s": round(bs / ms * 1e3, 1),
-                    "image_gb_per_s": round(image_bytes / ms / 1e6, 1), "frac_of_hbm_peak": round(image_bytes / ms / 1e6 / 8000.0, 3)})
-    return {"what": "faiss_search.profile's regime: ONE index.search call of <batch> queries over the resident corpus, top-%d, mean "
-                    "of 10 calls (inputs and outputs on the device)" % TOPK,
+        row = {"batch": bs}
+        for kk in (TOPK, 100):
+            q = query[:bs].contiguous()
+            index.search(q, kk)
+            torch.cuda.synchronize()
+            reps = 10
+            t = time.perf_counter()
+            for r in range(reps):
+                index.search(query[r * bs:(r + 1) * bs].contiguous(), kk)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t) / reps * 1e3
+            row["top%d" % kk] = {"ms_per_search": round(ms, 3), "queries_per_s": round(bs / ms * 1e3, 1),
+                                 "image_gb_per_s": round(image_bytes / ms / 1e6, 1),
+                                 "frac_of_hbm_peak": round(image_bytes / ms / 1e6 / 8000.0, 3)}
+        per.append(row)
+    best = per[0]["top%d" % TOPK]
+    return {"what": "faiss_search.profile's regime: ONE index.search call of <batch> queries over the resident corpus (top-%d as the "
+                    "scripts ask, and top-100), mean of 10 calls, inputs and outputs on the device" % TOPK,
             "dtype": "f16 pre-filter (selection) + exact f32 chains (results)",
+            "kernel": "ip_filter_h1_small_kernel for batch <= 32 (stationary query tile, every wave streaming its own corpus rows), "
+                      "ip_filter_h1_kernel above",
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
                          "algorithmic_bytes_per_search": image_bytes,
                          "note": "bytes = the corpus' f16 image (N x 768 x 2), read once per search; the f32 rows of the re-scored "
-                                 "survivors (K' x 3 KB per query) are not counted",
-                         "achieved": per[0]["image_gb_per_s"], "frac": per[0]["frac_of_hbm_peak"]},
+                                 "survivors (K' x 3 KB per query) are not counted; the guide's achievable copy rate is 6.3 TB/s",
+                         "achieved": best["image_gb_per_s"], "frac": best["frac_of_hbm_peak"]},
             "per_batch": per}
 
 
@@ -203,8 +210,10 @@ def index_build_leg(device, docs, rn, n_docs):
         ms = (time.perf_counter() - t) * 1e3
         byts = 4.0 * n_docs * DIM + 4.0 * n_docs * M_
         out["rq_encode_%dx%d" % (M_, K_)] = {
-            "ms": round(ms, 2), "rows_per_s": round(n_docs / ms * 1e3), "dtype": "f32 (exact (r - c)^2 fmaf chains decide every code)",
-            "stats": rq.last_encode_stats() if hasattr(rq, "last_encode_stats") else None,
+            "ms": round(ms, 2), "rows_per_s": round(n_docs / ms * 1e3), "dtype": "f16 MFMA shortlist + exact f32 (r - c)^2 fmaf chains wherever the shortlist holds more than one centroid: codes are the f32 codes",
+            "kernel": "rq_fast_kernel (f16 MFMA shortlist of every level from ONE product against all M*K centroids) + rf_fixup_kernel "
+                      "(exact chains of the ambiguous row-levels' candidates) + rq_level_kernel on the rows the speculation got wrong",
+            "stats": rq.last_encode_stats(),
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes": byts,
                          "bytes_note": "SURVEY 8(d): 4 N d (corpus once) + 4 N M (codes)",
                          "achieved": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / 8000.0, 4)}}

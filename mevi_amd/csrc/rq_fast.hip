@@ -86,10 +86,12 @@ struct RfParams {
   long long n_tiles;
 };
 
-template <int TA>
-constexpr int rf_unit_floats() { return (TA * 32 * 64 + RF_ROWS * 128) / 4; }
-template <int TA>
-constexpr size_t rf_lds_bytes(int dim) { return (size_t)RF_NBUF * rf_unit_floats<TA>() * 4 + (size_t)dim * 4; }
+// SPLIT: both operands as (hi, lo) f16 pairs, three MFMAs per product (hi.hi + hi.lo + lo.hi; lo scaled by 2^11 so that it
+// stays in the f16 normal range) -- the centroid image then holds TA*32 hi rows followed by TA*32 lo rows per unit
+template <int TA, bool SPLIT>
+constexpr int rf_unit_floats() { return (TA * 32 * 64 * (SPLIT ? 2 : 1) + RF_ROWS * 128) / 4; }
+template <int TA, bool SPLIT>
+constexpr size_t rf_lds_bytes(int dim) { return (size_t)RF_NBUF * rf_unit_floats<TA, SPLIT>() * 4 + (size_t)dim * 4; }
 
 // Delta of the header: candidates are the c with F(c) - m <= Delta.
 //   F*(c)  = D*(c) - rho  (real arithmetic; D* the distance to the real-number residual, rho = ||r*_j||^2),  |F - F*| <= E1
@@ -105,11 +107,12 @@ __device__ __forceinline__ float rf_delta(float m, float rho_hat, float E1, floa
   return (2.f * E1 + 2.1f * gam * dpos + 2.1f * e2) * 1.01f;
 }
 
-template <int TA, int KT>
+template <int TA, int KT, bool SPLIT>
 __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
-  constexpr int UNIT = rf_unit_floats<TA>();       // floats per unit buffer: A image then x rows
-  constexpr int AFL = TA * 32 * 16;                // floats of the A part (64 B per row)
-  constexpr int PA_PER_WAVE = TA / 4;              // A pieces (16 rows x 64 B) per wave and unit
+  constexpr int UNIT = rf_unit_floats<TA, SPLIT>();  // floats per unit buffer: A image then x rows
+  constexpr int AROWS = TA * 32 * (SPLIT ? 2 : 1);   // image rows per unit (hi rows, then lo rows)
+  constexpr int AFL = AROWS * 16;                    // floats of the A part (64 B per row)
+  constexpr int PA_PER_WAVE = AROWS / 128;           // A pieces (16 rows x 64 B) per wave and unit
   constexpr int P = 4 + PA_PER_WAVE;               // DMA pieces per wave and unit
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -136,7 +139,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     const int row = 16 * (w8 * PA_PER_WAVE + i) + (lane >> 2);
     voff_a[i] = row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
   }
-  const unsigned int a_block_bytes = (unsigned int)(TA * 32 * 64);  // one unit of one group's image
+  const unsigned int a_block_bytes = (unsigned int)(AROWS * 64);  // one unit of one group's image
 
   // work list of this workgroup: row tiles blockIdx.x, + gridDim.x, ...; inside a row tile the groups in order
   long long rt = blockIdx.x;
@@ -201,16 +204,21 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   // A fragments of a half-step are read while the previous half-step's MFMAs run, so 2 x H fragments are live instead of the
   // 2 x TA of a whole-k-step double buffer (at TA = 8 that version spilled 124 registers, some inside the loop).
   constexpr int H = TA / 2;
-  f16x8 alo[H], ahi[H], bq0, bq1;
+  constexpr int HS = SPLIT ? 2 * H : H;   // fragments of a half-step: [0, H) hi parts, [H, 2H) lo parts
+  f16x8 alo[HS], ahi[HS], bq0[SPLIT ? 2 : 1], bq1[SPLIT ? 2 : 1];
+  f32x16 accx[SPLIT ? TA : 1];            // SPLIT: the two cross terms (x 2^11)
   const float sx = p.scal[0];
   float rho_s = 0.f;  // sum of (x' S_x)^2 over this lane's k (the other half holds the rest)
-  auto read_a = [&](int gb, int j, int h0, f16x8 (&dst)[H]) {
+  auto read_a = [&](int gb, int j, int h0, f16x8 (&dst)[HS]) {
     const float *ub = lds + gb * UNIT + offa + (((2 * j + half) ^ a_sw) << 2);
 #pragma unroll
-    for (int ti = 0; ti < H; ++ti) dst[ti] = *reinterpret_cast<const f16x8 *>(ub + 32 * (h0 + ti) * 16);
+    for (int ti = 0; ti < H; ++ti) {
+      dst[ti] = *reinterpret_cast<const f16x8 *>(ub + 32 * (h0 + ti) * 16);
+      if constexpr (SPLIT) dst[H + ti] = *reinterpret_cast<const f16x8 *>(ub + (TA * 32 + 32 * (h0 + ti)) * 16);
+    }
   };
   // this lane's 8 x values of k-step (u, j): centred, scaled, rounded to f16 (and added to the row norm)
-  auto read_x = [&](int gb, int u, int j, f16x8 &b) {
+  auto read_x = [&](int gb, int u, int j, f16x8 (&b)[SPLIT ? 2 : 1]) {
     const float *ub = lds + gb * UNIT;
     const int c0 = 4 * j + 2 * half;
     const float4 x0 = *reinterpret_cast<const float4 *>(ub + offb + ((c0 ^ b_sw) << 2));
@@ -223,16 +231,30 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       rho_s = fmaf(v[i], v[i], rho_s);
-      b[i] = (_Float16)v[i];
+      const _Float16 h = (_Float16)v[i];
+      b[0][i] = h;
+      if constexpr (SPLIT) b[1][i] = (_Float16)((v[i] - (float)h) * 2048.f);
     }
   };
-  auto mma_lo = [&](const f16x8 &b) {
+  auto mma_lo = [&](const f16x8 (&b)[SPLIT ? 2 : 1]) {
 #pragma unroll
-    for (int ti = 0; ti < H; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ti], b, acc[ti], 0, 0, 0);
+    for (int ti = 0; ti < H; ++ti) {
+      acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ti], b[0], acc[ti], 0, 0, 0);
+      if constexpr (SPLIT) {
+        accx[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ti], b[1], accx[ti], 0, 0, 0);
+        accx[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[H + ti], b[0], accx[ti], 0, 0, 0);
+      }
+    }
   };
-  auto mma_hi = [&](const f16x8 &b) {
+  auto mma_hi = [&](const f16x8 (&b)[SPLIT ? 2 : 1]) {
 #pragma unroll
-    for (int ti = 0; ti < H; ++ti) acc[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ti], b, acc[H + ti], 0, 0, 0);
+    for (int ti = 0; ti < H; ++ti) {
+      acc[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ti], b[0], acc[H + ti], 0, 0, 0);
+      if constexpr (SPLIT) {
+        accx[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ti], b[1], accx[H + ti], 0, 0, 0);
+        accx[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[H + ti], b[0], accx[H + ti], 0, 0, 0);
+      }
+    }
   };
 
   RfRecord *rec_base = p.rec + (size_t)(blockIdx.x * 8 + w8) * p.region_cap;
@@ -289,6 +311,12 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     for (int ti = 0; ti < TA; ++ti)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ti = 0; ti < TA; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[ti][r] = 0.f;
+    }
     rho_s = 0.f;
     read_a(rb, 0, 0, alo);      // k-step (0, 0) of the tile: its unit has landed (prologue / the previous tile's last barrier)
     read_x(rb, 0, 0, bq0);
@@ -296,6 +324,12 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     cycle(U - 1, true);
 
     // ---- epilogue of (row tile rt, group grp): per level argmin of F, candidate test, record ---------------------------------
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ti = 0; ti < TA; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ti][r] = fmaf(accx[ti][r], 1.f / 2048.f, acc[ti][r]);
+    }
     const long long row = rt * RF_ROWS + 32 * w8 + lrow;
     if (grp == 0) {
       const float tot = rho_s + __shfl_xor(rho_s, 32);
@@ -423,10 +457,10 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
 
 // (the body lives in a __device__ function: the host pass instantiates a kernel template's own body, and the buffer / LDS
 // builtins above do not exist there)
-template <int TA, int KT>
+template <int TA, int KT, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void rq_fast_kernel(const RfParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rq_fast_body<TA, KT>(p, lds);
+  rq_fast_body<TA, KT, SPLIT>(p, lds);
 }
 
 // ---- prep kernels (codebook only: a few hundred KB) -------------------------------------------------------------------------
@@ -504,7 +538,7 @@ __global__ __launch_bounds__(256) void rf_mus_kernel(const float *__restrict__ m
 
 // image + A: one wave per (level, centroid incl. padding)
 __global__ __launch_bounds__(256) void rf_image_kernel(const float *__restrict__ C, int M, int K, int Kp, int dim, int LPG, int TA,
-                                                      const float *__restrict__ mu, const RfLevel *__restrict__ lev,
+                                                      int split, const float *__restrict__ mu, const RfLevel *__restrict__ lev,
                                                       _Float16 *__restrict__ img, float *__restrict__ A) {
   const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (wv >= M * Kp) return;
@@ -521,7 +555,10 @@ __global__ __launch_bounds__(256) void rf_image_kernel(const float *__restrict__
       if (j == 0) v = (float)((double)v - (double)mu[k]);
       ss += (double)v * (double)v;
     }
-    img[(((size_t)g * U + (k >> 5)) * (TA * 32) + rowi) * 32 + (k & 31)] = (_Float16)(v * sc);
+    const int arows = TA * 32 * (split ? 2 : 1);
+    const _Float16 h = (_Float16)(v * sc);
+    img[(((size_t)g * U + (k >> 5)) * arows + rowi) * 32 + (k & 31)] = h;
+    if (split) img[(((size_t)g * U + (k >> 5)) * arows + TA * 32 + rowi) * 32 + (k & 31)] = (_Float16)((v * sc - (float)h) * 2048.f);
   }
   for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
   if (lane == 0) A[(size_t)j * Kp + c] = real ? (float)ss : INFINITY;
@@ -665,10 +702,10 @@ using namespace mevi;
 namespace {
 struct RfPlan {
   int Kp, KT, LPG, ngroups, TA;
-  bool ok;
+  bool ok, split;
 };
 RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
-  RfPlan pl = {0, 0, 0, 0, 0, false};
+  RfPlan pl = {0, 0, 0, 0, 0, false, false};
   if (dim % 32 != 0 || dim < 96 || dim > 8192 || M < 1 || M > 8 || K < 1 || K > 256) return pl;
   int Kp = 32;
   while (Kp < K) Kp <<= 1;
@@ -678,6 +715,9 @@ RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
   pl.ngroups = (int)((M + pl.LPG - 1) / pl.LPG);
   const int tiles = (int)(M < pl.LPG ? M : pl.LPG) * pl.KT;  // MFMA tiles of the fullest group
   pl.TA = (tiles <= 4 && pl.KT == 1) ? 4 : 8;
+  // up to four levels of 32 centroids (the scripts' (4, 32)): the kernel waits for HBM with the matrix cores a quarter busy,
+  // so the product is taken in split precision (3 MFMAs) -- an error bound 6x tighter, 6x fewer ambiguous row-levels
+  pl.split = pl.TA == 4 && !getenv("MEVI_RQ_NO_SPLIT");
   pl.ok = true;
   return pl;
 }
@@ -702,11 +742,14 @@ size_t rf_carve(char *base, int64_t n, int64_t dim, int64_t M, int64_t K, const 
   const int64_t n_tiles = (n + RF_ROWS - 1) / RF_ROWS;
   const unsigned int grid = (unsigned int)(n_tiles < RF_GRID ? n_tiles : RF_GRID);
   const unsigned int n_regions = grid * 8;
-  // a wave sees ceil(tiles / grid) x 32 rows x M levels; ~12 % of the row-levels are ambiguous on gaussian data with the
-  // f16 bound: room for 35 %, the excess rows fall back to the exact kernel
+  // a wave sees ceil(tiles / grid) x 32 rows x M levels.  3 - 12 % of the row-levels are ambiguous on gaussian data with a
+  // random codebook, but ~50 % with a k-means codebook of 256 centroids trained on structureless residuals (256 nearly
+  // equidistant centroids: the best two are closer than the f16 bound; measured) -- so there is room for EVERY
+  // row-level (32 bytes each: 0.85 - 1.1 GB for the MS MARCO corpus); only rows with > 8 candidates or a wrong speculation
+  // fall back to the exact kernel
   const size_t rows_per_wave = (size_t)((n_tiles + grid - 1) / grid) * 32;
-  const unsigned int region_cap = (unsigned int)((rows_per_wave * (size_t)M * 35 + 99) / 100 + 64);
-  char *img = take((size_t)pl.ngroups * (dim / 32) * pl.TA * 32 * 32 * 2);
+  const unsigned int region_cap = (unsigned int)(rows_per_wave * (size_t)M + 64);
+  char *img = take((size_t)pl.ngroups * (dim / 32) * pl.TA * 32 * 32 * 2 * (pl.split ? 2 : 1));
   char *mu = take((size_t)dim * 4), *mus = take((size_t)dim * 4);
   char *A = take((size_t)M * pl.Kp * 4);
   char *G2 = take((size_t)M * K * M * pl.Kp * 4);
@@ -757,13 +800,13 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   const int d = (int)dim, Mi = (int)M, Ki = (int)K;
   MEVI_HIP_CHECK(hipMemsetAsync(ws.counters, 0, 256, stream));
   MEVI_HIP_CHECK(hipMemsetAsync(ws.row_flag, 0, (size_t)n, stream));
-  MEVI_HIP_CHECK(hipMemsetAsync(ws.img, 0, (size_t)pl.ngroups * (dim / 32) * pl.TA * 32 * 32 * 2, stream));
+  MEVI_HIP_CHECK(hipMemsetAsync(ws.img, 0, (size_t)pl.ngroups * (dim / 32) * pl.TA * 32 * 32 * 2 * (pl.split ? 2 : 1), stream));
   hipLaunchKernelGGL(rf_mu_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, stream, codebook, Ki, d, ws.mu);
   hipLaunchKernelGGL(rf_level_stats_kernel, dim3((unsigned)Mi), dim3(256), 0, stream, codebook, Mi, Ki, d, ws.mu, ws.stat);
   hipLaunchKernelGGL(rf_levels_kernel, dim3(1), dim3(64), 0, stream, ws.stat, Mi, d, ws.lev, ws.scal);
   hipLaunchKernelGGL(rf_mus_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, stream, ws.mu, ws.scal, d, ws.mus);
   hipLaunchKernelGGL(rf_image_kernel, dim3((unsigned)((Mi * pl.Kp + 3) / 4)), dim3(256), 0, stream, codebook, Mi, Ki, pl.Kp, d, pl.LPG,
-                     pl.TA, ws.mu, ws.lev, ws.img, ws.A);
+                     pl.TA, pl.split ? 1 : 0, ws.mu, ws.lev, ws.img, ws.A);
   {
     const long long total = (long long)Mi * Ki * Mi * pl.Kp;
     hipLaunchKernelGGL(rf_g_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, codebook, Mi, Ki, pl.Kp, d, ws.mu, ws.G2);
@@ -778,18 +821,26 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   // |x~.c~ / (S_x S_c) - x'.c'| <= ((2u + u^2) + 4 dim 2^-24 + 2^-22) ||x'|| ||c'||  (both operands rounded once to f16, u = 2^-11;
   // f16 x f16 products exact in f32; 4 x 2^-24 per accumulation step lets the matrix core truncate; 2^-22 covers the f32
   // roundings of x S_x - mu S_x and c' S_c); it enters F twice
-  p.e16 = (float)(2.0 * ((2.0 / 2048.0 + 1.0 / (2048.0 * 2048.0)) + 4.0 * (double)dim / 16777216.0 + 1.0 / 4194304.0) * 1.001);
+  // plain: both operands rounded once to f16 (u = 2^-11), f16 x f16 products exact in f32, 4 x 2^-24 per accumulation step lets
+  // the matrix core truncate, 2^-22 covers the f32 roundings of x S_x - mu S_x and c' S_c:
+  //   |x~.c~ / (S_x S_c) - x'.c'| <= ((2u + u^2) + 4 dim 2^-24 + 2^-22) ||x'|| ||c'||
+  // split: (hi, lo) pairs carry 22 bits (3 x 2^-22 for the two roundings of lo and the dropped lo.lo term); the cross terms'
+  // own accumulation is 2^-10 of the main chain's.  Either enters F twice (the factor -2).
+  const double acc_step = 4.0 * (double)dim / 16777216.0;
+  p.e16 = pl.split ? (float)(2.0 * (3.0 / 4194304.0 + acc_step * (1.0 + 1.0 / 512.0) + 1.0 / 4194304.0) * 1.001)
+                   : (float)(2.0 * ((2.0 / 2048.0 + 1.0 / (2048.0 * 2048.0)) + acc_step + 1.0 / 4194304.0) * 1.001);
   p.gam = (float)((double)(dim + 2) / 16777216.0 * 1.01);   // the oracle's chain: dim fma + the subtraction, relative
   p.n_tiles = (n + RF_ROWS - 1) / RF_ROWS;
   const unsigned grid = ws.grid;
   const void *fn = nullptr;
   size_t lds_bytes = 0;
-#define MEVI_RF_PICK(TA_, KT_)                                             \
-  if (pl.TA == TA_ && pl.KT == KT_) {                                      \
-    fn = reinterpret_cast<const void *>(rq_fast_kernel<TA_, KT_>);         \
-    lds_bytes = rf_lds_bytes<TA_>(d);                                      \
+#define MEVI_RF_PICK(TA_, KT_, SP_)                                        \
+  if (pl.TA == TA_ && pl.KT == KT_ && pl.split == SP_) {                   \
+    fn = reinterpret_cast<const void *>(rq_fast_kernel<TA_, KT_, SP_>);    \
+    lds_bytes = rf_lds_bytes<TA_, SP_>(d);                                 \
   }
-  MEVI_RF_PICK(4, 1) MEVI_RF_PICK(8, 1) MEVI_RF_PICK(8, 2) MEVI_RF_PICK(8, 4) MEVI_RF_PICK(8, 8)
+  MEVI_RF_PICK(4, 1, true) MEVI_RF_PICK(4, 1, false) MEVI_RF_PICK(8, 1, false) MEVI_RF_PICK(8, 2, false) MEVI_RF_PICK(8, 4, false)
+  MEVI_RF_PICK(8, 8, false)
 #undef MEVI_RF_PICK
   MEVI_REQUIRE(fn != nullptr, MEVI_ERR_UNSUPPORTED, "rq_encode_fast: no kernel for TA=%d KT=%d", pl.TA, pl.KT);
   MEVI_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -100,6 +100,13 @@ def dense_baseline(n_docs, nq_full, dim, topk, target_s=15.0, seed=7):
     order, n_phys = physical_core_cpus()
     out = {"unit": "queries/s", "host_cpus": host_cpus, "physical_cores": n_phys, "cgroup_cpu_max": _read("/sys/fs/cgroup/cpu.max"),
            "loadavg": _read("/proc/loadavg")}
+    quota = None
+    try:        # "max 100000" = unlimited; "1600000 100000" = 16 CPUs' worth of time whatever the number of threads
+        q_, per_ = (out["cgroup_cpu_max"] or "max 1").split()[:2]
+        quota = None if q_ == "max" else float(q_) / float(per_)
+    except ValueError:
+        pass
+    out["cgroup_quota_cpus"] = quota
 
     # ---- 1. faiss itself ------------------------------------------------------------------------------------------------
     try:
@@ -172,7 +179,9 @@ def dense_baseline(n_docs, nq_full, dim, topk, target_s=15.0, seed=7):
     except Exception:
         pass
     out.update({
-        "value": nq_s / dt * nd_s / n_docs, "cores": nt, "kind": "port",
+        "value": nq_s / dt * nd_s / n_docs, "cores": nt if quota is None else min(nt, int(round(quota))), "threads": nt, "kind": "port",
+        "cores_note": None if quota is None else f"{nt} threads, but the box's cgroup grants {quota:g} CPUs of time (cpu.max): that is what "
+                                                 f"bounds the sgemm rate, not the {n_phys} physical cores",
         "backend": f"{backend} sgemm ({'MKL' if backend == 'torch' else 'OpenBLAS'}), block {block}, {nt} threads pinned to "
                    f"{min(nt, n_phys)} physical cores" + (" + siblings" if nt > n_phys else ""),
         "sample": f"{nq_s} queries x {nd_s} docs x {dim} f32, top-{topk}: blocked sgemm + per-query heaps (faiss Flat-IP "

@@ -132,6 +132,36 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
     torch.cuda.synchronize()
     t_ens = time.perf_counter() - t0
     planted_top1 = float((di_h[:, 0] == planted).mean())
+    # ---- a variant in which the ensemble HAS something to say (untimed).  With random NCI weights the beam clusters hold no
+    # dense neighbour, and ensemble_marco.py gives the fine list's documents the cluster ranks of the DENSE documents at the same
+    # positions (its zip(chain(cranks, cranks)), ensemble_marco.py:200-208), so on this corpus the ensemble ranks like the dense arm
+    # whatever alpha is.  Here, for every fourth query, the cluster of the dense list's rank-11 document replaces beam slot 0 and
+    # that document is the query's only relevant one: the dense arm misses MRR@10 for it, a correct ensemble lifts it by
+    # alpha (1 - 1/(beta R + 1) (1 - gamma alpha)) = 0.149 -- a handful of ranks -- into the top 10.
+    planted_beam = None
+    try:
+        b2, gts2, changed = bcodes.copy(), dict(gts), 0
+        for i in range(nq):
+            if i % 4 != 1:
+                continue
+            cl = codes_h[di_h[i, 11]]
+            if any((b2[i, r_] == cl).all() for r_ in range(R)):
+                continue
+            b2[i, 0] = cl
+            gts2[f"q{i}"] = [int(di_h[i, 11])]
+            changed += 1
+        inp2 = consumers.EnsembleInputs(qs, torch.arange(nq + 1, device=dev) * topk, di.reshape(-1), ds.reshape(-1).double(),
+                                        b2, codes_h, (qs, np.arange(nq, dtype=np.int64), fseg, fdocs, fsc))
+        pairs2 = consumers._gt_pairs(gts2, inp2.row, missing_ok=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            od2, on2 = inp2.ensemble(inp2.ranks(), 0.6, 0.03, 0.02)
+            pd_ = consumers.evaluate_lists("d", [10], gts2, pairs2, inp2.docs_d, inp2.seg_d, None)
+            pe_ = consumers.evaluate_lists("e", [10], gts2, pairs2, od2, inp2.out_seg, on2)
+        planted_beam = {"queries_changed": changed, "mrr10_dense": pd_[1][10], "mrr10_ensemble": pe_[1][10],
+                        "note": "every fourth query: beam slot 0 := the cluster of the dense rank-11 document, which becomes the only "
+                                "relevant one; alpha .6 beta .03 gamma .02 as marco_ensemble.sh"}
+    except Exception as e:
+        planted_beam = {"error": f"{type(e).__name__}: {e}"}
     return {
         "workload": f"C4: {nq} queries, corpus {docs.shape[0]} x {d}, beams {R}, RQ ({M},{K}), top-{topk}; tower -> dense "
                     f"search -> NCI beam search -> tower again -> fine stage, inputs in HBM, timed directly (second pass)",
@@ -147,6 +177,7 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
         "setup_untimed_ms": {"rq_encode_corpus": round(t_rq * 1e3, 1), "dense_index_build": round(t_index * 1e3, 1)},
         "fine_candidates_per_query": float(ndoc.mean()), "fine_candidates_max": int(ndoc.max()),
         "mrr10": {k_: v[1][10] for k_, v in res.items()}, "recall1000": {k_: v[0][1000] for k_, v in res.items()},
+        "ensemble_with_planted_beam_cluster": planted_beam,
         "planted_top1_ok": planted_top1,
         "checksums": {n_: zlib.crc32(np.ascontiguousarray(a_).tobytes()) for n_, a_ in
                       (("qemb", qemb.cpu().numpy()), ("doc_codes", codes_h), ("beam_codes", bcodes), ("dense_ids", di_h),
