@@ -83,15 +83,29 @@ struct RfParams {
   unsigned int *region_n;  // [n_regions] records wanted by the region's wave (may exceed region_cap: the excess rows are flagged)
   unsigned int region_cap;
   float e16, gam;
+  int x_row_stride, x_unit_stride;  // bytes between rows / between 32-k units of a row (dim * 4, 128; an experiment sets others)
   long long n_tiles;
 };
 
 // SPLIT: both operands as (hi, lo) f16 pairs, three MFMAs per product (hi.hi + hi.lo + lo.hi; lo scaled by 2^11 so that it
 // stays in the f16 normal range) -- the centroid image then holds TA*32 hi rows followed by TA*32 lo rows per unit
+constexpr int RF_XFL = RF_ROWS * 32;  // floats of one x unit (256 rows x 128 B)
 template <int TA, bool SPLIT>
-constexpr int rf_unit_floats() { return (TA * 32 * 64 * (SPLIT ? 2 : 1) + RF_ROWS * 128) / 4; }
+constexpr int rf_a_floats() { return TA * 32 * 16 * (SPLIT ? 2 : 1); }  // floats of one centroid unit (64 B per image row)
+// Rings: three x buffers (two units of x in flight; a fourth, where it fits, measured no faster: the loop alone streams at
+// 5.2 TB/s, the per-tile epilogue is what costs -- DESIGN 4.3b), three centroid buffers (two with the split image, which
+// leaves room for the tables below; the centroid unit comes from L2 and lands within a cycle).
+// TA = 4 shapes (<= 4 levels x 32 centroids) keep the epilogue's tables in LDS: A [M][32] and the i < j blocks of G
+// [pair][32][32] (24.5 KiB at M = 4) -- the level chain is four DEPENDENT look-ups per tile, each an L2 round trip otherwise.
+constexpr int RF_XB = 3;
 template <int TA, bool SPLIT>
-constexpr size_t rf_lds_bytes(int dim) { return (size_t)RF_NBUF * rf_unit_floats<TA, SPLIT>() * 4 + (size_t)dim * 4; }
+constexpr int rf_abuf() { return SPLIT ? 2 : 3; }
+template <int TA>
+constexpr int rf_table_floats() { return TA == 4 ? 4 * 32 + 6 * 32 * 32 : 0; }
+template <int TA, bool SPLIT>
+constexpr size_t rf_lds_bytes(int dim) {
+  return (size_t)(rf_abuf<TA, SPLIT>() * rf_a_floats<TA, SPLIT>() + RF_XB * RF_XFL + rf_table_floats<TA>()) * 4 + (size_t)dim * 4;
+}
 
 // Delta of the header: candidates are the c with F(c) - m <= Delta.
 //   F*(c)  = D*(c) - rho  (real arithmetic; D* the distance to the real-number residual, rho = ||r*_j||^2),  |F - F*| <= E1
@@ -109,18 +123,32 @@ __device__ __forceinline__ float rf_delta(float m, float rho_hat, float E1, floa
 
 template <int TA, int KT, bool SPLIT>
 __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
-  constexpr int UNIT = rf_unit_floats<TA, SPLIT>();  // floats per unit buffer: A image then x rows
   constexpr int AROWS = TA * 32 * (SPLIT ? 2 : 1);   // image rows per unit (hi rows, then lo rows)
-  constexpr int AFL = AROWS * 16;                    // floats of the A part (64 B per row)
+  constexpr int AFL = rf_a_floats<TA, SPLIT>();      // floats of a centroid unit
+  constexpr int XB = RF_XB;                          // x ring: XB buffers, XB - 1 units in flight
+  constexpr int DX = XB - 1;
+  constexpr int AB = rf_abuf<TA, SPLIT>();           // centroid ring: AB buffers, AB - 1 units ahead
+  constexpr int DA = AB - 1;
+  constexpr int XBASE = AB * AFL;                    // floats: the x ring starts behind the centroid ring
+  constexpr int TBASE = XBASE + XB * RF_XFL;         // epilogue tables (TA = 4), then mu
+  constexpr bool TLDS = TA == 4;
   constexpr int PA_PER_WAVE = AROWS / 128;           // A pieces (16 rows x 64 B) per wave and unit
-  constexpr int P = 4 + PA_PER_WAVE;               // DMA pieces per wave and unit
+  static_assert((TBASE + rf_table_floats<TA>()) * 4 + 4096 <= 160 * 1024, "LDS budget");
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lrow = lane & 31, half = lane >> 5;
   const int U = p.dim >> 5;
-  float *mus_l = lds + RF_NBUF * UNIT;
+  float *mus_l = lds + TBASE + rf_table_floats<TA>();
   for (int i = t; i < p.dim; i += 512) mus_l[i] = p.mus[i];
+  float *tabA = lds + TBASE, *tabG = lds + TBASE + 4 * 32;   // TLDS: A [M][32]; G pair (i < j) at j (j - 1) / 2 + i: [K][32]
+  if constexpr (TLDS) {
+    for (int i = t; i < p.M * 32; i += 512) tabA[i] = p.A[i];              // Kp = 32 on this shape
+    for (int j = 1; j < p.M; ++j)
+      for (int i = 0; i < j; ++i)
+        for (int e = t; e < p.K * 32; e += 512)
+          tabG[(j * (j - 1) / 2 + i) * 1024 + e] = p.G2[((size_t)(i * p.K + (e >> 5)) * p.M + j) * 32 + (e & 31)];
+  }
   __syncthreads();
 
   // ---- DMA duties ---------------------------------------------------------------------------------------------------
@@ -130,7 +158,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r8 = lane >> 3, row = 32 * w8 + 8 * q + r8;
-    voff_x[q] = row * p.dim * 4 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    voff_x[q] = row * p.x_row_stride + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
   }
   // centroid image: piece (16 rows x 64 B); lane (r16 = lane >> 2, slot = lane & 3) fetches piece slot ^ ((row >> 2) & 3)
   int voff_a[PA_PER_WAVE];
@@ -175,29 +203,29 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   if (have_nxt) src_of(rt_n, grp_n, nxt);
   else nxt = cur, nxt.xbytes = 0u;
 
-  auto dma = [&](const Src &s, bool live, int u, int gb, int first, int count) {  // pieces [first, first+count) of the wave's P
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.x), 0, (int)s.xbytes, 0x00020000);
+  // the wave's pieces of centroid unit u -> centroid buffer ab (waves 0-7 share the unit), of x unit u -> x buffer xb (its own rows)
+  auto dma_a = [&](const Src &s, bool live, int u, int ab) {
     const __amdgpu_buffer_rsrc_t ra =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.a), 0, live ? (int)(U * a_block_bytes) : 0, 0x00020000);
-    float *ub = lds + gb * UNIT;
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
+    for (int ia = 0; ia < PA_PER_WAVE; ++ia)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void *)(lds + ab * AFL + (16 * (w8 * PA_PER_WAVE + ia)) * 16),
+                                               16, voff_a[ia], u * (int)a_block_bytes, 0, 0);
+  };
+  auto dma_x = [&](const Src &s, int u, int xb, int first, int count) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.x), 0, (int)s.xbytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
       if (i < first || i >= first + count) continue;
-      if (i < 4) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(ub + AFL + (32 * w8 + 8 * i) * 32), 16,
-                                                 voff_x[i], u * 128, 0, 0);
-      } else {
-        const int ia = i - 4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void *)(ub + (16 * (w8 * PA_PER_WAVE + ia)) * 16), 16,
-                                                 voff_a[ia], u * (int)a_block_bytes, 0, 0);
-      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(lds + XBASE + xb * RF_XFL + (32 * w8 + 8 * i) * 32), 16,
+                                               voff_x[i], u * p.x_unit_stride, 0, 0);
     }
   };
 
   // ---- fragment addresses ---------------------------------------------------------------------------------------------
   const int a_sw = (lrow >> 2) & 3;
   const int offa = lrow * 16;                                  // floats; + 32 t * 16 per MFMA tile
-  const int offb = AFL + (32 * w8 + lrow) * 32;                // floats
+  const int offb = XBASE + (32 * w8 + lrow) * 32;              // floats
   const int b_sw = (lrow >> 1) & 7;
   f32x16 acc[TA];
   // Fragments.  A k-step (16 k) is issued as two HALF-STEPS of H = TA/2 MFMAs (centroid tiles [0, H) then [H, TA)); the
@@ -210,7 +238,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   const float sx = p.scal[0];
   float rho_s = 0.f;  // sum of (x' S_x)^2 over this lane's k (the other half holds the rest)
   auto read_a = [&](int gb, int j, int h0, f16x8 (&dst)[HS]) {
-    const float *ub = lds + gb * UNIT + offa + (((2 * j + half) ^ a_sw) << 2);
+    const float *ub = lds + gb * AFL + offa + (((2 * j + half) ^ a_sw) << 2);
 #pragma unroll
     for (int ti = 0; ti < H; ++ti) {
       dst[ti] = *reinterpret_cast<const f16x8 *>(ub + 32 * (h0 + ti) * 16);
@@ -219,7 +247,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   };
   // this lane's 8 x values of k-step (u, j): centred, scaled, rounded to f16 (and added to the row norm)
   auto read_x = [&](int gb, int u, int j, f16x8 (&b)[SPLIT ? 2 : 1]) {
-    const float *ub = lds + gb * UNIT;
+    const float *ub = lds + gb * RF_XFL;
     const int c0 = 4 * j + 2 * half;
     const float4 x0 = *reinterpret_cast<const float4 *>(ub + offb + ((c0 ^ b_sw) << 2));
     const float4 x1 = *reinterpret_cast<const float4 *>(ub + offb + (((c0 + 1) ^ b_sw) << 2));
@@ -264,46 +292,59 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   float rho_hat = 0.f, xn = 0.f;
   bool row_bad = false;
 
-  int rb = 0;
-  constexpr int P_A = P / 2, P_B = P - P / 2;
-  // One unit (32 k) of the current tile.  On entry alo / bq0 hold k-step (u, 0).  Unit u+2 of the stream is requested at
-  // the start (its buffer was released by the previous cycle's barrier); the barrier sits before the LAST half-step: by
-  // then every read of unit u has been issued (and, with lgkmcnt(0), completed) and unit u+1 must have landed for the
-  // reads of k-step (u+1, 0) that the last half-step issues.
+  int ra_ = 0, rx_ = 0;  // ring slots of the unit being computed (centroid ring of 3, x ring of XB)
+  // One unit (32 k) of the current tile.  On entry alo / bq0 hold k-step (u, 0).  Centroid unit u+2 and x unit u+DX of the
+  // stream are requested at the start (their buffers were released by the previous cycle's barrier) -- the centroid pieces
+  // FIRST: vmcnt retires in order, and at the barrier everything issued after centroid unit u+1 may stay in flight.  The
+  // barrier sits before the LAST half-step: by then every read of unit u has been issued (and, with lgkmcnt(0), completed)
+  // and unit u+1 must have landed for the reads of k-step (u+1, 0) that the last half-step issues.
   auto cycle = [&](int u, bool last) {
-    const bool spill = u + 2 >= U;
-    const Src &tg = spill ? nxt : cur;
-    const bool live = spill ? have_nxt : true;
-    const int tu = spill ? u + 2 - U : u + 2;
-    const int wb = rb == 0 ? RF_NBUF - 1 : rb - 1;
-    read_a(rb, 0, H, ahi);
+    {
+      const bool sp = u + DA >= U;
+      dma_a(sp ? nxt : cur, sp ? have_nxt : true, sp ? u + DA - U : u + DA, ra_ == 0 ? AB - 1 : ra_ - 1);
+    }
+    const bool spx = u + DX >= U;
+    const Src &tx = spx ? nxt : cur;
+    const int tux = spx ? u + DX - U : u + DX;
+    const int wbx = rx_ == 0 ? XB - 1 : rx_ - 1;
+    read_a(ra_, 0, H, ahi);
     mma_lo(bq0);
-    dma(tg, live, tu, wb, 0, P_A);
+    dma_x(tx, tux, wbx, 0, 2);
     __builtin_amdgcn_sched_barrier(0);
-    read_a(rb, 1, 0, alo);
-    read_x(rb, u, 1, bq1);
+    read_a(ra_, 1, 0, alo);
+    read_x(rx_, u, 1, bq1);
     mma_hi(bq0);
-    dma(tg, live, tu, wb, P_A, P_B);
+    dma_x(tx, tux, wbx, 2, 2);
     __builtin_amdgcn_sched_barrier(0);
-    read_a(rb, 1, H, ahi);
+    read_a(ra_, 1, H, ahi);
     mma_lo(bq1);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (P == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // may stay outstanding: what was issued after centroid unit u+1 -- with DA = 2 that unit was requested a cycle ago, ahead of
+    // x unit u+2: this cycle's centroid unit u+2 and x unit u+2 stay; with DA = 1 it was requested THIS cycle: only x unit u+2
+    constexpr int KEEP = DA == 2 ? PA_PER_WAVE + 4 : 4;
+    static_assert(DX == 2 && (KEEP == 4 || KEEP == 5 || KEEP == 6), "vmcnt immediates below");
+    if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (KEEP == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    rb = rb == RF_NBUF - 1 ? 0 : rb + 1;
+    ra_ = ra_ == AB - 1 ? 0 : ra_ + 1;
+    rx_ = rx_ == XB - 1 ? 0 : rx_ + 1;
     if (!last) {
-      read_a(rb, 0, 0, alo);
-      read_x(rb, u + 1, 0, bq0);
+      read_a(ra_, 0, 0, alo);
+      read_x(rx_, u + 1, 0, bq0);
     }
     mma_hi(bq1);
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  dma(cur, true, 0, 0, 0, P);
-  dma(cur, true, 1, 1, 0, P);
-  if constexpr (P == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  // prologue: unit 0 (waited for); centroid units up to DA - 1 and x unit 1 stay in flight
+  dma_a(cur, true, 0, 0);
+  dma_x(cur, 0, 0, 0, 4);
+  if constexpr (DA == 2) dma_a(cur, true, 1, 1);
+  dma_x(cur, 1, 1, 0, 4);
+  if constexpr (DA == 2 && PA_PER_WAVE == 1) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+  else if constexpr (DA == 2) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
   while (true) {
@@ -318,8 +359,8 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
         for (int r = 0; r < 16; ++r) accx[ti][r] = 0.f;
     }
     rho_s = 0.f;
-    read_a(rb, 0, 0, alo);      // k-step (0, 0) of the tile: its unit has landed (prologue / the previous tile's last barrier)
-    read_x(rb, 0, 0, bq0);
+    read_a(ra_, 0, 0, alo);     // k-step (0, 0) of the tile: its unit has landed (prologue / the previous tile's last barrier)
+    read_x(rx_, 0, 0, bq0);
     for (int u = 0; u < U - 1; ++u) cycle(u, false);
     cycle(U - 1, true);
 
@@ -344,31 +385,49 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
       const int j = lev0 + l;
       if (l >= p.LPG || j >= p.M) break;  // uniform
       const RfLevel L = p.lev[j];
-      const float *Aj = p.A + (size_t)j * p.Kp;
       // F in place: acc <- acc * (-2 / (S_x S_c)) + A[c], then += 2 G[i][code_i][j][c] level by level (no second copy of the
-      // tile: 128 accumulators + one tile's table values is what fits the 256-register budget at K = 256)
+      // tile: 128 accumulators + one tile's table values is what fits the 256-register budget at K = 256).  The table values of
+      // MFMA tile tk+1 are requested before tile tk is computed (one L2 round trip per pass instead of one per tile: the first
+      // version's per-tile fences cost 20 us per K = 256 tile, a quarter of the kernel).
+      auto load4 = [&](const float *src, float4 (&v)[4]) {
 #pragma unroll
-      for (int tk = 0; tk < KT; ++tk) {
-        f32x16 &a = acc[l * KT + tk];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const float4 av = *reinterpret_cast<const float4 *>(Aj + 32 * tk + 8 * g4 + 4 * half);
-          a[4 * g4] = fmaf(a[4 * g4], L.inv2, av.x), a[4 * g4 + 1] = fmaf(a[4 * g4 + 1], L.inv2, av.y);
-          a[4 * g4 + 2] = fmaf(a[4 * g4 + 2], L.inv2, av.z), a[4 * g4 + 3] = fmaf(a[4 * g4 + 3], L.inv2, av.w);
-        }
-        if constexpr (KT > 2) __builtin_amdgcn_sched_barrier(0);
-      }
-      for (int i = 0; i < j; ++i) {
-        const unsigned int ci = (unsigned int)(prev >> (8 * i)) & 255u;
-        const float *Gi = p.G2 + ((size_t)(i * p.K + (int)ci) * p.M + j) * p.Kp + 4 * half;
+        for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const float4 *>(src + 8 * g4);
+      };
+      {
+        const float *Aj = (TLDS ? tabA + j * 32 : p.A + (size_t)j * p.Kp) + 4 * half;
+        float4 nv[4];
+        load4(Aj, nv);
 #pragma unroll
         for (int tk = 0; tk < KT; ++tk) {
           f32x16 &a = acc[l * KT + tk];
+          float4 cv[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) cv[g4] = nv[g4];
+          if (tk + 1 < KT) load4(Aj + 32 * (tk + 1), nv);
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 gv = *reinterpret_cast<const float4 *>(Gi + 32 * tk + 8 * g4);
-            a[4 * g4] += gv.x, a[4 * g4 + 1] += gv.y, a[4 * g4 + 2] += gv.z, a[4 * g4 + 3] += gv.w;
+            a[4 * g4] = fmaf(a[4 * g4], L.inv2, cv[g4].x), a[4 * g4 + 1] = fmaf(a[4 * g4 + 1], L.inv2, cv[g4].y);
+            a[4 * g4 + 2] = fmaf(a[4 * g4 + 2], L.inv2, cv[g4].z), a[4 * g4 + 3] = fmaf(a[4 * g4 + 3], L.inv2, cv[g4].w);
           }
+          if constexpr (KT > 2) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      for (int i = 0; i < j; ++i) {
+        const unsigned int ci = (unsigned int)(prev >> (8 * i)) & 255u;
+        const float *Gi = (TLDS ? tabG + ((j * (j - 1) / 2 + i) * 32 + (int)ci) * 32
+                                : p.G2 + ((size_t)(i * p.K + (int)ci) * p.M + j) * p.Kp) + 4 * half;
+        float4 nv[4];
+        load4(Gi, nv);
+#pragma unroll
+        for (int tk = 0; tk < KT; ++tk) {
+          f32x16 &a = acc[l * KT + tk];
+          float4 cv[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) cv[g4] = nv[g4];
+          if (tk + 1 < KT) load4(Gi + 32 * (tk + 1), nv);
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            a[4 * g4] += cv[g4].x, a[4 * g4 + 1] += cv[g4].y, a[4 * g4 + 2] += cv[g4].z, a[4 * g4 + 3] += cv[g4].w;
           if constexpr (KT > 2) __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -831,6 +890,10 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
                    : (float)(2.0 * ((2.0 / 2048.0 + 1.0 / (2048.0 * 2048.0)) + acc_step + 1.0 / 4194304.0) * 1.001);
   p.gam = (float)((double)(dim + 2) / 16777216.0 * 1.01);   // the oracle's chain: dim fma + the subtraction, relative
   p.n_tiles = (n + RF_ROWS - 1) / RF_ROWS;
+  // (experiment, round 3: reading every 256-row tile as if it were stored unit-major -- row stride 128, unit stride 32 KiB,
+  // i.e. 1 KiB-contiguous DMA pieces instead of 128-byte pieces 3 KB apart -- ran 3 % faster: the piece granularity is not what
+  // holds the x stream at 4 TB/s)
+  p.x_row_stride = d * 4, p.x_unit_stride = 128;
   const unsigned grid = ws.grid;
   const void *fn = nullptr;
   size_t lds_bytes = 0;
