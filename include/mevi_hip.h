@@ -126,8 +126,8 @@ int mevi_rq_encode_f32(const float *x, int64_t n, int64_t dim, const float *code
  * list whose exact reference-order chains (the arithmetic above) decide; rows the speculation got wrong, rows with
  * more than 8 candidates or f16 overflow are re-encoded by the exact kernel.  Same call site as mevi_rq_encode_f32
  * (MEVI/pq.py:124-131, 281-305; MEVI/main_models.py:3182-3220).
- *   Requirements: dim % 32 == 0, 96 <= dim <= 8192, M <= 8, K <= 256 (else MEVI_ERR_UNSUPPORTED: call
- *   mevi_rq_encode_f32); workspace of mevi_rq_encode_fast_workspace_bytes (256-byte aligned; 0 = shape unsupported).
+ *   Requirements: dim % 32 == 0, 96 <= dim <= ~4000 (the kernel's LDS holds dim floats beside its rings), M <= 8,
+ *   K <= 256 (else MEVI_ERR_UNSUPPORTED: call mevi_rq_encode_f32); workspace of mevi_rq_encode_fast_workspace_bytes (256-byte aligned; 0 = shape unsupported).
  * Stream-ordered, no host synchronisation.  mevi_rq_encode_fast_stats (tests / bench only; synchronises) reads
  * {ambiguity records, rows re-encoded exactly, ambiguous row-levels} of the last call that used `workspace`. */
 size_t mevi_rq_encode_fast_workspace_bytes(int64_t n, int64_t dim, int64_t M, int64_t K);

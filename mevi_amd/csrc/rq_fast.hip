@@ -777,7 +777,11 @@ RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
   // up to four levels of 32 centroids (the scripts' (4, 32)): the kernel waits for HBM with the matrix cores a quarter busy,
   // so the product is taken in split precision (3 MFMAs) -- an error bound 6x tighter, 6x fewer ambiguous row-levels
   pl.split = pl.TA == 4 && !getenv("MEVI_RQ_NO_SPLIT");
-  pl.ok = true;
+  // the rings, the tables and mu (dim floats) must fit the 160 KiB of LDS: wide rows give up the split image first
+  const size_t cap = 160 * 1024;
+  if (pl.split && rf_lds_bytes<4, true>((int)dim) > cap) pl.split = false;
+  const size_t need = pl.TA == 4 ? (pl.split ? rf_lds_bytes<4, true>((int)dim) : rf_lds_bytes<4, false>((int)dim)) : rf_lds_bytes<8, false>((int)dim);
+  pl.ok = need <= cap;
   return pl;
 }
 constexpr int RF_GRID = 256;  // persistent workgroups (one per CU of the MI355X); 8 record regions each
@@ -846,7 +850,7 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   MEVI_REQUIRE(n >= 0 && dim > 0 && M > 0 && K > 0, MEVI_ERR_INVALID_ARG, "rq_encode_fast: bad shape");
   if (n == 0) return MEVI_OK;
   const RfPlan pl = rf_plan(dim, M, K);
-  MEVI_REQUIRE(pl.ok, MEVI_ERR_UNSUPPORTED, "rq_encode_fast: needs dim %% 32 == 0, 96 <= dim <= 8192, M <= 8, K <= 256 (use mevi_rq_encode_f32)");
+  MEVI_REQUIRE(pl.ok, MEVI_ERR_UNSUPPORTED, "rq_encode_fast: needs dim %% 32 == 0, 96 <= dim <= ~4000 (LDS), M <= 8, K <= 256 (use mevi_rq_encode_f32)");
   MEVI_REQUIRE(x && codebook && codes && workspace, MEVI_ERR_INVALID_ARG, "rq_encode_fast: null pointer");
   MEVI_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)codebook % 16) == 0 && ((uintptr_t)workspace % 256) == 0,
                MEVI_ERR_INVALID_ARG, "rq_encode_fast: x / codebook must be 16-byte, the workspace 256-byte aligned");

@@ -51,7 +51,7 @@ def _both(x, cb, cuda):
 
 @pytest.mark.parametrize("n,dim,M,K", [
     (5000, 768, 4, 32), (3000, 768, 3, 256), (1, 96, 2, 4), (255, 128, 1, 32), (257, 96, 8, 32), (1000, 1024, 3, 40),
-    (2049, 256, 4, 64), (700, 160, 2, 100), (513, 768, 5, 32), (900, 96, 3, 3),
+    (2049, 256, 4, 64), (700, 160, 2, 100), (513, 768, 5, 32), (900, 96, 3, 3), (300, 2048, 4, 32), (200, 3968, 2, 16),
 ])
 def test_matrix_core_encoder_equals_exact_kernel_and_oracle(cuda, n, dim, M, K):
     """mevi_rq_encode_fast_f32 (f16 MFMA shortlist + exact re-check, csrc/rq_fast.hip) returns the oracle's codes bit for
@@ -63,6 +63,8 @@ def test_matrix_core_encoder_equals_exact_kernel_and_oracle(cuda, n, dim, M, K):
     fast, exact, st = _both(x, cb, cuda)
     want = orq.rq_encode(x, cb)
     assert st["path"] == "fast"
+    assert rq.rq_encode(torch.zeros((4, 8192), device=cuda), torch.zeros((2, 4, 8192), device=cuda)).shape == (4, 2)   # too wide for LDS: exact path
+    assert rq.last_encode_stats()["path"] == "exact"
     assert np.array_equal(exact, want)
     assert np.array_equal(fast, want), (st, int((fast != want).any(1).sum()))
     assert st["rows_reencoded_exactly"] <= max(8, 0.2 * n), st         # the bound must be useful, not only safe
