@@ -121,8 +121,13 @@ __device__ __forceinline__ float rf_delta(float m, float rho_hat, float E1, floa
   return (2.f * E1 + 2.1f * gam * dpos + 2.1f * e2) * 1.01f;
 }
 
-template <int TA, int KT, bool SPLIT>
+// XSPLIT (the TA = 8 shapes, where a second accumulator set does not fit): x alone as a (hi, lo) pair, the un-scaled lo part
+// accumulated into the SAME accumulator by a second MFMA -- the bound loses x's rounding (e16 x0.58), K = 256 stays bound by
+// its three passes over x.
+template <int TA, int KT, bool SPLIT, bool XSPLIT>
 __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
+  static_assert(!(SPLIT && XSPLIT), "one or the other");
+  constexpr int NB = (SPLIT || XSPLIT) ? 2 : 1;   // B fragments per k-step: hi (, lo)
   constexpr int AROWS = TA * 32 * (SPLIT ? 2 : 1);   // image rows per unit (hi rows, then lo rows)
   constexpr int AFL = rf_a_floats<TA, SPLIT>();      // floats of a centroid unit
   constexpr int XB = RF_XB;                          // x ring: XB buffers, XB - 1 units in flight
@@ -233,7 +238,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   // 2 x TA of a whole-k-step double buffer (at TA = 8 that version spilled 124 registers, some inside the loop).
   constexpr int H = TA / 2;
   constexpr int HS = SPLIT ? 2 * H : H;   // fragments of a half-step: [0, H) hi parts, [H, 2H) lo parts
-  f16x8 alo[HS], ahi[HS], bq0[SPLIT ? 2 : 1], bq1[SPLIT ? 2 : 1];
+  f16x8 alo[HS], ahi[HS], bq0[NB], bq1[NB];
   f32x16 accx[SPLIT ? TA : 1];            // SPLIT: the two cross terms (x 2^11)
   const float sx = p.scal[0];
   float rho_s = 0.f;  // sum of (x' S_x)^2 over this lane's k (the other half holds the rest)
@@ -246,7 +251,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     }
   };
   // this lane's 8 x values of k-step (u, j): centred, scaled, rounded to f16 (and added to the row norm)
-  auto read_x = [&](int gb, int u, int j, f16x8 (&b)[SPLIT ? 2 : 1]) {
+  auto read_x = [&](int gb, int u, int j, f16x8 (&b)[NB]) {
     const float *ub = lds + gb * RF_XFL;
     const int c0 = 4 * j + 2 * half;
     const float4 x0 = *reinterpret_cast<const float4 *>(ub + offb + ((c0 ^ b_sw) << 2));
@@ -262,22 +267,25 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
       const _Float16 h = (_Float16)v[i];
       b[0][i] = h;
       if constexpr (SPLIT) b[1][i] = (_Float16)((v[i] - (float)h) * 2048.f);
+      if constexpr (XSPLIT) b[1][i] = (_Float16)(v[i] - (float)h);
     }
   };
-  auto mma_lo = [&](const f16x8 (&b)[SPLIT ? 2 : 1]) {
+  auto mma_lo = [&](const f16x8 (&b)[NB]) {
 #pragma unroll
     for (int ti = 0; ti < H; ++ti) {
       acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ti], b[0], acc[ti], 0, 0, 0);
+      if constexpr (XSPLIT) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ti], b[1], acc[ti], 0, 0, 0);
       if constexpr (SPLIT) {
         accx[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ti], b[1], accx[ti], 0, 0, 0);
         accx[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[H + ti], b[0], accx[ti], 0, 0, 0);
       }
     }
   };
-  auto mma_hi = [&](const f16x8 (&b)[SPLIT ? 2 : 1]) {
+  auto mma_hi = [&](const f16x8 (&b)[NB]) {
 #pragma unroll
     for (int ti = 0; ti < H; ++ti) {
       acc[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ti], b[0], acc[H + ti], 0, 0, 0);
+      if constexpr (XSPLIT) acc[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ti], b[1], acc[H + ti], 0, 0, 0);
       if constexpr (SPLIT) {
         accx[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ti], b[1], accx[H + ti], 0, 0, 0);
         accx[H + ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[H + ti], b[0], accx[H + ti], 0, 0, 0);
@@ -516,10 +524,10 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
 
 // (the body lives in a __device__ function: the host pass instantiates a kernel template's own body, and the buffer / LDS
 // builtins above do not exist there)
-template <int TA, int KT, bool SPLIT>
+template <int TA, int KT, bool SPLIT, bool XSPLIT>
 __global__ __launch_bounds__(512, 2) void rq_fast_kernel(const RfParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rq_fast_body<TA, KT, SPLIT>(p, lds);
+  rq_fast_body<TA, KT, SPLIT, XSPLIT>(p, lds);
 }
 
 // ---- prep kernels (codebook only: a few hundred KB) -------------------------------------------------------------------------
@@ -623,24 +631,34 @@ __global__ __launch_bounds__(256) void rf_image_kernel(const float *__restrict__
   if (lane == 0) A[(size_t)j * Kp + c] = real ? (float)ss : INFINITY;
 }
 
-// G2[(i K + a)][j][c] = 2 c'_i[a] . c'_j[c] for i < j (f64 accumulation); one thread per entry
+// G2[(i K + a)][j][c] = 2 c'_i[a] . c'_j[c] for i < j (f64 accumulation, rounded once), 0 elsewhere.  One 16 x 16 output tile
+// per workgroup, 16-wide k tiles of both centroid blocks staged in LDS (a thread per entry walking its two rows took 0.56 ms
+// at (3, 256): its second operand was a 4-byte load per lane 3 KB apart).
 __global__ __launch_bounds__(256) void rf_g_kernel(const float *__restrict__ C, int M, int K, int Kp, int dim,
                                                   const float *__restrict__ mu, float *__restrict__ G2) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)M * K * M * Kp;
-  if (e >= total) return;
-  const int c = (int)(e % Kp);
-  const int j = (int)((e / Kp) % M);
-  const int a = (int)((e / ((long long)Kp * M)) % K);
-  const int i = (int)(e / ((long long)Kp * M * K));
-  float out = 0.f;
-  if (i < j && c < K) {
-    const float *ci = C + ((size_t)i * K + a) * dim, *cj = C + ((size_t)j * K + c) * dim;
-    double s = 0.0;
-    for (int k = 0; k < dim; ++k) s += ((double)ci[k] - (i == 0 ? (double)mu[k] : 0.0)) * (double)cj[k];
-    out = (float)(2.0 * s);
+  __shared__ double sa[16][17], sb[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int tiles_c = Kp / 16, tiles_a = (K + 15) / 16;
+  int b = blockIdx.x;
+  const int tc = b % tiles_c;
+  b /= tiles_c;
+  const int ta = b % tiles_a;
+  b /= tiles_a;
+  const int j = b % M, i = b / M;
+  const int a = 16 * ta + ty, c = 16 * tc + tx;
+  double s = 0.0;
+  if (i < j) {  // uniform per workgroup
+    for (int k0 = 0; k0 < dim; k0 += 16) {
+      const int ra = 16 * ta + ty, rc = 16 * tc + ty;  // thread (ty, tx) stages element k0 + tx of rows ra (level i) and rc (level j)
+      sa[ty][tx] = ra < K ? (double)C[((size_t)i * K + ra) * dim + k0 + tx] - (i == 0 ? (double)mu[k0 + tx] : 0.0) : 0.0;
+      sb[ty][tx] = rc < K ? (double)C[((size_t)j * K + rc) * dim + k0 + tx] : 0.0;
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) s += sa[ty][kk] * sb[tx][kk];
+      __syncthreads();
+    }
   }
-  G2[e] = out;
+  if (a < K) G2[((size_t)(i * K + a) * M + j) * Kp + c] = (i < j && c < K) ? (float)(2.0 * s) : 0.f;
 }
 
 // ---- fix-up: exact chains of a record's candidates -----------------------------------------------------------------------------
@@ -761,10 +779,10 @@ using namespace mevi;
 namespace {
 struct RfPlan {
   int Kp, KT, LPG, ngroups, TA;
-  bool ok, split;
+  bool ok, split, xsplit;
 };
 RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
-  RfPlan pl = {0, 0, 0, 0, 0, false, false};
+  RfPlan pl = {0, 0, 0, 0, 0, false, false, false};
   if (dim % 32 != 0 || dim < 96 || dim > 8192 || M < 1 || M > 8 || K < 1 || K > 256) return pl;
   int Kp = 32;
   while (Kp < K) Kp <<= 1;
@@ -782,6 +800,10 @@ RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
   if (pl.split && rf_lds_bytes<4, true>((int)dim) > cap) pl.split = false;
   const size_t need = pl.TA == 4 ? (pl.split ? rf_lds_bytes<4, true>((int)dim) : rf_lds_bytes<4, false>((int)dim)) : rf_lds_bytes<8, false>((int)dim);
   pl.ok = need <= cap;
+  // the other shapes with few columns per level (K <= 64: the x stream, not the matrix cores, paces them): x alone in split
+  // precision (two MFMAs, one accumulator).  At K = 256 it was measured and dropped: main kernel 20.6 -> 26.6 ms for 4.27 ->
+  // 2.68 M records (fix-up 5.6 -> 3.6 ms): 28.2 -> 32.9 ms per encode; at K = 128 the variant spills.
+  pl.xsplit = !pl.split && pl.KT <= 2 && !getenv("MEVI_RQ_NO_SPLIT");
   return pl;
 }
 constexpr int RF_GRID = 256;  // persistent workgroups (one per CU of the MI355X); 8 record regions each
@@ -871,8 +893,8 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   hipLaunchKernelGGL(rf_image_kernel, dim3((unsigned)((Mi * pl.Kp + 3) / 4)), dim3(256), 0, stream, codebook, Mi, Ki, pl.Kp, d, pl.LPG,
                      pl.TA, pl.split ? 1 : 0, ws.mu, ws.lev, ws.img, ws.A);
   {
-    const long long total = (long long)Mi * Ki * Mi * pl.Kp;
-    hipLaunchKernelGGL(rf_g_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, codebook, Mi, Ki, pl.Kp, d, ws.mu, ws.G2);
+    const long long blocks = (long long)Mi * Mi * ((Ki + 15) / 16) * (pl.Kp / 16);
+    hipLaunchKernelGGL(rf_g_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, codebook, Mi, Ki, pl.Kp, d, ws.mu, ws.G2);
   }
 
   RfParams p;
@@ -890,8 +912,10 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   // split: (hi, lo) pairs carry 22 bits (3 x 2^-22 for the two roundings of lo and the dropped lo.lo term); the cross terms'
   // own accumulation is 2^-10 of the main chain's.  Either enters F twice (the factor -2).
   const double acc_step = 4.0 * (double)dim / 16777216.0;
+  // x-split: x carries 22 bits (2^-22 + the f32 rounding), the centroids are rounded once (u): u + 2 x 2^-22, two MFMAs per step.
   p.e16 = pl.split ? (float)(2.0 * (3.0 / 4194304.0 + acc_step * (1.0 + 1.0 / 512.0) + 1.0 / 4194304.0) * 1.001)
-                   : (float)(2.0 * ((2.0 / 2048.0 + 1.0 / (2048.0 * 2048.0)) + acc_step + 1.0 / 4194304.0) * 1.001);
+          : pl.xsplit ? (float)(2.0 * ((1.0 / 2048.0) * (1.0 + 1.0 / 1048576.0) + 2.0 / 4194304.0 + acc_step * (1.0 + 1.0 / 1024.0) + 1.0 / 4194304.0) * 1.001)
+                      : (float)(2.0 * ((2.0 / 2048.0 + 1.0 / (2048.0 * 2048.0)) + acc_step + 1.0 / 4194304.0) * 1.001);
   p.gam = (float)((double)(dim + 2) / 16777216.0 * 1.01);   // the oracle's chain: dim fma + the subtraction, relative
   p.n_tiles = (n + RF_ROWS - 1) / RF_ROWS;
   // (experiment, round 3: reading every 256-row tile as if it were stored unit-major -- row stride 128, unit stride 32 KiB,
@@ -901,13 +925,14 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   const unsigned grid = ws.grid;
   const void *fn = nullptr;
   size_t lds_bytes = 0;
-#define MEVI_RF_PICK(TA_, KT_, SP_)                                        \
-  if (pl.TA == TA_ && pl.KT == KT_ && pl.split == SP_) {                   \
-    fn = reinterpret_cast<const void *>(rq_fast_kernel<TA_, KT_, SP_>);    \
-    lds_bytes = rf_lds_bytes<TA_, SP_>(d);                                 \
+#define MEVI_RF_PICK(TA_, KT_, SP_, XS_)                                        \
+  if (pl.TA == TA_ && pl.KT == KT_ && pl.split == SP_ && pl.xsplit == XS_) {    \
+    fn = reinterpret_cast<const void *>(rq_fast_kernel<TA_, KT_, SP_, XS_>);    \
+    lds_bytes = rf_lds_bytes<TA_, SP_>(d);                                      \
   }
-  MEVI_RF_PICK(4, 1, true) MEVI_RF_PICK(4, 1, false) MEVI_RF_PICK(8, 1, false) MEVI_RF_PICK(8, 2, false) MEVI_RF_PICK(8, 4, false)
-  MEVI_RF_PICK(8, 8, false)
+  MEVI_RF_PICK(4, 1, true, false) MEVI_RF_PICK(4, 1, false, true) MEVI_RF_PICK(4, 1, false, false)
+  MEVI_RF_PICK(8, 1, false, true) MEVI_RF_PICK(8, 2, false, true)
+  MEVI_RF_PICK(8, 1, false, false) MEVI_RF_PICK(8, 2, false, false) MEVI_RF_PICK(8, 4, false, false) MEVI_RF_PICK(8, 8, false, false)
 #undef MEVI_RF_PICK
   MEVI_REQUIRE(fn != nullptr, MEVI_ERR_UNSUPPORTED, "rq_encode_fast: no kernel for TA=%d KT=%d", pl.TA, pl.KT);
   MEVI_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
