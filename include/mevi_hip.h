@@ -236,6 +236,27 @@ int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const float *k, int6
                               float *out, int64_t o_ts, const int64_t *seq_off, int64_t nseq, int64_t max_len,
                               int64_t heads, int64_t dh, const float *bias, int64_t bias_rows, int64_t bias_ld,
                               int causal, float scale, void *stream);
+/* The three attention forms with the context written as the SPLIT IMAGE the o-projection reads (mevi_gemm_nt_split_f32's A
+ * operand: out_img [rows, 2 * img_np] f16, hi at column c, lo at img_np + c, both scaled by 2^out_exp) instead of f32 --
+ * the reference's `o(context)` (modeling_t5.py:407-410) is the only consumer of the context.  One exponent for all rows,
+ * because the heads of a row are written by different waves: the caller derives it from a bound on |V| (the context is a
+ * convex combination of V rows; mevi_amd/ops.py: split_bound) so that |context| 2^out_exp < 2^15, and fills the rows'
+ * exponent array with it.  img_bs / img_ts: batch / token strides in f16 elements (img_ts = 2 * img_np when rows are
+ * contiguous).  Same arithmetic as the f32 forms up to the final rounding into (hi, lo). */
+int mevi_attention_split_f16(const float *q, int64_t q_bs, int64_t q_ts, const float *k, int64_t k_bs, int64_t k_ts,
+                             const float *v, int64_t v_bs, int64_t v_ts, void *out_img, int64_t img_np, int out_exp,
+                             int64_t img_bs, int64_t img_ts, int64_t nb, int64_t tq, int64_t tk, int64_t heads, int64_t dh,
+                             int64_t kv_div, const float *bias, int64_t bias_rows, int64_t bias_ld, int64_t q_pos0,
+                             const int64_t *key_mask, int causal, float scale, const int64_t *kv_off, void *stream);
+int mevi_attention_cached_split_f16(const float *q, int64_t q_bs, const float *k, int64_t k_bs, int64_t k_ts, const float *v,
+                                    int64_t v_bs, int64_t v_ts, void *out_img, int64_t img_np, int out_exp, int64_t img_bs,
+                                    int64_t nb, int64_t tk, int64_t heads, int64_t dh, const int32_t *key_rows,
+                                    const float *bias, int64_t bias_rows, int64_t bias_ld, int64_t q_pos0, int causal,
+                                    float scale, void *stream);
+int mevi_attention_varlen_split_f16(const float *q, int64_t q_ts, const float *k, int64_t k_ts, const float *v, int64_t v_ts,
+                                    void *out_img, int64_t img_np, int out_exp, int64_t img_ts, const int64_t *seq_off,
+                                    int64_t nseq, int64_t max_len, int64_t heads, int64_t dh, const float *bias,
+                                    int64_t bias_rows, int64_t bias_ld, int causal, float scale, void *stream);
 /* PAWA adaptive head on the valid columns only (modeling_t5.py:1607, 1677-1689):
  * out[row, c] = sum_d s[row, d] * (t[trow, c*dim + d] + e[c, d]),  t = adaptor_linear slice, e = lm_head rows;
  * trow = row when t_index is NULL, else t_index[row] (i64, device): the adaptor sees only the code prefix of a beam,

@@ -11,6 +11,8 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace mevi {
 namespace {
@@ -125,7 +127,50 @@ struct AttnArgs {
   const long long *seq_off;   // packed sequences (attention_varlen_kernel): rows seq_off[b] .. seq_off[b+1]-1, else null
   const long long *kv_off;    // packed K|V only (cross-attention): keys of kv batch bk = rows kv_off[bk] .. kv_off[bk+1]-1
   const int *key_rows;        // attention_few_keys_kernel only: key j of row b lives in K|V batch row key_rows[b * tk + j] (else b / kv_div)
+  // Output as the split image the o-projection reads (gemm_split.hip) instead of f32: o_bs / o_ts are then in HALVES of
+  // the image [rows, 2 * onp], element (row, c) = hi at c, lo at onp + c, both scaled by 2^oexp -- ONE exponent for all rows,
+  // from a bound on |V| the host derives from the layer's constants (ops.attention*: split_bound), because a row's heads
+  // are written by different waves.  Costs range, not precision (see SplitOut in gemm_split.hip).
+  _Float16 *oimg;
+  int onp, oexp;
 };
+
+// context element at `off` = row offset + h * dh + column.  Called by whole lane PAIRS (2i, 2i + 1) holding consecutive
+// columns (every call site: column = lane or lane + 64 under a bound that is a multiple of 4): for the image the pair
+// exchanges its halves so that each lane issues ONE 4-byte store -- the even lane both hi, the odd lane both lo -- instead
+// of two 2-byte ones (the 2-byte form cost the cross-attention kernel 15 %).
+__device__ __forceinline__ void put_ctx(const AttnArgs &a, size_t off, float v) {
+  if (a.oimg) {
+    const float xs = ldexpf(v, a.oexp);
+    const _Float16 hi = (_Float16)xs;
+    const _Float16 lo = (_Float16)(xs - (float)hi);
+    const unsigned int mine = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
+                              ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
+    const unsigned int other = (unsigned int)__shfl_xor((int)mine, 1);
+    const bool odd = threadIdx.x & 1;
+    // even lane: (hi_even, hi_odd) at hi[off]; odd lane: (lo_even, lo_odd) at lo[off - 1]
+    const unsigned int word = odd ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+    *reinterpret_cast<unsigned int *>(a.oimg + (odd ? off - 1 + a.onp : off)) = word;
+  } else {
+    a.out[off] = v;
+  }
+}
+__device__ __forceinline__ void put_ctx4(const AttnArgs &a, size_t off, float4 v) {
+  if (a.oimg) {
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    const float x[4] = {ldexpf(v.x, a.oexp), ldexpf(v.y, a.oexp), ldexpf(v.z, a.oexp), ldexpf(v.w, a.oexp)};
+    half4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hi[i] = (_Float16)x[i];
+      lo[i] = (_Float16)(x[i] - (float)hi[i]);
+    }
+    *reinterpret_cast<half4 *>(a.oimg + off) = hi;
+    *reinterpret_cast<half4 *>(a.oimg + off + a.onp) = lo;
+  } else {
+    *reinterpret_cast<float4 *>(a.out + off) = v;
+  }
+}
 
 constexpr int ATT_KPL = 4;  // keys per lane: key j lives on lane j & 63, slot j >> 6 (tk <= 256)
 
@@ -191,7 +236,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   }
   attn_softmax(s, lane, tk);
 
-  float *o = a.out + (size_t)b * a.o_bs + (size_t)t * a.o_ts + (size_t)h * a.dh;
+  const size_t o_off = (size_t)b * a.o_bs + (size_t)t * a.o_ts + (size_t)h * a.dh;
   const float *vb = a.v + (a.kv_off ? (size_t)kr0 * a.v_ts : (size_t)bk * a.v_bs) + (size_t)h * a.dh;
   // every lane takes part in the shuffles (a lane outside dh must still SOURCE p for its key)
   float acc0 = 0.f, acc1 = 0.f;  // output dims lane and lane + 64 (dh <= 128)
@@ -205,8 +250,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       if (lane + 64 < a.dh) acc1 = fmaf(pj, vb[row + lane + 64], acc1);
     }
   }
-  if (lane < a.dh) o[lane] = acc0;
-  if (lane + 64 < a.dh) o[lane + 64] = acc1;
+  if (lane < a.dh) put_ctx(a, o_off + lane, acc0);
+  if (lane + 64 < a.dh) put_ctx(a, o_off + lane + 64, acc1);
 }
 
 // Self-attention of one (batch, head) per workgroup: Q, K, V tiles [tk x dh] staged ONCE in LDS
@@ -261,9 +306,9 @@ __global__ __launch_bounds__(256) void attention_tile_kernel(AttnArgs a) {
         if (lane + 64 < dh) acc1 = fmaf(pj, sv[(64 * i + j) * dh + lane + 64], acc1);
       }
     }
-    float *o = a.out + (size_t)b * a.o_bs + (size_t)tq * a.o_ts + (size_t)h * dh;
-    if (lane < dh) o[lane] = acc0;
-    if (lane + 64 < dh) o[lane + 64] = acc1;
+    const size_t o_off = (size_t)b * a.o_bs + (size_t)tq * a.o_ts + (size_t)h * dh;
+    if (lane < dh) put_ctx(a, o_off + lane, acc0);
+    if (lane + 64 < dh) put_ctx(a, o_off + lane + 64, acc1);
   }
 }
 
@@ -330,9 +375,9 @@ __global__ __launch_bounds__(256) void attention_varlen_kernel(AttnArgs a, int m
         if (lane + 64 < dh) acc1 = fmaf(pj, sv[(64 * i + j) * dh + lane + 64], acc1);
       }
     }
-    float *o = a.out + (size_t)(r0 + tq) * a.o_ts + (size_t)h * dh;
-    if (lane < dh) o[lane] = acc0;
-    if (lane + 64 < dh) o[lane + 64] = acc1;
+    const size_t o_off = (size_t)(r0 + tq) * a.o_ts + (size_t)h * dh;
+    if (lane < dh) put_ctx(a, o_off + lane, acc0);
+    if (lane + 64 < dh) put_ctx(a, o_off + lane + 64, acc1);
   }
 }
 
@@ -426,8 +471,8 @@ __global__ __launch_bounds__(256) void attention_varlen_short_kernel(AttnArgs a,
       ob = fmaf(pb, vj, ob);
     }
     if (lane < DH) {
-      a.out[(size_t)(r0 + tq) * a.o_ts + (size_t)h * DH + lane] = oa;
-      if (t1 != tq) a.out[(size_t)(r0 + t1) * a.o_ts + (size_t)h * DH + lane] = ob;
+      put_ctx(a, (size_t)(r0 + tq) * a.o_ts + (size_t)h * DH + lane, oa);
+      if (t1 != tq) put_ctx(a, (size_t)(r0 + t1) * a.o_ts + (size_t)h * DH + lane, ob);
     }
   }
 }
@@ -492,9 +537,155 @@ __global__ __launch_bounds__(256) void attention_few_keys_kernel(AttnArgs a) {
       if (lane < dh) acc0 = fmaf(pj, vb[lane], acc0);
       if (lane + 64 < dh) acc1 = fmaf(pj, vb[lane + 64], acc1);
     }
-    float *o = a.out + (size_t)bb * a.o_bs + (size_t)hh * dh;
-    if (lane < dh) o[lane] = acc0;
-    if (lane + 64 < dh) o[lane + 64] = acc1;
+    const size_t o_off = (size_t)bb * a.o_bs + (size_t)hh * dh;
+    if (lane < dh) put_ctx(a, o_off + lane, acc0);
+    if (lane + 64 < dh) put_ctx(a, o_off + lane + 64, acc1);
+  }
+}
+
+// The same kernel for 64- / 96-wide heads with the key rows and q TRANSPOSED THROUGH LDS.  Above, lane (g, j) walks its own
+// 256-byte key row with float4 loads: every load instruction of the wave touches 64 different cache lines (16 instructions
+// x 64 lines per wave; the context phase and q together ~200), so the per-key cost is the L1's line rate, not a bandwidth,
+// and the 64-bit pair / H, pair % H per pair (24 software divisions per wave) are most of the fixed cost
+// (tools/bench_attn_cached.py at 69.8 k rows x 12 heads: 0.22 ms + 0.11 ms per cached position).  Here
+//   * the wave fetches the key rows of its 8 TK live (pair, key) slots as four lanes x 16 bytes per row and quarter (16 rows
+//     per instruction), half a row in flight at a time, passes them through a [64 rows][16 + 4] LDS slab (the padding makes
+//     the b128 reads of 16 consecutive rows conflict-free) and every lane then runs the SAME sequential fmaf chain over its
+//     row: identical bits;
+//   * (row, head) of the eight pairs come from one 32-bit division and increments; the V row pointers of the context phase
+//     are computed once by the score lanes and read back with readlane; TK is a template argument (no per-key branches).
+template <int TK, int DH>   // DH = 64 (T5 heads) or 96 (the adaptor's eight heads over 768)
+__global__ __launch_bounds__(256, 5) void attention_few_keys_staged_kernel(AttnArgs a) {
+  constexpr int KS = 20, QS = DH + 4, NQH = DH / 32;   // NQH: 16-float pieces of a key row per half
+  constexpr int NSLOT = 8 * TK, N_IT = (NSLOT + 15) / 16;
+  __shared__ __attribute__((aligned(16))) float ks_all[4][64 * KS];
+  __shared__ __attribute__((aligned(16))) float qs_all[4][8 * QS];
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long wid = (long long)blockIdx.x * 4 + w;
+  const long long npair = (long long)a.nb * a.H;
+  if (wid * 8 >= npair) return;
+  float *ks = ks_all[w], *qs = qs_all[w];
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 3, j = lane & 7;
+  const int qpos = a.q_pos0;
+  const int pr0 = (int)(wid * 8);
+  const int ngg = (int)((npair - wid * 8) < 8 ? (npair - wid * 8) : 8);   // live pairs of this wave (wave-uniform)
+  int bb[8], hh[8];
+  {
+    int cb = pr0 / a.H, ch = pr0 - cb * a.H;
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) {
+      bb[gg] = gg < ngg ? cb : a.nb - 1;       // dead pairs repeat the last one (their results are not stored)
+      hh[gg] = gg < ngg ? ch : a.H - 1;
+      if (++ch == a.H) ch = 0, ++cb;
+    }
+  }
+  int b = bb[0], h = hh[0];
+#pragma unroll
+  for (int gg = 1; gg < 8; ++gg)
+    if (g == gg) b = bb[gg], h = hh[gg];
+  const int jc = j < TK ? j : 0;
+  int bk = 0;
+  if (j < TK) bk = a.key_rows ? a.key_rows[(size_t)b * TK + j] : b / a.kv_div;
+  const float *kr = a.k + (size_t)bk * a.k_bs + (size_t)jc * a.k_ts + (size_t)h * DH;
+  const float *vr = a.v + (size_t)bk * a.v_bs + (size_t)jc * a.v_ts + (size_t)h * DH;
+  const int vr_lo = (int)(unsigned long long)vr, vr_hi = (int)((unsigned long long)vr >> 32);
+  // q rows of the wave's eight pairs, 256 contiguous bytes each
+#pragma unroll
+  for (int gg = 0; gg < 8; ++gg) {
+    qs[gg * QS + lane] = a.q[(size_t)bb[gg] * a.q_bs + (size_t)hh[gg] * DH + lane];
+    if (DH > 64 && lane + 64 < DH) qs[gg * QS + 64 + lane] = a.q[(size_t)bb[gg] * a.q_bs + (size_t)hh[gg] * DH + 64 + lane];
+  }
+  // slot s = 16 it + (lane >> 2) of the wave's 8 TK live (pair, key) slots -> score lane 8 (s / TK) + s % TK
+  const int piece = lane & 3;
+  int srow[N_IT];
+  const float *sp[N_IT];
+#pragma unroll
+  for (int it = 0; it < N_IT; ++it) {
+    const int sl = 16 * it + (lane >> 2);
+    srow[it] = sl < NSLOT ? 8 * (sl / TK) + sl % TK : -1;
+    const int from = srow[it] < 0 ? 0 : srow[it];
+    const unsigned long long src = ((unsigned long long)(unsigned int)__shfl((int)((unsigned long long)kr >> 32), from) << 32) |
+                                   (unsigned int)__shfl((int)(unsigned long long)kr, from);
+    sp[it] = reinterpret_cast<const float *>(src) + 4 * piece;
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    float4 kf[NQH][N_IT];
+#pragma unroll
+    for (int it = 0; it < N_IT; ++it)
+#pragma unroll
+      for (int qi = 0; qi < NQH; ++qi)
+        kf[qi][it] = srow[it] >= 0 ? *reinterpret_cast<const float4 *>(sp[it] + 16 * (NQH * nb + qi)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int qi = 0; qi < NQH; ++qi) {
+      const int qt = NQH * nb + qi;
+#pragma unroll
+      for (int it = 0; it < N_IT; ++it)
+        if (srow[it] >= 0) *reinterpret_cast<float4 *>(&ks[srow[it] * KS + 4 * piece]) = kf[qi][it];
+      __builtin_amdgcn_wave_barrier();
+      if (j < TK) {
+#pragma unroll
+        for (int d = 0; d < 16; d += 4) {
+          const float4 kv = *reinterpret_cast<const float4 *>(&ks[lane * KS + d]);
+          const float4 qv = *reinterpret_cast<const float4 *>(&qs[g * QS + 16 * qt + d]);
+          acc = fmaf(qv.x * a.scale, kv.x, acc);
+          acc = fmaf(qv.y * a.scale, kv.y, acc);
+          acc = fmaf(qv.z * a.scale, kv.z, acc);
+          acc = fmaf(qv.w * a.scale, kv.w, acc);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  float s = -INFINITY;
+  if (j < TK) {
+    float add = 0.f;
+    if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + j];
+    if (a.key_mask && a.key_mask[(size_t)(b / a.kv_div) * TK + j] == 0) add += -1e9f;
+    if (a.causal && j > qpos) add += -1e9f;
+    s = acc + add;
+  }
+  float m = s;
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  const float e = j < TK ? expf(s - m) : 0.f;
+  float sum = e;
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const float p = e / sum;
+  // context: the V loads of VB pairs at a time (VB TK rows of 256 B, one row per instruction; their pointers pass through
+  // SGPRs, which is what limits VB), then the chains
+  constexpr int VB = TK > 5 ? 2 : 4;
+#pragma unroll
+  for (int g0 = 0; g0 < 8; g0 += VB) {
+    if (g0 >= ngg) break;
+    float vv[VB][TK], vw[VB][DH > 64 ? TK : 1];   // columns lane and (DH = 96) 64 + lane
+#pragma unroll
+    for (int gi = 0; gi < VB; ++gi)
+#pragma unroll
+      for (int jj = 0; jj < TK; ++jj) {   // a dead pair's pointer is the last live pair's: loaded, not stored
+        const unsigned long long vp = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(vr_hi, 8 * (g0 + gi) + jj) << 32) |
+                                      (unsigned int)__builtin_amdgcn_readlane(vr_lo, 8 * (g0 + gi) + jj);
+        vv[gi][jj] = reinterpret_cast<const float *>(vp)[lane];
+        if constexpr (DH > 64) vw[gi][jj] = lane + 64 < DH ? reinterpret_cast<const float *>(vp)[64 + lane] : 0.f;
+      }
+#pragma unroll
+    for (int gi = 0; gi < VB; ++gi) {
+      const int gg = g0 + gi;
+      if (gg >= ngg) break;
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < TK; ++jj) {
+        const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 8 * gg + jj));
+        acc0 = fmaf(pj, vv[gi][jj], acc0);
+        if constexpr (DH > 64) acc1 = fmaf(pj, vw[gi][jj], acc1);
+      }
+      const size_t o_off = (size_t)bb[gg] * a.o_bs + (size_t)hh[gg] * DH;
+      put_ctx(a, o_off + lane, acc0);
+      if (DH > 64 && lane + 64 < DH) put_ctx(a, o_off + 64 + lane, acc1);
+    }
   }
 }
 
@@ -573,9 +764,9 @@ __global__ __launch_bounds__(256) void attention_group_kernel(AttnArgs a) {
           if (lane < dh) acc0 = fmaf(pj, sv[jj * dh + lane], acc0);
           if (lane + 64 < dh) acc1 = fmaf(pj, sv[jj * dh + lane + 64], acc1);
         }
-        float *o = a.out + (size_t)b * a.o_bs + (size_t)h * dh;
-        if (lane < dh) o[lane] = acc0;
-        if (lane + 64 < dh) o[lane + 64] = acc1;
+        const size_t o_off = (size_t)b * a.o_bs + (size_t)h * dh;
+        if (lane < dh) put_ctx(a, o_off + lane, acc0);
+        if (lane + 64 < dh) put_ctx(a, o_off + lane + 64, acc1);
       }
     }
     return;
@@ -618,9 +809,9 @@ __global__ __launch_bounds__(256) void attention_group_kernel(AttnArgs a) {
         if (lane + 64 < dh) acc1 = fmaf(pj, sv[(64 * i + j) * dh + lane + 64], acc1);
       }
     }
-    float *o = a.out + (size_t)b * a.o_bs + (size_t)h * dh;
-    if (lane < dh) o[lane] = acc0;
-    if (lane + 64 < dh) o[lane + 64] = acc1;
+    const size_t o_off = (size_t)b * a.o_bs + (size_t)h * dh;
+    if (lane < dh) put_ctx(a, o_off + lane, acc0);
+    if (lane + 64 < dh) put_ctx(a, o_off + lane + 64, acc1);
   }
 }
 
@@ -656,7 +847,7 @@ __device__ __forceinline__ int am_sw4(int row, int c4) { return row * AM_D + 4 *
 // in front of every one of them)
 template <int NB>
 __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, const float *sv, const float *smask, float *so,
-                                        const float (&qf)[AM_D / 2], int w, int h, int tk, int tq, float *og) {
+                                        const float (&qf)[AM_D / 2], int w, int h, int tk, int tq, size_t og) {
   const int lane = threadIdx.x & 63, lrow = lane & 31, half = lane >> 5;
   const int qi = 32 * w + lrow;
   am_f32x16 sc[NB];
@@ -779,7 +970,7 @@ __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, cons
   for (int r4 = 0; r4 < nrow; r4 += 4) {
     const int rr = r4 + sub;
     if (rr < nrow)
-      *reinterpret_cast<float4 *>(og + (size_t)(32 * w + rr) * a.o_ts + 4 * c4) = *reinterpret_cast<const float4 *>(so + am_sw4(rr, c4));
+      put_ctx4(a, og + (size_t)(32 * w + rr) * a.o_ts + 4 * c4, *reinterpret_cast<const float4 *>(so + am_sw4(rr, c4)));
   }
 }
 
@@ -801,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnArgs a) {
   const float *qg = a.q + (a.seq_off ? (size_t)r0 * a.q_ts : (size_t)b * a.q_bs) + (size_t)h * AM_D;
   const float *kg = a.k + (a.seq_off ? (size_t)r0 * a.k_ts : (size_t)b * a.k_bs) + (size_t)h * AM_D;
   const float *vg = a.v + (a.seq_off ? (size_t)r0 * a.v_ts : (size_t)b * a.v_bs) + (size_t)h * AM_D;
-  float *og = a.out + (a.seq_off ? (size_t)r0 * a.o_ts : (size_t)b * a.o_bs) + (size_t)h * AM_D;
+  const size_t og = (a.seq_off ? (size_t)r0 * a.o_ts : (size_t)b * a.o_bs) + (size_t)h * AM_D;
   if (t < AM_S) smask[t] = (key_mask && t < tk && key_mask[(size_t)b * tk + t] == 0) ? -1e9f : 0.f;
   // all three operands with row-contiguous loads (16 lanes per 256-byte row); V waits in registers while Q uses its region
   float4 v4[8];
@@ -938,12 +1129,40 @@ extern "C" int mevi_scale_f32(const float *x, float alpha, int64_t n, float *out
   return MEVI_OK;
 }
 
-extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, const float *k, int64_t k_bs,
+// Where the context goes: f32 `out`, or (img != nullptr) the split image of the o-projection's operand (AttnArgs::oimg)
+struct CtxImage {
+  _Float16 *img;
+  int np, exp;
+};
+static int ctx_image_check(const CtxImage &ci, int64_t heads, int64_t dh, int64_t o_bs, int64_t o_ts) {
+  if (!ci.img) return MEVI_OK;
+  MEVI_REQUIRE(ci.np >= heads * dh && ci.np % 32 == 0 && ci.exp >= -100 && ci.exp <= 100 && o_bs % 4 == 0 && o_ts % 4 == 0 &&
+                   ((uintptr_t)ci.img % 8) == 0,
+               MEVI_ERR_INVALID_ARG, "attention: bad split-image output (np %d, exp %d)", ci.np, ci.exp);
+  return MEVI_OK;
+}
+
+// 64- and 96-wide heads take the LDS-transposed form; MEVI_ATTN_FEW_KEYS=direct keeps the per-lane row walk (A/B, same bits)
+typedef void (*few_keys_fn)(AttnArgs);
+static few_keys_fn few_keys_kernel(int64_t dh, int64_t tk) {
+  static const bool direct = [] { const char *e = getenv("MEVI_ATTN_FEW_KEYS"); return e && strcmp(e, "direct") == 0; }();
+  // tk = 8 (and 7 at 96-wide heads): the staged form runs out of registers -- measured 4x slower than the direct one there
+  if ((dh != 64 && dh != 96) || direct || tk < 1 || tk > (dh == 64 ? 7 : 6)) return attention_few_keys_kernel;
+#define MEVI_FK(DH_) {attention_few_keys_staged_kernel<1, DH_>, attention_few_keys_staged_kernel<2, DH_>, attention_few_keys_staged_kernel<3, DH_>, \
+                      attention_few_keys_staged_kernel<4, DH_>, attention_few_keys_staged_kernel<5, DH_>, attention_few_keys_staged_kernel<6, DH_>, \
+                      attention_few_keys_staged_kernel<7, DH_>}
+  static const few_keys_fn table64[7] = MEVI_FK(64), table96[7] = MEVI_FK(96);
+#undef MEVI_FK
+  const few_keys_fn *table = dh == 64 ? table64 : table96;
+  return table[tk - 1];
+}
+
+static int attention_launch(const float *q, int64_t q_bs, int64_t q_ts, const float *k, int64_t k_bs,
                                   int64_t k_ts, const float *v, int64_t v_bs, int64_t v_ts, float *out,
                                   int64_t o_bs, int64_t o_ts, int64_t nb, int64_t tq, int64_t tk, int64_t heads,
                                   int64_t dh, int64_t kv_div, const float *bias, int64_t bias_rows,
                                   int64_t bias_ld, int64_t q_pos0, const int64_t *key_mask, int causal,
-                                  float scale, const int64_t *kv_off, void *stream) {
+                                  float scale, const int64_t *kv_off, CtxImage ci, void *stream) {
   MEVI_REQUIRE(nb >= 0 && tq > 0 && tk > 0 && heads > 0 && dh > 0 && kv_div > 0, MEVI_ERR_INVALID_ARG,
                "attention: bad shape");
   MEVI_REQUIRE(tk <= 64 * ATT_KPL, MEVI_ERR_UNSUPPORTED, "attention: tk=%lld > %d keys not supported", (long long)tk,
@@ -952,10 +1171,12 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   MEVI_REQUIRE(dh % 4 == 0 && q_bs % 4 == 0 && q_ts % 4 == 0 && k_bs % 4 == 0 && k_ts % 4 == 0,
                MEVI_ERR_INVALID_ARG, "attention: dh and q/k strides must be multiples of 4");
   if (nb == 0) return MEVI_OK;
-  MEVI_REQUIRE(q && k && v && out, MEVI_ERR_INVALID_ARG, "attention: null pointer");
+  MEVI_REQUIRE(q && k && v && (out || ci.img), MEVI_ERR_INVALID_ARG, "attention: null pointer");
   MEVI_REQUIRE(!bias || q_pos0 + tq <= bias_rows, MEVI_ERR_INVALID_ARG, "attention: bias table too small");
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.out = out;
+  a.oimg = ci.img; a.onp = ci.np; a.oexp = ci.exp;
+  if (int st = ctx_image_check(ci, heads, dh, o_bs, o_ts)) return st;
   a.q_bs = q_bs; a.q_ts = q_ts; a.k_bs = k_bs; a.k_ts = k_ts; a.v_bs = v_bs; a.v_ts = v_ts; a.o_bs = o_bs; a.o_ts = o_ts;
   a.nb = (int)nb; a.tq = (int)tq; a.tk = (int)tk; a.H = (int)heads; a.dh = (int)dh; a.kv_div = (int)kv_div;
   a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = (int)q_pos0;
@@ -969,7 +1190,8 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
     hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(nb * heads)), dim3(256), AM_LDS, (hipStream_t)stream, a);
   } else if (!kv_off && tq == 1 && tk <= 8) {  // a handful of cached keys: eight (row, head) pairs per wave
-    hipLaunchKernelGGL(attention_few_keys_kernel, dim3(blocks4((nb * heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
+    MEVI_REQUIRE(nb * heads < (1LL << 31) - 8, MEVI_ERR_UNSUPPORTED, "attention: too many (row, head) pairs");
+    hipLaunchKernelGGL(few_keys_kernel(dh, tk), dim3(blocks4((nb * heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
   } else if (kv_div > 1 && tq == 1 && nb % kv_div == 0 && v_bs % 4 == 0 && v_ts % 4 == 0 &&
              ((size_t)tk * (2 * dh + 4) + (size_t)kv_div * dh) * sizeof(float) <= 65536) {
     // the beams of a query share K|V: stage them once per (query, head)
@@ -987,10 +1209,10 @@ extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, co
   return MEVI_OK;
 }
 
-extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const float *k, int64_t k_ts, const float *v,
+static int attention_varlen_launch(const float *q, int64_t q_ts, const float *k, int64_t k_ts, const float *v,
                                          int64_t v_ts, float *out, int64_t o_ts, const int64_t *seq_off, int64_t nseq,
                                          int64_t max_len, int64_t heads, int64_t dh, const float *bias,
-                                         int64_t bias_rows, int64_t bias_ld, int causal, float scale, void *stream) {
+                                         int64_t bias_rows, int64_t bias_ld, int causal, float scale, CtxImage ci, void *stream) {
   MEVI_REQUIRE(nseq >= 0 && max_len > 0 && heads > 0 && dh > 0, MEVI_ERR_INVALID_ARG, "attention_varlen: bad shape");
   MEVI_REQUIRE(max_len <= 64 * ATT_KPL, MEVI_ERR_UNSUPPORTED, "attention_varlen: %lld > %d keys not supported",
                (long long)max_len, 64 * ATT_KPL);
@@ -1000,11 +1222,13 @@ extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const flo
   MEVI_REQUIRE(per_wave <= 160 * 1024, MEVI_ERR_UNSUPPORTED, "attention_varlen: %lld keys x %lld do not fit LDS",
                (long long)max_len, (long long)dh);
   if (nseq == 0) return MEVI_OK;
-  MEVI_REQUIRE(q && k && v && out && seq_off, MEVI_ERR_INVALID_ARG, "attention_varlen: null pointer");
+  MEVI_REQUIRE(q && k && v && (out || ci.img) && seq_off, MEVI_ERR_INVALID_ARG, "attention_varlen: null pointer");
   MEVI_REQUIRE(!bias || (max_len <= bias_rows && max_len <= bias_ld), MEVI_ERR_INVALID_ARG,
                "attention_varlen: bias table too small");
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.out = out;
+  a.oimg = ci.img; a.onp = ci.np; a.oexp = ci.exp;
+  if (int st = ctx_image_check(ci, heads, dh, 0, o_ts)) return st;
   a.q_bs = a.k_bs = a.v_bs = a.o_bs = 0;
   a.q_ts = q_ts; a.k_ts = k_ts; a.v_ts = v_ts; a.o_ts = o_ts;
   a.nb = (int)nseq; a.tq = a.tk = (int)max_len; a.H = (int)heads; a.dh = (int)dh; a.kv_div = 1;
@@ -1041,30 +1265,98 @@ extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const flo
   return MEVI_OK;
 }
 
-extern "C" int mevi_attention_cached_f32(const float *q, int64_t q_bs, const float *k, int64_t k_bs, int64_t k_ts, const float *v,
+static int attention_cached_launch(const float *q, int64_t q_bs, const float *k, int64_t k_bs, int64_t k_ts, const float *v,
                                          int64_t v_bs, int64_t v_ts, float *out, int64_t o_bs, int64_t nb, int64_t tk,
                                          int64_t heads, int64_t dh, const int32_t *key_rows, const float *bias,
                                          int64_t bias_rows, int64_t bias_ld, int64_t q_pos0, int causal, float scale,
-                                         void *stream) {
+                                         CtxImage ci, void *stream) {
   MEVI_REQUIRE(nb >= 0 && tk > 0 && tk <= 8 && heads > 0 && dh > 0 && dh <= 128 && dh % 4 == 0, MEVI_ERR_UNSUPPORTED,
                "attention_cached: 1..8 cached positions, head width a multiple of 4 up to 128 (got tk %lld, dh %lld)",
                (long long)tk, (long long)dh);
   MEVI_REQUIRE(q_bs % 4 == 0 && k_bs % 4 == 0 && k_ts % 4 == 0 && v_bs % 4 == 0 && v_ts % 4 == 0, MEVI_ERR_INVALID_ARG,
                "attention_cached: strides must be multiples of 4");
   if (nb == 0) return MEVI_OK;
-  MEVI_REQUIRE(q && k && v && out && key_rows, MEVI_ERR_INVALID_ARG, "attention_cached: null pointer");
+  MEVI_REQUIRE(q && k && v && (out || ci.img) && key_rows, MEVI_ERR_INVALID_ARG, "attention_cached: null pointer");
   MEVI_REQUIRE(!bias || (q_pos0 < bias_rows && tk <= bias_ld), MEVI_ERR_INVALID_ARG, "attention_cached: bias table too small");
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.out = out;
+  a.oimg = ci.img; a.onp = ci.np; a.oexp = ci.exp;
+  if (int st = ctx_image_check(ci, heads, dh, o_bs, 0)) return st;
   a.q_bs = q_bs; a.q_ts = 0; a.k_bs = k_bs; a.k_ts = k_ts; a.v_bs = v_bs; a.v_ts = v_ts; a.o_bs = o_bs; a.o_ts = 0;
   a.nb = (int)nb; a.tq = 1; a.tk = (int)tk; a.H = (int)heads; a.dh = (int)dh; a.kv_div = 1;
   a.bias = bias; a.bias_rows = (int)bias_rows; a.bias_ld = (int)bias_ld; a.q_pos0 = (int)q_pos0;
   a.key_mask = nullptr; a.causal = causal; a.scale = scale;
   a.seq_off = nullptr; a.kv_off = nullptr;
   a.key_rows = key_rows;
-  hipLaunchKernelGGL(attention_few_keys_kernel, dim3(blocks4((nb * heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
+  MEVI_REQUIRE(nb * heads < (1LL << 31) - 8, MEVI_ERR_UNSUPPORTED, "attention_cached: too many (row, head) pairs");
+  hipLaunchKernelGGL(few_keys_kernel(dh, tk), dim3(blocks4((nb * heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
+}
+
+extern "C" int mevi_attention_f32(const float *q, int64_t q_bs, int64_t q_ts, const float *k, int64_t k_bs,
+                                  int64_t k_ts, const float *v, int64_t v_bs, int64_t v_ts, float *out,
+                                  int64_t o_bs, int64_t o_ts, int64_t nb, int64_t tq, int64_t tk, int64_t heads,
+                                  int64_t dh, int64_t kv_div, const float *bias, int64_t bias_rows,
+                                  int64_t bias_ld, int64_t q_pos0, const int64_t *key_mask, int causal,
+                                  float scale, const int64_t *kv_off, void *stream) {
+  return attention_launch(q, q_bs, q_ts, k, k_bs, k_ts, v, v_bs, v_ts, out, o_bs, o_ts, nb, tq, tk, heads, dh, kv_div, bias,
+                          bias_rows, bias_ld, q_pos0, key_mask, causal, scale, kv_off, CtxImage{nullptr, 0, 0}, stream);
+}
+
+// The *_split_f16 forms write the context as the (hi, lo) f16 image of the o-projection's operand (gemm_split.hip) scaled by
+// 2^out_exp: out_img [rows, 2 * img_np] halves; img_bs / img_ts are the batch / token strides in HALVES (img_ts = 2 * img_np
+// for contiguous rows).  The caller guarantees |context| * 2^out_exp < 2^15 (a bound on |V|: the context is a convex
+// combination of V rows) and fills the rows' exponent array with out_exp.
+extern "C" int mevi_attention_split_f16(const float *q, int64_t q_bs, int64_t q_ts, const float *k, int64_t k_bs,
+                                        int64_t k_ts, const float *v, int64_t v_bs, int64_t v_ts, void *out_img,
+                                        int64_t img_np, int out_exp, int64_t img_bs, int64_t img_ts, int64_t nb, int64_t tq,
+                                        int64_t tk, int64_t heads, int64_t dh, int64_t kv_div, const float *bias,
+                                        int64_t bias_rows, int64_t bias_ld, int64_t q_pos0, const int64_t *key_mask,
+                                        int causal, float scale, const int64_t *kv_off, void *stream) {
+  MEVI_REQUIRE(out_img || nb == 0, MEVI_ERR_INVALID_ARG, "attention_split: null image");
+  return attention_launch(q, q_bs, q_ts, k, k_bs, k_ts, v, v_bs, v_ts, nullptr, img_bs, img_ts, nb, tq, tk, heads, dh, kv_div,
+                          bias, bias_rows, bias_ld, q_pos0, key_mask, causal, scale, kv_off,
+                          CtxImage{reinterpret_cast<_Float16 *>(out_img), (int)img_np, out_exp}, stream);
+}
+
+extern "C" int mevi_attention_varlen_f32(const float *q, int64_t q_ts, const float *k, int64_t k_ts, const float *v,
+                                         int64_t v_ts, float *out, int64_t o_ts, const int64_t *seq_off, int64_t nseq,
+                                         int64_t max_len, int64_t heads, int64_t dh, const float *bias,
+                                         int64_t bias_rows, int64_t bias_ld, int causal, float scale, void *stream) {
+  return attention_varlen_launch(q, q_ts, k, k_ts, v, v_ts, out, o_ts, seq_off, nseq, max_len, heads, dh, bias, bias_rows,
+                                 bias_ld, causal, scale, CtxImage{nullptr, 0, 0}, stream);
+}
+
+extern "C" int mevi_attention_varlen_split_f16(const float *q, int64_t q_ts, const float *k, int64_t k_ts, const float *v,
+                                               int64_t v_ts, void *out_img, int64_t img_np, int out_exp, int64_t img_ts,
+                                               const int64_t *seq_off, int64_t nseq, int64_t max_len, int64_t heads,
+                                               int64_t dh, const float *bias, int64_t bias_rows, int64_t bias_ld,
+                                               int causal, float scale, void *stream) {
+  MEVI_REQUIRE(out_img || nseq == 0, MEVI_ERR_INVALID_ARG, "attention_varlen_split: null image");
+  return attention_varlen_launch(q, q_ts, k, k_ts, v, v_ts, nullptr, img_ts, seq_off, nseq, max_len, heads, dh, bias,
+                                 bias_rows, bias_ld, causal, scale,
+                                 CtxImage{reinterpret_cast<_Float16 *>(out_img), (int)img_np, out_exp}, stream);
+}
+
+extern "C" int mevi_attention_cached_f32(const float *q, int64_t q_bs, const float *k, int64_t k_bs, int64_t k_ts, const float *v,
+                                         int64_t v_bs, int64_t v_ts, float *out, int64_t o_bs, int64_t nb, int64_t tk,
+                                         int64_t heads, int64_t dh, const int32_t *key_rows, const float *bias,
+                                         int64_t bias_rows, int64_t bias_ld, int64_t q_pos0, int causal, float scale,
+                                         void *stream) {
+  return attention_cached_launch(q, q_bs, k, k_bs, k_ts, v, v_bs, v_ts, out, o_bs, nb, tk, heads, dh, key_rows, bias, bias_rows,
+                                 bias_ld, q_pos0, causal, scale, CtxImage{nullptr, 0, 0}, stream);
+}
+
+extern "C" int mevi_attention_cached_split_f16(const float *q, int64_t q_bs, const float *k, int64_t k_bs, int64_t k_ts,
+                                               const float *v, int64_t v_bs, int64_t v_ts, void *out_img, int64_t img_np,
+                                               int out_exp, int64_t img_bs, int64_t nb, int64_t tk, int64_t heads, int64_t dh,
+                                               const int32_t *key_rows, const float *bias, int64_t bias_rows, int64_t bias_ld,
+                                               int64_t q_pos0, int causal, float scale, void *stream) {
+  MEVI_REQUIRE(out_img || nb == 0, MEVI_ERR_INVALID_ARG, "attention_cached_split: null image");
+  return attention_cached_launch(q, q_bs, k, k_bs, k_ts, v, v_bs, v_ts, nullptr, img_bs, nb, tk, heads, dh, key_rows, bias,
+                                 bias_rows, bias_ld, q_pos0, causal, scale,
+                                 CtxImage{reinterpret_cast<_Float16 *>(out_img), (int)img_np, out_exp}, stream);
 }
 
 extern "C" int mevi_adaptive_logits_f32(const float *s, int64_t lds_, const float *t, int64_t ldt,

@@ -71,6 +71,16 @@ _SIGNATURES = {
     "mevi_attention_varlen_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                           c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                           c_int, c_float, c_void_p]),
+    "mevi_attention_split_f16": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                         c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                         c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_float, c_void_p,
+                                         c_void_p]),
+    "mevi_attention_cached_split_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                                c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                                c_void_p, c_int64, c_int64, c_int64, c_int, c_float, c_void_p]),
+    "mevi_attention_varlen_split_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                                c_int, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                                c_int64, c_int64, c_int, c_float, c_void_p]),
     "mevi_adaptive_logits_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                          c_int64, c_void_p, c_void_p]),
     "mevi_beam_step_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,

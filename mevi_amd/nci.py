@@ -231,6 +231,7 @@ class NCIModel:
         self.dec_emb = _dev(weights, "decode_embeddings.weight", self.dev)
         self.encoder = EncoderStack(weights, c, self.dev)
         self.decoder = DecoderStack(weights, c, self.dev, max_len=c.T)
+        self.decoder.set_encoder_norm(self.encoder.out_norm)
         self.adaptor = Adaptor(weights, c, self.dev)
         # adaptive head restricted to the valid columns of every position:
         # column 0 = eos (token 1), columns 1..K = tokens 2 + p*K + (c-1)     (modeling_t5.py:1578-1603)

@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/mevi_hip.h).  torch supplies device memory
 and the current stream only; every function launches hand-written HIP kernels and raises
 MeviHipError when the extension or the GPU is missing."""
+import math
 import os
 
 import torch
@@ -94,6 +95,49 @@ def _split_buffers(M, K, dev, zero=False):
     kp = int(hip.lib().mevi_split_kp(K))
     img = (torch.zeros if zero and kp != K else torch.empty)((M, 2 * kp), dtype=torch.int16, device=dev)
     return img, torch.empty((M,), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev)
+
+
+CTX_IMAGE = os.environ.get("MEVI_ATTN_CTX", "image") != "f32"      # A/B switch: attention contexts as f32 + split_rows
+_EXP_FILL = {}
+
+
+def norm_out_bound(ln_weight, d_model, ln_bias=None):
+    """l2 norm bound of a row of rmsnorm(x) * w (T5LayerNorm) or layernorm(x) * w + b: sqrt(d) max|w| (+ sqrt(d) max|b|)."""
+    xn = math.sqrt(d_model) * _abs_max(ln_weight)
+    if ln_bias is not None:
+        xn += math.sqrt(d_model) * _abs_max(ln_bias)
+    return xn
+
+
+def ctx_bound(x_norm, w, v_bias=None):
+    """Bound on |V| = |x W^T (+ b)| over rows x with ||x|| <= x_norm (norm_out_bound), for an attention whose context only
+    feeds the o-projection: the context is a convex combination of V rows, so with this bound it can be written as that
+    GEMM's split image directly (one exponent for all rows; `split_bound` of the attention wrappers).  Cauchy-Schwarz with
+    the largest weight row norm.  None unless the split GEMM is in use (then the f32 form runs)."""
+    if x_norm is None or GEMM_MODE != "split" or not CTX_IMAGE or not isinstance(w, SplitRows) or w.norm_max is None:
+        return None
+    b = x_norm * w.norm_max * 1.001
+    if v_bias is not None:
+        b += _abs_max(v_bias)
+    return b
+
+
+def _pow2_exp(m):
+    """e with m * 2^e in [2^14, 2^15), clamped to +-100 (pow2_exp of gemm_split.hip)."""
+    if not (m > 0.0) or math.isinf(m):
+        return 0
+    return max(-100, min(100, 15 - math.frexp(m)[1]))
+
+
+def _ctx_image(rows, k, bound, dev):
+    """SplitRows for `rows` context rows of width k, all with the exponent of `bound`; returns (image, np, exponent)."""
+    kp = int(hip.lib().mevi_split_kp(k))
+    img = (torch.zeros if kp != k else torch.empty)((rows, 2 * kp), dtype=torch.int16, device=dev)
+    e = _pow2_exp(bound * 1.001)
+    fill = _EXP_FILL.get((dev, e))
+    if fill is None or fill.numel() < rows:
+        fill = _EXP_FILL[(dev, e)] = torch.full((max(rows, 1 << 16),), e, dtype=torch.int8, device=dev)
+    return SplitRows(img, fill[:rows], k, None), kp, e
 
 
 def split_rows(x):
@@ -238,10 +282,11 @@ def scale(x, alpha):
 
 @hip.on_device
 def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=None, causal=False, scale=1.0,
-              kv_off=None, kv_longest=0):
+              kv_off=None, kv_longest=0, split_bound=None):
     """q [nb, tq, H*dh], k/v [nb/kv_div, tk, H*dh] (any batch/token strides, last dim contiguous) -- or, with
     kv_off (i64 [nb/kv_div + 1], device), PACKED k/v [rows, H*dh]: kv batch c owns rows kv_off[c] .. kv_off[c+1]-1, all
-    real, kv_longest = the longest of them."""
+    real, kv_longest = the longest of them.  split_bound (ctx_bound): return the context as the SplitRows image
+    [nb * tq, H*dh] of the o-projection instead of f32 [nb, tq, H*dh]."""
     assert q.dim() == 3 and q.stride(2) == 1 and q.is_cuda and q.dtype == torch.float32
     nb, tq, hd = q.shape
     dh = hd // heads
@@ -257,8 +302,6 @@ def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=
         assert kv_off.dtype == torch.int64 and kv_off.is_cuda and kv_off.numel() * kv_div == nb + kv_div and key_mask is None
         tk = int(kv_longest)
         kst, vst = (0, k.stride(0)), (0, v.stride(0))
-    if out is None:
-        out = torch.empty((nb, tq, hd), dtype=torch.float32, device=q.device)
     brows = bld = 0
     if bias is not None:
         assert bias.dim() == 3 and bias.is_contiguous() and bias.shape[0] == heads
@@ -266,6 +309,19 @@ def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=
     if key_mask is not None:
         key_mask = key_mask.to(device=q.device, dtype=torch.int64).contiguous()
         assert key_mask.shape == (nb // kv_div, tk)
+    if split_bound is not None:
+        assert out is None
+        ctx, kp, e = _ctx_image(nb * tq, hd, split_bound, q.device)
+        st = hip.lib().mevi_attention_split_f16(
+            hip.ptr(q), q.stride(0), q.stride(1), hip.ptr(k), kst[0], kst[1], hip.ptr(v), vst[0], vst[1],
+            hip.ptr(ctx.img), kp, e, tq * 2 * kp, 2 * kp, nb, tq, tk, heads, dh, kv_div,
+            hip.ptr(bias) if bias is not None else None, brows, bld, q_pos0,
+            hip.ptr(key_mask) if key_mask is not None else None, 1 if causal else 0, scale,
+            hip.ptr(kv_off) if kv_off is not None else None, hip.stream_ptr())
+        hip.check(st, "mevi_attention_split_f16")
+        return ctx
+    if out is None:
+        out = torch.empty((nb, tq, hd), dtype=torch.float32, device=q.device)
     st = hip.lib().mevi_attention_f32(
         hip.ptr(q), q.stride(0), q.stride(1), hip.ptr(k), kst[0], kst[1], hip.ptr(v), vst[0], vst[1],
         hip.ptr(out), out.stride(0), out.stride(1), nb, tq, tk, heads, dh, kv_div,
@@ -277,7 +333,7 @@ def attention(q, k, v, heads, out=None, kv_div=1, bias=None, q_pos0=0, key_mask=
 
 
 @hip.on_device
-def attention_cached(q, k, v, key_rows, heads, bias=None, q_pos0=0, causal=True, scale=1.0, out=None):
+def attention_cached(q, k, v, key_rows, heads, bias=None, q_pos0=0, causal=True, scale=1.0, out=None, split_bound=None):
     """One decode step over ancestor-indexed caches: q [n, H*dh]; k / v [rows, T, H*dh] views of the caches (any row / token
     strides); key_rows i32 [n, tk] (tk <= 8): position j of row b is cache row key_rows[b, j].  Same bits as `attention` on the
     caches physically re-ordered by the beams' parents (generation_utils.py:927-934)."""
@@ -287,12 +343,21 @@ def attention_cached(q, k, v, key_rows, heads, bias=None, q_pos0=0, causal=True,
     n, hd = q.shape
     assert key_rows.dtype == torch.int32 and key_rows.is_cuda and key_rows.is_contiguous() and key_rows.shape[0] == n
     tk = key_rows.shape[1]
-    if out is None:
-        out = torch.empty((n, hd), dtype=torch.float32, device=q.device)
     brows = bld = 0
     if bias is not None:
         assert bias.dim() == 3 and bias.is_contiguous() and bias.shape[0] == heads
         brows, bld = bias.shape[1], bias.shape[2]
+    if split_bound is not None:      # the context as the o-projection's SplitRows image (see attention)
+        assert out is None
+        ctx, kp, e = _ctx_image(n, hd, split_bound, q.device)
+        st = hip.lib().mevi_attention_cached_split_f16(
+            hip.ptr(q), q.stride(0), hip.ptr(k), k.stride(0), k.stride(1), hip.ptr(v), v.stride(0), v.stride(1),
+            hip.ptr(ctx.img), kp, e, 2 * kp, n, tk, heads, hd // heads, hip.ptr(key_rows),
+            hip.ptr(bias) if bias is not None else None, brows, bld, q_pos0, 1 if causal else 0, scale, hip.stream_ptr())
+        hip.check(st, "mevi_attention_cached_split_f16")
+        return ctx
+    if out is None:
+        out = torch.empty((n, hd), dtype=torch.float32, device=q.device)
     st = hip.lib().mevi_attention_cached_f32(
         hip.ptr(q), q.stride(0), hip.ptr(k), k.stride(0), k.stride(1), hip.ptr(v), v.stride(0), v.stride(1), hip.ptr(out),
         out.stride(0), n, tk, heads, hd // heads, hip.ptr(key_rows), hip.ptr(bias) if bias is not None else None, brows, bld,
@@ -302,19 +367,28 @@ def attention_cached(q, k, v, key_rows, heads, bias=None, q_pos0=0, causal=True,
 
 
 @hip.on_device
-def attention_varlen(q, k, v, seq_off, max_len, heads, bias=None, causal=False, scale=1.0, out=None):
+def attention_varlen(q, k, v, seq_off, max_len, heads, bias=None, causal=False, scale=1.0, out=None, split_bound=None):
     """Self-attention over packed sequences: q / k / v [T, H*dh] row-strided views, sequence b = rows
     seq_off[b] .. seq_off[b+1]-1 (i64 [nseq+1] on the device), max_len = longest sequence (<= 256)."""
     for t in (q, k, v):
         assert t.dim() == 2 and t.stride(1) == 1 and t.is_cuda and t.dtype == torch.float32
     T, hd = q.shape
     assert seq_off.dtype == torch.int64 and seq_off.is_cuda and seq_off.is_contiguous()
-    if out is None:
-        out = torch.empty((T, hd), dtype=torch.float32, device=q.device)
     brows = bld = 0
     if bias is not None:
         assert bias.dim() == 3 and bias.is_contiguous() and bias.shape[0] == heads
         brows, bld = bias.shape[1], bias.shape[2]
+    if split_bound is not None:      # the context as the o-projection's SplitRows image (see attention)
+        assert out is None
+        ctx, kp, e = _ctx_image(T, hd, split_bound, q.device)
+        st = hip.lib().mevi_attention_varlen_split_f16(
+            hip.ptr(q), q.stride(0), hip.ptr(k), k.stride(0), hip.ptr(v), v.stride(0), hip.ptr(ctx.img), kp, e, 2 * kp,
+            hip.ptr(seq_off), seq_off.numel() - 1, int(max_len), heads, hd // heads,
+            hip.ptr(bias) if bias is not None else None, brows, bld, 1 if causal else 0, scale, hip.stream_ptr())
+        hip.check(st, "mevi_attention_varlen_split_f16")
+        return ctx
+    if out is None:
+        out = torch.empty((T, hd), dtype=torch.float32, device=q.device)
     st = hip.lib().mevi_attention_varlen_f32(
         hip.ptr(q), q.stride(0), hip.ptr(k), k.stride(0), hip.ptr(v), v.stride(0), hip.ptr(out), out.stride(0),
         hip.ptr(seq_off), seq_off.numel() - 1, int(max_len), heads, hd // heads,

@@ -75,7 +75,10 @@ class EncoderStack:
                 wi=_dev(w, f"{p}.1.DenseReluDense.wi.weight", device),
                 wo2=_dev(w, f"{p}.1.DenseReluDense.wo.weight", device)))
         ops.prepare_weights(self.layers, ("wqkv", "wo", "wi", "wo2"))
+        for L in self.layers:   # |V| bound: the self-attention context goes to `o` as its split image (ops.ctx_bound)
+            L["vb"] = ops.ctx_bound(ops.norm_out_bound(L["ln0"], dims.d_model), L["wqkv"])
         self.final_ln = _dev(w, f"{prefix}.final_layer_norm.weight", device)
+        self.out_norm = ops.norm_out_bound(self.final_ln, dims.d_model)     # l2 bound of a returned state row
         self.rel = _dev(w, f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight", device)
         self._bias = {}
         self.pack = True   # padding-free per-token operators (see forward)
@@ -110,8 +113,8 @@ class EncoderStack:
                 h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
                 qkv = ops.linear(h, L["wqkv"]).view(B, S, 3 * d.inner)
                 ctx = ops.attention(qkv[:, :, :d.inner], qkv[:, :, d.inner:2 * d.inner], qkv[:, :, 2 * d.inner:],
-                                    d.num_heads, bias=bias, key_mask=attention_mask)
-                x = ops.linear(ctx.view(B * S, d.inner), L["wo"], residual=x)
+                                    d.num_heads, bias=bias, key_mask=attention_mask, split_bound=L["vb"])
+                x = ops.linear(ctx if L["vb"] is not None else ctx.view(B * S, d.inner), L["wo"], residual=x)
                 h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
                 x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
             return ops.rmsnorm(x, self.final_ln, d.eps).view(B, S, d.d_model)
@@ -123,7 +126,7 @@ class EncoderStack:
                 h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
                 qkv = ops.linear(h, L["wqkv"])
                 ctx = ops.attention_varlen(qkv[:, :d.inner], qkv[:, d.inner:2 * d.inner], qkv[:, 2 * d.inner:], seq_off,
-                                           longest, d.num_heads, bias=bias)
+                                           longest, d.num_heads, bias=bias, split_bound=L["vb"])
                 x = ops.linear(ctx, L["wo"], residual=x)
                 h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
                 x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
@@ -236,10 +239,19 @@ class DecoderStack:
                 wi=_dev(w, f"{p}.2.DenseReluDense.wi.weight", device),
                 wo2=_dev(w, f"{p}.2.DenseReluDense.wo.weight", device)))
         ops.prepare_weights(self.layers, ("wq", "wkv", "wo", "xq", "xkv", "xo", "wi", "wo2"))
+        for L in self.layers:
+            L["vb"] = ops.ctx_bound(ops.norm_out_bound(L["ln0"], dims.d_model), L["wkv"])
+            L["xvb"] = None          # cross-attention: needs the encoder's output norm (set_encoder_norm)
         self.final_ln = _dev(w, f"{prefix}.final_layer_norm.weight", device)
         rel = _dev(w, f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight", device)
         self.self_bias = bias_table(rel, max_len, max_len, False, dims.buckets)   # [H, T, T]
         self.max_len = max_len
+
+    def set_encoder_norm(self, enc_norm):
+        """l2 bound of the rows handed to cross_kv (EncoderStack.out_norm): lets the cross-attention contexts be written
+        as the split image of `EncDecAttention.o` (ops.ctx_bound).  Without it they stay f32."""
+        for L in self.layers:
+            L["xvb"] = ops.ctx_bound(enc_norm, L["xkv"])
 
     def cross_kv(self, enc, enc_mask=None, pack=True):
         """Per-layer cross-attention K|V of the encoder states, as a CrossKV.  With `enc_mask` (and pack) only the real
@@ -299,20 +311,22 @@ class DecoderStack:
                 ops.linear(h, L["wkv"], out=kvc[:n, t, :])
                 if key_rows is not None:
                     ctx = ops.attention_cached(q, kvc[:, :, :d.inner], kvc[:, :, d.inner:], key_rows, d.num_heads,
-                                               bias=self.self_bias, q_pos0=t, causal=True)
+                                               bias=self.self_bias, q_pos0=t, causal=True, split_bound=L["vb"])
                 else:
                     ctx = ops.attention(q.view(n, 1, d.inner), kvc[:, :t + 1, :d.inner], kvc[:, :t + 1, d.inner:],
-                                        d.num_heads, bias=self.self_bias, q_pos0=t, causal=True).view(n, d.inner)
+                                        d.num_heads, bias=self.self_bias, q_pos0=t, causal=True, split_bound=L["vb"])
+                    if L["vb"] is None:
+                        ctx = ctx.view(n, d.inner)
             x = ops.linear(ctx, L["wo"], residual=x)
             h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
             q = ops.linear(h, L["xq"])
             if xkv.kv_off is None:
                 ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :, :d.inner], xc[:, :, d.inner:], d.num_heads,
-                                    kv_div=kv_div, key_mask=xkv.mask)
+                                    kv_div=kv_div, key_mask=xkv.mask, split_bound=L["xvb"])
             else:
                 ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :d.inner], xc[:, d.inner:], d.num_heads, kv_div=kv_div,
-                                    kv_off=xkv.kv_off, kv_longest=xkv.longest)
-            x = ops.linear(ctx.view(n, d.inner), L["xo"], residual=x)
+                                    kv_off=xkv.kv_off, kv_longest=xkv.longest, split_bound=L["xvb"])
+            x = ops.linear(ctx if L["xvb"] is not None else ctx.view(n, d.inner), L["xo"], residual=x)
             h = ops.rmsnorm(x, L["ln2"], d.eps, for_gemm=True)
             x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
         return ops.rmsnorm(x, self.final_ln, d.eps)
@@ -336,6 +350,7 @@ class TwinTower:
         self.shared = _dev(weights, "shared.weight", self.dev)
         self.encoder = EncoderStack(weights, self.d, self.dev)
         self.decoder = DecoderStack(weights, self.d, self.dev, max_len=1)
+        self.decoder.set_encoder_norm(self.encoder.out_norm)
         self.batch_size = batch_size   # rows per device pass; None: DEVICE_PASS_TOKENS // sequence length
         self.dim = self.d.d_model      # width of the embeddings this tower emits
         self._graphs = GraphCache()

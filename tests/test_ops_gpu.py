@@ -306,3 +306,88 @@ def test_attention_over_ancestor_indexed_caches_equals_the_reordered_copy(cuda, 
     got = ops.attention_cached(q, cache[:, :, :H * dh], cache[:, :, H * dh:], key_rows, H, bias=bias, q_pos0=tk - 1, causal=True)
     assert torch.equal(got, want)
 
+
+
+def test_staged_few_keys_attention_has_the_bits_of_the_direct_form(cuda):
+    """attention_few_keys64_kernel (key rows transposed through LDS) against attention_few_keys_kernel (per-lane row walk,
+    MEVI_ATTN_FEW_KEYS=direct; the switch is read once per process, hence the child processes): tk = 1..8, 12 x 64 and 8 x 96 heads, a
+    row count that leaves the last wave ragged, beam-like ancestor tables."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for nrows, heads, dh in (("371", "12", "64"), ("8", "12", "64"), ("205", "8", "96")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_attn_cached.py")], capture_output=True, text=True,
+                           env=dict(os.environ, NROWS=nrows, HEADS=heads, DH=dh), timeout=600)
+        assert r.returncode == 0 and r.stdout.count("same bits: True") == 8, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def _image_to_f32(sr):
+    """(hi + lo) * 2^-e of a SplitRows image, as f32 [rows, k]."""
+    kp = sr.img.shape[1] // 2
+    h = sr.img.view(torch.float16).to(torch.float64)
+    x = (h[:, :sr.k] + h[:, kp:kp + sr.k]) * torch.pow(2.0, -sr.exp.to(torch.float64))[:, None]
+    return x.to(torch.float32)
+
+
+@pytest.mark.parametrize("form", ["padded", "cross_group", "cross_packed", "varlen", "cached", "passage_mfma"])
+def test_attention_context_written_as_split_image(cuda, form):
+    """mevi_attention*_split_f16: the context goes straight into the o-projection's (hi, lo) f16 image with ONE exponent from
+    a bound on |V| (ops.ctx_bound).  The image must decode to the f32 kernel's context to 2^-21 of the bound's binade (22
+    significant bits below the exponent's 2^15), and bound-sized values must not overflow."""
+    g = torch.Generator(device=cuda).manual_seed(11)
+    H, dh = 12, 64
+    hd = H * dh
+    rnd = lambda *s: torch.randn(s, device=cuda, generator=g)      # noqa: E731
+
+    if form == "padded":
+        nb, S = 3, 17
+        q, k, v = rnd(nb, S, hd), rnd(nb, S, hd), rnd(nb, S, hd)
+        mask = torch.ones((nb, S), dtype=torch.int64, device=cuda)
+        mask[1, 9:] = 0
+        kw = dict(bias=rnd(H, S, S), key_mask=mask)
+        run = lambda **e: ops.attention(q, k, v, H, **kw, **e)     # noqa: E731  (tile kernel)
+    elif form == "cross_group":
+        nq, R, S = 5, 10, 21
+        q, k, v = rnd(nq * R, 1, hd), rnd(nq, S, hd), rnd(nq, S, hd)
+        run = lambda **e: ops.attention(q, k, v, H, kv_div=R, **e)     # noqa: E731
+    elif form == "cross_packed":
+        lens = torch.tensor([4, 9, 1, 30], device=cuda)
+        off = torch.zeros(5, dtype=torch.int64, device=cuda)
+        off[1:] = lens.cumsum(0)
+        T = int(off[-1])
+        q, k, v = rnd(4 * 10, 1, hd), rnd(T, hd), rnd(T, hd)
+        run = lambda **e: ops.attention(q, k, v, H, kv_div=10, kv_off=off, kv_longest=30, **e)     # noqa: E731
+    elif form == "varlen":
+        lens = torch.tensor([7, 12, 1, 33, 5], device=cuda)
+        off = torch.zeros(6, dtype=torch.int64, device=cuda)
+        off[1:] = lens.cumsum(0)
+        T = int(off[-1])
+        q, k, v, bias = rnd(T, hd), rnd(T, hd), rnd(T, hd), rnd(H, 33, 33)
+        run = lambda **e: ops.attention_varlen(q, k, v, off, 33, H, bias=bias, **e)     # noqa: E731
+    elif form == "cached":
+        n, T, tk = 53, 6, 4
+        cache, q = rnd(n, T, 2 * hd), rnd(n, hd)
+        kr = torch.randint(0, n, (n, tk), device=cuda, generator=g).to(torch.int32)
+        b = rnd(H, T, T)
+        run = lambda **e: ops.attention_cached(q, cache[:, :, :hd], cache[:, :, hd:], kr, H, bias=b, q_pos0=tk - 1, **e)     # noqa: E731
+    else:
+        nb, S = 2, 100
+        q, k, v = rnd(nb, S, hd), rnd(nb, S, hd), rnd(nb, S, hd)
+        run = lambda **e: ops.attention(q, k, v, H, **e)     # noqa: E731
+    want = run()
+    vmax = float(v.abs().max()) if form != "cached" else float(cache[:, :, hd:].abs().max())
+    for bound in (vmax, 37.0 * vmax):          # tight, and a few binades loose (what Cauchy-Schwarz gives)
+        sr = run(split_bound=bound)
+        assert isinstance(sr, ops.SplitRows) and sr.shape == (want.numel() // hd, hd)
+        got = _image_to_f32(sr)
+        e = int(sr.exp[0])
+        assert (sr.exp == e).all() and 2.0 ** 14 <= bound * 1.001 * 2.0 ** e < 2.0 ** 15
+        err = (got - want.reshape(-1, hd)).abs().max().item()
+        assert err <= 2.0 ** (15 - e) * 2.0 ** -21, (form, bound, err)
+    # and the o-projection takes it like any SplitRows
+    w = ops.weight_split(rnd(hd, hd) * 0.05)
+    y_img = ops.linear(run(split_bound=vmax), w)
+    y_f32 = ops.linear(want.reshape(-1, hd).contiguous(), w)
+    assert (y_img - y_f32).abs().max().item() <= 1e-5 * float(y_f32.abs().max())
