@@ -171,6 +171,24 @@ __device__ __forceinline__ void put_ctx4(const AttnArgs &a, size_t off, float4 v
     *reinterpret_cast<float4 *>(a.out + off) = v;
   }
 }
+// A whole 64-wide head row of the context from LDS (`row`: 64 floats, written by this wave): f32 -- lane = column -- or the
+// image with lanes 0-31 storing the hi pairs of columns (2l, 2l+1) and lanes 32-63 the lo pairs: each half-wave covers one
+// contiguous 128-byte line (put_ctx's even / odd lanes interleave two lines inside every lane quad).
+__device__ __forceinline__ void put_ctx_row64(const AttnArgs &a, size_t off, const float *row) {
+  const int lane = threadIdx.x & 63;
+  if (a.oimg) {
+    const int c = 2 * (lane & 31);
+    const float x0 = ldexpf(row[c], a.oexp), x1 = ldexpf(row[c + 1], a.oexp);
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const bool lo = lane >= 32;
+    const _Float16 w0 = lo ? (_Float16)(x0 - (float)h0) : h0, w1 = lo ? (_Float16)(x1 - (float)h1) : h1;
+    const unsigned int word = (unsigned int)__builtin_bit_cast(unsigned short, w0) |
+                              ((unsigned int)__builtin_bit_cast(unsigned short, w1) << 16);
+    *reinterpret_cast<unsigned int *>(a.oimg + off + c + (lo ? a.onp : 0)) = word;
+  } else {
+    a.out[off + lane] = row[lane];
+  }
+}
 
 constexpr int ATT_KPL = 4;  // keys per lane: key j lives on lane j & 63, slot j >> 6 (tk <= 256)
 
@@ -470,11 +488,19 @@ __global__ __launch_bounds__(256) void attention_varlen_short_kernel(AttnArgs a,
       oa = fmaf(pa, vj, oa);
       ob = fmaf(pb, vj, ob);
     }
+    // the rows' q are dead: their contexts wait there.  Storing them here put the next pair's bias loads BEHIND the stores
+    // in the wave's in-order memory counter -- a write acknowledgement (microseconds) per row pair: the kernel ran at 560 us
+    // per call with its loads alone taking 127 us and its arithmetic nothing measurable (profiles/r03_seq2seq_experiments.txt)
     if (lane < DH) {
-      put_ctx(a, (size_t)(r0 + tq) * a.o_ts + (size_t)h * DH + lane, oa);
-      if (t1 != tq) put_ctx(a, (size_t)(r0 + t1) * a.o_ts + (size_t)h * DH + lane, ob);
+      sq[tq * DH + lane] = oa;
+      if (t1 != tq) sq[t1 * DH + lane] = ob;
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  static_assert(DH == 64, "put_ctx_row64");
+  for (int r = 0; r < tk; ++r) put_ctx_row64(a, (size_t)(r0 + r) * a.o_ts + (size_t)h * DH, sq + r * DH);
 }
 
 // Decode-step attention over a handful of cached keys (tq == 1, tk <= 8: the decoder's and the adaptor's

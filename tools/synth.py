@@ -1,5 +1,7 @@
 """Synthetic t5-base-shaped NCI model + T5-ANCE-shaped tower and MS MARCO-like query ids (config C3 of BASELINE.md),
 shared by tools/bench_stages.py and tools/bench_chain.py."""
+import os
+
 import numpy as np
 import torch
 
@@ -95,7 +97,7 @@ def query_ids(nq, dev, rng):
     ids = np.zeros((nq, 32), np.int64)
     mask = np.zeros((nq, 32), np.int64)
     for i in range(nq):
-        L = int(np.clip(rng.poisson(9) + 2, 3, 32))
+        L = int(np.clip(rng.poisson(9) + 2, 3, int(os.environ.get("SYNTH_MAX_QUERY_LEN", "32"))))     # env: experiments on the longest query
         ids[i, :L - 1] = rng.integers(3, 32100, size=L - 1)
         ids[i, L - 1] = 1
         mask[i, :L] = 1
