@@ -238,7 +238,15 @@ class DecoderStack:
                 ln2=_dev(w, f"{p}.2.layer_norm.weight", device),
                 wi=_dev(w, f"{p}.2.DenseReluDense.wi.weight", device),
                 wo2=_dev(w, f"{p}.2.DenseReluDense.wo.weight", device)))
-        ops.prepare_weights(self.layers, ("wq", "wkv", "wo", "xq", "xkv", "xo", "wi", "wo2"))
+        keys = ("wq", "wkv", "wo", "xq", "xkv", "xo", "wi", "wo2")
+        if max_len == 1 and ops.GEMM_MODE == "split":
+            # A single-position decoder (the towers) attends to ONE key: the softmax weight is exactly 1, the context is v, and
+            # o(v(h)) = h (Wo Wv)^T -- one projection instead of two (the product is taken once, in f64).  MEVI_GEMM=exact keeps
+            # the two sequential-chain GEMMs of the reference.
+            for L in self.layers:
+                L["wov"] = (L["wo"].double() @ L["wkv"][dims.inner:].double()).float().contiguous()
+            keys += ("wov",)
+        ops.prepare_weights(self.layers, keys)
         for L in self.layers:
             L["vb"] = ops.ctx_bound(ops.norm_out_bound(L["ln0"], dims.d_model), L["wkv"])
             L["xvb"] = None          # cross-attention: needs the encoder's output norm (set_encoder_norm)
@@ -298,7 +306,10 @@ class DecoderStack:
             cache = [kvc[:n] if t == 0 else kvc for kvc in cache]
         for L, kvc, xc in zip(self.layers, cache, xkv.layers):
             h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
-            if t == 0:
+            ctx = None
+            if t == 0 and "wov" in L:
+                x = ops.linear(h, L["wov"], residual=x)          # o(v(h)) in one projection (see __init__)
+            elif t == 0:
                 # one key: its softmax weight is exp(0) / exp(0) = 1 exactly, so the attention output IS v -- no query
                 # projection, no attention kernel; a single-position decoder (the towers) never needs k either
                 if self.max_len == 1:
@@ -317,7 +328,8 @@ class DecoderStack:
                                         d.num_heads, bias=self.self_bias, q_pos0=t, causal=True, split_bound=L["vb"])
                     if L["vb"] is None:
                         ctx = ctx.view(n, d.inner)
-            x = ops.linear(ctx, L["wo"], residual=x)
+            if ctx is not None:
+                x = ops.linear(ctx, L["wo"], residual=x)
             h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
             q = ops.linear(h, L["xq"])
             if xkv.kv_off is None:
