@@ -906,12 +906,13 @@ __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, cons
   if (a.bias) {
     const int qrow = qpos < a.bias_rows ? qpos : a.bias_rows - 1;
     const float *brow = a.bias + ((size_t)h * a.bias_rows + qrow) * a.bias_ld;
-    if ((a.bias_ld & 3) == 0 && a.bias_ld >= AM_S && ((uintptr_t)a.bias & 15) == 0) {
+    if ((a.bias_ld & 3) == 0 && a.bias_ld >= 32 * NB && ((uintptr_t)a.bias & 15) == 0) {   // 16-byte loads stay inside the row
 #pragma unroll
       for (int n = 0; n < NB; ++n)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 x = *reinterpret_cast<const float4 *>(brow + 32 * n + 8 * g + 4 * half);
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!(NB == 1 && 8 * g >= tk)) x = *reinterpret_cast<const float4 *>(brow + 32 * n + 8 * g + 4 * half);
           badd[n][4 * g] = x.x; badd[n][4 * g + 1] = x.y; badd[n][4 * g + 2] = x.z; badd[n][4 * g + 3] = x.w;
         }
     } else {
@@ -934,6 +935,11 @@ __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, cons
   for (int n = 0; n < NB; ++n)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      if (NB == 1 && 8 * g >= tk) {   // a key group past the sequence (one-block form): -inf without looking
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc[n][4 * g + e] = -INFINITY;
+        continue;
+      }
       const float4 mk = *reinterpret_cast<const float4 *>(smask + 32 * n + 8 * g + 4 * half);  // 0 | -1e9 (masked key, padded layout)
       const float mk4[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
@@ -953,7 +959,8 @@ __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, cons
   for (int n = 0; n < NB; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = expf(sc[n][r] - m);
+      // exp(-inf - m) = 0 exactly: a dead key group (one-block form) adds +0 to the sum without being evaluated
+      const float e = (NB == 1 && 8 * (r >> 2) >= tk) ? 0.f : expf(sc[n][r] - m);
       sc[n][r] = e;
       sum += e;
     }
@@ -969,6 +976,9 @@ __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, cons
   for (int n = 0; n < NB; ++n)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      // one-block form (queries): the eight keys of group g all lie past tk for most sequences -- their p are exact zeros,
+      // skipping the steps leaves the bits alone (wave-uniform test; per group, not per instruction)
+      if (NB == 1 && 8 * g >= tk) break;
       float vf[4][2];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -1059,6 +1069,73 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnArgs a) {
     case 3: am_wave<3>(a, sk, sv, smask, so, qf, w, h, tk, tq, og); break;
     default: am_wave<4>(a, sk, sv, smask, so, qf, w, h, tk, tq, og); break;
   }
+}
+
+// The same arithmetic for sequences of <= 32 tokens (queries): ONE WAVE per (sequence, head), four of them per workgroup, each
+// with its own K | V | mask region (16.1 KiB) -- am_wave<1> with the wave as its own "workgroup".  The scalar kernel for this
+// shape (attention_varlen_short_kernel: two 64-step fmaf chains and a tk-step context chain per row pair, ~10 of 64 lanes busy)
+// spent ~375 of its 558 us per call in that loop whatever was done to it (profiles/r03_seq2seq_experiments.txt); here a
+// (sequence, head) is 64 matrix instructions.  Summation order as attention_mfma_kernel (fixed: packed == padded bit for bit).
+constexpr int AM32_WAVE_FLOATS = 2 * 32 * AM_D + 32;
+constexpr size_t AM32_LDS = (size_t)4 * AM32_WAVE_FLOATS * sizeof(float);
+__global__ __launch_bounds__(256, 2) void attention_mfma32_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lrow = lane & 31, half = lane >> 5;
+  float *sk = sm + (size_t)w * AM32_WAVE_FLOATS;   // [32][64], chunk-swizzled; the output staging afterwards
+  float *sv = sk + 32 * AM_D;                       // [32][64]; holds Q (chunk-swizzled) until the fragments are read
+  float *smask = sv + 32 * AM_D;                    // [32] additive key mask
+  const long long pair = (long long)blockIdx.x * 4 + w;
+  const bool live = pair < (long long)a.nb * a.H;
+  const int b = live ? (int)(pair / a.H) : 0, h = live ? (int)(pair % a.H) : 0;
+  const long long r0 = a.seq_off ? a.seq_off[b] : 0;
+  const int tk = !live ? 0 : (a.seq_off ? (int)(a.seq_off[b + 1] - r0) : a.tk);   // == tq; a dead wave only keeps the barrier
+  const long long *key_mask = a.seq_off ? nullptr : a.key_mask;
+  const float *qg = a.q + (a.seq_off ? (size_t)r0 * a.q_ts : (size_t)b * a.q_bs) + (size_t)h * AM_D;
+  const float *kg = a.k + (a.seq_off ? (size_t)r0 * a.k_ts : (size_t)b * a.k_bs) + (size_t)h * AM_D;
+  const float *vg = a.v + (a.seq_off ? (size_t)r0 * a.v_ts : (size_t)b * a.v_bs) + (size_t)h * AM_D;
+  const size_t og = (a.seq_off ? (size_t)r0 * a.o_ts : (size_t)b * a.o_bs) + (size_t)h * AM_D;
+  if (lane < 32) smask[lane] = (key_mask && lane < tk && key_mask[(size_t)b * tk + lane] == 0) ? -1e9f : 0.f;
+  // rows of the key groups (of eight) that hold a real key: live rows are loaded, the rest of such a group is zero (its
+  // p are 0, its V rows must be finite); groups past that are never multiplied into anything that is stored
+  const int rows_used = (tk + 7) & ~7;
+  float4 v4[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    v4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * it >= rows_used) continue;   // wave-uniform
+    const int i = lane + 64 * it, r = i >> 4, c4 = i & 15;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4;
+    if (r < tk) {  // rows past tk are zero
+      q4 = *reinterpret_cast<const float4 *>(qg + (size_t)r * a.q_ts + 4 * c4);
+      k4 = *reinterpret_cast<const float4 *>(kg + (size_t)r * a.k_ts + 4 * c4);
+      v4[it] = *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + 4 * c4);
+    }
+    *reinterpret_cast<float4 *>(sk + am_sw4(r, c4)) = k4;
+    *reinterpret_cast<float4 *>(sv + am_sw4(r, c4)) = make_float4(q4.x * a.scale, q4.y * a.scale, q4.z * a.scale, q4.w * a.scale);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float qf[AM_D / 2];                 // the lane's Q fragments: qf[j] = scale * Q[lrow][32 half + j]
+#pragma unroll
+  for (int j4 = 0; j4 < AM_D / 8; ++j4) {
+    const float4 x = *reinterpret_cast<const float4 *>(sv + am_sw4(lrow, 8 * half + j4));
+    qf[4 * j4] = x.x; qf[4 * j4 + 1] = x.y; qf[4 * j4 + 2] = x.z; qf[4 * j4 + 3] = x.w;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    if (4 * it >= rows_used) continue;
+    const int i = lane + 64 * it, r = i >> 4, c4 = i & 15;
+    *reinterpret_cast<float4 *>(sv + r * AM_D + 4 * c4) = v4[it];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  am_wave<1>(a, sk, sv, smask, sk, qf, 0, h, tk, tk, og);
 }
 
 // logits[row, c] = sum_d s[row, d] * (T[trow, c*dim + d] + E[c, d]); one wave per (row, c); trow = row, or
@@ -1168,6 +1245,19 @@ static int ctx_image_check(const CtxImage &ci, int64_t heads, int64_t dh, int64_
   return MEVI_OK;
 }
 
+// Whole sequences of <= 32 tokens with 64-wide heads: the matrix-core kernel (MEVI_ATTN_SHORT=chain keeps the scalar chains)
+static bool short_mfma() {
+  static const bool chain = [] { const char *e = getenv("MEVI_ATTN_SHORT"); return e && strcmp(e, "chain") == 0; }();
+  return !chain;
+}
+static int launch_mfma32(const AttnArgs &a, long long pairs, hipStream_t stream) {
+  MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma32_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM32_LDS));
+  hipLaunchKernelGGL(attention_mfma32_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), AM32_LDS, stream, a);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
 // 64- and 96-wide heads take the LDS-transposed form; MEVI_ATTN_FEW_KEYS=direct keeps the per-lane row walk (A/B, same bits)
 typedef void (*few_keys_fn)(AttnArgs);
 static few_keys_fn few_keys_kernel(int64_t dh, int64_t tk) {
@@ -1215,6 +1305,8 @@ static int attention_launch(const float *q, int64_t q_bs, int64_t q_ts, const fl
     MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
     hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(nb * heads)), dim3(256), AM_LDS, (hipStream_t)stream, a);
+  } else if (!kv_off && kv_div == 1 && tq == tk && tk > 1 && tk <= 32 && dh == AM_D && short_mfma()) {  // query-length sequences
+    return launch_mfma32(a, (long long)nb * heads, (hipStream_t)stream);
   } else if (!kv_off && tq == 1 && tk <= 8) {  // a handful of cached keys: eight (row, head) pairs per wave
     MEVI_REQUIRE(nb * heads < (1LL << 31) - 8, MEVI_ERR_UNSUPPORTED, "attention: too many (row, head) pairs");
     hipLaunchKernelGGL(few_keys_kernel(dh, tk), dim3(blocks4((nb * heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
@@ -1272,6 +1364,7 @@ static int attention_varlen_launch(const float *q, int64_t q_ts, const float *k,
     MEVI_HIP_CHECK(hipGetLastError());
     return MEVI_OK;
   }
+  if (max_len <= 32 && dh == AM_D && short_mfma()) return launch_mfma32(a, pairs, (hipStream_t)stream);
   if (max_len <= 64 && dh == 64) {   // t5-base / bert-base heads, query-length sequences
     hipLaunchKernelGGL(attention_varlen_short_kernel<64>, dim3((unsigned)((pairs + 3) / 4)), dim3(256),
                        (size_t)4 * max_len * 2 * 64 * sizeof(float), (hipStream_t)stream, a, (int)max_len);

@@ -88,6 +88,9 @@ def test_rmsnorm_layernorm_gather_scale(cuda):
     (1, 65, 65, 3, 64, 1, False, 1.0),
     (2, 7, 200, 4, 32, 1, False, 1.0),      # four keys per lane, ragged tail
     (2, 130, 130, 2, 128, 1, True, 1.0),    # causal, tile kernel refused (LDS) -> wave-per-query kernel
+    (3, 17, 17, 12, 64, 1, False, 1.0),     # query-length sequences: one wave per (sequence, head) on the matrix cores
+    (2, 32, 32, 4, 64, 1, True, 0.5),       # the same, causal + scale, all 32 keys
+    (5, 3, 3, 2, 64, 1, False, 1.0),        # the same, one key group
 ])
 def test_attention(cuda, nb, tq, tk, H, dh, kv_div, causal, scale):
     rng = np.random.default_rng(nb * tk)
@@ -218,7 +221,8 @@ def test_fine_stage_matches_reference_procedure(cuda):
 
 @pytest.mark.parametrize("S,H,dh,causal,scale,with_bias", [(32, 12, 64, False, 1.0, True), (40, 4, 16, False, 0.25, False),
                                                           (64, 2, 8, True, 1.0, True), (200, 3, 32, False, 1.0, True),
-                                                          (128, 12, 64, False, 1.0, True), (100, 2, 64, False, 0.125, False)])
+                                                          (128, 12, 64, False, 1.0, True), (100, 2, 64, False, 0.125, False),
+                                                          (24, 12, 64, True, 1.0, True), (12, 3, 64, False, 0.125, False)])
 def test_packed_attention_equals_padded_attention_bit_for_bit(cuda, S, H, dh, causal, scale, with_bias):
     """attention_varlen on packed rows (ragged lengths incl. 0, 1 and S) against attention on the zero-padded [B, S]
     layout with the key mask: identical bits on every real row; and against a torch fp32 softmax (5e-5)."""
@@ -331,7 +335,7 @@ def _image_to_f32(sr):
     return x.to(torch.float32)
 
 
-@pytest.mark.parametrize("form", ["padded", "cross_group", "cross_packed", "varlen", "cached", "passage_mfma"])
+@pytest.mark.parametrize("form", ["padded", "cross_group", "cross_packed", "varlen", "varlen_mfma32", "cached", "passage_mfma"])
 def test_attention_context_written_as_split_image(cuda, form):
     """mevi_attention*_split_f16: the context goes straight into the o-projection's (hi, lo) f16 image with ONE exponent from
     a bound on |V| (ops.ctx_bound).  The image must decode to the f32 kernel's context to 2^-21 of the bound's binade (22
@@ -359,6 +363,13 @@ def test_attention_context_written_as_split_image(cuda, form):
         T = int(off[-1])
         q, k, v = rnd(4 * 10, 1, hd), rnd(T, hd), rnd(T, hd)
         run = lambda **e: ops.attention(q, k, v, H, kv_div=10, kv_off=off, kv_longest=30, **e)     # noqa: E731
+    elif form == "varlen_mfma32":
+        lens = torch.tensor([7, 12, 1, 30, 5, 16, 17, 8, 9], device=cuda)
+        off = torch.zeros(10, dtype=torch.int64, device=cuda)
+        off[1:] = lens.cumsum(0)
+        T = int(off[-1])
+        q, k, v, bias = rnd(T, hd), rnd(T, hd), rnd(T, hd), rnd(H, 32, 32)
+        run = lambda **e: ops.attention_varlen(q, k, v, off, 30, H, bias=bias, **e)     # noqa: E731
     elif form == "varlen":
         lens = torch.tensor([7, 12, 1, 33, 5], device=cuda)
         off = torch.zeros(6, dtype=torch.int64, device=cuda)

@@ -8,5 +8,5 @@ for v in "$@"; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/bench_tower.py > $OUT/log.txt 2>&1
   echo "== $v: $(tail -n 1 $OUT/log.txt)"
   f=$(find $OUT -name "*kernel_stats.csv" | head -1)
-  grep -i "varlen\|attention_kernel\|rmsnorm_split\|split_rows" $f | cut -d, -f1-4 | cut -c1-150
+  grep -i "varlen\|mfma32\|attention_kernel" $f | cut -d, -f1-4 | cut -c1-150
 done
