@@ -911,8 +911,7 @@ __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, cons
       for (int n = 0; n < NB; ++n)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (!(NB == 1 && 8 * g >= tk)) x = *reinterpret_cast<const float4 *>(brow + 32 * n + 8 * g + 4 * half);
+          const float4 x = *reinterpret_cast<const float4 *>(brow + 32 * n + 8 * g + 4 * half);
           badd[n][4 * g] = x.x; badd[n][4 * g + 1] = x.y; badd[n][4 * g + 2] = x.z; badd[n][4 * g + 3] = x.w;
         }
     } else {
@@ -935,11 +934,6 @@ __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, cons
   for (int n = 0; n < NB; ++n)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      if (NB == 1 && 8 * g >= tk) {   // a key group past the sequence (one-block form): -inf without looking
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sc[n][4 * g + e] = -INFINITY;
-        continue;
-      }
       const float4 mk = *reinterpret_cast<const float4 *>(smask + 32 * n + 8 * g + 4 * half);  // 0 | -1e9 (masked key, padded layout)
       const float mk4[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
@@ -959,8 +953,7 @@ __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, cons
   for (int n = 0; n < NB; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      // exp(-inf - m) = 0 exactly: a dead key group (one-block form) adds +0 to the sum without being evaluated
-      const float e = (NB == 1 && 8 * (r >> 2) >= tk) ? 0.f : expf(sc[n][r] - m);
+      const float e = expf(sc[n][r] - m);
       sc[n][r] = e;
       sum += e;
     }
@@ -976,9 +969,6 @@ __device__ __forceinline__ void am_wave(const AttnArgs &a, const float *sk, cons
   for (int n = 0; n < NB; ++n)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      // one-block form (queries): the eight keys of group g all lie past tk for most sequences -- their p are exact zeros,
-      // skipping the steps leaves the bits alone (wave-uniform test; per group, not per instruction)
-      if (NB == 1 && 8 * g >= tk) break;
       float vf[4][2];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -1071,71 +1061,226 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnArgs a) {
   }
 }
 
-// The same arithmetic for sequences of <= 32 tokens (queries): ONE WAVE per (sequence, head), four of them per workgroup, each
-// with its own K | V | mask region (16.1 KiB) -- am_wave<1> with the wave as its own "workgroup".  The scalar kernel for this
-// shape (attention_varlen_short_kernel: two 64-step fmaf chains and a tk-step context chain per row pair, ~10 of 64 lanes busy)
-// spent ~375 of its 558 us per call in that loop whatever was done to it (profiles/r03_seq2seq_experiments.txt); here a
-// (sequence, head) is 64 matrix instructions.  Summation order as attention_mfma_kernel (fixed: packed == padded bit for bit).
-constexpr int AM32_WAVE_FLOATS = 2 * 32 * AM_D + 32;
-constexpr size_t AM32_LDS = (size_t)4 * AM32_WAVE_FLOATS * sizeof(float);
-__global__ __launch_bounds__(256, 2) void attention_mfma32_kernel(AttnArgs a) {
+// Attention of SMALL groups on the f32 matrix cores in 16 x 16 blocks (v_mfma_f32_16x16x4_f32): one wave per (group, head),
+// a group = the <= 32 tokens of a sequence (self-attention of the query encoders, mode 0: rows attend to the rows of their own
+// sequence) or the <= 32 rows that share one K|V (decode-step cross-attention, mode 1: the kv_div beams of a query against
+// its <= 32 encoder positions; kv_div = 1: the towers' single decoder position).  A typical group -- 11 tokens, or 10 beams x
+// 11 keys -- is ONE block pair = 32 matrix instructions of 32 cycles; 32 x 32 blocks (am_wave<1>, tried first: 401 us per call
+// for the encoders' self-attention) cost 64 instructions of 64 cycles for the same group, the scalar kernels (549 us) a
+// 64-step fmaf chain per (row, key) with most lanes idle.
+//   S^T = K . Q^T   per (key block, query block): A = K (lane: key l & 15, dims 4 s + (l >> 4)), B = Q^T -- a lane ends up with
+//                    keys 16 kb + 4 (l >> 4) + r (r = 0..3) of ONE query (l & 15); the softmax reduces over r and lanes l ^ 16, l ^ 32
+//   O^T = V^T . P^T per (query block, 16-dim tile c): step r multiplies the four keys the lanes of a column hold in
+//                    register r (keys 4 (l >> 4) + r) -- any pairing the A operand follows, as in attention_mfma_kernel
+// Blocks are independent and a masked / absent key contributes exact zeros, so the padded and the packed layouts agree bit for
+// bit, whatever the padding.  Operands pass through LDS once (row-contiguous global loads; K and Q rows stored with their
+// dims permuted d -> (d & 3) * 16 + (d >> 2) so that a lane's 16 fragment values are four b128 reads); Q passes through the V
+// region on its way to the registers.  Summation order (fixed): scores over dims in groups (4 s .. 4 s + 3), row sums over
+// the lane's registers then lanes ^16, ^32, context over keys in groups {r, 4 + r, 8 + r, 12 + r} per block.
+typedef float a16_f4 __attribute__((ext_vector_type(4)));
+constexpr int A16_LD = 68;                               // floats per staged row: 16-byte aligned, 4 banks apart
+constexpr int A16_WAVE_FLOATS = 2 * 32 * A16_LD + 32;    // K | V (Q first) | key mask
+constexpr size_t A16_LDS = (size_t)4 * A16_WAVE_FLOATS * sizeof(float);
+__global__ __launch_bounds__(256, 2) void attention_mfma16_kernel(AttnArgs a, int mode) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int lrow = lane & 31, half = lane >> 5;
-  float *sk = sm + (size_t)w * AM32_WAVE_FLOATS;   // [32][64], chunk-swizzled; the output staging afterwards
-  float *sv = sk + 32 * AM_D;                       // [32][64]; holds Q (chunk-swizzled) until the fragments are read
-  float *smask = sv + 32 * AM_D;                    // [32] additive key mask
+  constexpr int D = 64;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n = lane & 15, kq = lane >> 4;
+  float *sk = sm + (size_t)w * A16_WAVE_FLOATS, *sv = sk + 32 * A16_LD, *smask = sv + 32 * A16_LD;
+  const long long ngroups = mode == 0 ? a.nb : a.nb / a.kv_div;
   const long long pair = (long long)blockIdx.x * 4 + w;
-  const bool live = pair < (long long)a.nb * a.H;
-  const int b = live ? (int)(pair / a.H) : 0, h = live ? (int)(pair % a.H) : 0;
-  const long long r0 = a.seq_off ? a.seq_off[b] : 0;
-  const int tk = !live ? 0 : (a.seq_off ? (int)(a.seq_off[b + 1] - r0) : a.tk);   // == tq; a dead wave only keeps the barrier
-  const long long *key_mask = a.seq_off ? nullptr : a.key_mask;
-  const float *qg = a.q + (a.seq_off ? (size_t)r0 * a.q_ts : (size_t)b * a.q_bs) + (size_t)h * AM_D;
-  const float *kg = a.k + (a.seq_off ? (size_t)r0 * a.k_ts : (size_t)b * a.k_bs) + (size_t)h * AM_D;
-  const float *vg = a.v + (a.seq_off ? (size_t)r0 * a.v_ts : (size_t)b * a.v_bs) + (size_t)h * AM_D;
-  const size_t og = (a.seq_off ? (size_t)r0 * a.o_ts : (size_t)b * a.o_bs) + (size_t)h * AM_D;
-  if (lane < 32) smask[lane] = (key_mask && lane < tk && key_mask[(size_t)b * tk + lane] == 0) ? -1e9f : 0.f;
-  // rows of the key groups (of eight) that hold a real key: live rows are loaded, the rest of such a group is zero (its
-  // p are 0, its V rows must be finite); groups past that are never multiplied into anything that is stored
-  const int rows_used = (tk + 7) & ~7;
+  const bool live = pair < ngroups * a.H;
+  const long long gi = live ? pair / a.H : 0;
+  const int h = live ? (int)(pair - gi * a.H) : 0;
+  size_t qoff, ooff, q_rs, o_rs;
+  const float *kb_, *vb_;
+  size_t k_rs, v_rs;
+  int nq, tk, qstep;
+  const long long *mrow = nullptr;
+  if (mode == 0) {
+    if (a.seq_off) {
+      const long long r0 = a.seq_off[gi];
+      tk = (int)(a.seq_off[gi + 1] - r0);
+      qoff = (size_t)r0 * a.q_ts, ooff = (size_t)r0 * a.o_ts;
+      kb_ = a.k + (size_t)r0 * a.k_ts, vb_ = a.v + (size_t)r0 * a.v_ts;
+    } else {
+      tk = a.tk;
+      qoff = (size_t)gi * a.q_bs, ooff = (size_t)gi * a.o_bs;
+      kb_ = a.k + (size_t)gi * a.k_bs, vb_ = a.v + (size_t)gi * a.v_bs;
+      if (a.key_mask) mrow = a.key_mask + (size_t)gi * a.tk;
+    }
+    q_rs = a.q_ts, o_rs = a.o_ts, nq = tk, qstep = 1;
+  } else {
+    qoff = (size_t)gi * a.kv_div * a.q_bs, ooff = (size_t)gi * a.kv_div * a.o_bs;
+    q_rs = a.q_bs, o_rs = a.o_bs, nq = a.kv_div, qstep = 0;
+    if (a.kv_off) {
+      const long long r0 = a.kv_off[gi];
+      tk = (int)(a.kv_off[gi + 1] - r0);
+      kb_ = a.k + (size_t)r0 * a.k_ts, vb_ = a.v + (size_t)r0 * a.v_ts;
+    } else {
+      tk = a.tk;
+      kb_ = a.k + (size_t)gi * a.k_bs, vb_ = a.v + (size_t)gi * a.v_bs;
+      if (a.key_mask) mrow = a.key_mask + (size_t)gi * a.tk;
+    }
+  }
+  k_rs = a.k_ts, v_rs = a.v_ts;
+  if (!live) nq = tk = 0;
+  const float *qg = a.q + qoff + (size_t)h * D;
+  const float *kg = kb_ + (size_t)h * D, *vg = vb_ + (size_t)h * D;
+  ooff += (size_t)h * D;
+  const int KB = (tk + 15) >> 4, QB = (nq + 15) >> 4;      // <= 2 each (wave-uniform)
+  const int rows_staged = 16 * (KB > QB ? KB : QB);
+  if (lane < 32) smask[lane] = (mrow && lane < tk && mrow[lane] == 0) ? -1e9f : 0.f;
+  // staging: iteration `it` = rows 4 it .. 4 it + 3, 16 lanes x 16 B per row
   float4 v4[8];
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     v4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (4 * it >= rows_used) continue;   // wave-uniform
-    const int i = lane + 64 * it, r = i >> 4, c4 = i & 15;
+    if (4 * it >= rows_staged) continue;   // wave-uniform
+    const int r = 4 * it + kq, c4 = n;
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4;
-    if (r < tk) {  // rows past tk are zero
-      q4 = *reinterpret_cast<const float4 *>(qg + (size_t)r * a.q_ts + 4 * c4);
-      k4 = *reinterpret_cast<const float4 *>(kg + (size_t)r * a.k_ts + 4 * c4);
-      v4[it] = *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + 4 * c4);
+    if (r < tk) {
+      k4 = *reinterpret_cast<const float4 *>(kg + (size_t)r * k_rs + 4 * c4);
+      v4[it] = *reinterpret_cast<const float4 *>(vg + (size_t)r * v_rs + 4 * c4);
     }
-    *reinterpret_cast<float4 *>(sk + am_sw4(r, c4)) = k4;
-    *reinterpret_cast<float4 *>(sv + am_sw4(r, c4)) = make_float4(q4.x * a.scale, q4.y * a.scale, q4.z * a.scale, q4.w * a.scale);
+    if (r < nq) q4 = *reinterpret_cast<const float4 *>(qg + (size_t)r * q_rs + 4 * c4);
+    float *kr = sk + r * A16_LD + c4, *qr = sv + r * A16_LD + c4;   // dim 4 c4 + e -> position e * 16 + c4
+    kr[0] = k4.x; kr[16] = k4.y; kr[32] = k4.z; kr[48] = k4.w;
+    qr[0] = q4.x * a.scale; qr[16] = q4.y * a.scale; qr[32] = q4.z * a.scale; qr[48] = q4.w * a.scale;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float qf[AM_D / 2];                 // the lane's Q fragments: qf[j] = scale * Q[lrow][32 half + j]
+  float qf[2][16];
 #pragma unroll
-  for (int j4 = 0; j4 < AM_D / 8; ++j4) {
-    const float4 x = *reinterpret_cast<const float4 *>(sv + am_sw4(lrow, 8 * half + j4));
-    qf[4 * j4] = x.x; qf[4 * j4 + 1] = x.y; qf[4 * j4 + 2] = x.z; qf[4 * j4 + 3] = x.w;
-  }
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qb < QB) x = *reinterpret_cast<const float4 *>(sv + (16 * qb + n) * A16_LD + kq * 16 + 4 * j);
+      qf[qb][4 * j] = x.x; qf[qb][4 * j + 1] = x.y; qf[qb][4 * j + 2] = x.z; qf[qb][4 * j + 3] = x.w;
+    }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    if (4 * it >= rows_used) continue;
-    const int i = lane + 64 * it, r = i >> 4, c4 = i & 15;
-    *reinterpret_cast<float4 *>(sv + r * AM_D + 4 * c4) = v4[it];
+    if (4 * it >= 16 * KB) continue;
+    *reinterpret_cast<float4 *>(sv + (4 * it + kq) * A16_LD + 4 * n) = v4[it];
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // S^T blocks
+  a16_f4 sc[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) sc[kb][qb] = a16_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    if (kb >= KB) break;
+    float kf[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 x = *reinterpret_cast<const float4 *>(sk + (16 * kb + n) * A16_LD + kq * 16 + 4 * j);
+      kf[4 * j] = x.x; kf[4 * j + 1] = x.y; kf[4 * j + 2] = x.z; kf[4 * j + 3] = x.w;
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if (qb >= QB) break;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[qb][s], sc[kb][qb], 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // V is in place for the context phase
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  am_wave<1>(a, sk, sv, smask, sk, qf, 0, h, tk, tk, og);
+  // scores + bias + masks, softmax per query column
+  const bool bias4 = a.bias && (a.bias_ld & 3) == 0 && a.bias_ld >= 16 * KB && ((uintptr_t)a.bias & 15) == 0;
+  float sum[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    sum[qb] = 1.f;
+    if (qb >= QB) break;
+    const int qpos = a.q_pos0 + qstep * (16 * qb + n);
+    const float *brow = nullptr;
+    if (a.bias) brow = a.bias + ((size_t)h * a.bias_rows + (qpos < a.bias_rows ? qpos : a.bias_rows - 1)) * a.bias_ld;
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb >= KB) break;
+      const int k0 = 16 * kb + 4 * kq;
+      float badd[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+        if (bias4) {
+          const float4 x = *reinterpret_cast<const float4 *>(brow + k0);
+          badd[0] = x.x; badd[1] = x.y; badd[2] = x.z; badd[3] = x.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) badd[r] = brow[k0 + r < a.bias_ld ? k0 + r : a.bias_ld - 1];
+        }
+      }
+      const float4 mk = *reinterpret_cast<const float4 *>(smask + k0);
+      const float mk4[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + r;
+        float add = mk4[r] + badd[r];
+        add += (a.causal && key > qpos) ? -1e9f : 0.f;
+        const float v = key < tk ? sc[kb][qb][r] + add : -INFINITY;
+        sc[kb][qb][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sm_ = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb >= KB) break;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(sc[kb][qb][r] - m);
+        sc[kb][qb][r] = e;
+        sm_ += e;
+      }
+    }
+    sm_ += __shfl_xor(sm_, 16);
+    sm_ += __shfl_xor(sm_, 32);
+    sum[qb] = sm_;
+  }
+  // O^T = V^T . P^T
+  a16_f4 o[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[qb][c] = a16_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    if (kb >= KB) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float vf[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vf[c] = sv[(16 * kb + 4 * kq + r) * A16_LD + 16 * c + n];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        if (qb >= QB) break;
+        const float p = sc[kb][qb][r] / sum[qb];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[qb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c], p, o[qb][c], 0, 0, 0);
+      }
+    }
+  }
+  // a lane holds dims 16 c + 4 kq .. + 3 of query 16 qb + n
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    if (qb >= QB) break;
+    const int qi = 16 * qb + n;
+    if (qi < nq) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        put_ctx4(a, ooff + (size_t)qi * o_rs + 16 * c + 4 * kq, make_float4(o[qb][c][0], o[qb][c][1], o[qb][c][2], o[qb][c][3]));
+    }
+  }
 }
 
 // logits[row, c] = sum_d s[row, d] * (T[trow, c*dim + d] + E[c, d]); one wave per (row, c); trow = row, or
@@ -1246,18 +1391,18 @@ static int ctx_image_check(const CtxImage &ci, int64_t heads, int64_t dh, int64_
 }
 
 // Whole sequences of <= 32 tokens with 64-wide heads: the matrix-core kernel (MEVI_ATTN_SHORT=chain keeps the scalar chains)
+// Groups of <= 32 rows / keys with 64-wide heads: the matrix-core kernel (MEVI_ATTN_SHORT=chain keeps the scalar kernels)
 static bool short_mfma() {
   static const bool chain = [] { const char *e = getenv("MEVI_ATTN_SHORT"); return e && strcmp(e, "chain") == 0; }();
   return !chain;
 }
-static int launch_mfma32(const AttnArgs &a, long long pairs, hipStream_t stream) {
-  MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma32_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM32_LDS));
-  hipLaunchKernelGGL(attention_mfma32_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), AM32_LDS, stream, a);
+static int launch_mfma16(const AttnArgs &a, int mode, long long pairs, hipStream_t stream) {
+  MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma16_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)A16_LDS));
+  hipLaunchKernelGGL(attention_mfma16_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), A16_LDS, stream, a, mode);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }
-
 // 64- and 96-wide heads take the LDS-transposed form; MEVI_ATTN_FEW_KEYS=direct keeps the per-lane row walk (A/B, same bits)
 typedef void (*few_keys_fn)(AttnArgs);
 static few_keys_fn few_keys_kernel(int64_t dh, int64_t tk) {
@@ -1306,7 +1451,10 @@ static int attention_launch(const float *q, int64_t q_bs, int64_t q_ts, const fl
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
     hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(nb * heads)), dim3(256), AM_LDS, (hipStream_t)stream, a);
   } else if (!kv_off && kv_div == 1 && tq == tk && tk > 1 && tk <= 32 && dh == AM_D && short_mfma()) {  // query-length sequences
-    return launch_mfma32(a, (long long)nb * heads, (hipStream_t)stream);
+    return launch_mfma16(a, 0, (long long)nb * heads, (hipStream_t)stream);
+  } else if (tq == 1 && tk <= 32 && kv_div <= 32 && nb % kv_div == 0 && dh == AM_D && short_mfma() &&
+             (kv_off || key_mask || kv_div > 1 || tk > 8)) {   // a few rows against a few shared keys (cross-attention)
+    return launch_mfma16(a, 1, (nb / kv_div) * heads, (hipStream_t)stream);
   } else if (!kv_off && tq == 1 && tk <= 8) {  // a handful of cached keys: eight (row, head) pairs per wave
     MEVI_REQUIRE(nb * heads < (1LL << 31) - 8, MEVI_ERR_UNSUPPORTED, "attention: too many (row, head) pairs");
     hipLaunchKernelGGL(few_keys_kernel(dh, tk), dim3(blocks4((nb * heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
@@ -1364,7 +1512,8 @@ static int attention_varlen_launch(const float *q, int64_t q_ts, const float *k,
     MEVI_HIP_CHECK(hipGetLastError());
     return MEVI_OK;
   }
-  if (max_len <= 32 && dh == AM_D && short_mfma()) return launch_mfma32(a, pairs, (hipStream_t)stream);
+  if (max_len <= 32 && dh == AM_D && short_mfma())
+    return launch_mfma16(a, 0, pairs, (hipStream_t)stream);
   if (max_len <= 64 && dh == 64) {   // t5-base / bert-base heads, query-length sequences
     hipLaunchKernelGGL(attention_varlen_short_kernel<64>, dim3((unsigned)((pairs + 3) / 4)), dim3(256),
                        (size_t)4 * max_len * 2 * 64 * sizeof(float), (hipStream_t)stream, a, (int)max_len);

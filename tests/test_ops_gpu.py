@@ -88,9 +88,12 @@ def test_rmsnorm_layernorm_gather_scale(cuda):
     (1, 65, 65, 3, 64, 1, False, 1.0),
     (2, 7, 200, 4, 32, 1, False, 1.0),      # four keys per lane, ragged tail
     (2, 130, 130, 2, 128, 1, True, 1.0),    # causal, tile kernel refused (LDS) -> wave-per-query kernel
-    (3, 17, 17, 12, 64, 1, False, 1.0),     # query-length sequences: one wave per (sequence, head) on the matrix cores
-    (2, 32, 32, 4, 64, 1, True, 0.5),       # the same, causal + scale, all 32 keys
-    (5, 3, 3, 2, 64, 1, False, 1.0),        # the same, one key group
+    (3, 17, 17, 12, 64, 1, False, 1.0),     # query-length sequences: one wave per (sequence, head), 16 x 16 matrix-core blocks
+    (2, 32, 32, 4, 64, 1, True, 0.5),       # the same, causal + scale, 2 x 2 blocks
+    (5, 3, 3, 2, 64, 1, False, 1.0),        # the same, one block
+    (30, 1, 21, 12, 64, 10, False, 1.0),    # decode-step cross-attention: ten beams per query, 21 keys (two key blocks)
+    (7, 1, 12, 4, 64, 1, False, 0.5),       # the towers' single decoder position against 12 keys
+    (64, 1, 9, 2, 64, 32, True, 1.0),       # 32 rows per group (two query blocks), causal at q_pos0
 ])
 def test_attention(cuda, nb, tq, tk, H, dh, kv_div, causal, scale):
     rng = np.random.default_rng(nb * tk)
@@ -335,7 +338,7 @@ def _image_to_f32(sr):
     return x.to(torch.float32)
 
 
-@pytest.mark.parametrize("form", ["padded", "cross_group", "cross_packed", "varlen", "varlen_mfma32", "cached", "passage_mfma"])
+@pytest.mark.parametrize("form", ["padded", "cross_group", "cross_packed", "varlen", "varlen_mfma16", "cached", "passage_mfma"])
 def test_attention_context_written_as_split_image(cuda, form):
     """mevi_attention*_split_f16: the context goes straight into the o-projection's (hi, lo) f16 image with ONE exponent from
     a bound on |V| (ops.ctx_bound).  The image must decode to the f32 kernel's context to 2^-21 of the bound's binade (22
@@ -363,7 +366,7 @@ def test_attention_context_written_as_split_image(cuda, form):
         T = int(off[-1])
         q, k, v = rnd(4 * 10, 1, hd), rnd(T, hd), rnd(T, hd)
         run = lambda **e: ops.attention(q, k, v, H, kv_div=10, kv_off=off, kv_longest=30, **e)     # noqa: E731
-    elif form == "varlen_mfma32":
+    elif form == "varlen_mfma16":
         lens = torch.tensor([7, 12, 1, 30, 5, 16, 17, 8, 9], device=cuda)
         off = torch.zeros(10, dtype=torch.int64, device=cuda)
         off[1:] = lens.cumsum(0)
