@@ -1446,13 +1446,16 @@ static int attention_launch(const float *q, int64_t q_bs, int64_t q_ts, const fl
   a.kv_off = reinterpret_cast<const long long *>(kv_off);
   a.key_rows = nullptr;
   const size_t tile_lds = (size_t)tk * (3 * dh + 1) * sizeof(float);
+  // attention_mfma16_kernel moves rows as 16-byte pieces (q / k strides are checked above)
+  const bool mfma16_aligned = v_bs % 4 == 0 && v_ts % 4 == 0 && o_bs % 4 == 0 && o_ts % 4 == 0 &&
+                              (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0;
   if (!kv_off && kv_div == 1 && tq == tk && tk > 64 && tk <= AM_S && dh == AM_D) {  // passages: f32 matrix cores
     MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
     hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(nb * heads)), dim3(256), AM_LDS, (hipStream_t)stream, a);
-  } else if (!kv_off && kv_div == 1 && tq == tk && tk > 1 && tk <= 32 && dh == AM_D && short_mfma()) {  // query-length sequences
+  } else if (!kv_off && kv_div == 1 && tq == tk && tk > 1 && tk <= 32 && dh == AM_D && short_mfma() && mfma16_aligned) {  // query-length sequences
     return launch_mfma16(a, 0, (long long)nb * heads, (hipStream_t)stream);
-  } else if (tq == 1 && tk <= 32 && kv_div <= 32 && nb % kv_div == 0 && dh == AM_D && short_mfma() &&
+  } else if (tq == 1 && tk <= 32 && kv_div <= 32 && nb % kv_div == 0 && dh == AM_D && short_mfma() && mfma16_aligned &&
              (kv_off || key_mask || kv_div > 1 || tk > 8)) {   // a few rows against a few shared keys (cross-attention)
     return launch_mfma16(a, 1, (nb / kv_div) * heads, (hipStream_t)stream);
   } else if (!kv_off && tq == 1 && tk <= 8) {  // a handful of cached keys: eight (row, head) pairs per wave
@@ -1512,7 +1515,8 @@ static int attention_varlen_launch(const float *q, int64_t q_ts, const float *k,
     MEVI_HIP_CHECK(hipGetLastError());
     return MEVI_OK;
   }
-  if (max_len <= 32 && dh == AM_D && short_mfma())
+  if (max_len <= 32 && dh == AM_D && short_mfma() && o_ts % 4 == 0 &&
+      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0)
     return launch_mfma16(a, 0, pairs, (hipStream_t)stream);
   if (max_len <= 64 && dh == 64) {   // t5-base / bert-base heads, query-length sequences
     hipLaunchKernelGGL(attention_varlen_short_kernel<64>, dim3((unsigned)((pairs + 3) / 4)), dim3(256),
