@@ -45,6 +45,9 @@ class BertEncoder:
                 ln2=(g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"))))
         ops.prepare_weights(self.layers, ("wqkv", "wo", "wi", "wo2"))
         self.d = self.word.shape[1]
+        for l, L in enumerate(self.layers):   # |V| bound of a layer: its input is the previous LayerNorm's output (ops.ctx_bound)
+            ln_w, ln_b = self.emb_ln if l == 0 else self.layers[l - 1]["ln2"]
+            L["vb"] = ops.ctx_bound(ops.norm_out_bound(ln_w, self.d, ln_b), L["wqkv"], v_bias=L["bqkv"])
         self.pack = True   # padding-free per-token operators (see forward)
         self.dh = self.d // num_heads
 
@@ -77,12 +80,16 @@ class BertEncoder:
                 q3 = ops.linear(xg, L["wqkv"], bias=L["bqkv"]).view(B, S, 3 * d)
             elif varlen:
                 q2 = ops.linear(xg, L["wqkv"], bias=L["bqkv"])
-                ctx = ops.attention_varlen(q2[:, :d], q2[:, d:2 * d], q2[:, 2 * d:], seq_off, longest, self.H, scale=scale)
+                ctx = ops.attention_varlen(q2[:, :d], q2[:, d:2 * d], q2[:, 2 * d:], seq_off, longest, self.H, scale=scale,
+                                           split_bound=L["vb"])
             else:
                 q3 = ops.scatter_rows(ops.linear(xg, L["wqkv"], bias=L["bqkv"]), idx, qkv).view(B, S, 3 * d)
             if not varlen:
+                vb = L["vb"] if idx is None else None      # the scattered form gathers its context rows: f32
                 ctx = ops.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], self.H, key_mask=attention_mask,
-                                    scale=scale).view(B * S, d)
+                                    scale=scale, split_bound=vb)
+                if vb is None:
+                    ctx = ctx.view(B * S, d)
                 if idx is not None:
                     ctx = ops.gather_rows(ctx, idx)
             a = ops.linear(ctx, L["wo"], bias=L["bo"])
