@@ -420,3 +420,32 @@ def test_tower_directory_with_safetensors_only(tmp_path):
         os.makedirs(tmp_path / "none")
         json.dump(cfg, open(tmp_path / "none" / "config.json", "w"))
         load_tower_weights(str(tmp_path / "none"))
+
+
+def test_context_image_exponent_and_bounds():
+    """Host side of the split-image attention contexts (mevi_amd/ops.py): the exponent of a bound puts it in [2^14, 2^15) as
+    pow2_exp of csrc/gemm_split.hip does for a row maximum, and the |V| bound is a true bound for rmsnorm / layernorm inputs."""
+    import math
+
+    from mevi_amd import ops
+
+    for b in (1e-30, 3.7e-5, 0.999, 1.0, 1.0001, 37.0, 16384.0, 32768.0, 1e20):
+        e = ops._pow2_exp(b)
+        if -100 < e < 100:
+            assert 2.0 ** 14 <= b * 2.0 ** e < 2.0 ** 15, (b, e)
+    assert ops._pow2_exp(0.0) == 0 and ops._pow2_exp(float("inf")) == 0 and ops._pow2_exp(float("nan")) == 0
+    assert ops._pow2_exp(1e-40) == 100 and ops._pow2_exp(1e38) == -100
+    g = torch.Generator().manual_seed(3)
+    d, inner = 96, 64
+    ln_w, ln_b = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    wv, bv = torch.randn(inner, d, generator=g), torch.randn(inner, generator=g)
+    x = torch.randn(50, d, generator=g) * torch.logspace(-3, 3, 50)[:, None]
+    rms = x / torch.sqrt((x * x).mean(1, keepdim=True) + 1e-6) * ln_w                      # T5LayerNorm
+    ln = torch.nn.functional.layer_norm(x, (d,), ln_w, ln_b, 1e-12)                          # BERT LayerNorm
+    wmax = float(wv.norm(dim=1).max())
+    assert float(rms.norm(dim=1).max()) <= ops.norm_out_bound(ln_w, d) * (1 + 1e-6)
+    assert float(ln.norm(dim=1).max()) <= ops.norm_out_bound(ln_w, d, ln_b) * (1 + 1e-6)
+    assert float((rms @ wv.T).abs().max()) <= ops.norm_out_bound(ln_w, d) * wmax * 1.001
+    assert float((ln @ wv.T + bv).abs().max()) <= ops.norm_out_bound(ln_w, d, ln_b) * wmax * 1.001 + float(bv.abs().max())
+    assert math.isclose(ops.norm_out_bound(ln_w, d), math.sqrt(d) * float(ln_w.abs().max()), rel_tol=1e-6)
+    assert ops.ctx_bound(None, None) is None      # no bound, no image: the f32 form runs
