@@ -228,8 +228,9 @@ class DecoderStack:
             sa, xa = f"{p}.0.SelfAttention", f"{p}.1.EncDecAttention"
             self.layers.append(dict(
                 ln0=_dev(w, f"{p}.0.layer_norm.weight", device),
-                wq=_dev(w, f"{sa}.q.weight", device),
-                wkv=torch.cat([_dev(w, f"{sa}.k.weight", device), _dev(w, f"{sa}.v.weight", device)]).contiguous(),
+                # q | k | v as ONE projection: a decode step writes all three into the cache row of its position (q is read back
+                # from there), one GEMM of 9 column tiles instead of 3 + 6 -- one tile round less per layer and step on 256 CUs
+                wqkv=torch.cat([_dev(w, f"{sa}.{n}.weight", device) for n in "qkv"]).contiguous(),
                 wo=_dev(w, f"{sa}.o.weight", device),
                 ln1=_dev(w, f"{p}.1.layer_norm.weight", device),
                 xq=_dev(w, f"{xa}.q.weight", device),
@@ -238,17 +239,17 @@ class DecoderStack:
                 ln2=_dev(w, f"{p}.2.layer_norm.weight", device),
                 wi=_dev(w, f"{p}.2.DenseReluDense.wi.weight", device),
                 wo2=_dev(w, f"{p}.2.DenseReluDense.wo.weight", device)))
-        keys = ("wq", "wkv", "wo", "xq", "xkv", "xo", "wi", "wo2")
+        keys = ("wqkv", "wo", "xq", "xkv", "xo", "wi", "wo2")
         if max_len == 1 and ops.GEMM_MODE == "split":
             # A single-position decoder (the towers) attends to ONE key: the softmax weight is exactly 1, the context is v, and
             # o(v(h)) = h (Wo Wv)^T -- one projection instead of two (the product is taken once, in f64).  MEVI_GEMM=exact keeps
             # the two sequential-chain GEMMs of the reference.
             for L in self.layers:
-                L["wov"] = (L["wo"].double() @ L["wkv"][dims.inner:].double()).float().contiguous()
+                L["wov"] = (L["wo"].double() @ L["wqkv"][2 * dims.inner:].double()).float().contiguous()
             keys += ("wov",)
         ops.prepare_weights(self.layers, keys)
         for L in self.layers:
-            L["vb"] = ops.ctx_bound(ops.norm_out_bound(L["ln0"], dims.d_model), L["wkv"])
+            L["vb"] = ops.ctx_bound(ops.norm_out_bound(L["ln0"], dims.d_model), L["wqkv"])
             L["xvb"] = None          # cross-attention: needs the encoder's output norm (set_encoder_norm)
         self.final_ln = _dev(w, f"{prefix}.final_layer_norm.weight", device)
         rel = _dev(w, f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight", device)
@@ -288,12 +289,13 @@ class DecoderStack:
         return CrossKV(out, enc_mask)
 
     def new_cache(self, rows):
-        return [torch.empty((rows, self.max_len, 2 * self.d.inner), dtype=torch.float32, device=self.dev)
+        """Per layer f32 [rows, T, 3 * inner]: q | k | v of every position (q of position t is only read at step t)."""
+        return [torch.empty((rows, self.max_len, 3 * self.d.inner), dtype=torch.float32, device=self.dev)
                 for _ in self.layers]
 
     def step(self, x, t, cache, xkv, enc_mask, kv_div, key_rows=None):
-        """x f32[n, d_model]: embeddings of the token at position t of every row; cache[l] f32[n, T, 2*inner]
-        holds self-attention K|V of positions < t (position t is written here); rows r attend to the
+        """x f32[n, d_model]: embeddings of the token at position t of every row; cache[l] f32[n, T, 3*inner]
+        holds self-attention q|K|V of positions < t (position t is written here); rows r attend to the
         encoder states of query r // kv_div (`xkv`: the CrossKV of cross_kv, which carries its own mask / offsets;
         `enc_mask` is kept for callers of the older signature).  Returns the final-normed hidden state f32[n, d_model].
 
@@ -313,18 +315,18 @@ class DecoderStack:
                 # one key: its softmax weight is exp(0) / exp(0) = 1 exactly, so the attention output IS v -- no query
                 # projection, no attention kernel; a single-position decoder (the towers) never needs k either
                 if self.max_len == 1:
-                    ctx = ops.linear(h, L["wkv"][d.inner:])
+                    ctx = ops.linear(h, L["wqkv"][2 * d.inner:])
                 else:
-                    ops.linear(h, L["wkv"], out=kvc[:, 0, :])
-                    ctx = kvc[:, 0, d.inner:]
+                    ops.linear(h, L["wqkv"][d.inner:], out=kvc[:, 0, d.inner:])
+                    ctx = kvc[:, 0, 2 * d.inner:]
             else:
-                q = ops.linear(h, L["wq"])
-                ops.linear(h, L["wkv"], out=kvc[:n, t, :])
+                ops.linear(h, L["wqkv"], out=kvc[:n, t, :])
+                q = kvc[:n, t, :d.inner]
                 if key_rows is not None:
-                    ctx = ops.attention_cached(q, kvc[:, :, :d.inner], kvc[:, :, d.inner:], key_rows, d.num_heads,
+                    ctx = ops.attention_cached(q, kvc[:, :, d.inner:2 * d.inner], kvc[:, :, 2 * d.inner:], key_rows, d.num_heads,
                                                bias=self.self_bias, q_pos0=t, causal=True, split_bound=L["vb"])
                 else:
-                    ctx = ops.attention(q.view(n, 1, d.inner), kvc[:, :t + 1, :d.inner], kvc[:, :t + 1, d.inner:],
+                    ctx = ops.attention(q.unsqueeze(1), kvc[:, :t + 1, d.inner:2 * d.inner], kvc[:, :t + 1, 2 * d.inner:],
                                         d.num_heads, bias=self.self_bias, q_pos0=t, causal=True, split_bound=L["vb"])
                     if L["vb"] is None:
                         ctx = ctx.view(n, d.inner)
