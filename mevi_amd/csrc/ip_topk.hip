@@ -416,6 +416,93 @@ __global__ __launch_bounds__(256) void compact_kernel(unsigned long long *__rest
     compact_query(skeys, hist, buf + (size_t)q * S, count, tau, failed, q, k, cap);
 }
 
+// The same selection by ONE WAVE per query with the keys in REGISTERS (n = k + c <= 64 KPL keys, KPL per lane): no LDS, no
+// workgroup barrier, no atomics.  compact_kernel spends ~23 us per query -- twenty barriers, LDS atomic chains and its global
+// loads behind two to four resident workgroups per CU -- for a few thousand instructions of work.  Here the k-th largest key
+// T is built bit by bit from the top (T |= bit whenever at least k keys are >= T | bit; the count is a ballot + popcount per
+// register, no cross-lane reduction), stopping as soon as exactly k keys remain above the candidate (T is then their minimum).
+// Same contract as compact_query: the keys above T in slots [0, m) in arbitrary order, T in slot k - 1, zeros between, tau,
+// count reset, overflow flag.  Queries with more keys than fit are left untouched (count != 0) for compact_kernel, which is
+// launched right after and skips every query whose count is already 0.
+template <int KPL>
+__global__ __launch_bounds__(256) void compact_wave_kernel(unsigned long long *__restrict__ buf, unsigned int *__restrict__ count,
+                                                          float *__restrict__ tau, unsigned int *__restrict__ failed, int nq,
+                                                          int S, int k, int cap) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (q >= nq) return;
+  const unsigned int c_raw = count[q];
+  if (c_raw == 0u) return;  // nothing new for this query (wave-uniform)
+  const int c = c_raw > (unsigned int)cap ? cap : (int)c_raw;
+  const int n = k + c;
+  if (n > 64 * KPL) return;  // compact_kernel takes it
+  unsigned long long *row = buf + (size_t)q * S;
+  unsigned long long key[KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) key[j] = (64 * j + lane < n) ? row[64 * j + lane] : 0ull;
+  const int nj = (n + 63) >> 6;   // registers that hold keys (wave-uniform); the rest are 0 and never count
+  // the loops over the registers run in blocks of eight under a wave-uniform test: a `break` inside an unrolled loop sent the
+  // key array to scratch (runtime-indexed), 528 bytes per lane
+  unsigned long long T = 0ull;
+  bool exact = false;              // exactly k keys >= T: T is not the k-th key yet, their minimum is
+  for (int b = 63; b >= 0; --b) {
+    const unsigned long long cand = T | (1ull << b);
+    int cnt = 0;
+#pragma unroll
+    for (int jb = 0; jb < KPL / 8; ++jb)
+      if (8 * jb < nj) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) cnt += __popcll(__ballot(key[8 * jb + jj] >= cand));
+      }
+    if (cnt >= k) {
+      T = cand;
+      if (cnt == k) {
+        exact = true;
+        break;
+      }
+    }
+  }
+  if (exact) {
+    unsigned long long mn = ~0ull;
+#pragma unroll
+    for (int jb = 0; jb < KPL / 8; ++jb)
+      if (8 * jb < nj) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const unsigned long long kk = key[8 * jb + jj];
+          if (kk >= T && kk < mn) mn = kk;
+        }
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = ((unsigned long long)(unsigned int)__shfl_xor((int)(mn >> 32), off) << 32) |
+                                   (unsigned int)__shfl_xor((int)mn, off);
+      mn = o < mn ? o : mn;
+    }
+    T = mn;
+  }
+  int base = 0;
+#pragma unroll
+  for (int jb = 0; jb < KPL / 8; ++jb)
+    if (8 * jb < nj) {
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const unsigned long long kk = key[8 * jb + jj];
+        const bool pass = kk > T;
+        const unsigned long long mask = __ballot(pass);
+        if (pass)
+          row[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u))] = kk;
+        base += __popcll(mask);
+      }
+    }
+  for (int i = base + lane; i < k; i += 64) row[i] = (i == k - 1) ? T : 0ull;
+  if (lane == 0) {
+    tau[q] = (T != 0ull) ? key_score(T) : -INFINITY;
+    count[q] = 0u;
+    if (c_raw > (unsigned int)cap) failed[q] = 1u;
+  }
+}
+
 // Sort every query's list (row[0, k)) descending: the last step of a pass whose lists are read as ranked output.
 __global__ __launch_bounds__(256) void sort_lists_kernel(unsigned long long *__restrict__ buf, int S, int k) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
@@ -1168,6 +1255,12 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
     profile_mark(stream);
     {
       const int nq_i = (int)nq;
+      // one wave per query with the keys in registers first (MEVI_IP_TOPK_COMPACT=lds: the LDS kernel alone); what it leaves
+      // -- queries with more than 4096 keys -- is the LDS kernel's, which returns at once for every query already done
+      static const bool wave_compact = [] { const char *e = getenv("MEVI_IP_TOPK_COMPACT"); return !(e && strcmp(e, "lds") == 0); }();
+      if (wave_compact)
+        hipLaunchKernelGGL(compact_wave_kernel<64>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, st.buf, st.count, st.tau,
+                           st.failed, nq_i, g.S, g.k, g.cap);
       hipLaunchKernelGGL(compact_kernel, dim3((unsigned)(nq < 8 * n_cu ? nq : 8 * n_cu)), dim3(256), compact_lds, stream,
                          st.buf, st.count, st.tau, st.failed, nq_i, g.S, g.k, g.cap);
     }
