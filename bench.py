@@ -6,8 +6,13 @@ Workload (BASELINE.json configs[1], "C2"): the dense arm of MEVI, i.e. what
 against the 8,841,823 x 768 f32 passage-embedding matrix (27.16 GB, resident in
 HBM), exact inner-product top-1000.  One "step" = one full search of all queries.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W]                            (N > 1: starts its own N ranks)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (the driver's launch line)
+
+Plain `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself -- a CHILD
+`python -m torch.distributed.run` on a free 127.0.0.1 port, before this process has touched the GPU, as the reference's
+entry points spawn theirs (MEVI/main.py:286-298, MEVI/generate.py:215-219) -- relays rank 0's line and exits with the
+child's return code.
 
 N > 1: the corpus is row-sharded (ceil(N_docs/N) rows per rank), queries are
 replicated, every rank searches its shard with global ids, one RCCL all-gather of
@@ -24,14 +29,41 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mevi_amd import dense, hip  # noqa: E402
+np = torch = dist = dense = hip = None      # bound by late_imports(): the self-launching parent never imports them
+
+
+def late_imports():
+    global np, torch, dist, dense, hip
+    import numpy
+    import torch as _torch
+    import torch.distributed as _dist
+
+    from mevi_amd import dense as _dense
+    from mevi_amd import hip as _hip
+
+    np, torch, dist, dense, hip = numpy, _torch, _dist, _dense, _hip
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as a CHILD process -- the same command
+    line the driver uses -- on a free localhost port; stdout / stderr are inherited, so rank 0's one JSON line is this
+    process's one JSON line.  Nothing here touches the GPU, and nothing is exec'ed.  Returns the child's return code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
 
 N_DOCS = 8_841_823   # MEVI/marco_eval_nci_rq.sh:26 (--save_hard_neg = corpus size)
 N_QUERIES = 6980     # MSMARCO dev
@@ -98,6 +130,16 @@ def seq2seq_flops(M, K, R, real_tokens_per_query, d=768, dff=3072, enc_layers=12
     head = steps * 2 * (K + 1) * d * d
     head_exec = R * 2 * (K + 1) * d * d                         # last position only
     return enc_pad + dec + xkv_pad + adaptor + head, enc_real + dec + xkv_real + head_exec
+
+
+def tower_flops(lens, d=768, dff=3072, layers=12):
+    """Executed FLOP of one T5-ANCE tower pass over sequences of `lens` real tokens (padding-free encoder incl. attention,
+    one-token decoder: self-attention = o(v(x)), cross q / o, FFN; cross K|V projections of the real tokens)."""
+    lens = np.asarray(lens, np.float64)
+    n, real = len(lens), float(lens.sum())
+    lin = 2 * (4 * d * d + 2 * d * dff)
+    return layers * (real * lin + 4 * d * float((lens ** 2).sum())) + layers * n * (lin + 2 * 2 * d * d) \
+        + layers * real * 4 * d * d + layers * 4 * d * real
 
 
 def gemm_roofline(device, rows):
@@ -199,6 +241,7 @@ def index_build_leg(device, docs, rn, n_docs):
     import synth
 
     out = {}
+    rq.KEEP_ENCODE_WORKSPACE = True            # the record counters of `stats` below
     g = torch.Generator(device=device).manual_seed(5)
     for M_, K_ in ((4, 32), (3, 256)):
         cb = torch.stack([torch.randn((K_, DIM), device=device, generator=g) * (0.05 / (1 + j)) for j in range(M_)])
@@ -218,6 +261,8 @@ def index_build_leg(device, docs, rn, n_docs):
                          "bytes_note": "SURVEY 8(d): 4 N d (corpus once) + 4 N M (codes)",
                          "achieved": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / 8000.0, 4)}}
         del codes, cb
+    rq.KEEP_ENCODE_WORKSPACE = False
+    rq._LAST_ENCODE.clear()
     TW = synth.tower_weights(device) if hasattr(synth, "tower_weights") else None
     if TW is not None:
         tower = t5.TwinTower(TW, device=device, num_layers=12, num_decoder_layers=12, batch_size=512)
@@ -333,6 +378,16 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
     # ---- C4, timed directly on the resident corpus ---------------------------------------------------------------------
     chain, dindex = chain_c4.run(model, tower, docs, ids, mask, planted_ids(nq, n_docs), rn, M, K, R, TOPK, gen_batch, rng)
     chain["dtype"] = "tower / NCI: " + SPLIT_DTYPE + "; dense: f16 pre-filter + exact f32 chains; fine stage: f32 chains; ensemble: f64"
+    # the chain's own roofline: f16 matrix-core FLOP executed by its stages (three per product of the split GEMMs of both tower
+    # passes and the beam search, one per product of the dense pre-filter) over the chain's wall clock
+    tw = tower_flops(mask.sum(1).cpu().numpy())
+    mfma = 3.0 * (2 * tw + exe * nq) + 2.0 * nq * float(n_docs) * DIM
+    chain["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F16_MFMA_TFLOPS,
+                         "executed_f16_mfma_flop": mfma, "achieved": mfma / chain["chain_ms"] / 1e9,
+                         "frac": mfma / chain["chain_ms"] / 1e9 / PEAK_F16_MFMA_TFLOPS,
+                         "flop_split": {"tower_x2_f32_products": 2 * tw, "nci_f32_products": exe * nq,
+                                        "dense_filter_f16_products": 2.0 * nq * float(n_docs) * DIM},
+                         "peak_note": "f16 MFMA dense peak; f32 products of the split GEMMs counted three times (three f16 MFMAs each)"}
     out["chain_c4"] = chain
     guarded("faiss_search_cli_inclusive", lambda: cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs))
     del dindex
@@ -421,6 +476,87 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
     return out
 
 
+# ---- the ONE line ---------------------------------------------------------------------------------------------------------
+LINE_BUDGET = 7600      # bytes: the driver keeps the last 8 KB of stdout beside `parsed`; the whole line must fit in it
+_DROP = ("note", "sample_detail", "what", "slice", "per_rank", "per_batch", "layers", "checksums", "statistic", "stats",
+         "prefix_tables", "flop_split", "setup_untimed_ms", "recall1000", "loadavg", "cgroup_cpu_max", "backend", "faiss",
+         "upload_sample", "seconds", "cpu_seconds", "oracle_seconds", "algorithmic_bytes", "flop_executed",
+         "flop_per_query_survey_8d_padded", "flop_per_query_executed", "executed_f16_mfma_flop", "algorithmic_bytes_per_search")
+_DROP_ORDER = ("faiss_search_cli_inclusive", "seq2seq_cpu_sample", "dense_small_batch", "gemm_roofline", "dense_arm_with_tower",
+               "seq2seq_arm_rq_3x256", "index_build", "multi_gpu")      # least important first, should the line still be long
+
+
+_KEEP_PATHS = {("dtype",), ("config", "workload"), ("roofline", "kernel")}
+
+
+def _compact(v, path=()):
+    if isinstance(v, dict):
+        return {k: _compact(x, path + (k,)) for k, x in v.items()
+                if path + (k,) in _KEEP_PATHS
+                or not (any(d in k for d in _DROP) or k in ("dtype", "workload", "cpu", "kernel", "sweep"))}
+    if isinstance(v, (list, tuple)):
+        return [_compact(x, path) for x in v]
+    if isinstance(v, float):
+        return float("%.5g" % v)
+    if isinstance(v, str) and len(v) > 120:
+        return v[:117] + "..."
+    return v
+
+
+def summaries_into_config(out):
+    """What the metric is ABOUT goes where the driver's record keeps it (`config`): the MRR@10-match certificate and the
+    BASELINE.md section 3 number (the whole chain, timed over >= 3 repeats)."""
+    cfg = out["config"]
+    mm = out.get("mrr10_match") or {}
+    cert = {}
+    if "dense" in mm:
+        cert["dense_lists_identical"] = mm["dense"].get("lists_identical")
+        cert["dense_mrr10_abs_diff"] = mm["dense"].get("abs_diff")
+    ch = mm.get("chain")
+    if ch:
+        diffs = [v["abs_diff"] for v in ch.values() if isinstance(v, dict) and "abs_diff" in v]
+        same = [v["top10_identical"] for v in ch.values() if isinstance(v, dict) and "top10_identical" in v]
+        cert.update(beams_identical=ch.get("beams_identical"), chain_mrr10_abs_diff=max(diffs) if diffs else None,
+                    chain_top10_identical_frac=min(same) if same else None, tower_max_abs_diff=ch.get("tower_max_abs_diff"),
+                    rq_codes_identical_on_sample=ch.get("rq_codes_identical_on_sample"),
+                    within_1e_4=ch.get("mrr10_within_1e-4"))
+    if "chain_error" in mm:
+        cert["chain_error"] = mm["chain_error"][:120]
+    if cert:
+        cfg["mrr10_match"] = cert
+    c4 = out.get("chain_c4")
+    if c4:
+        cfg["chain_c4"] = {"queries_per_s": c4["queries_per_s"], "queries_per_s_best": c4.get("queries_per_s_best"),
+                           "repeats": c4.get("repeats"), "chain_ms": c4["chain_ms"], "stage_ms": c4["ms"],
+                           "roofline_frac": round(c4["roofline"]["frac"], 4) if "roofline" in c4 else None,
+                           "mrr10": c4.get("mrr10")}
+    c5 = out.get("chain_c5")
+    if c5:
+        cfg["chain_c5"] = {"queries_per_s": c5["queries_per_s"], "chain_ms": c5["chain_ms"], "mrr10": c5.get("mrr10"),
+                           "dense_lists_identical_on_all_ranks": c5.get("dense_lists_identical_on_all_ranks")}
+
+
+def print_line(out):
+    """Full record -> $MEVI_BENCH_DETAIL (default gpurun_out/bench_detail_n<N>.json, best effort) and stderr-free; the ONE
+    stdout line is its compact form: every number, no prose, under LINE_BUDGET bytes."""
+    summaries_into_config(out)
+    path = os.environ.get("MEVI_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail_n%d.json" % out["n_gpus"]))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        out["detail_file"] = os.path.relpath(path, ROOT)
+    except OSError:
+        pass
+    line = _compact(out)
+    for leg in _DROP_ORDER:
+        if len(json.dumps(line)) <= LINE_BUDGET:
+            break
+        if leg in line:
+            line[leg] = "see detail_file"
+    print(json.dumps(line), flush=True)
+
+
 def chain_c5(device, rank, world, backend, n_docs, nq, start, end, limit_s):
     """N > 1: BASELINE.json configs[4] is the FULL ensemble on the sharded corpus, so after the timed dense
     steps every rank runs the C5 chain (tools/chain_c4.run_sharded) -- full f32 corpus per rank, dense arm sharded, seq2seq
@@ -462,12 +598,14 @@ def main():
                     help="search with the f32-MFMA kernel only (no f16 pre-filter); same results")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))          # before any GPU call; the child's rc is ours
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
+    late_imports()
     hip.require_gpu()
     # MEVI_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the
     # collectives go through host memory) -- for checking the sharded search end to end, not for timing
@@ -646,11 +784,12 @@ def main():
             printed.set()
             if rank == 0:
                 out.update(extra)
-                print(json.dumps(out), flush=True)
+                print_line(out)
 
-        def give_up():      # a hung collective / a dead rank: rank 0 still prints the headline, everybody leaves
+        def give_up():      # a hung collective / a dead rank: rank 0 still prints the headline, then every rank leaves
             emit({"chain_c5_error": f"not finished within {args.chain_limit_s}s (watchdog)"})
-            os._exit(0)
+            sys.stdout.flush()
+            os._exit(3)     # non-zero: the launcher (and a self-launching parent) must see that the C5 leg did not finish
 
         dog = threading.Timer(args.chain_limit_s, give_up)
         dog.daemon = True
@@ -669,7 +808,7 @@ def main():
         dog.cancel()
         emit(extra)
     elif rank == 0:
-        print(json.dumps(out), flush=True)
+        print_line(out)
     if world > 1:
         try:
             dist.barrier()
@@ -680,3 +819,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+else:
+    late_imports()      # imported (tests, tools): the helpers above need numpy / torch / mevi_amd bound

@@ -743,13 +743,15 @@ __global__ __launch_bounds__(256) void rf_fixup_kernel(const float *__restrict__
     __builtin_amdgcn_wave_barrier();
   }
   int best = has ? cand : 0x7fffffff;
+  bool nan = has && !(d == d);              // a NaN distance in ANY live slot forces the exact re-encode (comparisons below would skip it)
 #pragma unroll
   for (int off = 1; off < SLOTS; off <<= 1) {
     const float od = __shfl_xor(d, off);
     const int oc = __shfl_xor(best, off);
+    nan |= (bool)__shfl_xor((int)nan, off);
     if (od < d || (od == d && oc < best)) d = od, best = oc;
   }
-  if (mine && slot == 0 && best != (int)R.spec) row_flag[R.row] = 1;  // speculation wrong (or NaN distances): exact re-encode
+  if (mine && slot == 0 && (best != (int)R.spec || nan)) row_flag[R.row] = 1;  // speculation wrong or NaN distances: exact re-encode
 }
 
 // flagged rows -> index list (order irrelevant); one atomic per wave

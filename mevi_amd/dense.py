@@ -138,7 +138,8 @@ def truncated_list_len(k, world):
     if world <= 1:
         return k
     share = (k + world - 1) // world
-    return min(k, share + 5 * int(np.ceil(np.sqrt(share))) + 8)
+    sig = float(os.environ.get("MEVI_SHARD_HEADROOM_SIGMAS", "5"))
+    return min(k, share + int(np.ceil(sig * np.ceil(np.sqrt(share)))) + 8)
 
 
 def merge_truncated(all_s, all_i, k, merge=None):
@@ -239,10 +240,14 @@ def sharded_ip_topk(query, local_docs, k, id_offset, group=None, local_search=No
 
     Every rank passes the full (replicated) query matrix and its own shard; every rank returns the
     identical merged (scores, ids), equal to the un-sharded search whatever the shard count.
-    Round 1 exchanges only k_local = ~2k/world entries per shard (per-rank re-scoring, compaction and
-    the all-gather shrink with the world size); queries whose merged list cannot be proven complete
-    (a shard's last entry reached the global top-k) are repeated with full k-entry lists -- every rank
-    takes the same decision from the same gathered data.
+    Round 1 exchanges only k_local = truncated_list_len(k, world) entries per shard -- k/world + 5 sqrt(k/world) + 8
+    (193 at k = 1000, world = 8; MEVI_SHARD_HEADROOM_SIGMAS overrides the 5) -- so per-rank re-scoring, compaction
+    and the all-gather shrink with the world size; queries whose merged list cannot be proven complete (a shard's
+    last entry reached the global top-k) are repeated with full k-entry lists -- every rank takes the same decision
+    from the same gathered data.  The binomial head-room assumes the top-k rows are spread evenly over the shards; a
+    corpus stored cluster by cluster concentrates them, the second round then runs for most queries (correct, but a
+    second search + all-gather): `trace.second_round_queries` reports it, bench.py prints it for N > 1, and
+    tools/bench_shard_sim.py --layout sorted measures that case.
     `local_search` / `merge` default to the HIP kernels; they are injection points for the CPU (gloo)
     test of the collective plumbing and are never set by product code.
     """

@@ -53,20 +53,32 @@ class SplitRows:
         return self
 
 
-def weight_split(w):
+def weight_split(w, keep_norm=False):
     """Split image of a static [out, in] weight, with the largest row norm (the bound of image-writing GEMMs)."""
     ws = split_rows(w.contiguous())
     ws.norm_max = float(ws.norm.max().item()) if ws.norm.numel() else 0.0
-    ws.norm = None
+    if not keep_norm:
+        ws.norm = None
     return ws
 
 
-def weight(w):
-    """A linear layer's [out, in] weight in the operand format of the current GEMM_MODE (static: converted once)."""
+def weight(w, keep_norm=False):
+    """A linear layer's [out, in] weight in the operand format of the current GEMM_MODE (static: converted once).
+    keep_norm: the row norms stay on a split image until weight_rows() has cut it into per-layer weights."""
     if GEMM_MODE == "split":
-        return weight_split(w)
+        return weight_split(w, keep_norm)
     assert GEMM_MODE == "exact", f"MEVI_GEMM must be 'split' or 'exact', not {GEMM_MODE!r}"
     return w
+
+
+def weight_rows(w, a, b):
+    """Output rows [a, b) of a prepared weight as a weight of their own (views; the slice's own largest row norm)."""
+    if isinstance(w, SplitRows):
+        s = w[a:b]
+        if s.norm is not None and s.norm.numel():
+            s.norm_max, s.norm = float(s.norm.max().item()), None
+        return s
+    return w[a:b]
 
 
 def prepare_weights(layers, keys):
@@ -99,6 +111,7 @@ def _split_buffers(M, K, dev, zero=False):
 
 CTX_IMAGE = os.environ.get("MEVI_ATTN_CTX", "image") != "f32"      # A/B switch: attention contexts as f32 + split_rows
 _EXP_FILL = {}
+_EXP_FILL_RETIRED = []     # see _ctx_image
 
 
 def norm_out_bound(ln_weight, d_model, ln_bias=None):
@@ -136,6 +149,10 @@ def _ctx_image(rows, k, bound, dev):
     e = _pow2_exp(bound * 1.001)
     fill = _EXP_FILL.get((dev, e))
     if fill is None or fill.numel() < rows:
+        if fill is not None:
+            # a HIP graph captured earlier (t5.GraphCache: the <= 8-row latency path) holds this buffer's raw address as the
+            # exponent array of its o-projection GEMM and does not keep it alive: a superseded fill is retired, never freed
+            _EXP_FILL_RETIRED.append(fill)
         fill = _EXP_FILL[(dev, e)] = torch.full((max(rows, 1 << 16),), e, dtype=torch.int8, device=dev)
     return SplitRows(img, fill[:rows], k, None), kp, e
 

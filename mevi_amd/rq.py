@@ -39,6 +39,9 @@ def last_encode_stats():
     return st
 
 
+KEEP_ENCODE_WORKSPACE = False     # bench / tests set this: last_encode_stats() then reads the fast path's record counters
+
+
 def rq_encode(x, codebook, mode=None):
     """codes i32[n, M] of x f32[n, dim] against codebook f32[M, K, dim] (CUDA tensors).
 
@@ -65,7 +68,9 @@ def rq_encode(x, codebook, mode=None):
             st = L.mevi_rq_encode_fast_f32(hip.ptr(x), n, dim, hip.ptr(codebook), M, K, hip.ptr(codes), hip.ptr(ws), nbytes,
                                            hip.stream_ptr())
             hip.check(st, "mevi_rq_encode_fast_f32")
-            _LAST_ENCODE.update(path="fast", n=n, dim=dim, M=M, K=K, _ws=ws)
+            _LAST_ENCODE.update(path="fast", n=n, dim=dim, M=M, K=K)
+            if KEEP_ENCODE_WORKSPACE:       # ~n*M*32 bytes (1.2 GB at MS MARCO size): never pinned in the product path
+                _LAST_ENCODE["_ws"] = ws
         else:
             st = L.mevi_rq_encode_f32(hip.ptr(x), n, dim, hip.ptr(codebook), M, K, hip.ptr(codes), hip.stream_ptr())
             hip.check(st, "mevi_rq_encode_f32")

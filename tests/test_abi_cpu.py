@@ -61,3 +61,63 @@ def test_product_never_imports_oracle():
     pat = re.compile(r"^\s*(from|import)\s+oracle\b|#include\s+[\"<][^\">]*oracle|libmevi_oracle|dlopen", re.M)
     for f in files:
         assert not pat.search(open(f).read()), f
+
+
+def test_bench_starts_its_ranks_itself_and_reports_their_failure():
+    """`python bench.py --gpus 2` outside a launcher: the parent starts two ranks through
+    torch.distributed.run as a child process -- it never imports torch itself, so it cannot have touched the GPU -- and
+    hands their exit status on.  Without a GPU both ranks fail loudly (no CPU fallback), so the status is non-zero."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the GPU suite runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("no MI355X visible") >= 2, r.stderr[-1500:]          # both ranks got as far as the GPU check
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def late_imports")]
+    assert "import torch" not in head and "mevi_amd" not in head.split('"""', 2)[2]   # nothing GPU-capable before the spawn
+
+
+def test_bench_line_is_compact_and_keeps_the_certificate_in_config():
+    """The ONE stdout line must fit the driver's 8 KB tail and carry the MRR@10-match certificate and the chain's rate in
+    `config`: checked on a recorded full record."""
+    import contextlib
+    import io
+    import json
+    import tempfile
+
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")) as f:
+        rec = json.load(f)
+    old = os.environ.get("MEVI_BENCH_DETAIL")
+    os.environ["MEVI_BENCH_DETAIL"] = os.path.join(tempfile.mkdtemp(), "d.json")
+    try:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bench.print_line(rec)
+        with open(os.environ["MEVI_BENCH_DETAIL"]) as f:
+            full = json.load(f)
+    finally:
+        if old is None:
+            del os.environ["MEVI_BENCH_DETAIL"]
+        else:
+            os.environ["MEVI_BENCH_DETAIL"] = old
+    out = buf.getvalue()
+    assert out.count("\n") == 1 and len(out) < 8192
+    line = json.loads(out)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("C2") and line["roofline"]["kernel"] == "ip_filter_h1_kernel"
+    m = line["config"]["mrr10_match"]
+    assert m["dense_lists_identical"] is True and m["beams_identical"] is True and m["chain_mrr10_abs_diff"] == 0.0
+    assert line["config"]["chain_c4"]["queries_per_s"] > 0
+    assert "per_batch" in full["dense_small_batch"] and "per_batch" not in line.get("dense_small_batch", {})

@@ -97,7 +97,10 @@ def _bench_two_ranks(backend_env, extra=("--docs", "700000", "--queries", "600",
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, PYTHONPATH=root, **backend_env)
+    import tempfile
+
+    detail = os.path.join(tempfile.mkdtemp(), "detail.json")       # the full record (per-rank entries) beside the compact line
+    env = dict(os.environ, PYTHONPATH=root, MEVI_BENCH_DETAIL=detail, **backend_env)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
                         "--warmup", "1", *extra],
@@ -105,7 +108,12 @@ def _bench_two_ranks(backend_env, extra=("--docs", "700000", "--queries", "600",
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE JSON line
-    return json.loads(lines[0])
+    line = json.loads(lines[0])
+    assert len(lines[0]) < 8192 and line["n_gpus"] == 2 and "multi_gpu" in line
+    with open(detail) as f:
+        full = json.load(f)
+    assert full["value"] == pytest.approx(line["value"], rel=1e-4)
+    return full
 
 
 def _check_two_rank_line(d, rows=700000):
@@ -142,6 +150,37 @@ def test_bench_c5_chain_rehearsal_with_two_ranks_sharing_the_device():
                                                  "tower_again", "fine_stage"}
     assert set(c["mrr10"]) == {"dense", "fine", "ensemble", "ensemble_alpha20"} and 0.0 <= c["mrr10"]["ensemble"] <= 1.0
     assert "REHEARSAL" in c["workload"]
+
+
+def test_bench_starts_its_own_ranks_from_the_plain_command():
+    """`python bench.py --gpus 2` with no launcher around it: the process starts its two ranks itself before
+    touching the GPU (as MEVI/main.py:286-298 spawns its workers), relays rank 0's ONE line -- with the C5 chain in it --
+    and returns the child's exit status."""
+    import os
+    import subprocess
+    import sys
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip("two t5-base model replicas + prefix tables: needs ~40 GB of HBM")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=root, MEVI_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--docs", "300000", "--queries", "101", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 8192                                   # the whole line fits the driver's stdout tail
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["planted_top1_ok"] == 1.0 and d["value"] > 0
+    assert "chain_c5_error" not in d and d["chain_c5"]["queries_per_s"] > 0
+    assert d["config"]["chain_c5"]["dense_lists_identical_on_all_ranks"] is True
+    # a wrong world size is an error, not a silent single-rank run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
 
 
 def test_bench_over_rccl_when_two_gpus_are_visible():

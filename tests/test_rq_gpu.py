@@ -11,6 +11,7 @@ from mevi_amd import rq
 from oracle import rq as orq
 
 pytestmark = pytest.mark.gpu
+rq.KEEP_ENCODE_WORKSPACE = True      # last_encode_stats() reads the fast path's record counters (never kept by the product path)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 

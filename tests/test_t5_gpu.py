@@ -334,6 +334,39 @@ def test_graph_replay_of_small_batches_equals_the_eager_pass(cuda):
     assert len(tower._graphs.graphs) == 2
 
 
+def test_captured_graphs_survive_a_larger_eager_pass(cuda):
+    """the attention contexts' shared exponent array (ops._ctx_image) grows when a pass has more rows
+    than it holds; a graph captured before holds the OLD array's address.  Capture the small-batch graphs, poison-proof the
+    allocator with a pass of > 65536 context rows (which re-allocates the fill) plus scratch garbage over freed memory,
+    replay: same bits as before."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    from mevi_amd import ops
+
+    model, tower, _, _ = synth.build(cuda, 4, 32, None)
+    ids, mask = synth.query_ids(2400, cuda, np.random.default_rng(5))
+    q = {"input_ids": ids[:2], "attention_mask": mask[:2]}
+    for _ in range(2):                                   # eager, then capture
+        e0 = tower.encode_query(q, graph=True)
+        d0, s0, _, _ = model.generate(ids[:2], mask[:2], num_beams=10, graph=True)
+    fills = {k: v.data_ptr() for k, v in ops._EXP_FILL.items()}
+    assert fills and max(v.numel() for v in ops._EXP_FILL.values()) == 1 << 16
+    full = {"input_ids": ids, "attention_mask": torch.ones_like(mask)}       # 2400 x 32 = 76800 context rows > 65536
+    tower.encode_query(full)
+    model.generate(ids, torch.ones_like(mask), num_beams=10)
+    assert any(ops._EXP_FILL[k].data_ptr() != p for k, p in fills.items()), "the pass did not outgrow the fill"
+    assert ops._EXP_FILL_RETIRED, "a superseded fill must be retired, not freed"
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 16,), 77, dtype=torch.int8, device=cuda) for _ in range(64)]   # lands on any freed 64 KB block
+    torch.cuda.synchronize()
+    e1 = tower.encode_query(q, graph=True)               # replay
+    d1, s1, _, _ = model.generate(ids[:2], mask[:2], num_beams=10, graph=True)
+    del junk
+    assert torch.equal(e0, e1) and torch.equal(d0, d1) and np.array_equal(np.asarray(s0), np.asarray(s1))
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1a_nci_all_*.npz"))))
 def test_nci_generate_all_matches_reference_golden(cuda, path):
     """generate(..., eval_all_documents=True) = _generate_all (generation_utils.py:1013-1136, the use_topic_model

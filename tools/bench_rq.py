@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from mevi_amd import rq  # noqa: E402
 
+rq.KEEP_ENCODE_WORKSPACE = True
+
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else bench.N_DOCS
 docs = bench.gen_shard(0, n, dev, n)
