@@ -119,11 +119,12 @@ __device__ __forceinline__ void stash_flush(Stash &st, unsigned long long *__res
 //           skipped wave-wide; in the others count the passing elements per lane
 //   atomics base slot per column
 //   pass 2  store the keys of the quads that had any (plain stores)
-template <int NI>
-__device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq)[NI], int q0, long long d0,
-                                          long long doc_end, unsigned long long *__restrict__ buf,
-                                          unsigned int *__restrict__ count, int S, int k, int cap,
-                                          unsigned int id_base, Stash *stash = nullptr) {
+template <int NI, bool STASH>
+__device__ __forceinline__ void emit_tile_impl(f32x16 (&acc)[2][NI], const float (&tq)[NI], int q0, long long d0,
+                                               long long doc_end, unsigned long long *__restrict__ buf,
+                                               unsigned int *__restrict__ count, int S, int k, int cap,
+                                               unsigned int id_base, Stash &stash_ref) {
+  Stash *const stash = &stash_ref;
   const int lane = threadIdx.x & 63;
   const int lrow = lane & 31, half = lane >> 5;
   if (d0 + 64 > doc_end) {  // ragged last tile (wave-uniform): rows past the shard never pass
@@ -168,7 +169,7 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq
   if (qmask == 0u) return;  // nothing passes anywhere in the wave tile
   // key = ord(score) << 32 | ~id;  ~(id0 + c) = ~id0 - c
   const unsigned int nid0 = 0xFFFFFFFFu - (id_base + (unsigned int)(d0 + 4 * half));
-  if (stash) {
+  if constexpr (STASH) {
     unsigned int tot = 0u;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) tot += n[ni];
@@ -237,6 +238,22 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq
       }
     }
   }
+}
+
+// the stash is taken BY REFERENCE (a pointer parameter kept the struct in scratch in the streaming kernel: 32 bytes per lane,
+// a scratch load per use)
+template <int NI>
+__device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq)[NI], int q0, long long d0, long long doc_end,
+                                          unsigned long long *__restrict__ buf, unsigned int *__restrict__ count, int S, int k,
+                                          int cap, unsigned int id_base) {
+  Stash none = {nullptr, nullptr, 0};
+  emit_tile_impl<NI, false>(acc, tq, q0, d0, doc_end, buf, count, S, k, cap, id_base, none);
+}
+template <int NI>
+__device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq)[NI], int q0, long long d0, long long doc_end,
+                                          unsigned long long *__restrict__ buf, unsigned int *__restrict__ count, int S, int k,
+                                          int cap, unsigned int id_base, Stash &stash) {
+  emit_tile_impl<NI, true>(acc, tq, q0, d0, doc_end, buf, count, S, k, cap, id_base, stash);
 }
 
 // thresholds of the NI query columns of this lane
@@ -886,7 +903,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
     head_d = tail_d, head_q = tail_q;
     --n_pend;
     const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
-    emit_tile<4>(acc, tq, qtile * H1_QT + 128 * wn, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base, &stash);
+    emit_tile<4>(acc, tq, qtile * H1_QT + 128 * wn, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base, stash);
   };
   h1_tile_stream(64, dimp / 32, lds, next, begin, emit, H1BlockedUnits());
   stash_flush(stash, buf, count, S, k, cap);
@@ -978,7 +995,7 @@ __global__ __launch_bounds__(512, 2) void ip_filter_h1_small_kernel(
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is re-filled by the next iteration's request
       rs = rs == SM_NB - 1 ? 0 : rs + 1;
     }
-    emit_tile<1>(acc, tq, 0, doc_begin + blk * 256 + 32 * w8, doc_end, buf, count, S, k, cap, id_base, &stash);
+    emit_tile<1>(acc, tq, 0, doc_begin + blk * 256 + 32 * w8, doc_end, buf, count, S, k, cap, id_base, stash);
     if (!have_nxt) break;
     blk = blk_n;
     cur = nxt;

@@ -156,6 +156,7 @@ def test_bench_starts_its_own_ranks_from_the_plain_command():
     """`python bench.py --gpus 2` with no launcher around it: the process starts its two ranks itself before
     touching the GPU (as MEVI/main.py:286-298 spawns its workers), relays rank 0's ONE line -- with the C5 chain in it --
     and returns the child's exit status."""
+    import json
     import os
     import subprocess
     import sys
