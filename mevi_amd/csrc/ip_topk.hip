@@ -23,7 +23,7 @@
 // Numerics: every returned score is the f32 fmaf chain over k = 0..dim-1 in order (MFMA lane half h supplies
 // k = 2j + h); oracle/mevi_oracle.c computes the same chain on the CPU, so parity is bit-exact on both paths.
 
-#include "mfma_pp_f16.h"
+#include "mfma_pp_f16x16.h"
 
 #include <float.h>
 #include <math.h>
@@ -254,6 +254,160 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq
                                           unsigned long long *__restrict__ buf, unsigned int *__restrict__ count, int S, int k,
                                           int cap, unsigned int id_base, Stash &stash) {
   emit_tile_impl<NI, true>(acc, tq, q0, d0, doc_end, buf, count, S, k, cap, id_base, stash);
+}
+
+// ---------------------------------------------------------------------------
+// Epilogue of the 16 x 16 x 32 tile stream (mfma_pp_f16x16.h).  A wave tile is 4 x 8 blocks of 16 corpus rows x 16 queries; a
+// lane holds, per block, FOUR CONSECUTIVE corpus rows (4 (lane >> 4) + j) of ONE query (lane & 15).
+//
+// What the 32x32x16 epilogue (emit_tile) costs is not its arithmetic but its SIZE: every element has its own copy of the
+// append code (128 copies, ~50 KB of instructions), a candidate lands in a different copy each time, and the instruction
+// cache misses (kernel trace by chunk: +600 cycles per candidate and wave between the 3-per-wave-tile and the 9-per-wave-tile
+// chunk).  Here the per-block code is 5 instructions when nothing passes and ~12 when something does, whatever passes:
+//   per block   m = max of the lane's four scores (v_max3 + v_max); vote m > tau[query]; no lane -> next block.
+//               Lanes that pass write ONE 32-byte RECORD to the wave's LDS stash: their four raw scores + (tau, query, ~id
+//               of the first row) -- which of the four pass is decided when the stash is flushed.
+//   flush       (one copy of the code) a lane per record: count its passing scores, ONE returning atomic on the query's
+//               slot counter for all of them, plain stores of the keys.  All eight waves flush on the same tiles (every
+//               H16_FLUSH_EVERY-th, or when a stash is two thirds full), so their atomic round trips overlap instead of
+//               stalling the workgroup's barrier eight times.
+//   dense tiles (the first chunks, where most rows still pass): the stash overflows -> the tile's records are dropped, and
+//               the tile takes the direct path: per query column one slot-allocating atomic for the four lanes that share
+//               it, then plain stores -- as emit_tile.
+// Keys and thresholds are the RAW accumulators, as in emit_tile.  An accumulator's low bits may differ between the two
+// instruction shapes (the sums are taken in another order), so the candidate sets can differ in near-ties at tau -- every
+// returned score comes from the exact re-scoring chains and every list is proven complete per query, never from here.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int H16_REC_N = 96;            // records per wave: 96 x 32 B = 3 KiB (STASH_BYTES_PER_WAVE)
+constexpr int H16_FLUSH_AT = 64;         // flush before a tile when this many records are waiting
+constexpr int H16_FLUSH_EVERY = 8;       // ... and on every 8th (4th, 2nd: the host sizes the cadence to the chunk's expected
+                                         // candidate density, ip_search_pass) tile of the workgroup -- all waves together
+static_assert((size_t)H16_REC_N * 32 <= STASH_BYTES_PER_WAVE, "record stash must fit the wave's stash area");
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+struct RecStash {
+  lds_f32x4 *vals;   // [H16_REC_N] the lane's four raw scores          (LDS pointers: 32 bits, ds_ instructions)
+  lds_u32x4 *meta;   // [H16_REC_N] {tau bits, query, ~id of row 0 of the four, unused}
+  int n;             // wave-uniform
+};
+
+__device__ __forceinline__ void load_tq16(float (&tq)[8], const float *__restrict__ tau, int q0, int nq) {
+  const int r16 = threadIdx.x & 15;
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) {
+    const int qi = q0 + 16 * ni + r16;
+    tq[ni] = tau[qi < nq ? qi : nq - 1];     // branch-free (the caller masks columns >= nq to +inf)
+  }
+}
+
+__device__ __forceinline__ void rec_flush(RecStash &st, unsigned long long *__restrict__ buf, unsigned int *__restrict__ count,
+                                          int S, int k, int cap) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_wave_barrier();
+  for (int base = 0; base < st.n; base += 64) {
+    const int e = base + lane;
+    if (e < st.n) {
+      const f32x4 a = st.vals[e];
+      const u32x4 m = st.meta[e];
+      const float t = __uint_as_float(m[0]);
+      const unsigned int q = m[1];
+      unsigned int c = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c += a[j] > t ? 1u : 0u;
+      unsigned int slot = atomicAdd(&count[q], c);       // c >= 1: the lane wrote the record because one of the four passed
+      unsigned long long *dst = buf + (size_t)q * S + k;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (a[j] > t) {
+          if (slot < (unsigned int)cap) dst[slot] = ((unsigned long long)f32_to_ord(a[j]) << 32) | (unsigned long long)(m[2] - (unsigned int)j);
+          ++slot;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  st.n = 0;
+}
+
+__device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq)[8], int q0, long long d0, long long doc_end,
+                                            unsigned long long *__restrict__ buf, unsigned int *__restrict__ count, int S,
+                                            int k, int cap, unsigned int id_base, RecStash &st, bool flush_now) {
+  const int lane = threadIdx.x & 63;
+  const int r16 = lane & 15, kq = lane >> 4;
+  if (d0 + 64 > doc_end) {  // ragged last tile (wave-uniform): rows past the shard never pass
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (d0 + 16 * mi + 4 * kq + j >= doc_end) {
+#pragma unroll
+          for (int ni = 0; ni < 8; ++ni) acc[mi][ni][j] = -INFINITY;
+        }
+  }
+  if (st.n >= H16_FLUSH_AT || (flush_now && st.n > 0)) rec_flush(st, buf, count, S, k, cap);
+  // ~id of the lane's first row of block row 0: key = ord(score) << 32 | ~id;  ~(id0 + c) = ~id0 - c
+  const unsigned int nid0 = 0xFFFFFFFFu - (id_base + (unsigned int)(d0 + 4 * kq));
+  const int n0 = st.n;
+  int n = n0;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+      const f32x4 a = acc[mi][ni];
+      // v_max3 + v_max through asm: fmaxf() makes the compiler canonicalise every input first (five vector instructions per
+      // block instead of two); a NaN accumulator cannot pass either way
+      float m;
+      asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+      const bool pass = m > tq[ni];
+      const unsigned long long vote = __ballot(pass);
+      if (vote != 0ull) {
+        if (pass) {
+          const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(vote >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)vote, 0u));
+          if (pos < H16_REC_N) {
+            st.vals[pos] = a;
+            st.meta[pos] = u32x4{__float_as_uint(tq[ni]), (unsigned int)(q0 + 16 * ni + r16), nid0 - (unsigned int)(16 * mi), 0u};
+          }
+        }
+        n += __popcll(vote);
+      }
+    }
+  st.n = n;
+  if (n <= H16_REC_N) return;
+  // dense tile: forget its records, empty the stash, then per query column (16 ni + r16) the four lanes kq = 0..3 pool their
+  // counts and lane kq = 0 takes the slots
+  st.n = n0;
+  rec_flush(st, buf, count, S, k, cap);
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) {
+    unsigned int c = 0u;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c += acc[mi][ni][j] > tq[ni] ? 1u : 0u;
+    if (!__any(c != 0u)) continue;
+    const unsigned int c1 = __shfl_xor(c, 16), s01 = c + c1;       // pair (kq, kq ^ 1)
+    const unsigned int s23 = __shfl_xor(s01, 32);                  // the other pair's total
+    const unsigned int total = s01 + s23;
+    unsigned int base = 0u;
+    if (kq == 0 && total != 0u) base = atomicAdd(&count[q0 + 16 * ni + r16], total);
+    base = __shfl(base, r16);
+    unsigned int before = (kq & 1) ? c1 : 0u;                      // the lower lane of the own pair
+    if (kq & 2) before += s23;                                     // the whole lower pair
+    unsigned int slot = base + before;
+    unsigned long long *dst = buf + (size_t)(q0 + 16 * ni + r16) * S + k;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = acc[mi][ni][j];
+        if (v > tq[ni]) {
+          if (slot < (unsigned int)cap)
+            dst[slot] = ((unsigned long long)f32_to_ord(v) << 32) | (unsigned long long)(nid0 - (unsigned int)(16 * mi + j));
+          ++slot;
+        }
+      }
+  }
 }
 
 // thresholds of the NI query columns of this lane
@@ -909,6 +1063,73 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
   stash_flush(stash, buf, count, S, k, cap);
 }
 
+// The same kernel on v_mfma_f32_16x16x32_f16 (mfma_pp_f16x16.h; the default: +10 % sustained rate of the tile loop on this
+// part, tools/probes/mfma16_probe.hip) with the 16 x 16 epilogue.  dimp must be a multiple of 64 (pad_k).
+__global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h16_kernel(
+    const float *__restrict__ Qh, int nq, const float *__restrict__ Dh, long long doc_begin, long long doc_end,
+    int dimp, const float *__restrict__ tau, unsigned long long *__restrict__ buf,
+    unsigned int *__restrict__ count, int S, int k, int cap, unsigned int id_base, int n_qtiles, int n_dpairs,
+    int flush_mask) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nwg = n_qtiles * n_dpairs;
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int range_base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;  // as xcd_remap
+  const int range_len = q8 + (xcd < r8 ? 1 : 0);
+  int item = blockIdx.x >> 3;
+  const int t = threadIdx.x;
+  const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = w8 >> 2, wm = (w8 >> 1) & 1, wn = w8 & 1;
+  const size_t block_bytes = (size_t)256 * dimp * 2;
+  int head_d = 0, head_q = 0, tail_d = 0, tail_q = 0, n_pend = 0;
+
+  auto next = [&](H1Src &s) -> bool {
+    if (item >= range_len) return false;
+    int dpair, qtile;
+    supertile_order<4, 8>(range_base + item, n_dpairs, n_qtiles, dpair, qtile);
+    item += per_xcd;
+    if (n_pend == 0) head_d = dpair, head_q = qtile;
+    else tail_d = dpair, tail_q = qtile;
+    ++n_pend;
+    if (w8 < 4) {
+      const long long first = doc_begin + (long long)dpair * 2 * BM;
+      s.src = reinterpret_cast<const char *>(Dh) + (size_t)(first >> 8) * block_bytes;
+    } else {
+      s.src = reinterpret_cast<const char *>(Qh) + (size_t)qtile * block_bytes;
+    }
+    s.bytes = (unsigned int)block_bytes;
+    return true;
+  };
+  float tq[8];
+  RecStash stash;
+  {
+    char *sb = reinterpret_cast<char *>(lds) + h1_lds_bytes() + (size_t)w8 * STASH_BYTES_PER_WAVE;
+    stash.vals = (lds_f32x4 *)(sb);
+    stash.meta = (lds_u32x4 *)(sb + (size_t)H16_REC_N * 16);
+    stash.n = 0;
+  }
+  int tiles_done = 0;
+  auto begin = [&]() {
+    load_tq16(tq, tau, head_q * H1_QT + 128 * wn, nq);
+  };
+  auto emit = [&](f32x4 (&acc)[4][8]) {
+    const int dpair = head_d, qtile = head_q;
+    head_d = tail_d, head_q = tail_q;
+    --n_pend;
+    const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
+    const int qb = qtile * H1_QT + 128 * wn;
+    if (qb + 128 > nq) {   // the last query tile (wave-uniform): columns past nq never pass
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni)
+        if (qb + 16 * ni + (t & 15) >= nq) tq[ni] = INFINITY;
+    }
+    ++tiles_done;
+    emit_tile16(acc, tq, qb, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base, stash, (tiles_done & flush_mask) == 0);
+  };
+  h16_tile_stream(64, dimp / 32, lds, next, begin, emit, H1BlockedUnits());
+  rec_flush(stash, buf, count, S, k, cap);
+}
+
 // ---------------------------------------------------------------------------
 // Few queries (nq <= 32: faiss_search.profile's batch sizes, MEVI/faiss_search.py:32-68).  With one MFMA tile of query
 // columns the filter is bound by streaming the corpus image from HBM, and the tile stream above keeps only three 16 KiB
@@ -1214,7 +1435,11 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   const bool small = h1 && nq <= 32 && dim >= 160 && sm_lds_bytes(dim) + 8 * STASH_BYTES_PER_WAVE <= 160 * 1024 &&
                      !getenv("MEVI_IP_TOPK_NO_SMALL");
   if (small) fn = reinterpret_cast<const void *>(ip_filter_h1_small_kernel);
-  else if (h1) fn = reinterpret_cast<const void *>(ip_filter_h1_kernel);  // Q, D = f16 images, dim = padded dim
+  else if (h1) {  // Q, D = f16 images, dim = padded dim.  MEVI_IP_FILTER_MFMA=32: the 32x32x16 form (A/B; same lists)
+    static const bool shape32 = [] { const char *e = getenv("MEVI_IP_FILTER_MFMA"); return e && atoi(e) == 32; }();
+    fn = (shape32 || dim % 64 != 0) ? reinterpret_cast<const void *>(ip_filter_h1_kernel)
+                                    : reinterpret_cast<const void *>(ip_filter_h16_kernel);
+  }
   else if (ktail) MEVI_PICK(2, true);
   else MEVI_PICK(2, false);
 #undef MEVI_PICK
@@ -1258,13 +1483,27 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
         const int64_t per_xcd = (nwg + 7) / 8 < n_cu / 8 ? (nwg + 7) / 8 : n_cu / 8;
         grid = (unsigned)(8 * per_xcd);
       }
+      // flush cadence of the 16x16 kernel's record stashes: with `seen` rows behind tau a chunk is expected to yield
+      // k * chunk / seen candidates per query (exchangeable row order; every row in the first chunk), i.e. r per 64 x 128
+      // wave tile; flush every T tiles with T r <= ~40 records
+      int flush_mask = H16_FLUSH_EVERY - 1;
+      {
+        const double per_q = seen >= g.k ? (double)g.k * (double)chunk / (double)seen : (double)chunk;
+        const double r = per_q / (double)chunk * 64.0 * 128.0;
+        int T = H16_FLUSH_EVERY;
+        while (T > 1 && T * r > 40.0) T >>= 1;
+        flush_mask = T - 1;
+      }
+      void *args16[] = {(void *)&Q, &nq_i, (void *)&D, &d0, &d1, &dim, (void *)&tau_c, (void *)&st.buf,
+                        (void *)&st.count, (void *)&g.S, (void *)&g.k, (void *)&g.cap, &id_base, &n_qt, &n_dp, &flush_mask};
       void *args_small[] = {(void *)&Q, &nq_i, (void *)&D, &d0, &d1, &dim, (void *)&tau_c, (void *)&st.buf,
                             (void *)&st.count, (void *)&g.S, (void *)&g.k, (void *)&g.cap, &id_base};
       if (small) {  // one workgroup per CU, each walking 256-row blocks of the chunk
         const int64_t nb = (chunk + 255) / 256;
         grid = (unsigned)(nb < n_cu ? nb : n_cu);
       }
-      if (hipLaunchKernel(fn, dim3(grid), dim3(PP_THREADS), small ? args_small : args, pp_lds, stream) != hipSuccess) {
+      const bool k16 = fn == reinterpret_cast<const void *>(ip_filter_h16_kernel);
+      if (hipLaunchKernel(fn, dim3(grid), dim3(PP_THREADS), small ? args_small : (k16 ? args16 : args), pp_lds, stream) != hipSuccess) {
         set_error("ip_topk: filter kernel launch failed");
         return -1;
       }
@@ -1395,7 +1634,9 @@ struct IndexView {
 };
 inline int64_t pad32(int64_t d) { return (d + 31) / 32 * 32; }
 // k extent of the f16 images: whole 32-wide units, at least three (h1_tile_stream prefetches three units ahead)
-inline int64_t pad_k(int64_t d) { return pad32(d) < 96 ? 96 : pad32(d); }
+// images are padded to whole PAIRS of 32-k units, at least four (the 16x16x32 tile stream alternates two fragment sets per unit
+// pair and keeps three units in flight)
+inline int64_t pad_k(int64_t d) { return (d + 63) / 64 * 64 < 128 ? 128 : (d + 63) / 64 * 64; }
 inline size_t index_image_bytes(int64_t nd, int64_t dim) { return align_up((size_t)image_rows(nd) * pad_k(dim) * 2, 256); }
 inline IndexView view_index(const void *index, int64_t nd, int64_t dim) {
   const char *p = reinterpret_cast<const char *>(index);

@@ -28,6 +28,8 @@
 // time): images are padded to a multiple of 64 k.
 #pragma once
 
+#include <type_traits>
+
 #include "mfma_pp_f16.h"
 
 namespace mevi {
@@ -92,14 +94,18 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
     for (int ni = 0; ni < 4; ++ni) f.b[ni] = *reinterpret_cast<const f16x8 *>(p + 16 * ni * H1_LD);
   };
   f32x4 acc[4][8];
-  auto mma = [&](const FragA &fa, const FragB &fb, int hi) {
+  // zero: the first product of a tile into these sixteen blocks -- the instruction's C operand is the constant 0, so the 128
+  // accumulator registers are never cleared by vector moves (128 v_mov per wave and tile otherwise)
+  auto mma = [&](const FragA &fa, const FragB &fb, int hi, auto zero) {
     if constexpr (ABL & 8) return;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
-        acc[mi][4 * hi + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.a[mi], fb.b[ni], acc[mi][4 * hi + ni], 0, 0, 0);
+        acc[mi][4 * hi + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.a[mi], fb.b[ni], decltype(zero)::value ? z : acc[mi][4 * hi + ni], 0, 0, 0);
   };
+  using No = std::integral_constant<bool, false>;
 
   FragA A0, A1;
   FragB BL, BH;
@@ -110,8 +116,11 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
   }
   int rb = 0;
 
-  // one window: unit u of the tile, corpus fragments into `An` (the previous unit's are in `Ap`)
-  auto window = [&](int u, bool first, FragA &An, const FragA &Ap) {
+  // one window: unit u of the tile, corpus fragments into `An` (the previous unit's are in `Ap`).  kind 0: the tile's first
+  // window (no product pending; its PB is the first into blocks 0-3), 1: the second (its PA is the first into blocks 4-7), 2: the rest
+  auto window = [&](int u, auto kind, FragA &An, const FragA &Ap) {
+    constexpr int KIND = decltype(kind)::value;
+    constexpr bool first = KIND == 0;
     const bool spill = u + DEPTH >= nunits;
     H1Src tgt;
     tgt.src = spill ? nxt.src : cur.src;
@@ -120,9 +129,9 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
     const int wb = rb == 0 ? NBUF - 1 : rb - 1;
     read_a(rb, An);
     read_b(rb, 0, BL);
-    if (!first) mma(Ap, BH, 1);
+    if constexpr (!first) mma(Ap, BH, 1, std::integral_constant<bool, KIND == 1>());
     dma2(tgt, tu, wb, 0);
-    if (!first) {
+    if constexpr (!first) {
       // 8 reads spread over the first half of the 16 MFMAs, the DMA pieces after them
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
@@ -135,7 +144,7 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
     }
     __builtin_amdgcn_sched_barrier(0);
     read_b(rb, 1, BH);
-    mma(An, BL, 0);
+    mma(An, BL, 0, std::integral_constant<bool, KIND == 0>());
     dma2(tgt, tu, wb, 2);
     // the first MFMAs ahead of the reads: their wait covers the fragments issued a phase ago, not these
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -160,18 +169,20 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
   asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // unit 0 landed
   __builtin_amdgcn_sched_barrier(0);
   while (true) {
+    if constexpr (ABL & 8) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    begin();
-    window(0, true, A0, A1);
-    window(1, false, A1, A0);
-    for (int u = 2; u < nunits; u += 2) {
-      window(u, false, A0, A1);
-      window(u + 1, false, A1, A0);
+        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    mma(A1, BH, 1);
+    begin();
+    window(0, std::integral_constant<int, 0>(), A0, A1);
+    window(1, std::integral_constant<int, 1>(), A1, A0);
+    for (int u = 2; u < nunits; u += 2) {
+      window(u, std::integral_constant<int, 2>(), A0, A1);
+      window(u + 1, std::integral_constant<int, 2>(), A1, A0);
+    }
+    mma(A1, BH, 1, No());
     emit(acc);
     if (!have_nxt) break;
     cur = nxt;

@@ -80,6 +80,25 @@ static size_t image_at(long long r, int k, int dimp) {
   return ((size_t)((r >> 8) * (dimp >> 5) + (k >> 5)) * 256 + (size_t)(r & 255)) * 32 + (k & 31);
 }
 
+// sustained rate: `launches` back-to-back launches timed as one batch (the chip's clock under load settles over seconds)
+template <int SHAPE>
+float run_batch(const _Float16 *A, int M, const _Float16 *W, int N, int kp, float *sink, int launches) {
+  hipFuncSetAttribute(reinterpret_cast<const void *>(probe_kernel<SHAPE, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)h1_lds_bytes());
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipEventRecord(e0);
+  for (int i = 0; i < launches; ++i)
+    hipLaunchKernelGGL((probe_kernel<SHAPE, false>), dim3(256), dim3(PP_THREADS), h1_lds_bytes(), 0, A, W, kp, nullptr, 0, sink,
+                       M / 256, N / 256);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / launches;
+}
+
 template <int SHAPE>
 float run(const _Float16 *A, int M, const _Float16 *W, int N, int kp, float *sink, int reps = 6) {
   hipFuncSetAttribute(reinterpret_cast<const void *>(probe_kernel<SHAPE, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -146,6 +165,13 @@ int main() {
       const float m32 = run<32>(A, M, W, N, kp, sink), m16 = run<16>(A, M, W, N, kp, sink);
       printf("k %4d round %d: 32x32x16 %7.3f ms %7.1f TFLOP/s | 16x16x32 %7.3f ms %7.1f TFLOP/s | ratio %.3f\n", kp, round, m32,
              flop / m32 / 1e9, m16, flop / m16 / 1e9, m32 / m16);
+    }
+    // sustained: ~1.5 s batches, alternating shapes
+    const int launches = (int)(1.5 / (flop / 1.1e15)) + 1;   // ~1.5 s at 1.1 PFLOP/s
+    for (int round = 0; round < 3; ++round) {
+      const float m32 = run_batch<32>(A, M, W, N, kp, sink, launches), m16 = run_batch<16>(A, M, W, N, kp, sink, launches);
+      printf("k %4d sustained (%d launches) round %d: 32x32x16 %7.3f ms %7.1f TFLOP/s | 16x16x32 %7.3f ms %7.1f TFLOP/s | ratio %.3f\n",
+             kp, launches, round, m32, flop / m32 / 1e9, m16, flop / m16 / 1e9, m32 / m16);
     }
     hipFree(A); hipFree(W); hipFree(sink);
   }
