@@ -19,7 +19,7 @@
 // latency path) issues the identical MFMA sequence from global memory and therefore returns the same bits.
 #include <cstdlib>
 
-#include "mfma_split_stream.h"
+#include "mfma_split_stream16.h"
 
 namespace mevi {
 namespace {
@@ -439,6 +439,312 @@ __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
   }
 }
 
+// ---- the same two kernels on v_mfma_f32_16x16x32_f16 (mfma_split_stream16.h; the default) -------------------------------------
+// Roles as above: the MFMA's first operand is W, the second the activations.  A lane ends up, per 16 x 16 block (mi, ni), with
+// ONE output row m = m0 + 128 wn + 16 ni + (lane & 15) and FOUR CONSECUTIVE columns n = n0 + 128 grp + 64 wm + 16 mi + 4 (lane >> 4)
+// + j: 16 bytes per lane and block, 64 contiguous bytes per row and store instruction.  The epilogue walks the 32 blocks in
+// eight steps of four (mi, half of the rows), the residual rows of step i + 1 loaded before the stores of step i.
+template <int ACT, int OUT>   // OUT: 0 = f32 C, 1 = f32 C + residual, 2 = split image
+__global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
+    const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
+    const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int n_mtiles, int n_ntiles, SplitOut so) {
+  constexpr bool SPLIT_OUT = OUT == 2, HAS_RES = OUT == 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nwg = n_mtiles * n_ntiles;
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int range_base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;  // as xcd_remap
+  const int range_len = q8 + (xcd < r8 ? 1 : 0);
+  int item = blockIdx.x >> 3;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = w8 >> 2, wm = (w8 >> 1) & 1, wn = w8 & 1;
+  const int row_bytes = kp * 4;
+  int head_m = 0, head_n = 0, tail_m = 0, tail_n = 0, n_pend = 0;  // tiles fetched ahead of their epilogue (<= 2)
+
+  auto next = [&](H1Src &s) -> bool {
+    if (item >= range_len) return false;
+    int mt, nt;
+    supertile_order<4, 8>(range_base + item, n_ntiles, n_mtiles, nt, mt);
+    item += per_xcd;
+    if (n_pend == 0) head_m = mt, head_n = nt;
+    else tail_m = mt, tail_n = nt;
+    ++n_pend;
+    long long rows_left;
+    if (w8 < 4) {  // waves 0-3 stage the 256 W rows (LDS rows [0, 256)), waves 4-7 the 256 activation rows
+      s.src = reinterpret_cast<const char *>(W) + (size_t)nt * 256 * (size_t)row_bytes;
+      rows_left = (long long)N - (long long)nt * 256;
+    } else {
+      s.src = reinterpret_cast<const char *>(A) + (size_t)mt * 256 * (size_t)row_bytes;
+      rows_left = (long long)M - (long long)mt * 256;
+    }
+    if (rows_left > 256) rows_left = 256;
+    s.bytes = (unsigned int)(rows_left * row_bytes);
+    return true;
+  };
+  auto begin = [&]() {};
+  auto emit = [&](f32x4 (&acc)[4][8]) {
+    const int mt = head_m, nt = head_n;
+    head_m = tail_m, head_n = tail_n;
+    --n_pend;
+    // the lane coordinates are re-derived per tile from opaque copies: left visible, the compiler hoists the 64 per-block store /
+    // residual offsets (tile-invariant) out of the tile loop and spills them (17-25 registers per lane in the residual variants)
+    int r16 = lane & 15, kq = lane >> 4;
+    asm volatile("" : "+v"(r16), "+v"(kq));
+    const int m0 = mt * 256 + 128 * wn + r16;            // + 16 ni
+    const bool interior = (mt + 1) * 256 <= M && (nt + 1) * 256 <= N;
+    const int ldc4 = (int)ldc * 4, ldr4 = (int)ldr * 4;
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(SPLIT_OUT ? nullptr : C + (size_t)mt * 256 * ldc + (size_t)nt * 256);
+    const __amdgpu_buffer_rsrc_t rr =
+        tile_rsrc(residual ? residual + (size_t)mt * 256 * ldr + (size_t)nt * 256 : nullptr);
+    const __amdgpu_buffer_rsrc_t ri =
+        tile_rsrc(SPLIT_OUT ? so.img + (size_t)mt * 256 * 2 * so.np + (size_t)nt * 256 : nullptr);
+    const __amdgpu_buffer_rsrc_t rw = tile_rsrc(ew + nt * 256);
+    const __amdgpu_buffer_rsrc_t rb = tile_rsrc(bias ? bias + nt * 256 : nullptr);
+    const int ncol = 128 * grp + 64 * wm + 4 * kq;        // column of the lane's quad in block column mi = 0 (+ 16 mi)
+    const int nvalid = N - nt * 256;                      // columns of this tile that exist (edge tiles)
+    // per-row scalars of the lane's eight rows, packed four int8 per register: A-row exponents, output exponents (split out)
+    unsigned int emp[2] = {0u, 0u}, eop[2] = {0u, 0u};
+    const int mlim = interior ? 0x7fffffff : M;          // row m exists iff m < mlim
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+      const int m = m0 + 16 * ni;
+      emp[ni >> 2] |= ((unsigned int)(unsigned char)ea[min(m, M - 1)]) << (8 * (ni & 3));
+      if constexpr (SPLIT_OUT) {
+        const float bound = fmaf(so.anorm[min(m, M - 1)], so.wnorm_max, so.babs_max);
+        const int e = pow2_exp(bound * 1.001f);
+        eop[ni >> 2] |= ((unsigned int)(unsigned char)(signed char)e) << (8 * (ni & 3));
+        if (nt == 0 && grp == 0 && wm == 0 && kq == 0 && m < mlim) {  // one writer per row
+          so.exps[m] = (signed char)e;
+          if (so.norms) so.norms[m] = bound * so.onorm_scale;
+        }
+      }
+    }
+    auto sx8 = [](unsigned int packed, int i) { return (int)(packed << (24 - 8 * i)) >> 24; };   // sign-extended byte i
+    // every load is issued BEFORE the stores it does not depend on (vmcnt retires in issue order): the column exponents of the
+    // four block columns up front; bias of block column mi + 1 and the residual rows of step i + 1 before the stores of step i.
+    // A step = two blocks (one block column mi, rows 16 (2 p) and 16 (2 p + 1)): sixteen steps per tile.
+    unsigned int wq[4];   // four int8 exponents per block column
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int c = ncol + 16 * mi;
+      wq[mi] = __builtin_amdgcn_raw_buffer_load_b32(rw, (interior || c < nvalid) ? c : OOB, 0, 0);
+    }
+    u32x4 bq[2], res[2][HAS_RES ? 2 : 1];
+    auto load_step = [&](int i, u32x4 &b, u32x4 (&r)[HAS_RES ? 2 : 1]) {
+      const int mi = i >> 2, pr = i & 3;
+      const int c = ncol + 16 * mi;
+      const bool cok = interior || c < nvalid;
+      if (pr == 0) {
+        b = u32x4{0u, 0u, 0u, 0u};
+        if (bias) b = __builtin_amdgcn_raw_buffer_load_b128(rb, cok ? c * 4 : OOB, 0, 0);
+      }
+      if constexpr (HAS_RES) {
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int ni = 2 * pr + n2;
+          const int rowt = 128 * wn + 16 * ni + r16;
+          r[n2] = __builtin_amdgcn_raw_buffer_load_b128(rr, (cok && m0 + 16 * ni < mlim) ? rowt * ldr4 + c * 4 : OOB, 0, 0);
+        }
+      }
+    };
+    load_step(0, bq[0], res[0]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int mi = i >> 2, pr = i & 3;
+      const int c = ncol + 16 * mi;
+      const bool cok = interior || c < nvalid;
+      if (i + 1 < 16) load_step(i + 1, bq[((i + 1) >> 2) & 1], res[(i + 1) & 1]);
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) {
+        const int ni = 2 * pr + n2;
+        const int rowt = 128 * wn + 16 * ni + r16;       // row inside the tile
+        const bool ok = cok && m0 + 16 * ni < mlim;
+        const int em = sx8(emp[ni >> 2], ni & 3);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = ldexpf(acc[mi][ni][j], -(em + sx8(wq[mi], j))) + __uint_as_float(bq[mi & 1][j]);
+          x = act_fn<ACT>(x);
+          if constexpr (HAS_RES) x += __uint_as_float(res[i & 1][n2][j]);
+          v[j] = x;
+        }
+        if constexpr (SPLIT_OUT) {
+          const int eo = sx8(eop[ni >> 2], ni & 3);
+          h4 hi, lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xs = ldexpf(v[j], eo);
+            hi[j] = (_Float16)xs;
+            lo[j] = (_Float16)(xs - (float)hi[j]);
+          }
+          const int off = ok ? rowt * (so.np * 4) + c * 2 : OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), ri, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), ri, off, so.np * 2, 0);
+        } else {
+          const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rc, ok ? rowt * ldc4 + c * 4 : OOB, 0, 0);
+        }
+      }
+      // keep the steps apart: left alone the scheduler hoists the residual loads of ALL steps to the top (64 registers of
+      // loads in flight on top of the 128 accumulators: the residual variants spilled 17-25 registers per lane)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  split_tile_stream16(row_bytes, kp * 2, kp / 32, lds, next, begin, emit);
+}
+
+// Few outputs (the latency path), 16x16x32 form: one workgroup per 32 x 32 outputs = 2 x 2 blocks, wave 0 multiplies; per 32 k
+// and block a_lo w_hi, a_hi w_hi, a_hi w_lo -- the sequence of split_tile_stream16, hence the same bits.  Staging, ring and
+// swizzle as gemm_split_skinny_kernel (the swizzle key (r >> 1) & 7 is conflict-free for this fragment shape too: the eight
+// row pairs of a ds_read_b128 lane group land in eight different slots).
+__global__ __launch_bounds__(256) void gemm_split16_skinny_kernel(
+    const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
+    const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int act, SplitOut so) {
+  __shared__ __attribute__((aligned(16))) float sm[SK_RING * SK_CHUNK];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const bool is_w = wave >= 2;
+  const int rows_left = (is_w ? N - n0 : M - m0) - 1;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      tile_rsrc((is_w ? W + (size_t)n0 * 2 * kp : A + (size_t)m0 * 2 * kp) + ((wave & 1) ? kp : 0));
+  int voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 8 * i + (lane >> 3);
+    voff[i] = min(r, rows_left) * 4 * kp + 16 * ((lane & 7) ^ ((r >> 1) & 7));
+  }
+  const int nchunk = (kp + 63) / 64;
+  auto issue = [&](int c) {
+    float *dst = sm + (c & (SK_RING - 1)) * SK_CHUNK + wave * SK_SLAB;
+    const int soff = 2 * min(64 * c, kp - 64);
+    const bool past = c >= nchunk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + 256 * i), 16,
+                                               past ? OOB : voff[i], soff, 0, 0);
+  };
+  // the epilogue's operands, fetched ahead of the stream: rows m0 + 16 ni + r16, column quads n0 + 16 mi + 4 kq
+  int em[2], eo[2] = {0, 0}, mc[2];
+  bool mok[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int m = m0 + 16 * ni + r16;
+    mok[ni] = m < M;
+    mc[ni] = min(m, M - 1);
+    em[ni] = ea[mc[ni]];
+    if (so.img) {
+      eo[ni] = out_exp(so, mc[ni]);
+      if (wave == 0 && mok[ni] && n0 == 0 && kq == 0) {
+        so.exps[m] = (signed char)eo[ni];
+        if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
+      }
+    }
+  }
+  int pw[2];
+  f32x4 pb[2], pr[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int n = min(n0 + 16 * mi + 4 * kq, N - 4);
+    pw[mi] = *reinterpret_cast<const int *>(ew + n);
+    pb[mi] = bias ? *reinterpret_cast<const f32x4 *>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+      pr[mi][ni] = residual ? *reinterpret_cast<const f32x4 *>(residual + (size_t)mc[ni] * ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment of rows 16 i + r16, unit uu of the chunk: piece 4 uu + kq of the 128-byte row, slot ^ key(row)
+  int foff[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const int r = 16 * i + r16;
+      foff[i][uu] = r * 32 + 4 * ((4 * uu + kq) ^ ((r >> 1) & 7));
+    }
+#pragma unroll
+  for (int c = 0; c < SK_RING - 1; ++c) issue(c);
+  for (int c = 0; c < nchunk; ++c) {
+    asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    issue(c + SK_RING - 1);
+    if (wave == 0) {
+      const int k0 = 64 * c;
+      const int skip = k0 > kp - 64 ? (k0 - (kp - 64)) / 32 : 0;   // units of the clamped last chunk already multiplied
+      const float *b = sm + (c & (SK_RING - 1)) * SK_CHUNK;
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        if (uu < skip) continue;
+        f16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = *reinterpret_cast<const f16x8 *>(b + 0 * SK_SLAB + foff[i][uu]);
+          al[i] = *reinterpret_cast<const f16x8 *>(b + 1 * SK_SLAB + foff[i][uu]);
+          wh[i] = *reinterpret_cast<const f16x8 *>(b + 2 * SK_SLAB + foff[i][uu]);
+          wl[i] = *reinterpret_cast<const f16x8 *>(b + 3 * SK_SLAB + foff[i][uu]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mi], al[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mi], ah[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mi], ah[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the empty tail pieces: nothing may target LDS past the loop
+  if (wave != 0) return;
+  const int a8 = act;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int n = n0 + 16 * mi + 4 * kq;       // n, N, ldc multiples of 4: a quad is whole or absent, and 16-byte aligned
+    if (n >= N) continue;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      if (!mok[ni]) continue;
+      const int m = m0 + 16 * ni + r16;
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = ldexpf(acc[mi][ni][j], -(em[ni] + (int)(signed char)(pw[mi] >> (8 * j))));
+        if (bias) x += pb[mi][j];
+        x = a8 == 1 ? act_fn<1>(x) : (a8 == 2 ? act_fn<2>(x) : x);
+        if (residual) x += pr[mi][ni][j];
+        v[j] = x;
+      }
+      if (so.img) {
+        f16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xs = ldexpf(v[j], eo[ni]);
+          hi[j] = (_Float16)xs;
+          lo[j] = (_Float16)(xs - (float)hi[j]);
+        }
+        _Float16 *o = so.img + (size_t)m * 2 * so.np + n;
+        *reinterpret_cast<f16x4 *>(o) = hi;
+        *reinterpret_cast<f16x4 *>(o + so.np) = lo;
+      } else {
+        *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
+      }
+    }
+  }
+}
+
 // crossover measured with tools/bench_skinny_crossover.py (profiles/r02_skinny_crossover.txt): the latency kernel takes
 // ~13 us (K = 768) per round of 256 workgroups, the tile stream ~50 us for any grid below one wave of tiles
 constexpr long long SPLIT_SKINNY_MAX_OUTPUTS = 1500000;
@@ -498,8 +804,12 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
   const _Float16 *A = reinterpret_cast<const _Float16 *>(a_img), *W = reinterpret_cast<const _Float16 *>(w_img);
   // MEVI_GEMM_SKINNY_MAX: the crossover in outputs (tools/bench_gemm_split.py measures it; 0 = tile stream only)
   static const long long skinny_max = [] { const char *e = getenv("MEVI_GEMM_SKINNY_MAX"); return e ? atoll(e) : SPLIT_SKINNY_MAX_OUTPUTS; }();
+  // MEVI_GEMM_MFMA=32: the 32x32x16 kernels (A/B switch; BOTH kernels change together -- a row's bits are the same in the
+  // tile stream and in the latency kernel of one shape, not across shapes)
+  static const bool shape32 = [] { const char *e = getenv("MEVI_GEMM_MFMA"); return e && atoi(e) == 32; }();
   if (m * n <= skinny_max) {
-    hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0,
+    hipLaunchKernelGGL(shape32 ? gemm_split_skinny_kernel : gemm_split16_skinny_kernel,
+                       dim3((unsigned)((n + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0,
                        stream, A, reinterpret_cast<const signed char *>(a_exp), (int)m, W, reinterpret_cast<const signed char *>(w_exp), (int)n, kp, c,
                        (long long)ldc, bias, residual, (long long)ldr, act, so);
     MEVI_HIP_CHECK(hipGetLastError());
@@ -524,7 +834,10 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
   static const kern_t table[3][3] = {{gemm_split_kernel<0, 0>, gemm_split_kernel<0, 1>, gemm_split_kernel<0, 2>},
                                      {gemm_split_kernel<1, 0>, gemm_split_kernel<1, 1>, gemm_split_kernel<1, 2>},
                                      {gemm_split_kernel<2, 0>, gemm_split_kernel<2, 1>, gemm_split_kernel<2, 2>}};
-  const kern_t fn = table[a8][so.img ? 2 : (residual ? 1 : 0)];
+  static const kern_t table16[3][3] = {{gemm_split16_kernel<0, 0>, gemm_split16_kernel<0, 1>, gemm_split16_kernel<0, 2>},
+                                       {gemm_split16_kernel<1, 0>, gemm_split16_kernel<1, 1>, gemm_split16_kernel<1, 2>},
+                                       {gemm_split16_kernel<2, 0>, gemm_split16_kernel<2, 1>, gemm_split16_kernel<2, 2>}};
+  const kern_t fn = (shape32 ? table : table16)[a8][so.img ? 2 : (residual ? 1 : 0)];
   MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(PP_THREADS), lds_bytes, stream, A, reinterpret_cast<const signed char *>(a_exp), (int)m, W,

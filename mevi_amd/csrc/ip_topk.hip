@@ -332,7 +332,8 @@ __device__ __forceinline__ void rec_flush(RecStash &st, unsigned long long *__re
 __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq)[8], int q0, long long d0, long long doc_end,
                                             unsigned long long *__restrict__ buf, unsigned int *__restrict__ count, int S,
                                             int k, int cap, unsigned int id_base, RecStash &st, bool flush_now) {
-  const int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));   // opaque per tile: keeps the compiler from hoisting per-block invariants out of the tile loop (spills)
   const int r16 = lane & 15, kq = lane >> 4;
   if (d0 + 64 > doc_end) {  // ragged last tile (wave-uniform): rows past the shard never pass
 #pragma unroll

@@ -38,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int h16_swz(int quad) { return (quad & 2) ? 3 : 0; }
 
-// next / begin / emit / uoff as h1_tile_stream; emit receives f32x4 acc[4][8]: block (mi, ni) = corpus rows 16 mi + [0, 16)
+// next / begin / emit / uoff as h1_tile_stream (begin() is called two windows before the tile's emit, not at its start); emit receives f32x4 acc[4][8]: block (mi, ni) = corpus rows 16 mi + [0, 16)
 // of the wave's 64, queries 16 ni + [0, 16) of the wave's 128.  nunits even, >= 4.
 template <class Next, class Begin, class Emit, class UOff = H1PlainUnits, int ABL = 0>
 __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float *lds, Next next, Begin begin, Emit emit,
@@ -175,10 +175,10 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    begin();
     window(0, std::integral_constant<int, 0>(), A0, A1);
     window(1, std::integral_constant<int, 1>(), A1, A0);
     for (int u = 2; u < nunits; u += 2) {
+      if (u + 2 >= nunits) begin();   // two windows (~2 us) ahead of the epilogue: what begin() loads is not held in registers through the tile
       window(u, std::integral_constant<int, 2>(), A0, A1);
       window(u + 1, std::integral_constant<int, 2>(), A1, A0);
     }
