@@ -280,6 +280,20 @@ int mevi_beam_step_f32(const float *logits, const float *beam_scores, int64_t nq
                        int64_t R, int final_step, float *out_scores, int32_t *out_parent,
                        int32_t *out_code, void *stream);
 
+/* The same step under a GENERIC prefix tree -- TreeBuilder(share_sons=False).add(path) per existing code path
+ * (MEVI/main_models.py:50-63, 1707-1728) and the per-beam trie walk of MEVI/transformers/generation_utils.py:803-818.
+ * The trie arrives level by level: for the level being decoded, node i32 [nq, nb] = every beam's node, tree_mask
+ * u32 [n_nodes, ceil(K/32)] = which codes its children carry, tree_base i32 [n_nodes] = index (in the NEXT level) of its
+ * first child, children contiguous in code order.  Candidates are the children only; the log-softmax normaliser spans eos
+ * and all K codes as in the reference (its tree mask is added after log_softmax).  All R beams run from the first step
+ * (nb >= R; the reference seeds beams 1..R-1 with -1e9), so R candidates always exist.  out_node i32 [nq, R] = the kept
+ * candidates' nodes in the next level; the other outputs as mevi_beam_step_f32 (final_step 0).  The eos step after the last
+ * level is mevi_beam_step_f32 with final_step = 1 (a leaf's only child is eos). */
+int mevi_beam_step_tree_f32(const float *logits, const float *beam_scores, int64_t nq, int64_t nb, int64_t K,
+                            int64_t R, const int32_t *node, const uint32_t *tree_mask, const int32_t *tree_base,
+                            int64_t n_nodes, float *out_scores, int32_t *out_parent, int32_t *out_code,
+                            int32_t *out_node, void *stream);
+
 /* Row-wise (log-)softmax with the beam step's arithmetic (max, sum of expf(x - max), logf), for the branches that keep
  * EVERY candidate instead of a top-R: mode 0 = log_softmax of x f32 [rows, cols] (the all-paths walk `_generate_all`,
  * MEVI/transformers/generation_utils.py:1013-1136); mode 1 = scale[row] * softmax(x) (pq.beam_search while beams * K <= R,

@@ -18,10 +18,18 @@ namespace {
 
 // mode 0: NCI step (K+1 columns, col 0 = eos, log-domain);  mode 1: NCI final step;
 // mode 2: pq.beam_search step (K columns of -distance): cand = beam_prob[r] * softmax(row)[c]  (pq.py:660-676)
+// Generic prefix trees (TreeBuilder(share_sons=False), MEVI/main_models.py:50-63; the mask walk of
+// generation_utils.py:803-818): `node` i32 [nq, nb] is every beam's trie node at this level, `tmask` u32 [nodes, W] the
+// set of codes its children carry (bit c of word c / 32), `tbase` i32 [nodes] the next level's index of its first child
+// (children in code order, contiguous).  A candidate (r, c) exists iff bit c of tmask[node[r]] is set; the log-softmax
+// normaliser still spans eos and all K codes of the level (the tree mask is ADDED to the log-probabilities).  out_node =
+// the child's index in the next level.  node == nullptr: the shared-sons tree (every code allowed).
 __global__ __launch_bounds__(256) void beam_step_kernel(const float *__restrict__ logits,
                                                        const float *__restrict__ beam_scores, int nb, int K,
                                                        int R, int final_step, float *__restrict__ out_scores,
-                                                       int *__restrict__ out_parent, int *__restrict__ out_code) {
+                                                       int *__restrict__ out_parent, int *__restrict__ out_code,
+                                                       const int *__restrict__ node, const unsigned int *__restrict__ tmask,
+                                                       const int *__restrict__ tbase, int W, int *__restrict__ out_node) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // P keys, then nb floats x2
   const int q = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float *__restrict_
       if (final_step == 2) {
         const float p = expf(lq[(size_t)r * ncol + c] - smax[r]) / expf(slog[r]);
         key = make_key(beam_scores[(size_t)q * nb + r] * p, (unsigned int)i);
-      } else {
+      } else if (!node || ((tmask[(size_t)node[(size_t)q * nb + r] * W + (c >> 5)] >> (c & 31)) & 1u)) {
         const float lsm = (lq[(size_t)r * ncol + 1 + c] - smax[r]) - slog[r];
         key = make_key(beam_scores[(size_t)q * nb + r] + lsm, (unsigned int)i);
       }
@@ -73,9 +81,22 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float *__restrict_
   for (int i = t; i < R; i += 256) {
     const unsigned long long key = skeys[i];
     const int flat = (int)key_id(key);
-    out_scores[(size_t)q * R + i] = key_score(key);
-    out_parent[(size_t)q * R + i] = flat / K;
-    out_code[(size_t)q * R + i] = flat % K;
+    const int r = flat / K, c = flat % K;
+    out_scores[(size_t)q * R + i] = key == 0ull ? -INFINITY : key_score(key);   // key 0: fewer candidates than R (host refuses)
+    out_parent[(size_t)q * R + i] = key == 0ull ? 0 : r;
+    out_code[(size_t)q * R + i] = key == 0ull ? -1 : c;
+    if (node) {
+      int nn = -1;
+      if (key != 0ull) {
+        const int n0 = node[(size_t)q * nb + r];
+        const unsigned int *m = tmask + (size_t)n0 * W;
+        int below = 0;
+        for (int w = 0; w < (c >> 5); ++w) below += __popc(m[w]);
+        below += __popc(m[c >> 5] & ((1u << (c & 31)) - 1u));
+        nn = tbase[n0] + below;
+      }
+      out_node[(size_t)q * R + i] = nn;
+    }
   }
 }
 
@@ -140,7 +161,33 @@ extern "C" int mevi_beam_step_f32(const float *logits, const float *beam_scores,
     MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(beam_step_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)nq), dim3(256), lds, (hipStream_t)stream, logits, beam_scores,
-                     (int)nb, (int)K, (int)R, final_step, out_scores, out_parent, out_code);
+                     (int)nb, (int)K, (int)R, final_step, out_scores, out_parent, out_code, (const int *)nullptr,
+                     (const unsigned int *)nullptr, (const int *)nullptr, 0, (int *)nullptr);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_beam_step_tree_f32(const float *logits, const float *beam_scores, int64_t nq, int64_t nb, int64_t K,
+                                       int64_t R, const int32_t *node, const uint32_t *tree_mask, const int32_t *tree_base,
+                                       int64_t n_nodes, float *out_scores, int32_t *out_parent, int32_t *out_code,
+                                       int32_t *out_node, void *stream) {
+  MEVI_REQUIRE(nq >= 0 && nb > 0 && K > 0 && R > 0 && n_nodes > 0, MEVI_ERR_INVALID_ARG, "beam_step_tree: bad shape");
+  if (nq == 0) return MEVI_OK;
+  MEVI_REQUIRE(logits && beam_scores && node && tree_mask && tree_base && out_scores && out_parent && out_code && out_node,
+               MEVI_ERR_INVALID_ARG, "beam_step_tree: null pointer");
+  MEVI_REQUIRE(nb * K <= 16384, MEVI_ERR_UNSUPPORTED, "beam_step_tree: nb*K=%lld > 16384", (long long)(nb * K));
+  MEVI_REQUIRE(nb >= R, MEVI_ERR_UNSUPPORTED,
+               "beam_step_tree: needs nb >= R beams (every beam sits on a trie node with at least one child, so nb >= R "
+               "guarantees R candidates; the reference runs all R beams from the first step)");
+  int P = 64;
+  while (P < nb * K) P <<= 1;
+  const size_t lds = (size_t)P * 8 + (size_t)nb * 8;
+  if (lds > 65536)
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(beam_step_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)nq), dim3(256), lds, (hipStream_t)stream, logits, beam_scores,
+                     (int)nb, (int)K, (int)R, 0, out_scores, out_parent, out_code, node, tree_mask, tree_base,
+                     (int)((K + 31) / 32), out_node);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

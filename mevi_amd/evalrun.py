@@ -492,6 +492,21 @@ class EvalRun:
         return results
 
     @torch.no_grad()
+    def decode_tree(self):
+        """The tree the beams are held to.  `--codebook 1` (every script) = the shared-sons tree of all K codes per level
+        (main_models.py:1698-1706): None.  MEVI_DECODE_TREE=clusters (a switch of this build; the reference reaches the same
+        structure only outside --codebook mode, main_models.py:1707-1728): the generic trie of the code paths that own a
+        populated cluster, TreeBuilder(share_sons=False) -- no beam is spent on an empty cluster."""
+        if os.environ.get("MEVI_DECODE_TREE", "") != "clusters":
+            return None
+        if getattr(self, "_decode_tree", None) is None:
+            from .nci import PrefixTree
+
+            keys = np.asarray(self.index.keys, dtype=np.int64)
+            w = self.K ** np.arange(self.M - 1, -1, -1, dtype=np.int64)
+            self._decode_tree = PrefixTree((keys[:, None] // w) % self.K, self.M, self.K, self.dev)
+        return self._decode_tree
+
     def infer(self, texts, doc_ids, rows=None):
         """One batch: returns [(text, ndoc, coarse ranks, fine ranks)] like infer() with recall_level='both'.
         rows: the samples' line numbers in the query file (only read with --query_embedding_path)."""
@@ -504,7 +519,8 @@ class EvalRun:
             torch.cuda.synchronize()
             t0 = time.time()
         decoded, scores, _, _ = self.nci.generate(ids, mask, num_beams=R, num_return_sequences=R,
-                                                  length_penalty=a.length_penalty, max_length=self.M + 2, graph=timing)
+                                                  length_penalty=a.length_penalty, max_length=self.M + 2, graph=timing,
+                                                  decode_tree=self.decode_tree())
         B = len(texts)
         codes = decode_token(decoded, self.K).view(B, R, self.M).cpu().numpy()
         scores = np.array(scores).reshape(B, R)

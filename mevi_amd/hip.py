@@ -85,6 +85,8 @@ _SIGNATURES = {
                                          c_int64, c_void_p, c_void_p]),
     "mevi_beam_step_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
+    "mevi_beam_step_tree_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                        c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mevi_row_softmax_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "mevi_pair_dot_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                   c_void_p, c_void_p]),

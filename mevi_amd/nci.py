@@ -216,6 +216,37 @@ class PrefixTables:
         return cache
 
 
+class PrefixTree:
+    """The generic decode tree of the reference -- TreeBuilder(share_sons=False).add(tokens of one code path) for every
+    existing path (MEVI/main_models.py:50-63, built from the doc -> code mapping at :1707-1728) -- level by level as
+    arrays: level p holds the distinct prefixes of length p in lexicographic order (level 0 = the root), `mask[p]` i32
+    [n_p, ceil(K/32)] = the codes of a node's children, `base[p]` i32 [n_p] = the index in level p + 1 of its first child
+    (children are contiguous there, in code order).  All paths have M codes (the RQ setting); eos follows every leaf."""
+
+    def __init__(self, paths, M, K, device):
+        paths = np.unique(np.asarray(paths, dtype=np.int64).reshape(-1, M), axis=0)      # lexicographic
+        assert paths.shape[0] > 0 and paths.min() >= 0 and paths.max() < K
+        self.M, self.K, self.n_paths = M, K, paths.shape[0]
+        W = (K + 31) // 32
+        self.mask, self.base = [], []
+        n = paths.shape[0]
+        for p in range(M):
+            first_child = np.ones(n, bool)                                 # first path of every distinct (p + 1)-prefix
+            first_child[1:] = (paths[1:, :p + 1] != paths[:-1, :p + 1]).any(1)
+            first_par = np.zeros(n, bool)                                  # first path of every distinct p-prefix
+            first_par[0] = True
+            if p > 0:
+                first_par[1:] = (paths[1:, :p] != paths[:-1, :p]).any(1)
+            par_of_row = np.cumsum(first_par) - 1
+            child_of_row = np.cumsum(first_child) - 1
+            rows = np.flatnonzero(first_child)
+            codes, par = paths[rows, p], par_of_row[rows]
+            mask = np.zeros((int(par_of_row[-1]) + 1, W), np.uint32)
+            np.bitwise_or.at(mask, (par, codes >> 5), np.left_shift(np.uint32(1), (codes & 31).astype(np.uint32)))
+            self.mask.append(torch.from_numpy(mask.view(np.int32)).to(device))
+            self.base.append(torch.from_numpy(child_of_row[first_par].astype(np.int32)).to(device))
+
+
 class NCIModel:
     """`generate()` mirrors the reference call; weights use the reference's state_dict names
     (T5ForConditionalGeneration: shared, encoder.*, decoder.*, decode_embeddings, adaptor*, lm_head)."""
@@ -283,19 +314,23 @@ class NCIModel:
             return None, scores, enc, None
         R = num_beams
         assert num_return_sequences in (None, R), "needs num_beams == num_return_sequences"
+        # decode_tree: None = the shared-sons tree of every script (TreeBuilder(share_sons=True): all K codes at every level),
+        # or a PrefixTree = the reference's generic trie of the existing code paths (TreeBuilder(share_sons=False))
+        tree = reference_kwargs.get("decode_tree")
+        assert tree is None or (isinstance(tree, PrefixTree) and tree.M == c.M and tree.K == c.K), "decode_tree: a PrefixTree of this model's (M, K)"
         # K < R (SURVEY 8(a') note ii): the reference carries -1e9 placeholder beams until K**p real prefixes exist; they
         # never win against a real candidate, so the search keeps min(R, live * K) beams per level (golden G1 (3,8,10), (2,4,10))
-        assert R <= c.K ** c.M, "fewer code paths than beams: the reference would return -1e9 placeholder hypotheses"
+        assert tree is not None or R <= c.K ** c.M, "fewer code paths than beams: the reference would return -1e9 placeholder hypotheses"
         assert max_length in (None, c.M + 2)
         ids = input_ids.to(self.dev, torch.int64).contiguous()
         mask = attention_mask.to(self.dev, torch.int64).contiguous()
         if graph and 0 < ids.shape[0] <= GRAPH_MAX_ROWS:
             if self.prefix_table_bytes:
                 self.tables()
-            decoded, hyp, enc = self._graphs.run(("generate", R, float(length_penalty)) + tuple(ids.shape),
-                                                 lambda i, m: self._search(i, m, R, length_penalty, pack=False), ids, mask)
+            decoded, hyp, enc = self._graphs.run(("generate", R, float(length_penalty), id(tree)) + tuple(ids.shape),
+                                                 lambda i, m: self._search(i, m, R, length_penalty, pack=False, tree=tree), ids, mask)
         else:
-            decoded, hyp, enc = self._search(ids, mask, R, length_penalty, pack=True)
+            decoded, hyp, enc = self._search(ids, mask, R, length_penalty, pack=True, tree=tree)
         return decoded, hyp.reshape(-1).tolist(), enc, None
 
     @torch.no_grad()
@@ -365,27 +400,34 @@ class NCIModel:
         zeros = torch.zeros(nq, dtype=torch.int64, device=self.dev)
         expand(0, xkv, 1, 0, zeros, zeros, torch.zeros(nq, dtype=torch.float32, device=self.dev), self.decoder.new_cache(nq), None)
 
-    def _search(self, ids, mask, R, length_penalty, pack):
-        """The device part of generate(): (decoded i64[B*R, M+2], hypothesis scores f64[B, R], encoder states)."""
+    def _search(self, ids, mask, R, length_penalty, pack, tree=None):
+        """The device part of generate(): (decoded i64[B*R, M+2], hypothesis scores f64[B, R], encoder states).
+        `tree` (a PrefixTree): beams continue along the trie's children only (mevi_beam_step_tree_f32).  The reference then
+        runs all R beams from the first step, beams 1..R-1 seeded with -1e9 (generation_utils.py:752-756): they follow the
+        same trie and fill the slots real candidates cannot whenever fewer than R exist -- so does this search (every beam
+        sits on a trie node, each node has a child, hence R candidates at every level)."""
         c = self.cfg
         B = ids.shape[0]
         enc = self.encoder.forward(self.shared, ids, mask, pack=None if pack else False)
         xkv = self.decoder.cross_kv(enc, mask, pack=pack)
 
-        nb = 1
-        tokens = torch.zeros(B, dtype=torch.int64, device=self.dev)          # decoder_start_token_id = 0
-        scores = torch.zeros((B, 1), dtype=torch.float32, device=self.dev)
-        codes = torch.zeros((B, 1, 0), dtype=torch.int64, device=self.dev)
+        nb = 1 if tree is None else R
+        tokens = torch.zeros(B * nb, dtype=torch.int64, device=self.dev)     # decoder_start_token_id = 0
+        scores = torch.zeros((B, nb), dtype=torch.float32, device=self.dev)
+        if tree is not None:
+            scores[:, 1:] = -1e9
+            node = torch.zeros((B, nb), dtype=torch.int32, device=self.dev)  # every beam starts at the root
+        codes = torch.zeros((B, nb, 0), dtype=torch.int64, device=self.dev)
         levels = self.tables().levels if self.prefix_table_bytes else 0      # positions the prefix tables cover
-        pidx = torch.zeros(B, dtype=torch.int64, device=self.dev)            # prefix index of every live beam
+        pidx = torch.zeros(B * nb, dtype=torch.int64, device=self.dev)       # prefix index of every live beam
         # The decoder's K|V caches are never re-ordered (the reference index_selects every layer's cache by the surviving
         # beams' parents after each step, generation_utils.py:927-934): position p of step-p row r stays in cache row r and
         # every live beam carries the cache rows of its ancestors, `anc` i32 [rows, p].  Up to 8 positions (the few-keys
         # attention kernel); longer codes keep the copying form.
         indexed = c.M + 1 <= 8
-        dcache = self.decoder.new_cache(B * min(R, c.K ** c.M) if indexed else B)
-        anc = torch.zeros((B, 0), dtype=torch.int32, device=self.dev)
-        acache = self.adaptor.new_cache(B) if levels == 0 else None
+        dcache = self.decoder.new_cache(B * (min(R, c.K ** c.M) if tree is None else R) if indexed else B * nb)
+        anc = torch.zeros((B * nb, 0), dtype=torch.int32, device=self.dev)
+        acache = self.adaptor.new_cache(B * nb) if levels == 0 else None
         base = torch.arange(B, device=self.dev)[:, None]
         for p in range(c.M + 1):
             if p == levels and p > 0:       # first position beyond the tables: its cache comes from them
@@ -397,7 +439,10 @@ class NCIModel:
             if p == c.M:
                 break
             Rp = min(R, nb * c.K)                                             # beams alive after this level
-            scores, parent, code = ops.beam_step(logits, scores, c.K, Rp)
+            if tree is None:
+                scores, parent, code = ops.beam_step(logits, scores, c.K, Rp)
+            else:
+                scores, parent, code, node = ops.beam_step_tree(logits, scores, c.K, Rp, node, tree.mask[p], tree.base[p])
             parent, code = parent.long(), code.long()
             rows = (base * nb + parent).reshape(-1)                           # surviving parents, [B*Rp]
             if indexed:

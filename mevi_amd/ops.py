@@ -457,6 +457,26 @@ def beam_step(logits, beam_scores, K, R, final_step=False):
 
 
 @hip.on_device
+def beam_step_tree(logits, beam_scores, K, R, node, tree_mask, tree_base):
+    """The beam step under a generic prefix tree (mevi_beam_step_tree_f32): logits [nq*nb, K+1], beam_scores [nq, nb],
+    node i32 [nq, nb] (trie node of every beam at this level), tree_mask i32/u32 [n_nodes, ceil(K/32)], tree_base i32
+    [n_nodes] -> (scores, parent, code, child node) [nq, R]."""
+    logits = _f32(logits).contiguous()
+    beam_scores = _f32(beam_scores).contiguous()
+    nq, nb = beam_scores.shape
+    assert logits.shape == (nq * nb, K + 1) and node.shape == (nq, nb) and node.dtype == torch.int32
+    assert tree_mask.dtype == torch.int32 and tree_base.dtype == torch.int32 and tree_mask.shape == (tree_base.numel(), (K + 31) // 32)
+    dev = logits.device
+    sc = torch.empty((nq, R), dtype=torch.float32, device=dev)
+    parent, code, child = (torch.empty((nq, R), dtype=torch.int32, device=dev) for _ in range(3))
+    st = hip.lib().mevi_beam_step_tree_f32(hip.ptr(logits), hip.ptr(beam_scores), nq, nb, K, R, hip.ptr(node.contiguous()),
+                                           hip.ptr(tree_mask.contiguous()), hip.ptr(tree_base.contiguous()), tree_base.numel(),
+                                           hip.ptr(sc), hip.ptr(parent), hip.ptr(code), hip.ptr(child), hip.stream_ptr())
+    hip.check(st, "mevi_beam_step_tree_f32")
+    return sc, parent, code, child
+
+
+@hip.on_device
 def row_softmax(x, log=True, scale=None):
     """Row-wise log-softmax (log=True) or scale[row] * softmax of x f32 [rows, cols], with the beam step's arithmetic
     (mevi_row_softmax_f32): for the branches that keep every candidate (_generate_all, pq.beam_search below R candidates)."""

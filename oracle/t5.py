@@ -214,6 +214,48 @@ def nci_generate(W, cfg, ids, mask, beams, length_penalty=0.8, return_steps=Fals
     return (dec, sc, enc, steps) if return_steps else (dec, sc, enc)
 
 
+def nci_generate_tree(W, cfg, ids, mask, beams, paths, length_penalty=0.8):
+    """The same search under a GENERIC prefix tree: `paths` i[n, M] = the existing code paths (TreeBuilder(share_sons=False)
+    .add per path, MEVI/main_models.py:50-63; trie walk MEVI/transformers/generation_utils.py:803-818).  Restated as the
+    reference runs it: all R beams from the first step, beams 1..R-1 seeded with -1e9 (generation_utils.py:752-756), every
+    beam continued along the children of its trie node only (the log-softmax spans eos and all K level codes: the tree mask
+    is added afterwards), the R best of the candidates kept (ties: lower beam, lower code).  Every beam sits on a path of
+    the trie, so the reference's "path not in tree -> eos" branch is never taken; the -1e9 beams surface in the result only
+    when the trie holds fewer than R paths.  Returns (decoded i64[B*R, M+2], scores f64[B*R])."""
+    M, K = cfg["M"], cfg["K"]
+    pset = [set() for _ in range(M + 1)]
+    for pth in np.asarray(paths).tolist():
+        for p in range(M + 1):
+            pset[p].add(tuple(pth[:p]))
+    B, R = ids.shape[0], beams
+    enc = encoder(W, cfg, ids, mask)
+    out_tok, out_sc = [], []
+    for b in range(B):
+        e, m = enc[b:b + 1], mask[b:b + 1]
+        prefix = torch.zeros((R, 1), dtype=torch.long)
+        score = torch.full((R,), -1e9)
+        score[0] = 0.0
+        codes = [() for _ in range(R)]
+        for p in range(M):
+            logits = nci_last_logits(W, cfg, prefix, e.expand(R, -1, -1), m.expand(R, -1))
+            lsm = F.log_softmax(logits, dim=-1)[:, 2 + p * K: 2 + (p + 1) * K]
+            cand = score[:, None] + lsm
+            allowed = torch.tensor([[codes[r] + (c,) in pset[p + 1] for c in range(K)] for r in range(R)])
+            cand = torch.where(allowed, cand, torch.full_like(cand, -float("inf"))).reshape(-1)
+            order = torch.argsort(-cand, stable=True)[:R]          # (score desc, flat index asc)
+            parent, code = order // K, order % K
+            prefix = torch.cat([prefix[parent], (2 + p * K + code)[:, None]], 1)
+            codes = [codes[int(r)] + (int(c),) for r, c in zip(parent, code)]
+            score = cand[order]
+        logits = nci_last_logits(W, cfg, prefix, e.expand(R, -1, -1), m.expand(R, -1))
+        final = score + F.log_softmax(logits, dim=-1)[:, 1]
+        res = final.double() / (M + 1) ** length_penalty
+        order = torch.argsort(-res, stable=True)
+        out_tok.append(torch.cat([prefix[order], torch.ones((R, 1), dtype=torch.long)], 1))
+        out_sc.append(res[order])
+    return torch.cat(out_tok), torch.cat(out_sc), enc
+
+
 def nci_generate_all(W, cfg, ids, mask, length_penalty=0.8):
     """_generate_all (MEVI/transformers/generation_utils.py:1013-1136; generate(..., eval_all_documents=True), the
     `use_topic_model` ablation): the score of EVERY code path, f32 [B, K**M] with path index sum_p c_p K**(M-1-p):

@@ -108,6 +108,39 @@ def test_nci_generate_matches_reference_golden(cuda, path):
     assert np.array_equal(codes.cpu().numpy(), ot5.decode_token(torch.from_numpy(g["decoded"]), cfg["K"]).numpy())
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1t_nci_tree_*.npz"))))
+def test_nci_generate_under_a_generic_prefix_tree_matches_reference_golden(cuda, path):
+    """Golden G1T: generate(decode_tree = the trie of the existing code paths, TreeBuilder(share_sons=False),
+    MEVI/main_models.py:50-63 + generation_utils.py:803-818) -- CSR-children mode of the beam step (mevi_beam_step_tree_f32).
+    Identical token matrices, scores within 1e-5 (relative for the reference's -1e9-seeded beams of the one-path trie);
+    every hypothesis is a path of the trie; the prefix tables on / off and the graph replay change nothing."""
+    g = np.load(path)
+    cfg = json.loads(str(g["cfg"]))
+    beams = cfg.pop("beams")
+    model = nci.NCIModel(nci.load_npz_weights(g), device=cuda, **cfg)
+    tree = nci.PrefixTree(g["paths"], cfg["M"], cfg["K"], cuda)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    dec, scores, _, _ = model.generate(ids, mask, num_beams=beams, decode_tree=tree)
+    assert np.array_equal(dec.cpu().numpy(), g["decoded"])
+    ref = g["scores"]
+    assert (np.abs(np.array(scores) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref))).all()
+    allowed = {tuple(int(c) for c in pth) for pth in g["paths"]}
+    codes = nci.decode_token(dec, cfg["K"]).cpu().numpy()
+    assert all(tuple(int(c) for c in row) in allowed for row in codes)
+    model.prefix_table_bytes, model._tables = 0, None                 # the adaptor evaluated per beam: same bits
+    d2, s2, _, _ = model.generate(ids, mask, num_beams=beams, decode_tree=tree)
+    assert torch.equal(d2, dec) and s2 == scores
+    for _ in range(3):                                                # eager, capture, replay
+        d3, s3, _, _ = model.generate(ids[:2], mask[:2], num_beams=beams, decode_tree=tree, graph=True)
+        assert torch.equal(d3, dec[:2 * beams]) and s3 == scores[:2 * beams]
+    # the trie of ALL K**M paths is the shared-sons tree: same beams as the default search (K >= R cases)
+    if cfg["K"] >= beams and cfg["K"] ** cfg["M"] <= 1 << 20:
+        full = np.stack(np.meshgrid(*[np.arange(cfg["K"])] * cfg["M"], indexing="ij"), -1).reshape(-1, cfg["M"])
+        d4, s4, _, _ = model.generate(ids, mask, num_beams=beams, decode_tree=nci.PrefixTree(full, cfg["M"], cfg["K"], cuda))
+        d5, s5, _, _ = model.generate(ids, mask, num_beams=beams)
+        assert torch.equal(d4, d5) and s4 == s5
+
+
 def _seeded_nci_weights(M, K, d, d_ff, heads, enc_layers=2, dec_layers=2, adaptor_layers=2):
     """Seeded random weights with the reference's initialiser scales (modeling_t5.py:603-633; nn.TransformerDecoder
     defaults for the adaptor; adaptor_embeddings ~ U(0,1) :1252) under the reference's state_dict names."""

@@ -68,6 +68,24 @@ def test_nci_generate_matches_reference(path):
     assert codes.min() >= 0 and codes.max() < cfg["K"] and codes.shape[1] == cfg["M"]
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1t_nci_tree_*.npz"))))
+def test_nci_generate_under_a_generic_prefix_tree_matches_reference(path):
+    """Golden G1T: model.generate(decode_tree=TreeBuilder(share_sons=False) trie of `paths`) of the imported reference --
+    dense trie, sparse tries (fewer live candidates than beams at some levels) and a one-path trie, whose result shows the
+    reference's -1e9-seeded beams (the path R times, scores s, then -1e9 / (M + 1)^0.8)."""
+    g = np.load(path)
+    cfg = json.loads(str(g["cfg"]))
+    W = ot5.load_weights(g)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    dec, sc, _ = ot5.nci_generate_tree(W, cfg, ids, mask, cfg["beams"], g["paths"])
+    assert np.array_equal(dec.numpy(), g["decoded"])
+    ref = g["scores"]
+    assert np.abs(sc.numpy() - ref).max() <= 5e-6 * np.maximum(1.0, np.abs(ref)).max()
+    allowed = {tuple(int(c) for c in pth) for pth in g["paths"]}
+    codes = ot5.decode_token(dec, cfg["K"]).numpy()
+    assert all(tuple(int(c) for c in row) in allowed for row in codes)        # every hypothesis is a path of the trie
+
+
 def test_bert_tower_oracle_matches_reference_bertmodel():
     """oracle/bert.py against the vendored BertModel's own outputs (mtype 'bert' towers: coCondenser / AR2)."""
     from oracle import bert as obert

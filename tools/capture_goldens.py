@@ -386,6 +386,60 @@ def g1_nci_generate():
         print("g1", M, K, beams, "decoded", tuple(outs.shape), "steps", len(step_logits), "score0", scores[0])
 
 
+def g1t_nci_generate_generic_tree():
+    """generate(...) under a GENERIC prefix tree -- TreeBuilder(share_sons=False).add(path) for every existing code path, as
+    main_models.build_tree does outside --codebook mode (main_models.py:50-63,1707-1728): a beam may only continue along paths
+    of the trie (generation_utils.py:803-818, incl. its "path not in decode tree -> eos" branch).  Cases: a dense trie (every
+    beam survives), a sparse one (fewer live candidates than beams at some levels), and one with a single path."""
+    ref_import.setup()
+    import torch
+    from transformers import T5Config, T5ForConditionalGeneration
+    from main_models import TreeBuilder, encode_single_newid
+
+    for (M, K, beams, npaths, seed) in [(4, 32, 10, 400, 20), (3, 16, 4, 12, 21), (3, 8, 10, 30, 22), (2, 4, 4, 1, 23)]:
+        torch.manual_seed(seed)
+        cfg = _mevi_t5_config(T5Config, M, K)
+        with io.StringIO() as buf, redirect_stdout(buf):
+            model = T5ForConditionalGeneration(cfg)
+        model.eval()
+        with torch.no_grad():
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("layer_norm.weight") or "final_layer_norm" in n_:
+                    p_.copy_(1.0 + 0.2 * torch.randn_like(p_))
+                if "relative_attention_bias" in n_:
+                    p_.copy_(torch.randn_like(p_))
+                if n_.startswith("adaptor.") and n_.endswith("bias"):
+                    p_.copy_(0.05 * torch.randn_like(p_))
+        args = Namespace(kary=K, position=1, label_length_cutoff=M, max_output_length=M + 2)
+        rng = np.random.default_rng(seed + 50)
+        paths = np.unique(rng.integers(0, K, size=(npaths, M)), axis=0)
+        builder = TreeBuilder()
+        for pth in paths:
+            builder.add(encode_single_newid(args, [int(c) for c in pth]))
+        root = builder.build()
+        ids, mask = _synthetic_queries(rng, 4, 32, cfg.vocab_size)
+        kwargs = dict(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), use_cache=False,
+                      max_length=M + 2, length_penalty=0.8, num_return_sequences=beams, early_stopping=False,
+                      decode_embedding=2, decode_vocab_size=cfg.decode_vocab_size, decode_tree=root,
+                      output_hidden_states=True, output_scores=True, decoder_integration="series",
+                      decoder_attention_mask=torch.tensor([[1] * (M + 1) + [0]] * 4), num_beams=beams)
+        with torch.no_grad():
+            outs, scores, enc_h, dec_h = model.generate(**kwargs)
+        sd = {k_: v_.detach().numpy() for k_, v_ in model.state_dict().items()}
+        np.savez(os.path.join(GOLD, f"g1t_nci_tree_M{M}_K{K}_R{beams}_P{len(paths)}.npz"),
+                 input_ids=ids, attention_mask=mask, decoded=outs.numpy(), scores=np.array(scores, dtype=np.float64),
+                 paths=paths.astype(np.int32),
+                 **{"w." + k_: v_ for k_, v_ in sd.items()},
+                 cfg=np.array(json.dumps(dict(M=M, K=K, beams=beams, d_model=cfg.d_model, d_ff=cfg.d_ff,
+                                              num_heads=cfg.num_heads, d_kv=cfg.d_kv, num_layers=cfg.num_layers,
+                                              num_decoder_layers=cfg.num_decoder_layers,
+                                              adaptor_layer_num=cfg.adaptor_layer_num, vocab_size=cfg.vocab_size,
+                                              layer_norm_epsilon=cfg.layer_norm_epsilon,
+                                              relative_attention_num_buckets=cfg.relative_attention_num_buckets))))
+        print("g1t", M, K, beams, "paths", len(paths), "decoded", tuple(outs.shape))
+        print(outs.numpy()[:beams], np.round(np.array(scores[:beams]), 4))
+
+
 def g1a_nci_generate_all():
     """generate(..., eval_all_documents=True, num_beams=1, num_return_sequences=1) -> _generate_all
     (generation_utils.py:507-521,1013-1136): the scores of all K**M code paths per query, as infer() asks for them under
@@ -674,7 +728,7 @@ def g9_ip_rank():
 
 
 ALL = dict(g4=g4_rq, g5=g5_tree_codec, g6=g6_consumers, g6n=g6n_consumers_nq, g7=g7_writers, g1=g1_nci_generate, g2=g2_t5_tower, g2p=g2p_t5_passage, g8=g8_bert_tower,
-           g3=g3_relative_buckets, g9=g9_ip_rank, g1a=g1a_nci_generate_all)
+           g3=g3_relative_buckets, g9=g9_ip_rank, g1a=g1a_nci_generate_all, g1t=g1t_nci_generate_generic_tree)
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
