@@ -149,6 +149,43 @@ def test_eval_driver_matches_cpu_restatement(cuda, mini):
     assert os.path.exists(a.metric_path) and "ndocs@cluster10" in open(a.metric_path).read()
 
 
+def test_eval_driver_with_the_trie_of_populated_clusters(cuda, mini, tmp_path, monkeypatch):
+    """MEVI_DECODE_TREE=clusters: the beams are held to the generic trie of the code paths that own a cluster
+    (TreeBuilder(share_sons=False) over the mapping, MEVI/main_models.py:50-63,1707-1728): the coarse log equals the oracle's
+    tree search over the same paths, every beam cluster is populated, and the fine list is the union of those clusters."""
+    import copy
+
+    from mevi_amd.evalrun import EvalRun, load_queries
+
+    monkeypatch.setenv("MEVI_DECODE_TREE", "clusters")
+    a = copy.copy(mini["args"])
+    a.custom_save_path = str(tmp_path / "trie.tsv")
+    tok = FakeTokenizer(512)
+    run = EvalRun(a, tokenizer=tok, device=cuda)
+    run.run(load_queries(a.data_dir))
+    prefix = a.custom_save_path[:-4]
+    coarse = [l.rstrip("\n").split("\t") for l in open(prefix + "_coarse.tsv")]
+    fine = [l.rstrip("\n").split("\t") for l in open(prefix + "_fine.tsv")]
+    cluster, _ = orq.cluster_dict(orq.rq_encode(mini["emb"], mini["C"]))
+    paths = np.array(sorted(cluster), dtype=np.int64)
+    enc = tok.batch_encode_plus(mini["queries"])
+    ids, mask = enc["input_ids"], enc["attention_mask"]
+    dec, sc, _ = ot5.nci_generate_tree(mini["W"], mini["cfg"], ids, mask, 10, paths)
+    codes = ot5.decode_token(dec, 32).view(len(ids), 10, 4).numpy()
+    sc = sc.numpy().reshape(len(ids), 10)
+    changed = 0
+    for i in range(len(mini["queries"])):
+        got = eval(coarse[i][1])
+        assert got == codes[i].tolist() and np.abs(np.array(eval(coarse[i][3])) - sc[i]).max() <= 1e-5
+        assert all(tuple(c) in cluster for c in got)                          # no beam spent on an empty cluster
+        assert sorted(eval(fine[i][1])) == sorted(d for c in got for d in cluster[tuple(c)])
+    base = [l.rstrip("\n").split("\t") for l in open(mini["args"].custom_save_path[:-4] + "_coarse.tsv")] \
+        if os.path.exists(mini["args"].custom_save_path[:-4] + "_coarse.tsv") else None
+    if base is not None:                                                      # the shared-sons run of the first test
+        changed = sum(eval(b[1]) != eval(c[1]) for b, c in zip(base, coarse))
+        assert changed > 0                                                    # the trie did change some beam lists
+
+
 def test_recall_levels_coarse_and_fine(cuda, mini, tmp_path):
     """--recall_level coarse | fine (main_models.py:3736,3781,4103-4201): the same beams and fine lists as 'both', each with
     its own result tuples, log files and metric keys -- cluster ranks at the cut-offs <= R and no tower pass for 'coarse',
