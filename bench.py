@@ -175,20 +175,33 @@ def gemm_roofline(device, rows):
 
 
 def cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs):
-    """What one `faiss_search.py` process pays around the resident-corpus search: corpus upload (host -> HBM through the
-    pinned, threaded staging of mevi_amd.io.upload_rows, measured on a 2 GB sample and scaled), index build, search."""
+    """What one `faiss_search.py` process pays around the resident-corpus search: corpus upload (file in the page cache ->
+    HBM: mevi_amd.io.upload_rows preads the mapped file straight into pinned staging buffers, threaded; measured on a 2 GB
+    sample file and scaled), index build, search."""
+    import tempfile
+
     from mevi_amd import io as mio
 
     rows = min(docs.shape[0], (2 << 30) // (4 * DIM))
-    host = docs[:rows].cpu().numpy()
-    mio.upload_rows(host[: rows // 8], device)
-    t = time.perf_counter()
-    mio.upload_rows(host, device)
-    torch.cuda.synchronize()
-    gbs = rows * DIM * 4 / (time.perf_counter() - t) / 1e9
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(tmpdir, "mevi_bench_upload_%d.bin" % os.getpid())
+    try:
+        docs[:rows].cpu().numpy().tofile(path)
+        m = mio.map_rows(path, DIM)
+        mio.upload_rows(m[: rows // 8], device)
+        t = time.perf_counter()
+        mio.upload_rows(m, device)
+        torch.cuda.synchronize()
+        gbs = rows * DIM * 4 / (time.perf_counter() - t) / 1e9
+        del m
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
     upload_s = n_docs * DIM * 4 / 1e9 / gbs
     total = upload_s + index_build_s + search_ms / 1e3
-    return {"upload_gb_per_s": gbs, "upload_s": upload_s, "upload_sample": f"{rows} rows ({rows * DIM * 4 / 1e9:.2f} GB) from pageable host memory",
+    return {"upload_gb_per_s": gbs, "upload_frac_of_pcie_gen5_x16": gbs / 63.0, "upload_s": upload_s,
+            "upload_sample": f"{rows} rows ({rows * DIM * 4 / 1e9:.2f} GB) of a mapped file in the page cache ({tmpdir}), pread into pinned buffers",
+            "host_cpus_granted": len(os.sched_getaffinity(0)),
             "index_build_s": index_build_s, "search_s": search_ms / 1e3, "queries_per_s": nq / total,
             "note": "PCIe-inclusive rate of ONE faiss_search.py invocation (corpus file in the page cache); every further "
                     "search on the resident corpus runs at `value`"}

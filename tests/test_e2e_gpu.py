@@ -909,6 +909,20 @@ def test_pinned_upload_equals_plain_copy(cuda):
         assert torch.equal(upload_rows(a, cuda, chunk_rows=chunk).cpu(), torch.from_numpy(a))
 
 
+def test_pinned_upload_of_a_mapped_file_reads_straight_into_the_staging_buffers(cuda, tmp_path):
+    """faiss_search.read hands upload_rows a file-backed memmap: the rows are pread into the pinned buffers (no user-space
+    copy of the mapping) -- same tensor as the plain copy, for a mapping that starts inside the file and ragged chunks."""
+    from mevi_amd.io import map_rows, upload_rows
+
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((1003, 24)).astype(np.float32)
+    a.tofile(tmp_path / "rows.bin")
+    for first, rows, chunk in ((0, None, 250), (17, 500, 64), (1000, 3, 8)):
+        m = map_rows(str(tmp_path / "rows.bin"), 24, rows=rows, first_row=first)
+        want = a[first:first + (rows if rows is not None else len(a))]
+        assert isinstance(m, np.memmap) and torch.equal(upload_rows(m, cuda, chunk_rows=chunk).cpu(), torch.from_numpy(want))
+
+
 def _two_rank_eval_worker(rank, world, port, args_dict, ret):
     import torch.distributed as dist
 

@@ -196,6 +196,9 @@ def _seeded_nci_weights(M, K, d, d_ff, heads, enc_layers=2, dec_layers=2, adapto
     (3, 256, 256, 1024, 4, 200 << 20, "tables end before position 2"),
     # BASELINE.json configs[2] at its REAL width (t5-base: d 768, ff 3072, 12 x 64 heads), 2 + 2 + 2 layers
     (3, 256, 768, 3072, 12, 6 << 30, "t5-base width: adaptor vectors only at position 2"),
+    # BASELINE.json configs[2] as it stands: (3, 256) at t5-base width AND full depth (pinned by the suite, not
+    # only by bench.py's agreement sample); the oracle takes ~1 min of host time for the 5 queries
+    (3, 256, 768, 3072, 12, 6 << 30, "full depth: configs[2], adaptor vectors only at position 2"),
 ])
 def test_base_shape_model_against_oracle(cuda, M, K, d, d_ff, heads, table_bytes, regime):
     """t5-base widths (d 768, ff 3072, 12x64 heads, adaptor heads of 96) with few layers, and the (3, 256) code shape
