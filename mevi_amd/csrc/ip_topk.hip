@@ -278,16 +278,18 @@ __device__ __forceinline__ void emit_tile(f32x16 (&acc)[2][NI], const float (&tq
 // instruction shapes (the sums are taken in another order), so the candidate sets can differ in near-ties at tau -- every
 // returned score comes from the exact re-scoring chains and every list is proven complete per query, never from here.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int H16_REC_N = 96;            // records per wave: 96 x 32 B = 3 KiB (STASH_BYTES_PER_WAVE)
-constexpr int H16_FLUSH_AT = 64;         // flush before a tile when this many records are waiting
+constexpr int H16_REC_N = 128;           // records per wave: 128 x (16 + 8) B = 3 KiB (STASH_BYTES_PER_WAVE)
+constexpr int H16_FLUSH_AT = 80;         // flush before a tile when this many records are waiting
 constexpr int H16_FLUSH_EVERY = 8;       // ... and on every 8th (4th, 2nd: the host sizes the cadence to the chunk's expected
                                          // candidate density, ip_search_pass) tile of the workgroup -- all waves together
-static_assert((size_t)H16_REC_N * 32 <= STASH_BYTES_PER_WAVE, "record stash must fit the wave's stash area");
+static_assert((size_t)H16_REC_N * 24 <= STASH_BYTES_PER_WAVE, "record stash must fit the wave's stash area");
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) u32x2v lds_u32x2;
 struct RecStash {
   lds_f32x4 *vals;   // [H16_REC_N] the lane's four raw scores          (LDS pointers: 32 bits, ds_ instructions)
-  lds_u32x4 *meta;   // [H16_REC_N] {tau bits, query, ~id of row 0 of the four, unused}
+  lds_u32x2 *meta;   // [H16_REC_N] {query, ~id of row 0 of the four}   (the query's tau is re-read at the flush: it does not
+                     //                                                   change during a launch)
   int n;             // wave-uniform
 };
 
@@ -300,17 +302,18 @@ __device__ __forceinline__ void load_tq16(float (&tq)[8], const float *__restric
   }
 }
 
-__device__ __forceinline__ void rec_flush(RecStash &st, unsigned long long *__restrict__ buf, unsigned int *__restrict__ count,
-                                          int S, int k, int cap) {
+__device__ __forceinline__ void rec_flush(RecStash &st, const float *__restrict__ tau, unsigned long long *__restrict__ buf,
+                                          unsigned int *__restrict__ count, int S, int k, int cap) {
   const int lane = threadIdx.x & 63;
   __builtin_amdgcn_wave_barrier();
   for (int base = 0; base < st.n; base += 64) {
     const int e = base + lane;
     if (e < st.n) {
       const f32x4 a = st.vals[e];
-      const u32x4 m = st.meta[e];
-      const float t = __uint_as_float(m[0]);
-      const unsigned int q = m[1];
+      const u32x2v mm = st.meta[e];
+      const unsigned int q = mm[0];
+      const unsigned int m[3] = {0u, q, mm[1]};
+      const float t = tau[q];
       unsigned int c = 0u;
 #pragma unroll
       for (int j = 0; j < 4; ++j) c += a[j] > t ? 1u : 0u;
@@ -330,8 +333,9 @@ __device__ __forceinline__ void rec_flush(RecStash &st, unsigned long long *__re
 }
 
 __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq)[8], int q0, long long d0, long long doc_end,
-                                            unsigned long long *__restrict__ buf, unsigned int *__restrict__ count, int S,
-                                            int k, int cap, unsigned int id_base, RecStash &st, bool flush_now) {
+                                            const float *__restrict__ tau, unsigned long long *__restrict__ buf,
+                                            unsigned int *__restrict__ count, int S, int k, int cap, unsigned int id_base,
+                                            RecStash &st, bool flush_now) {
   int lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));   // opaque per tile: keeps the compiler from hoisting per-block invariants out of the tile loop (spills)
   const int r16 = lane & 15, kq = lane >> 4;
@@ -345,7 +349,7 @@ __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq
           for (int ni = 0; ni < 8; ++ni) acc[mi][ni][j] = -INFINITY;
         }
   }
-  if (st.n >= H16_FLUSH_AT || (flush_now && st.n > 0)) rec_flush(st, buf, count, S, k, cap);
+  if (st.n >= H16_FLUSH_AT || (flush_now && st.n > 0)) rec_flush(st, tau, buf, count, S, k, cap);
   // ~id of the lane's first row of block row 0: key = ord(score) << 32 | ~id;  ~(id0 + c) = ~id0 - c
   const unsigned int nid0 = 0xFFFFFFFFu - (id_base + (unsigned int)(d0 + 4 * kq));
   const int n0 = st.n;
@@ -367,7 +371,7 @@ __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq
                                                              __builtin_amdgcn_mbcnt_lo((unsigned int)vote, 0u));
           if (pos < H16_REC_N) {
             st.vals[pos] = a;
-            st.meta[pos] = u32x4{__float_as_uint(tq[ni]), (unsigned int)(q0 + 16 * ni + r16), nid0 - (unsigned int)(16 * mi), 0u};
+            st.meta[pos] = u32x2v{(unsigned int)(q0 + 16 * ni + r16), nid0 - (unsigned int)(16 * mi)};
           }
         }
         n += __popcll(vote);
@@ -376,9 +380,10 @@ __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq
   st.n = n;
   if (n <= H16_REC_N) return;
   // dense tile: forget its records, empty the stash, then per query column (16 ni + r16) the four lanes kq = 0..3 pool their
-  // counts and lane kq = 0 takes the slots
+  // counts and lane kq = 0 takes the slots -- the eight columns' atomics are issued together (one round trip, not eight)
   st.n = n0;
-  rec_flush(st, buf, count, S, k, cap);
+  rec_flush(st, tau, buf, count, S, k, cap);
+  unsigned int before[8], base[8];
 #pragma unroll
   for (int ni = 0; ni < 8; ++ni) {
     unsigned int c = 0u;
@@ -386,16 +391,16 @@ __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int j = 0; j < 4; ++j) c += acc[mi][ni][j] > tq[ni] ? 1u : 0u;
-    if (!__any(c != 0u)) continue;
     const unsigned int c1 = __shfl_xor(c, 16), s01 = c + c1;       // pair (kq, kq ^ 1)
     const unsigned int s23 = __shfl_xor(s01, 32);                  // the other pair's total
     const unsigned int total = s01 + s23;
-    unsigned int base = 0u;
-    if (kq == 0 && total != 0u) base = atomicAdd(&count[q0 + 16 * ni + r16], total);
-    base = __shfl(base, r16);
-    unsigned int before = (kq & 1) ? c1 : 0u;                      // the lower lane of the own pair
-    if (kq & 2) before += s23;                                     // the whole lower pair
-    unsigned int slot = base + before;
+    base[ni] = 0u;
+    if (kq == 0 && total != 0u) base[ni] = atomicAdd(&count[q0 + 16 * ni + r16], total);
+    before[ni] = ((kq & 1) ? c1 : 0u) + ((kq & 2) ? s23 : 0u);    // lanes in kq order: the lower lane of the own pair, the whole lower pair
+  }
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) {
+    unsigned int slot = __shfl(base[ni], r16) + before[ni];
     unsigned long long *dst = buf + (size_t)(q0 + 16 * ni + r16) * S + k;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -1106,7 +1111,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h16_kernel(
   {
     char *sb = reinterpret_cast<char *>(lds) + h1_lds_bytes() + (size_t)w8 * STASH_BYTES_PER_WAVE;
     stash.vals = (lds_f32x4 *)(sb);
-    stash.meta = (lds_u32x4 *)(sb + (size_t)H16_REC_N * 16);
+    stash.meta = (lds_u32x2 *)(sb + (size_t)H16_REC_N * 16);
     stash.n = 0;
   }
   int tiles_done = 0;
@@ -1125,10 +1130,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h16_kernel(
         if (qb + 16 * ni + (t & 15) >= nq) tq[ni] = INFINITY;
     }
     ++tiles_done;
-    emit_tile16(acc, tq, qb, drow0 + 64 * wm, doc_end, buf, count, S, k, cap, id_base, stash, (tiles_done & flush_mask) == 0);
+    emit_tile16(acc, tq, qb, drow0 + 64 * wm, doc_end, tau, buf, count, S, k, cap, id_base, stash, (tiles_done & flush_mask) == 0);
   };
   h16_tile_stream(64, dimp / 32, lds, next, begin, emit, H1BlockedUnits());
-  rec_flush(stash, buf, count, S, k, cap);
+  rec_flush(stash, tau, buf, count, S, k, cap);
 }
 
 // ---------------------------------------------------------------------------
@@ -1486,13 +1491,13 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       }
       // flush cadence of the 16x16 kernel's record stashes: with `seen` rows behind tau a chunk is expected to yield
       // k * chunk / seen candidates per query (exchangeable row order; every row in the first chunk), i.e. r per 64 x 128
-      // wave tile; flush every T tiles with T r <= ~40 records
+      // wave tile; flush every T tiles with T r <= ~56 records (a stash holds 128)
       int flush_mask = H16_FLUSH_EVERY - 1;
       {
         const double per_q = seen >= g.k ? (double)g.k * (double)chunk / (double)seen : (double)chunk;
         const double r = per_q / (double)chunk * 64.0 * 128.0;
         int T = H16_FLUSH_EVERY;
-        while (T > 1 && T * r > 40.0) T >>= 1;
+        while (T > 1 && T * r > 56.0) T >>= 1;
         flush_mask = T - 1;
       }
       void *args16[] = {(void *)&Q, &nq_i, (void *)&D, &d0, &d1, &dim, (void *)&tau_c, (void *)&st.buf,
