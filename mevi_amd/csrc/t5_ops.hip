@@ -1061,6 +1061,289 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnArgs a) {
   }
 }
 
+// ---- the same attention on the f16 matrix cores in split precision (the default wherever the split GEMM runs) -----------------
+// attention_mfma_kernel is bound by the f32 matrix rate (64 cycles per v_mfma_f32_32x32x2f32: 1.14 ms per call for 2048
+// passages x 12 heads, 12 % of the passage tower).  Here Q, K, V and P are (hi, lo) f16 pairs -- hi = f16(x 2^e), lo = f16(x 2^e
+// - hi), 22 significant bits, as the linear layers' operands (gemm_split.hip) -- and a product is three v_mfma_f32_32x32x16_f16
+// (lo.hi + hi.hi + hi.lo, f32 accumulate): 16 k per 32-cycle instruction instead of 2 k per 64-cycle one.
+//   scaling      one power of two per operand and (sequence, head): max |x| 2^e in [2^13, 2^14) (exact; no f16 overflow whatever
+//                the checkpoint), P by 2^14; undone on the f32 accumulators (ldexp, exact);
+//   S^T = K.Q^T  A = K fragments from LDS ([key][64] halves, hi and lo planes, 16-byte chunks XORed by (key >> 1) & 7: conflict
+//                free), B = the wave's Q rows in registers; four k-steps of 16 head dims x three products per key block;
+//   softmax      as attention_mfma_kernel (same registers: C/D map col = lane & 31 = query, row = key);
+//   O^T = V^T.P^T  the B operand of k-step (n, u) -- keys 32 n + 16 u + [0, 16) -- is taken from the registers the lane already
+//                holds: slot j of half h = register 8 u + j = key 32 n + 16 u + 8 (j >> 2) + 4 h + (j & 3); V is staged TRANSPOSED,
+//                [dim][key slots in that order] halves (chunks XORed by dim & 15), so the A fragment of a lane (dim, h) is one
+//                16-byte read.
+// LDS: K planes 32 KiB (re-used for the output rows), V^T planes 32 KiB (Q passes through them first), key mask: 64.5 KiB, two
+// workgroups per CU, as before.  Masked / absent keys contribute exact zeros, so packed and padded layouts agree bit for bit;
+// the summation order per output is fixed (dims in k-steps of 16, keys in k-steps of 16, per step lo.hi, hi.hi, hi.lo).
+// Accuracy: operand images 2^-22 relative, products exact in f32 -- the f32 kernel's own accumulation error is the same order;
+// MEVI_ATTN_PASSAGE=f32 keeps attention_mfma_kernel (A/B switch).
+typedef _Float16 ah_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ah_f16x4 __attribute__((ext_vector_type(4)));
+constexpr size_t AH_LDS = (size_t)(4 * AM_S * AM_D) * sizeof(_Float16) + (AM_S + 16) * sizeof(float);
+// byte offset of the 8-byte piece (dims 4 c4 .. 4 c4 + 3) of row r in a [rows][64] halves plane
+__device__ __forceinline__ int ah_row8(int r, int c4) { return r * 128 + (((c4 >> 1) ^ ((r >> 1) & 7)) << 4) + ((c4 & 1) << 3); }
+// byte offset of the 16-byte fragment piece (dims 8 c8 .. 8 c8 + 7) of row r
+__device__ __forceinline__ int ah_row16(int r, int c8) { return r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4); }
+// byte offset of chunk c (16 bytes = 8 key slots) of dim row d in a [64][128] halves plane
+__device__ __forceinline__ int ah_vt16(int d, int c) { return d * 256 + ((c ^ (d & 15)) << 4); }
+
+__device__ __forceinline__ int ah_exp_for(float m) {   // e with m 2^e in [2^13, 2^14); 0 for m = 0 / inf / nan
+  if (!(m > 0.f) || isinf(m)) return 0;
+  int e;
+  (void)frexpf(m, &e);
+  const int s_ = 14 - e;
+  return s_ > 100 ? 100 : (s_ < -100 ? -100 : s_);
+}
+
+template <int NB>
+__device__ __forceinline__ void ah_wave(const AttnArgs &a, const char *kh, const char *kl, const char *vth, const char *vtl,
+                                        const float *smask, float *so, const ah_f16x8 (&qh)[4], const ah_f16x8 (&ql)[4],
+                                        int e_s, int e_o, int w, int h, int tk, int tq, size_t og) {
+  const int lane = threadIdx.x & 63, lrow = lane & 31, half = lane >> 5;
+  const int qi = 32 * w + lrow;
+  am_f32x16 sc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[n][r] = 0.f;
+  const bool active = 32 * w < tq;    // wave-uniform
+  if (active) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      ah_f16x8 fh[NB], fl[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        fh[n] = *reinterpret_cast<const ah_f16x8 *>(kh + ah_row16(32 * n + lrow, 2 * st + half));
+        fl[n] = *reinterpret_cast<const ah_f16x8 *>(kl + ah_row16(32 * n + lrow, 2 * st + half));
+      }
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        sc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[n], qh[st], sc[n], 0, 0, 0);
+        sc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[n], qh[st], sc[n], 0, 0, 0);
+        sc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[n], ql[st], sc[n], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();       // every wave is done with K: the output staging may overwrite it
+  if (!active) return;   // no workgroup barrier below
+  const int qpos = a.q_pos0 + qi;
+  float badd[NB][16];
+  if (a.bias) {
+    const int qrow = qpos < a.bias_rows ? qpos : a.bias_rows - 1;
+    const float *brow = a.bias + ((size_t)h * a.bias_rows + qrow) * a.bias_ld;
+    if ((a.bias_ld & 3) == 0 && a.bias_ld >= 32 * NB && ((uintptr_t)a.bias & 15) == 0) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 x = *reinterpret_cast<const float4 *>(brow + 32 * n + 8 * g + 4 * half);
+          badd[n][4 * g] = x.x; badd[n][4 * g + 1] = x.y; badd[n][4 * g + 2] = x.z; badd[n][4 * g + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * half;
+          badd[n][r] = brow[key < a.bias_ld ? key : a.bias_ld - 1];
+        }
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) badd[n][r] = 0.f;
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 mk = *reinterpret_cast<const float4 *>(smask + 32 * n + 8 * g + 4 * half);
+      const float mk4[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e, key = 32 * n + 8 * g + 4 * half + e;
+        float add = mk4[e];
+        if (a.bias) add += badd[n][r];
+        add += (a.causal && key > qpos) ? -1e9f : 0.f;
+        const float v = key < tk ? ldexpf(sc[n][r], -e_s) + add : -INFINITY;
+        sc[n][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = expf(sc[n][r] - m);
+      sc[n][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32);
+  am_f32x16 o[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      ah_f16x8 ph, pl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float pv = ldexpf(sc[n][8 * u + j] / sum, 14);     // P 2^14: the pair keeps 22 bits down to p = 2^-17
+        ph[j] = (_Float16)pv;
+        pl[j] = (_Float16)(pv - (float)ph[j]);
+      }
+      const int ch = 2 * (2 * n + u) + half;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const ah_f16x8 vh = *reinterpret_cast<const ah_f16x8 *>(vth + ah_vt16(32 * c + lrow, ch));
+        const ah_f16x8 vl = *reinterpret_cast<const ah_f16x8 *>(vtl + ah_vt16(32 * c + lrow, ch));
+        o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[c], 0, 0, 0);
+        o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[c], 0, 0, 0);
+        o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[c], 0, 0, 0);
+      }
+    }
+  // O^T: col = lane & 31 = query, row = head dim -> through the wave's own rows of the K region, then whole rows out
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4 *>(so + am_sw4(lrow, 8 * c + 2 * g + half)) =
+          make_float4(ldexpf(o[c][4 * g], -e_o), ldexpf(o[c][4 * g + 1], -e_o), ldexpf(o[c][4 * g + 2], -e_o),
+                      ldexpf(o[c][4 * g + 3], -e_o));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int nrow = tq - 32 * w < 32 ? tq - 32 * w : 32;
+  const int sub = lane >> 4, c4 = lane & 15;
+  for (int r4 = 0; r4 < nrow; r4 += 4) {
+    const int rr = r4 + sub;
+    if (rr < nrow)
+      put_ctx4(a, og + (size_t)(32 * w + rr) * a.o_ts + 4 * c4, *reinterpret_cast<const float4 *>(so + am_sw4(rr, c4)));
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attention_h16_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smb[];
+  char *kh = smb, *kl = smb + AM_S * AM_D * 2;                   // K hi | lo planes, [128][64] halves
+  char *vth = smb + 2 * AM_S * AM_D * 2, *vtl = vth + AM_S * AM_D * 2;   // V^T hi | lo planes, [64][128] halves (Q first)
+  float *smask = reinterpret_cast<float *>(smb + 4 * AM_S * AM_D * 2);   // [128] additive key mask, then 12 floats of maxima
+  float *smax = smask + AM_S;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lrow = lane & 31, half = lane >> 5;
+  const long long r0 = a.seq_off ? a.seq_off[b] : 0;
+  const int tk = a.seq_off ? (int)(a.seq_off[b + 1] - r0) : a.tk;  // == tq
+  const int tq = tk;
+  const long long *key_mask = a.seq_off ? nullptr : a.key_mask;
+  const float *qg = a.q + (a.seq_off ? (size_t)r0 * a.q_ts : (size_t)b * a.q_bs) + (size_t)h * AM_D;
+  const float *kg = a.k + (a.seq_off ? (size_t)r0 * a.k_ts : (size_t)b * a.k_bs) + (size_t)h * AM_D;
+  const float *vg = a.v + (a.seq_off ? (size_t)r0 * a.v_ts : (size_t)b * a.v_bs) + (size_t)h * AM_D;
+  const size_t og = (a.seq_off ? (size_t)r0 * a.o_ts : (size_t)b * a.o_bs) + (size_t)h * AM_D;
+  if (t < AM_S) smask[t] = (key_mask && t < tk && key_mask[(size_t)b * tk + t] == 0) ? -1e9f : 0.f;
+  // row-contiguous loads: q / k as (row, dim quad) per thread and pass, v as (four consecutive keys, dim quad)
+  float4 q4[8], k4[8], v4[2][4];
+  float mq = 0.f, mk_ = 0.f, mv = 0.f;
+  auto amax4 = [](float m_, const float4 &x) { return fmaxf(fmaxf(m_, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w))); };
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = t + 256 * it, r = i >> 4, c4 = i & 15;
+    q4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    k4[it] = q4[it];
+    if (r < tk) {  // rows past tk are zero
+      const float4 x = *reinterpret_cast<const float4 *>(qg + (size_t)r * a.q_ts + 4 * c4);
+      q4[it] = make_float4(x.x * a.scale, x.y * a.scale, x.z * a.scale, x.w * a.scale);
+      k4[it] = *reinterpret_cast<const float4 *>(kg + (size_t)r * a.k_ts + 4 * c4);
+    }
+    mq = amax4(mq, q4[it]);
+    mk_ = amax4(mk_, k4[it]);
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = t + 256 * it, kg4 = i >> 4, c4 = i & 15;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * kg4 + e;
+      v4[it][e] = r < tk ? *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      mv = amax4(mv, v4[it][e]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mq = fmaxf(mq, __shfl_xor(mq, off));
+    mk_ = fmaxf(mk_, __shfl_xor(mk_, off));
+    mv = fmaxf(mv, __shfl_xor(mv, off));
+  }
+  if (lane == 0) smax[3 * w] = mq, smax[3 * w + 1] = mk_, smax[3 * w + 2] = mv;
+  __syncthreads();
+  mq = fmaxf(fmaxf(smax[0], smax[3]), fmaxf(smax[6], smax[9]));
+  mk_ = fmaxf(fmaxf(smax[1], smax[4]), fmaxf(smax[7], smax[10]));
+  mv = fmaxf(fmaxf(smax[2], smax[5]), fmaxf(smax[8], smax[11]));
+  const int eq = ah_exp_for(mq), ek = ah_exp_for(mk_), ev = ah_exp_for(mv);
+  auto split4 = [](const float4 &x, int e, ah_f16x4 &hi, ah_f16x4 &lo) {
+    const float y[4] = {ldexpf(x.x, e), ldexpf(x.y, e), ldexpf(x.z, e), ldexpf(x.w, e)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hi[i] = (_Float16)y[i];
+      lo[i] = (_Float16)(y[i] - (float)hi[i]);
+    }
+  };
+  // K into its planes, Q through the V^T region
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = t + 256 * it, r = i >> 4, c4 = i & 15;
+    ah_f16x4 hi, lo;
+    split4(k4[it], ek, hi, lo);
+    *reinterpret_cast<ah_f16x4 *>(kh + ah_row8(r, c4)) = hi;
+    *reinterpret_cast<ah_f16x4 *>(kl + ah_row8(r, c4)) = lo;
+    split4(q4[it], eq, hi, lo);
+    *reinterpret_cast<ah_f16x4 *>(vth + ah_row8(r, c4)) = hi;
+    *reinterpret_cast<ah_f16x4 *>(vtl + ah_row8(r, c4)) = lo;
+  }
+  __syncthreads();
+  ah_f16x8 qh[4], ql[4];     // the lane's Q fragments: row 32 w + lrow, dims 16 st + 8 half .. + 7
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    qh[st] = *reinterpret_cast<const ah_f16x8 *>(vth + ah_row16(32 * w + lrow, 2 * st + half));
+    ql[st] = *reinterpret_cast<const ah_f16x8 *>(vtl + ah_row16(32 * w + lrow, 2 * st + half));
+  }
+  __syncthreads();
+  // V transposed: keys 4 kg4 .. + 3 of dim d = 4 c4 + i -> slots 8 (kg4 & 1) + 4 ((kg4 >> 1) & 1) + e of key block kg4 >> 2
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = t + 256 * it, kg4 = i >> 4, c4 = i & 15;
+    const int chunk = 2 * (kg4 >> 2) + (kg4 & 1), inner = ((kg4 >> 1) & 1) << 3;
+    const float vd[4][4] = {{v4[it][0].x, v4[it][1].x, v4[it][2].x, v4[it][3].x}, {v4[it][0].y, v4[it][1].y, v4[it][2].y, v4[it][3].y},
+                            {v4[it][0].z, v4[it][1].z, v4[it][2].z, v4[it][3].z}, {v4[it][0].w, v4[it][1].w, v4[it][2].w, v4[it][3].w}};
+#pragma unroll
+    for (int d_ = 0; d_ < 4; ++d_) {
+      ah_f16x4 hi, lo;
+      split4(make_float4(vd[d_][0], vd[d_][1], vd[d_][2], vd[d_][3]), ev, hi, lo);
+      const int d = 4 * c4 + d_;
+      *reinterpret_cast<ah_f16x4 *>(vth + ah_vt16(d, chunk) + inner) = hi;
+      *reinterpret_cast<ah_f16x4 *>(vtl + ah_vt16(d, chunk) + inner) = lo;
+    }
+  }
+  __syncthreads();
+  float *so = reinterpret_cast<float *>(smb) + w * 32 * AM_D;      // output rows of wave w: 8 KiB of the K planes
+  const int e_s = eq + ek, e_o = ev + 14;
+  switch ((tk + 31) / 32) {
+    case 1: ah_wave<1>(a, kh, kl, vth, vtl, smask, so, qh, ql, e_s, e_o, w, h, tk, tq, og); break;
+    case 2: ah_wave<2>(a, kh, kl, vth, vtl, smask, so, qh, ql, e_s, e_o, w, h, tk, tq, og); break;
+    case 3: ah_wave<3>(a, kh, kl, vth, vtl, smask, so, qh, ql, e_s, e_o, w, h, tk, tq, og); break;
+    default: ah_wave<4>(a, kh, kl, vth, vtl, smask, so, qh, ql, e_s, e_o, w, h, tk, tq, og); break;
+  }
+}
+
 // Attention of SMALL groups on the f32 matrix cores in 16 x 16 blocks (v_mfma_f32_16x16x4_f32): one wave per (group, head),
 // a group = the <= 32 tokens of a sequence (self-attention of the query encoders, mode 0: rows attend to the rows of their own
 // sequence) or the <= 32 rows that share one K|V (decode-step cross-attention, mode 1: the kv_div beams of a query against
@@ -1396,6 +1679,22 @@ static bool short_mfma() {
   static const bool chain = [] { const char *e = getenv("MEVI_ATTN_SHORT"); return e && strcmp(e, "chain") == 0; }();
   return !chain;
 }
+// passage-length self-attention: split-precision f16 matrix cores when the context goes out as a split image (= the caller runs
+// the split GEMMs); the f32-MFMA kernel otherwise (MEVI_GEMM=exact) or with MEVI_ATTN_PASSAGE=f32
+static int launch_passage(const AttnArgs &a, long long pairs, hipStream_t stream) {
+  static const bool f32only = [] { const char *e = getenv("MEVI_ATTN_PASSAGE"); return e && strcmp(e, "f32") == 0; }();
+  if (a.oimg && !f32only) {
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_h16_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)AH_LDS));
+    hipLaunchKernelGGL(attention_h16_kernel, dim3((unsigned)pairs), dim3(256), AH_LDS, stream, a);
+  } else {
+    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)pairs), dim3(256), AM_LDS, stream, a);
+  }
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
 static int launch_mfma16(const AttnArgs &a, int mode, long long pairs, hipStream_t stream) {
   MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma16_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)A16_LDS));
@@ -1449,10 +1748,8 @@ static int attention_launch(const float *q, int64_t q_bs, int64_t q_ts, const fl
   // attention_mfma16_kernel moves rows as 16-byte pieces (q / k strides are checked above)
   const bool mfma16_aligned = v_bs % 4 == 0 && v_ts % 4 == 0 && o_bs % 4 == 0 && o_ts % 4 == 0 &&
                               (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0;
-  if (!kv_off && kv_div == 1 && tq == tk && tk > 64 && tk <= AM_S && dh == AM_D) {  // passages: f32 matrix cores
-    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
-    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(nb * heads)), dim3(256), AM_LDS, (hipStream_t)stream, a);
+  if (!kv_off && kv_div == 1 && tq == tk && tk > 64 && tk <= AM_S && dh == AM_D) {  // passages: matrix cores
+    return launch_passage(a, (long long)nb * heads, (hipStream_t)stream);
   } else if (!kv_off && kv_div == 1 && tq == tk && tk > 1 && tk <= 32 && dh == AM_D && short_mfma() && mfma16_aligned) {  // query-length sequences
     return launch_mfma16(a, 0, (long long)nb * heads, (hipStream_t)stream);
   } else if (tq == 1 && tk <= 32 && kv_div <= 32 && nb % kv_div == 0 && dh == AM_D && short_mfma() && mfma16_aligned &&
@@ -1507,13 +1804,9 @@ static int attention_varlen_launch(const float *q, int64_t q_ts, const float *k,
   a.kv_off = nullptr;
   a.key_rows = nullptr;
   const long long pairs = (long long)nseq * heads;
-  if (max_len > 64 && max_len <= AM_S && dh == AM_D) {   // passage-length sequences: f32 matrix cores
+  if (max_len > 64 && max_len <= AM_S && dh == AM_D) {   // passage-length sequences: matrix cores
     a.q_pos0 = 0;
-    MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)AM_LDS));
-    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)pairs), dim3(256), AM_LDS, (hipStream_t)stream, a);
-    MEVI_HIP_CHECK(hipGetLastError());
-    return MEVI_OK;
+    return launch_passage(a, pairs, (hipStream_t)stream);
   }
   if (max_len <= 32 && dh == AM_D && short_mfma() && o_ts % 4 == 0 &&
       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0)
