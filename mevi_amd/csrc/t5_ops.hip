@@ -1181,11 +1181,18 @@ __device__ __forceinline__ void ah_wave(const AttnArgs &a, const char *kh, const
   for (int n = 0; n < NB; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = expf(sc[n][r] - m);
+      // exp(x) = 2^t (1 + c ln 2) with t = fl(x log2 e) and c the product's rounding error + x times log2 e's own low part:
+      // six vector instructions, ~1 ulp (plain v_exp_f32 of fl(x log2 e) is off by |x| 2^-24 relative: 2e-6 at x = -38)
+      const float x = fmaxf(sc[n][r] - m, -200.f);         // masked keys are -inf: clamp (2^-288 = 0), no inf - inf below
+      const float t_ = x * 1.44269502162933349609375f;
+      const float c_ = fmaf(x, 1.44269502162933349609375f, -t_) + x * 1.925963033500011e-8f;
+      const float e2 = __builtin_amdgcn_exp2f(t_);
+      const float e = fmaf(e2, c_ * 0.693147182464599609375f, e2);
       sc[n][r] = e;
       sum += e;
     }
   sum += __shfl_xor(sum, 32);
+  const float inv = 16384.f / sum;               // P 2^14 = e (2^14 / sum): one division per row, not per probability
   am_f32x16 o[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -1198,7 +1205,7 @@ __device__ __forceinline__ void ah_wave(const AttnArgs &a, const char *kh, const
       ah_f16x8 ph, pl;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float pv = ldexpf(sc[n][8 * u + j] / sum, 14);     // P 2^14: the pair keeps 22 bits down to p = 2^-17
+        const float pv = sc[n][8 * u + j] * inv;                 // P 2^14: the pair keeps 22 bits down to p = 2^-17
         ph[j] = (_Float16)pv;
         pl[j] = (_Float16)(pv - (float)ph[j]);
       }
