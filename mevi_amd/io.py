@@ -47,6 +47,8 @@ def upload_rows(src, device, chunk_rows=1 << 18, threads=8):
             fd = None
 
     def fill(dst, a, b):
+        if b <= a:
+            return
         if fd is None:
             np.copyto(dst, src[a:b])
             return

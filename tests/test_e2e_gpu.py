@@ -160,6 +160,7 @@ def test_eval_driver_with_the_trie_of_populated_clusters(cuda, mini, tmp_path, m
     monkeypatch.setenv("MEVI_DECODE_TREE", "clusters")
     a = copy.copy(mini["args"])
     a.custom_save_path = str(tmp_path / "trie.tsv")
+    a.metric_path = str(tmp_path / "trie_metrics.txt")       # the module's shared metric file is compared by later tests
     tok = FakeTokenizer(512)
     run = EvalRun(a, tokenizer=tok, device=cuda)
     run.run(load_queries(a.data_dir))

@@ -11,7 +11,9 @@
 
 using namespace mevi;
 
-template <int SHAPE, bool STORE>
+// HOT: every workgroup of an XCD walks the SAME few operand tiles (4 A tiles x 8 W tiles, re-visited forever): the L2-hot
+// ceiling of the loop -- what perfect super-tile locality would give
+template <int SHAPE, bool STORE, bool HOT = false>
 __global__ __launch_bounds__(PP_THREADS, 2) void probe_kernel(const _Float16 *A, const _Float16 *W, int kp, float *C, int ldc,
                                                               float *sink, int n_mtiles, int n_ntiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void probe_kernel(const _Float16 *A,
     int mt, nt;
     supertile_order<4, 8>(range_base + item, n_mtiles, n_ntiles, mt, nt);
     item += per_xcd;
+    if constexpr (HOT) mt = (blockIdx.x >> 3) & 3, nt = ((blockIdx.x >> 3) >> 2) & 7;
     if (np == 0) hm = mt, hn = nt; else tm = mt, tn = nt;
     ++np;
     s.src = w8 < 4 ? reinterpret_cast<const char *>(A) + (size_t)mt * block_bytes
@@ -91,6 +94,24 @@ float run_batch(const _Float16 *A, int M, const _Float16 *W, int N, int kp, floa
   hipEventRecord(e0);
   for (int i = 0; i < launches; ++i)
     hipLaunchKernelGGL((probe_kernel<SHAPE, false>), dim3(256), dim3(PP_THREADS), h1_lds_bytes(), 0, A, W, kp, nullptr, 0, sink,
+                       M / 256, N / 256);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / launches;
+}
+
+template <int SHAPE>
+float run_hot(const _Float16 *A, int M, const _Float16 *W, int N, int kp, float *sink, int launches) {
+  hipFuncSetAttribute(reinterpret_cast<const void *>(probe_kernel<SHAPE, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)h1_lds_bytes());
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipEventRecord(e0);
+  for (int i = 0; i < launches; ++i)
+    hipLaunchKernelGGL((probe_kernel<SHAPE, false, true>), dim3(256), dim3(PP_THREADS), h1_lds_bytes(), 0, A, W, kp, nullptr, 0, sink,
                        M / 256, N / 256);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
@@ -172,6 +193,11 @@ int main() {
       const float m32 = run_batch<32>(A, M, W, N, kp, sink, launches), m16 = run_batch<16>(A, M, W, N, kp, sink, launches);
       printf("k %4d sustained (%d launches) round %d: 32x32x16 %7.3f ms %7.1f TFLOP/s | 16x16x32 %7.3f ms %7.1f TFLOP/s | ratio %.3f\n",
              kp, launches, round, m32, flop / m32 / 1e9, m16, flop / m16 / 1e9, m32 / m16);
+    }
+    {
+      const float h32 = run_hot<32>(A, M, W, N, kp, sink, launches), h16 = run_hot<16>(A, M, W, N, kp, sink, launches);
+      printf("k %4d L2-hot (every workgroup of an XCD on the same 4 x 8 operand tiles): 32x32x16 %7.1f TFLOP/s | 16x16x32 %7.1f TFLOP/s\n",
+             kp, flop / h32 / 1e9, flop / h16 / 1e9);
     }
     hipFree(A); hipFree(W); hipFree(sink);
   }
