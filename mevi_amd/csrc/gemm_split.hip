@@ -629,119 +629,88 @@ __global__ __launch_bounds__(256) void gemm_split16_skinny_kernel(
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + 256 * i), 16,
                                                past ? OOB : voff[i], soff, 0, 0);
   };
-  // the epilogue's operands, fetched ahead of the stream: rows m0 + 16 ni + r16, column quads n0 + 16 mi + 4 kq
-  int em[2], eo[2] = {0, 0}, mc[2];
-  bool mok[2];
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int m = m0 + 16 * ni + r16;
-    mok[ni] = m < M;
-    mc[ni] = min(m, M - 1);
-    em[ni] = ea[mc[ni]];
-    if (so.img) {
-      eo[ni] = out_exp(so, mc[ni]);
-      if (wave == 0 && mok[ni] && n0 == 0 && kq == 0) {
-        so.exps[m] = (signed char)eo[ni];
-        if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
-      }
+  // Every wave stages one slab (above) AND owns one of the tile's four 16 x 16 blocks: wave w = block (mi, ni) = (w >> 1, w & 1),
+  // W rows n0 + 16 mi + [0, 16), activation rows m0 + 16 ni + [0, 16).  A block is one accumulation chain of three MFMAs per
+  // 32 k -- with one wave multiplying all four (the first version) the chain of K = 3072 took 25 us, 48 chunks of 0.45 us.
+  const int mi = wave >> 1, ni = wave & 1;
+  // the epilogue's operands, fetched ahead of the stream: row m0 + 16 ni + r16, column quad n0 + 16 mi + 4 kq
+  const int m = m0 + 16 * ni + r16;
+  const bool mok = m < M;
+  const int mc = min(m, M - 1);
+  const int em = ea[mc];
+  int eo = 0;
+  if (so.img) {
+    eo = out_exp(so, mc);
+    if (mi == 0 && mok && n0 == 0 && kq == 0) {   // one writer per row: the waves of block column 0
+      so.exps[m] = (signed char)eo;
+      if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
     }
   }
-  int pw[2];
-  f32x4 pb[2], pr[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int n = min(n0 + 16 * mi + 4 * kq, N - 4);
-    pw[mi] = *reinterpret_cast<const int *>(ew + n);
-    pb[mi] = bias ? *reinterpret_cast<const f32x4 *>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-      pr[mi][ni] = residual ? *reinterpret_cast<const f32x4 *>(residual + (size_t)mc[ni] * ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nq_ = min(n0 + 16 * mi + 4 * kq, N - 4);
+  const int pw = *reinterpret_cast<const int *>(ew + nq_);
+  const f32x4 pb = bias ? *reinterpret_cast<const f32x4 *>(bias + nq_) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 pr = residual ? *reinterpret_cast<const f32x4 *>(residual + (size_t)mc * ldr + nq_) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // fragment of rows 16 i + r16, unit uu of the chunk: piece 4 uu + kq of the 128-byte row, slot ^ key(row)
-  int foff[2][2];
+  int foff_w[2], foff_a[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int uu = 0; uu < 2; ++uu) {
-      const int r = 16 * i + r16;
-      foff[i][uu] = r * 32 + 4 * ((4 * uu + kq) ^ ((r >> 1) & 7));
-    }
+  for (int uu = 0; uu < 2; ++uu) {
+    const int rw = 16 * mi + r16, ra = 16 * ni + r16;
+    foff_w[uu] = rw * 32 + 4 * ((4 * uu + kq) ^ ((rw >> 1) & 7));
+    foff_a[uu] = ra * 32 + 4 * ((4 * uu + kq) ^ ((ra >> 1) & 7));
+  }
 #pragma unroll
   for (int c = 0; c < SK_RING - 1; ++c) issue(c);
   for (int c = 0; c < nchunk; ++c) {
+    // chunk c landed (this wave's pieces: all but the six chunks issued after it), then everybody's; every wave has read c - 1
     asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     issue(c + SK_RING - 1);
-    if (wave == 0) {
-      const int k0 = 64 * c;
-      const int skip = k0 > kp - 64 ? (k0 - (kp - 64)) / 32 : 0;   // units of the clamped last chunk already multiplied
-      const float *b = sm + (c & (SK_RING - 1)) * SK_CHUNK;
+    const int k0 = 64 * c;
+    const int skip = k0 > kp - 64 ? (k0 - (kp - 64)) / 32 : 0;   // units of the clamped last chunk already multiplied
+    const float *b = sm + (c & (SK_RING - 1)) * SK_CHUNK;
+    f16x8 ah[2], al[2], wh[2], wl[2];
 #pragma unroll
-      for (int uu = 0; uu < 2; ++uu) {
-        if (uu < skip) continue;
-        f16x8 ah[2], al[2], wh[2], wl[2];
+    for (int uu = 0; uu < 2; ++uu) {
+      ah[uu] = *reinterpret_cast<const f16x8 *>(b + 0 * SK_SLAB + foff_a[uu]);
+      al[uu] = *reinterpret_cast<const f16x8 *>(b + 1 * SK_SLAB + foff_a[uu]);
+      wh[uu] = *reinterpret_cast<const f16x8 *>(b + 2 * SK_SLAB + foff_w[uu]);
+      wl[uu] = *reinterpret_cast<const f16x8 *>(b + 3 * SK_SLAB + foff_w[uu]);
+    }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          ah[i] = *reinterpret_cast<const f16x8 *>(b + 0 * SK_SLAB + foff[i][uu]);
-          al[i] = *reinterpret_cast<const f16x8 *>(b + 1 * SK_SLAB + foff[i][uu]);
-          wh[i] = *reinterpret_cast<const f16x8 *>(b + 2 * SK_SLAB + foff[i][uu]);
-          wl[i] = *reinterpret_cast<const f16x8 *>(b + 3 * SK_SLAB + foff[i][uu]);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mi], al[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mi], ah[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mi], ah[ni], acc[mi][ni], 0, 0, 0);
-      }
+    for (int uu = 0; uu < 2; ++uu) {
+      if (uu < skip) continue;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[uu], al[uu], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[uu], ah[uu], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[uu], ah[uu], acc, 0, 0, 0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the empty tail pieces: nothing may target LDS past the loop
-  if (wave != 0) return;
+  const int n = n0 + 16 * mi + 4 * kq;         // n, N, ldc multiples of 4: a quad is whole or absent, and 16-byte aligned
+  if (n >= N || !mok) return;
   const int a8 = act;
+  f32x4 v;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int n = n0 + 16 * mi + 4 * kq;       // n, N, ldc multiples of 4: a quad is whole or absent, and 16-byte aligned
-    if (n >= N) continue;
+  for (int j = 0; j < 4; ++j) {
+    float x = ldexpf(acc[j], -(em + (int)(signed char)(pw >> (8 * j))));
+    if (bias) x += pb[j];
+    x = a8 == 1 ? act_fn<1>(x) : (a8 == 2 ? act_fn<2>(x) : x);
+    if (residual) x += pr[j];
+    v[j] = x;
+  }
+  if (so.img) {
+    f16x4 hi, lo;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      if (!mok[ni]) continue;
-      const int m = m0 + 16 * ni + r16;
-      f32x4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x = ldexpf(acc[mi][ni][j], -(em[ni] + (int)(signed char)(pw[mi] >> (8 * j))));
-        if (bias) x += pb[mi][j];
-        x = a8 == 1 ? act_fn<1>(x) : (a8 == 2 ? act_fn<2>(x) : x);
-        if (residual) x += pr[mi][ni][j];
-        v[j] = x;
-      }
-      if (so.img) {
-        f16x4 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float xs = ldexpf(v[j], eo[ni]);
-          hi[j] = (_Float16)xs;
-          lo[j] = (_Float16)(xs - (float)hi[j]);
-        }
-        _Float16 *o = so.img + (size_t)m * 2 * so.np + n;
-        *reinterpret_cast<f16x4 *>(o) = hi;
-        *reinterpret_cast<f16x4 *>(o + so.np) = lo;
-      } else {
-        *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
-      }
+    for (int j = 0; j < 4; ++j) {
+      const float xs = ldexpf(v[j], eo);
+      hi[j] = (_Float16)xs;
+      lo[j] = (_Float16)(xs - (float)hi[j]);
     }
+    _Float16 *o = so.img + (size_t)m * 2 * so.np + n;
+    *reinterpret_cast<f16x4 *>(o) = hi;
+    *reinterpret_cast<f16x4 *>(o + so.np) = lo;
+  } else {
+    *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
   }
 }
 
