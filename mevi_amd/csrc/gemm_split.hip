@@ -600,39 +600,47 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
 // and block a_lo w_hi, a_hi w_hi, a_hi w_lo -- the sequence of split_tile_stream16, hence the same bits.  Staging, ring and
 // swizzle as gemm_split_skinny_kernel (the swizzle key (r >> 1) & 7 is conflict-free for this fragment shape too: the eight
 // row pairs of a ds_read_b128 lane group land in eight different slots).
-__global__ __launch_bounds__(256) void gemm_split16_skinny_kernel(
+template <int TB>   // tile = 16 TB x 16 TB outputs: TB = 2 (four blocks, one per wave) or 1 (one block: below ~128 32 x 32 tiles the
+                    // 16 x 16 form puts four times as many workgroups -- CUs streaming operands -- on the same GEMM)
+__device__ __forceinline__ void skinny16_body(
     const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
     const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
-    const float *__restrict__ residual, long long ldr, int act, SplitOut so) {
-  __shared__ __attribute__((aligned(16))) float sm[SK_RING * SK_CHUNK];
+    const float *__restrict__ residual, long long ldr, int act, const SplitOut &so) {
+  constexpr int T = 16 * TB;                        // tile edge
+  constexpr int SLAB = T * 32;                      // floats: T rows x 128 B
+  constexpr int CHUNK = 4 * SLAB;                   // a_hi, a_lo, w_hi, w_lo
+  constexpr int PIECES = 2 * TB;                    // 8-row DMA pieces per slab
+  __shared__ __attribute__((aligned(16))) float sm[SK_RING * CHUNK];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int n0 = blockIdx.x * T, m0 = blockIdx.y * T;
   const bool is_w = wave >= 2;
   const int rows_left = (is_w ? N - n0 : M - m0) - 1;
   const __amdgpu_buffer_rsrc_t rsrc =
       tile_rsrc((is_w ? W + (size_t)n0 * 2 * kp : A + (size_t)m0 * 2 * kp) + ((wave & 1) ? kp : 0));
-  int voff[4];
+  int voff[PIECES];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < PIECES; ++i) {
     const int r = 8 * i + (lane >> 3);
     voff[i] = min(r, rows_left) * 4 * kp + 16 * ((lane & 7) ^ ((r >> 1) & 7));
   }
   const int nchunk = (kp + 63) / 64;
   auto issue = [&](int c) {
-    float *dst = sm + (c & (SK_RING - 1)) * SK_CHUNK + wave * SK_SLAB;
+    float *dst = sm + (c & (SK_RING - 1)) * CHUNK + wave * SLAB;
     const int soff = 2 * min(64 * c, kp - 64);
     const bool past = c >= nchunk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < PIECES; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + 256 * i), 16,
                                                past ? OOB : voff[i], soff, 0, 0);
   };
-  // Every wave stages one slab (above) AND owns one of the tile's four 16 x 16 blocks: wave w = block (mi, ni) = (w >> 1, w & 1),
-  // W rows n0 + 16 mi + [0, 16), activation rows m0 + 16 ni + [0, 16).  A block is one accumulation chain of three MFMAs per
-  // 32 k -- with one wave multiplying all four (the first version) the chain of K = 3072 took 25 us, 48 chunks of 0.45 us.
-  const int mi = wave >> 1, ni = wave & 1;
+  // Every wave stages one slab (above); TB = 2: it also owns one of the tile's four 16 x 16 blocks, wave w = block (mi, ni) =
+  // (w >> 1, w & 1): W rows n0 + 16 mi + [0, 16), activation rows m0 + 16 ni + [0, 16).  A block is one accumulation chain of
+  // three MFMAs per 32 k -- with one wave multiplying all four (the first version) the chain of K = 3072 took 25 us.
+  // TB = 1: the single block is computed by every wave, stored by wave 0.
+  const int mi = TB == 2 ? wave >> 1 : 0, ni = TB == 2 ? wave & 1 : 0;
+  const bool storer = TB == 2 || wave == 0;
   // the epilogue's operands, fetched ahead of the stream: row m0 + 16 ni + r16, column quad n0 + 16 mi + 4 kq
   const int m = m0 + 16 * ni + r16;
   const bool mok = m < M;
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(256) void gemm_split16_skinny_kernel(
   int eo = 0;
   if (so.img) {
     eo = out_exp(so, mc);
-    if (mi == 0 && mok && n0 == 0 && kq == 0) {   // one writer per row: the waves of block column 0
+    if (storer && mi == 0 && mok && n0 == 0 && kq == 0) {   // one writer per row
       so.exps[m] = (signed char)eo;
       if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
     }
@@ -659,35 +667,47 @@ __global__ __launch_bounds__(256) void gemm_split16_skinny_kernel(
     foff_w[uu] = rw * 32 + 4 * ((4 * uu + kq) ^ ((rw >> 1) & 7));
     foff_a[uu] = ra * 32 + 4 * ((4 * uu + kq) ^ ((ra >> 1) & 7));
   }
+  // Two chunks (128 k) per workgroup barrier: chunks c, c + 1 are read while c + 2 .. c + 7 fly (six chunks in flight per
+  // workgroup: 96 KiB at TB = 2, 48 KiB at TB = 1, where two or three workgroups share a CU).
 #pragma unroll
-  for (int c = 0; c < SK_RING - 1; ++c) issue(c);
-  for (int c = 0; c < nchunk; ++c) {
-    // chunk c landed (this wave's pieces: all but the six chunks issued after it), then everybody's; every wave has read c - 1
-    asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+  for (int c = 0; c < SK_RING - 2; ++c) issue(c);
+  for (int c = 0; c < nchunk; c += 2) {
+    // chunks c and c + 1 landed (this wave's pieces: all but the four chunks issued after them), then everybody's; every wave
+    // has read chunks c - 2 and c - 1, whose ring slots the two issues below overwrite
+    if constexpr (TB == 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    issue(c + SK_RING - 2);
     issue(c + SK_RING - 1);
-    const int k0 = 64 * c;
-    const int skip = k0 > kp - 64 ? (k0 - (kp - 64)) / 32 : 0;   // units of the clamped last chunk already multiplied
-    const float *b = sm + (c & (SK_RING - 1)) * SK_CHUNK;
-    f16x8 ah[2], al[2], wh[2], wl[2];
+    f16x8 ah[4], al[4], wh[4], wl[4];
 #pragma unroll
-    for (int uu = 0; uu < 2; ++uu) {
-      ah[uu] = *reinterpret_cast<const f16x8 *>(b + 0 * SK_SLAB + foff_a[uu]);
-      al[uu] = *reinterpret_cast<const f16x8 *>(b + 1 * SK_SLAB + foff_a[uu]);
-      wh[uu] = *reinterpret_cast<const f16x8 *>(b + 2 * SK_SLAB + foff_w[uu]);
-      wl[uu] = *reinterpret_cast<const f16x8 *>(b + 3 * SK_SLAB + foff_w[uu]);
+    for (int cc = 0; cc < 2; ++cc) {
+      const float *b = sm + ((c + cc) & (SK_RING - 1)) * CHUNK;
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        ah[2 * cc + uu] = *reinterpret_cast<const f16x8 *>(b + 0 * SLAB + foff_a[uu]);
+        al[2 * cc + uu] = *reinterpret_cast<const f16x8 *>(b + 1 * SLAB + foff_a[uu]);
+        wh[2 * cc + uu] = *reinterpret_cast<const f16x8 *>(b + 2 * SLAB + foff_w[uu]);
+        wl[2 * cc + uu] = *reinterpret_cast<const f16x8 *>(b + 3 * SLAB + foff_w[uu]);
+      }
     }
 #pragma unroll
-    for (int uu = 0; uu < 2; ++uu) {
-      if (uu < skip) continue;
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[uu], al[uu], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[uu], ah[uu], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[uu], ah[uu], acc, 0, 0, 0);
+    for (int cc = 0; cc < 2; ++cc) {
+      if (c + cc >= nchunk) continue;                              // odd chunk count: the pair's second chunk does not exist
+      const int k0 = 64 * (c + cc);
+      const int skip = k0 > kp - 64 ? (k0 - (kp - 64)) / 32 : 0;   // units of the clamped last chunk already multiplied
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        if (uu < skip) continue;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[2 * cc + uu], al[2 * cc + uu], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[2 * cc + uu], ah[2 * cc + uu], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[2 * cc + uu], ah[2 * cc + uu], acc, 0, 0, 0);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the empty tail pieces: nothing may target LDS past the loop
   const int n = n0 + 16 * mi + 4 * kq;         // n, N, ldc multiples of 4: a quad is whole or absent, and 16-byte aligned
-  if (n >= N || !mok) return;
+  if (!storer || n >= N || !mok) return;
   const int a8 = act;
   f32x4 v;
 #pragma unroll
@@ -712,6 +732,19 @@ __global__ __launch_bounds__(256) void gemm_split16_skinny_kernel(
   } else {
     *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
   }
+}
+
+__global__ __launch_bounds__(256) void gemm_split16_skinny_kernel(
+    const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
+    const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int act, SplitOut so) {
+  skinny16_body<2>(A, ea, M, W, ew, N, kp, C, ldc, bias, residual, ldr, act, so);
+}
+__global__ __launch_bounds__(256) void gemm_split16_skinny_t16_kernel(
+    const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
+    const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int act, SplitOut so) {
+  skinny16_body<1>(A, ea, M, W, ew, N, kp, C, ldc, bias, residual, ldr, act, so);
 }
 
 // crossover measured with tools/bench_skinny_crossover.py (profiles/r02_skinny_crossover.txt): the latency kernel takes
@@ -777,8 +810,15 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
   // tile stream and in the latency kernel of one shape, not across shapes)
   static const bool shape32 = [] { const char *e = getenv("MEVI_GEMM_MFMA"); return e && atoi(e) == 32; }();
   if (m * n <= skinny_max) {
-    hipLaunchKernelGGL(shape32 ? gemm_split_skinny_kernel : gemm_split16_skinny_kernel,
-                       dim3((unsigned)((n + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0,
+    // fewer 32 x 32 tiles than half the CUs: 16 x 16 tiles (MEVI_GEMM_SKINNY_TILE=32 keeps the large tile; same bits)
+    static const bool tile32 = [] { const char *e = getenv("MEVI_GEMM_SKINNY_TILE"); return e && atoi(e) == 32; }();
+    const bool small16 = !shape32 && !tile32 && ((n + 31) / 32) * ((m + 31) / 32) <= 128;
+    const int T = small16 ? 16 : 32;
+    typedef void (*skinny_t)(const _Float16 *, const signed char *, int, const _Float16 *, const signed char *, int, int, float *,
+                             long long, const float *, const float *, long long, int, SplitOut);
+    static const skinny_t skinny[3] = {gemm_split_skinny_kernel, gemm_split16_skinny_t16_kernel, gemm_split16_skinny_kernel};
+    hipLaunchKernelGGL(skinny[shape32 ? 0 : (small16 ? 1 : 2)],
+                       dim3((unsigned)((n + T - 1) / T), (unsigned)((m + T - 1) / T)), dim3(256), 0,
                        stream, A, reinterpret_cast<const signed char *>(a_exp), (int)m, W, reinterpret_cast<const signed char *>(w_exp), (int)n, kp, c,
                        (long long)ldc, bias, residual, (long long)ldr, act, so);
     MEVI_HIP_CHECK(hipGetLastError());
