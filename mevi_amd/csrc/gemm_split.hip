@@ -86,6 +86,49 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float *__restr
   const int lane = threadIdx.x & 63;
   const float4 *xr = reinterpret_cast<const float4 *>(x + r * ldx);
   const float4 *wv = reinterpret_cast<const float4 *>(w);
+  if (dim == 768 && kp == 768) {
+    // the t5-base / bert-base width: the row stays in registers (three float4 per lane) -- one trip to memory instead of
+    // three dependent ones (the latency path runs this kernel on a handful of rows: 5.1 us per call, most of it those trips).
+    // Same arithmetic in the same order as the general form below: same bits.
+    float4 v[3], g[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[j] = xr[lane + 64 * j], g[j] = wv[lane + 64 * j];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ss = fmaf(v[j].x, v[j].x, ss); ss = fmaf(v[j].y, v[j].y, ss); ss = fmaf(v[j].z, v[j].z, ss); ss = fmaf(v[j].w, v[j].w, ss);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float denom = sqrtf(ss / (float)dim + eps);
+    float mx = 0.f, s2 = 0.f;
+    float4 y[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      y[j] = make_float4(g[j].x * (v[j].x / denom), g[j].y * (v[j].y / denom), g[j].z * (v[j].z / denom), g[j].w * (v[j].w / denom));
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(y[j].x), fabsf(y[j].y))), fmaxf(fabsf(y[j].z), fabsf(y[j].w)));
+      s2 = fmaf(y[j].x, y[j].x, fmaf(y[j].y, y[j].y, fmaf(y[j].z, y[j].z, fmaf(y[j].w, y[j].w, s2))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, off));
+      s2 += __shfl_xor(s2, off);
+    }
+    const int e = pow2_exp(mx);
+    _Float16 *o = img + (size_t)r * 2 * kp;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      h4 hi, lo;
+      split4(y[j], e, hi, lo);
+      *reinterpret_cast<h4 *>(o + 4 * (lane + 64 * j)) = hi;
+      *reinterpret_cast<h4 *>(o + kp + 4 * (lane + 64 * j)) = lo;
+    }
+    if (lane == 0) {
+      exps[r] = (signed char)e;
+      norms[r] = sqrtf(s2) * 1.0001f;
+    }
+    return;
+  }
   float ss = 0.f;
   for (int i = lane; i < dim / 4; i += 64) {
     const float4 v = xr[i];
