@@ -273,6 +273,14 @@ def index_build_leg(device, docs, rn, n_docs):
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes": byts,
                          "bytes_note": "SURVEY 8(d): 4 N d (corpus once) + 4 N M (codes)",
                          "achieved": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / 8000.0, 4)}}
+        # the matrix side of the same encode (2 N (M K) d products): (4, 32) takes every product in split precision
+        # (three f16 MFMAs), (3, 256) as one -- neither is what binds: the x stream is (128-byte pieces of the f32 rows at
+        # ~3.9 TB/s, once at (4, 32), once PER LEVEL at K = 256)
+        mf = 2.0 * n_docs * (M_ * K_) * DIM * (3 if M_ * K_ <= 128 else 1)
+        out["rq_encode_%dx%d" % (M_, K_)]["roofline_mfma"] = {
+            "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F16_MFMA_TFLOPS, "executed_f16_mfma_flop": mf,
+            "achieved": round(mf / ms / 1e9, 1), "frac": round(mf / ms / 1e9 / PEAK_F16_MFMA_TFLOPS, 4),
+            "x_stream_gb_per_s": round(4.0 * n_docs * DIM * (1 if K_ <= 32 else M_) / ms / 1e6, 1)}
         del codes, cb
     rq.KEEP_ENCODE_WORKSPACE = False
     rq._LAST_ENCODE.clear()
