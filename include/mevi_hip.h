@@ -264,6 +264,20 @@ int mevi_attention_varlen_split_f16(const float *q, int64_t q_ts, const float *k
 int mevi_adaptive_logits_f32(const float *s, int64_t lds, const float *t, int64_t ldt, const int64_t *t_index,
                              const float *e, int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream);
 
+/* T5LayerNorm + the ONE projection it feeds (q|k|v, the cross-attention q, wi: MEVI/transformers/modeling_t5.py:155-171 followed by
+ * :181, :350-352) in one launch, for the few rows of the latency path (the reference's --timing_infer_step regime): every workgroup
+ * normalises its rows itself, with mevi_rmsnorm_split_f16's arithmetic, and multiplies with mevi_gemm_nt_split_*'s accumulation
+ * chain -- results equal the two-call form bit for bit.  mevi_gemm_rmsnorm_supported(m, n, k) says whether a shape is on this path
+ * (k == 768, few output tiles); elsewhere use the two calls. */
+int mevi_gemm_rmsnorm_supported(int64_t m, int64_t n, int64_t k);
+int mevi_gemm_nt_rmsnorm_split_f32(const float *x, int64_t ldx, const float *ln_w, float eps, const void *w_img,
+                                   const int8_t *w_exp, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+                                   const float *bias, const float *residual, int64_t ldr, int act, void *stream);
+int mevi_gemm_nt_rmsnorm_split_to_split(const float *x, int64_t ldx, const float *ln_w, float eps, const void *w_img,
+                                        const int8_t *w_exp, float w_norm_max, int64_t m, int64_t n, int64_t k,
+                                        const float *bias, float bias_abs_max, int act, void *out_img, int8_t *out_exp,
+                                        float *out_norm, void *stream);
+
 /* ------------------------------------------------------------------------
  * Constrained beam step over the shared-layer RQ tree (one decoding step).
  * Replaces select_valid_embedding + log_softmax + prefix-tree mask + top-k + the Python

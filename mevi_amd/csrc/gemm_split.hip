@@ -790,6 +790,169 @@ __global__ __launch_bounds__(256) void gemm_split16_skinny_t16_kernel(
   skinny16_body<1>(A, ea, M, W, ew, N, kp, C, ldc, bias, residual, ldr, act, so);
 }
 
+// The latency path's norm + GEMM in one kernel: y = act(rmsnorm(x) W^T + b) (+ residual) for a handful of rows at the t5-base
+// width.  T5 feeds every T5LayerNorm into exactly one projection (q|k|v, the cross-attention q, wi); as two kernels the norm is a
+// 3 us launch + boundary in front of a 5.5 us GEMM, sixty times per tower pass.  Here every workgroup (16 x 16 outputs, as
+// skinny16_body<1>) normalises its 16 rows itself -- one wave per row, the arithmetic of rmsnorm_split_kernel's 768-wide path in
+// the same order, so the (hi, lo) image it builds in LDS (two planes of [16][768] halves, rows 1664 B apart: 128 B of padding
+// keep two rows on different bank halves, 16-byte chunks XORed by (row >> 1) & 7) is the image that kernel would have written,
+// bit for bit -- while the W stream is already in flight (all of it at K = 768: the ring holds 16 chunks of 64 k).  The
+// accumulation chain per output is skinny16_body's, so a row keeps its bits in any batch and on either path.
+constexpr int NG_RING = 16;                      // W chunks of 64 k in LDS: [hi | lo][16 rows][128 B] = 4 KiB each
+constexpr int NG_AROW = 1664;                    // bytes between rows of an A plane (768 halves + 128 B)
+constexpr int NG_APLANE = 16 * NG_AROW;
+constexpr size_t NG_LDS = (size_t)NG_RING * 4096 + 2 * NG_APLANE + 16 * 8;
+__global__ __launch_bounds__(1024) void gemm_rmsnorm_split16_kernel(
+    const float *__restrict__ X, long long ldx, const float *__restrict__ lnw, float eps, int M, const _Float16 *__restrict__ W,
+    const signed char *__restrict__ ew, int N, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
+    const float *__restrict__ residual, long long ldr, int act, SplitOut so) {
+  constexpr int kp = 768;
+  extern __shared__ __attribute__((aligned(16))) char ng[];
+  char *ring = ng;                                 // NG_RING x 4 KiB
+  char *ahi = ng + NG_RING * 4096, *alo = ahi + NG_APLANE;
+  int *sexp = reinterpret_cast<int *>(alo + NG_APLANE);          // [16] row exponents
+  float *snorm = reinterpret_cast<float *>(sexp + 16);           // [16] row norms (rounded up)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  // Sixteen waves: one per row of the norm (a wave per row is what fixes the order of its sums; four rows per wave in turn
+  // made the norm 3 us of every workgroup).  W staging by waves 0-3: wave w moves plane (w >> 1) (hi | lo), rows 8 (w & 1) .. + 7
+  // of every chunk, one 1-KiB piece per chunk and wave; wave 0 multiplies; waves 4-15 only keep the barriers company.
+  const bool stager = wave < 4;
+  const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(W + (size_t)n0 * 2 * kp + (((wave >> 1) & 1) ? kp : 0));
+  const int wr = 8 * (wave & 1) + (lane >> 3);
+  const int voff = min(wr, N - n0 - 1) * 4 * kp + 16 * ((lane & 7) ^ ((wr >> 1) & 7));
+  constexpr int nchunk = kp / 64;
+  // the epilogue's column operands first (oldest in the vmcnt queue: the counted waits below then only ever see W pieces)
+  const int nq_ = min(n0 + 4 * kq, N - 4);
+  const int pw = *reinterpret_cast<const int *>(ew + nq_);
+  const f32x4 pb = bias ? *reinterpret_cast<const f32x4 *>(bias + nq_) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 pr = residual ? *reinterpret_cast<const f32x4 *>(residual + (size_t)min(m0 + r16, M - 1) * ldr + nq_)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issue = [&](int c) {
+    if (!stager) return;
+    char *dst = ring + (c & (NG_RING - 1)) * 4096 + (wave >> 1) * 2048 + (wave & 1) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)dst, 16, c >= nchunk ? OOB : voff,
+                                             2 * 64 * (c < nchunk ? c : 0), 0, 0);
+  };
+#pragma unroll
+  for (int c = 0; c < NG_RING - 2; ++c) issue(c);
+  // the norm: wave w takes row w (clamped to the last real row: duplicates are never stored)
+  {
+    const float4 *wv = reinterpret_cast<const float4 *>(lnw);
+    const float4 *xr = reinterpret_cast<const float4 *>(X + (size_t)min(m0 + wave, M - 1) * ldx);
+    float4 g[3], v[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[j] = wv[lane + 64 * j], v[j] = xr[lane + 64 * j];
+    const int r = wave;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ss = fmaf(v[j].x, v[j].x, ss); ss = fmaf(v[j].y, v[j].y, ss); ss = fmaf(v[j].z, v[j].z, ss); ss = fmaf(v[j].w, v[j].w, ss);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float denom = sqrtf(ss / (float)kp + eps);
+    float mx = 0.f, s2 = 0.f;
+    float4 y[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      y[j] = make_float4(g[j].x * (v[j].x / denom), g[j].y * (v[j].y / denom), g[j].z * (v[j].z / denom), g[j].w * (v[j].w / denom));
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(y[j].x), fabsf(y[j].y))), fmaxf(fabsf(y[j].z), fabsf(y[j].w)));
+      s2 = fmaf(y[j].x, y[j].x, fmaf(y[j].y, y[j].y, fmaf(y[j].z, y[j].z, fmaf(y[j].w, y[j].w, s2))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, off));
+      s2 += __shfl_xor(s2, off);
+    }
+    const int e = pow2_exp(mx);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      h4 hi, lo;
+      split4(y[j], e, hi, lo);
+      const int q4 = lane + 64 * j;                                     // elements 4 q4 .. 4 q4 + 3 = half of 16-byte chunk q4 >> 1
+      const int off = r * NG_AROW + ((((q4 >> 1)) ^ ((r >> 1) & 7)) << 4) + ((q4 & 1) << 3);
+      *reinterpret_cast<h4 *>(ahi + off) = hi;
+      *reinterpret_cast<h4 *>(alo + off) = lo;
+    }
+    if (lane == 0) {
+      sexp[r] = e;
+      snorm[r] = sqrtf(s2) * 1.0001f;
+    }
+  }
+  __syncthreads();
+  // the epilogue's operands: row m0 + r16, column quad n0 + 4 kq
+  const int m = m0 + r16;
+  const bool mok = m < M;
+  const int em = sexp[r16];
+  int eo = 0;
+  if (so.img) {
+    eo = pow2_exp(fmaf(snorm[r16], so.wnorm_max, so.babs_max) * 1.001f);
+    if (wave == 0 && mok && n0 == 0 && kq == 0) {
+      so.exps[m] = (signed char)eo;
+      if (so.norms) so.norms[m] = fmaf(snorm[r16], so.wnorm_max, so.babs_max) * so.onorm_scale;
+    }
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int key = (r16 >> 1) & 7;
+  const int aoff = r16 * NG_AROW, woff = r16 * 128;
+  for (int c = 0; c < nchunk; c += 2) {
+    // chunks c, c + 1 landed (this wave's pieces: all but the twelve issued after them), then everybody's; chunks c - 2, c - 1 read
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    issue(c + NG_RING - 2);
+    issue(c + NG_RING - 1);
+    if (wave != 0) continue;
+    f16x8 ah[4], al[4], wh[4], wl[4];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const char *b = ring + ((c + cc) & (NG_RING - 1)) * 4096;
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        const int pc = 4 * uu + kq;                                        // 16-byte piece of the chunk's 128-byte row
+        ah[2 * cc + uu] = *reinterpret_cast<const f16x8 *>(ahi + aoff + (((8 * (c + cc) + pc) ^ key) << 4));
+        al[2 * cc + uu] = *reinterpret_cast<const f16x8 *>(alo + aoff + (((8 * (c + cc) + pc) ^ key) << 4));
+        wh[2 * cc + uu] = *reinterpret_cast<const f16x8 *>(b + woff + ((pc ^ key) << 4));
+        wl[2 * cc + uu] = *reinterpret_cast<const f16x8 *>(b + 2048 + woff + ((pc ^ key) << 4));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], al[i], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], ah[i], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], ah[i], acc, 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int n = n0 + 4 * kq;
+  if (wave != 0 || n >= N || !mok) return;
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x = ldexpf(acc[j], -(em + (int)(signed char)(pw >> (8 * j))));
+    if (bias) x += pb[j];
+    x = act == 1 ? act_fn<1>(x) : (act == 2 ? act_fn<2>(x) : x);
+    if (residual) x += pr[j];
+    v[j] = x;
+  }
+  if (so.img) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xs = ldexpf(v[j], eo);
+      hi[j] = (_Float16)xs;
+      lo[j] = (_Float16)(xs - (float)hi[j]);
+    }
+    _Float16 *o = so.img + (size_t)m * 2 * so.np + n;
+    *reinterpret_cast<f16x4 *>(o) = hi;
+    *reinterpret_cast<f16x4 *>(o + so.np) = lo;
+  } else {
+    *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
+  }
+}
+
 // crossover measured with tools/bench_skinny_crossover.py (profiles/r02_skinny_crossover.txt): the latency kernel takes
 // ~13 us (K = 768) per round of 256 workgroups, the tile stream ~50 us for any grid below one wave of tiles
 constexpr long long SPLIT_SKINNY_MAX_OUTPUTS = 1500000;
@@ -922,4 +1085,57 @@ extern "C" int mevi_gemm_nt_split_to_split(const void *a_img, const int8_t *a_ex
   so.babs_max = bias_abs_max;
   so.onorm_scale = sqrtf((float)n) * 1.0001f;  // ||row||_2 <= sqrt(n) * max|element|
   return gemm_split_launch(a_img, a_exp, w_img, w_exp, nullptr, 0, m, n, k, bias, nullptr, 0, act, so, stream);
+}
+
+// ---- norm + projection in one launch (the latency path; see gemm_rmsnorm_split16_kernel) -------------------------------------
+// Supported: k == 768 (the t5-base / bert-base width), m <= 1024 rows, n % 16 == 0 not required (n % 4 == 0); the caller keeps
+// the two-kernel form (mevi_rmsnorm_split_f16 + mevi_gemm_nt_split_*) elsewhere -- same results, bit for bit, either way.
+extern "C" int mevi_gemm_rmsnorm_supported(int64_t m, int64_t n, int64_t k) {
+  return k == 768 && m >= 1 && n >= 4 && n % 4 == 0 && ((n + 31) / 32) * ((m + 31) / 32) <= 128 && m * n <= SPLIT_SKINNY_MAX_OUTPUTS;
+}
+
+static int gemm_rmsnorm_launch(const float *x, int64_t ldx, const float *ln_w, float eps, const void *w_img, const int8_t *w_exp,
+                               float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias, const float *residual,
+                               int64_t ldr, int act, SplitOut so, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(mevi_gemm_rmsnorm_supported(m, n, k), MEVI_ERR_UNSUPPORTED, "gemm_rmsnorm: shape %lld x %lld x %lld not on the fused path",
+               (long long)m, (long long)n, (long long)k);
+  MEVI_REQUIRE(x && ln_w && w_img && w_exp && (c || so.img), MEVI_ERR_INVALID_ARG, "gemm_rmsnorm: null pointer");
+  MEVI_REQUIRE(act >= 0 && act <= 2, MEVI_ERR_INVALID_ARG, "gemm_rmsnorm: act must be 0, 1 or 2");
+  MEVI_REQUIRE(ldx % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)ln_w % 16) == 0 &&
+                   ((uintptr_t)w_img % 16) == 0 && ((uintptr_t)c % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
+                   ((uintptr_t)bias % 16) == 0 && ((uintptr_t)w_exp % 4) == 0,
+               MEVI_ERR_UNSUPPORTED, "gemm_rmsnorm: strides must be multiples of 4 and pointers 16-byte (w_exp 4-byte) aligned");
+  MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rmsnorm_split16_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NG_LDS));
+  hipLaunchKernelGGL(gemm_rmsnorm_split16_kernel, dim3((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16)), dim3(1024), NG_LDS, stream,
+                     x, (long long)ldx, ln_w, eps, (int)m, reinterpret_cast<const _Float16 *>(w_img),
+                     reinterpret_cast<const signed char *>(w_exp), (int)n, c, (long long)ldc, bias, residual, (long long)ldr, act, so);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_gemm_nt_rmsnorm_split_f32(const float *x, int64_t ldx, const float *ln_w, float eps, const void *w_img,
+                                              const int8_t *w_exp, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+                                              const float *bias, const float *residual, int64_t ldr, int act, void *stream) {
+  SplitOut so = {};
+  return gemm_rmsnorm_launch(x, ldx, ln_w, eps, w_img, w_exp, c, ldc, m, n, k, bias, residual, ldr, act, so, stream);
+}
+
+extern "C" int mevi_gemm_nt_rmsnorm_split_to_split(const float *x, int64_t ldx, const float *ln_w, float eps, const void *w_img,
+                                                   const int8_t *w_exp, float w_norm_max, int64_t m, int64_t n, int64_t k,
+                                                   const float *bias, float bias_abs_max, int act, void *out_img, int8_t *out_exp,
+                                                   float *out_norm, void *stream) {
+  MEVI_REQUIRE(out_img && out_exp, MEVI_ERR_INVALID_ARG, "gemm_rmsnorm_to_split: null pointer");
+  MEVI_REQUIRE(w_norm_max >= 0.f && bias_abs_max >= 0.f, MEVI_ERR_INVALID_ARG, "gemm_rmsnorm_to_split: negative bound");
+  SplitOut so = {};
+  so.img = reinterpret_cast<_Float16 *>(out_img);
+  so.exps = reinterpret_cast<signed char *>(out_exp);
+  so.norms = out_norm;
+  so.anorm = nullptr;     // the kernel computes the rows' norms itself
+  so.np = (int)mevi_split_kp(n);
+  so.wnorm_max = w_norm_max;
+  so.babs_max = bias_abs_max;
+  so.onorm_scale = sqrtf((float)n) * 1.0001f;
+  return gemm_rmsnorm_launch(x, ldx, ln_w, eps, w_img, w_exp, nullptr, 0, m, n, k, bias, nullptr, 0, act, so, stream);
 }

@@ -56,6 +56,11 @@ _SIGNATURES = {
                                             c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mevi_gemm_nt_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                        c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mevi_gemm_rmsnorm_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "mevi_gemm_nt_rmsnorm_split_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                               c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mevi_gemm_nt_rmsnorm_split_to_split": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_float, c_int64, c_int64,
+                                                    c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mevi_rmsnorm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "mevi_add_layernorm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float,
                                        c_int64, c_int64, c_void_p, c_int64, c_void_p]),

@@ -167,7 +167,53 @@ def split_rows(x):
     return SplitRows(img, exp, K, norm)
 
 
+def _linear_normed(nr, weight, bias, residual, act, out, for_gemm):
+    """rmsnorm + projection in one launch where the C ABI has the shape on its fused path; else None."""
+    x = nr.x
+    M, K = x.shape
+    N = weight.shape[0]
+    L = hip.lib()
+    if nr._rows is not None or not L.mevi_gemm_rmsnorm_supported(M, N, K):
+        return None
+    if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or nr.weight.data_ptr() % 16 or \
+            (bias is not None and bias.data_ptr() % 16):
+        return None
+    dev = weight.device
+    with torch.cuda.device(dev):
+        if for_gemm:
+            if residual is not None or out is not None or weight.norm_max is None:
+                return None
+            babs = _abs_max(bias) if bias is not None else 0.0
+            img, exp, norm = _split_buffers(M, N, dev, zero=True)
+            st = L.mevi_gemm_nt_rmsnorm_split_to_split(hip.ptr(x), x.stride(0), hip.ptr(nr.weight), nr.eps, hip.ptr(weight.img),
+                                                       hip.ptr(weight.exp), weight.norm_max, M, N, K,
+                                                       hip.ptr(bias) if bias is not None else None, babs, act, hip.ptr(img),
+                                                       hip.ptr(exp), hip.ptr(norm), hip.stream_ptr())
+            hip.check(st, "mevi_gemm_nt_rmsnorm_split_to_split")
+            return SplitRows(img, exp, N, norm)
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=dev)
+        if out.shape != (M, N) or out.stride(1) != 1 or out.stride(0) % 4 or out.data_ptr() % 16:
+            return None
+        ldr = 0
+        if residual is not None:
+            if residual.shape != (M, N) or residual.stride(1) != 1 or residual.stride(0) % 4 or residual.data_ptr() % 16:
+                return None
+            ldr = residual.stride(0)
+        st = L.mevi_gemm_nt_rmsnorm_split_f32(hip.ptr(x), x.stride(0), hip.ptr(nr.weight), nr.eps, hip.ptr(weight.img),
+                                              hip.ptr(weight.exp), hip.ptr(out), out.stride(0), M, N, K,
+                                              hip.ptr(bias) if bias is not None else None,
+                                              hip.ptr(residual) if residual is not None else None, ldr, act, hip.stream_ptr())
+        hip.check(st, "mevi_gemm_nt_rmsnorm_split_f32")
+        return out
+
+
 def _linear_split(x, weight, bias, residual, act, out, for_gemm):
+    if isinstance(x, NormedRows):
+        y = _linear_normed(x, weight, bias, residual, act, out, for_gemm)
+        if y is not None:
+            return y
+        x = x.rows()
     xs = x if isinstance(x, SplitRows) else split_rows(x)
     (M, K), (N, K2) = xs.shape, weight.shape
     assert K == K2, (xs.shape, weight.shape)
@@ -228,11 +274,53 @@ def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False
     return out
 
 
+class NormedRows:
+    """rmsnorm(x) that has not been computed yet: T5 feeds every T5LayerNorm into exactly ONE projection, and for the few rows
+    of the latency path linear() runs norm + GEMM as one kernel (mevi_gemm_nt_rmsnorm_split_*: same bits as the two-kernel
+    form).  Anything else asks for `.rows()` -- the SplitRows image mevi_rmsnorm_split_f16 writes."""
+
+    __slots__ = ("x", "weight", "eps", "_rows")
+
+    def __init__(self, x, weight, eps):
+        self.x, self.weight, self.eps, self._rows = x, weight, eps, None
+
+    @property
+    def shape(self):
+        return tuple(self.x.shape)
+
+    @property
+    def device(self):
+        return self.x.device
+
+    def rows(self):
+        if self._rows is None:
+            self._rows = _rmsnorm_split(self.x, self.weight, self.eps)
+        return self._rows
+
+
+# Norm + projection as ONE kernel on the latency path (mevi_gemm_nt_rmsnorm_split_*): built, bit-identical to the two-kernel form
+# (tests/test_gemm_split_gpu.py), and measured NO faster -- batch-1 tower 1.43 vs 1.40 ms, NCI generate 3.42 vs 3.40 ms: the
+# workgroup's own norm (x round trip + one wave per row) serialises in front of its K loop what the separate 3 us kernel + 1 us
+# boundary cost.  Off by default; MEVI_FUSE_NORM=1 turns it on.
+FUSE_NORM = os.environ.get("MEVI_FUSE_NORM", "0") == "1"
+
+
+def _rmsnorm_split(x, weight, eps):
+    M, D = x.shape
+    img, exp, norm = _split_buffers(M, D, x.device)
+    st = hip.lib().mevi_rmsnorm_split_f16(hip.ptr(x), x.stride(0), hip.ptr(weight), eps, M, D, hip.ptr(img), hip.ptr(exp),
+                                          hip.ptr(norm), hip.stream_ptr())
+    hip.check(st, "mevi_rmsnorm_split_f16")
+    return SplitRows(img, exp, D, norm)
+
+
 @hip.on_device
 def rmsnorm(x, weight, eps, out=None, for_gemm=False):
     """T5LayerNorm.  for_gemm: the normed rows only feed linear() -- under GEMM_MODE 'split' they are written as a
-    SplitRows image directly."""
+    SplitRows image directly, or (few rows, width 768) left to the projection's own kernel (NormedRows)."""
     x, M, D, ldx = _rows2d(_f32(x))
+    if for_gemm and GEMM_MODE == "split" and FUSE_NORM and D == 768 and 0 < M <= 256 and weight.is_contiguous():
+        return NormedRows(x, weight, eps)
     if for_gemm and GEMM_MODE == "split":
         img, exp, norm = _split_buffers(M, D, x.device)
         st = hip.lib().mevi_rmsnorm_split_f16(hip.ptr(x), ldx, hip.ptr(weight), eps, M, D, hip.ptr(img), hip.ptr(exp),

@@ -143,3 +143,40 @@ def test_extreme_rows(cuda):
     got = ops.linear(ops.split_rows(x), ops.split_rows(w))
     bad = ~torch.isfinite(got)
     assert bad[5].any() and bad[6].any() and not bad[[0, 1, 2, 3, 4, 7, 8]].any()
+
+
+def test_norm_and_projection_in_one_kernel_keep_the_two_kernel_bits(cuda, monkeypatch):
+    """mevi_gemm_nt_rmsnorm_split_* (the latency path: every workgroup normalises its rows itself) against
+    mevi_rmsnorm_split_f16 + mevi_gemm_nt_split_*: identical outputs -- f32 with bias / relu / residual / strided output, and
+    the image-writing form (image, exponents, norms) -- for 1 .. 40 rows; unsupported shapes fall back silently."""
+    monkeypatch.setattr(ops, "FUSE_NORM", True)       # off by default (measured no faster): MEVI_FUSE_NORM=1
+    g = torch.Generator(device=cuda).manual_seed(21)
+    rnd = lambda *s_: torch.randn(s_, device=cuda, generator=g)      # noqa: E731
+    lnw = 1 + 0.1 * rnd(768)
+    for M, N in ((1, 768), (10, 2304), (11, 3072), (32, 768), (33, 1536), (40, 1536)):
+        x = rnd(M, 768) * torch.exp(rnd(M, 1))
+        w = ops.weight_split(rnd(N, 768) * 768 ** -0.5)
+        b, r = rnd(N) * 0.1, rnd(M, N)
+        assert ops.FUSE_NORM and hip_lib().mevi_gemm_rmsnorm_supported(M, N, 768)
+        two = lambda **kw: ops.linear(ops._rmsnorm_split(x, lnw, 1e-6), w, **kw)         # noqa: E731
+        one = lambda **kw: ops.linear(ops.rmsnorm(x, lnw, 1e-6, for_gemm=True), w, **kw)  # noqa: E731
+        assert isinstance(ops.rmsnorm(x, lnw, 1e-6, for_gemm=True), ops.NormedRows)
+        for kw in ({}, {"bias": b}, {"bias": b, "relu": True}, {"residual": r}, {"bias": b, "residual": r, "gelu": True}):
+            assert torch.equal(one(**kw), two(**kw)), (M, N, sorted(kw))
+        big = torch.full((M, 3, N), float("nan"), device=cuda)
+        one(out=big[:, 1, :])
+        assert torch.equal(big[:, 1, :], two()) and torch.isnan(big[:, 0, :]).all()
+        h1, h2 = one(bias=b, relu=True, for_gemm=True), two(bias=b, relu=True, for_gemm=True)
+        assert torch.equal(h1.img, h2.img) and torch.equal(h1.exp, h2.exp) and torch.equal(h1.norm, h2.norm)
+    # not on the fused path: many rows (the tile stream), another width -- the lazy rows materialise, same results
+    x = rnd(3000, 768)
+    w = ops.weight_split(rnd(768, 768) * 0.03)
+    nr = ops.rmsnorm(x[:300], lnw, 1e-6, for_gemm=True)
+    assert not isinstance(nr, ops.NormedRows) or torch.equal(ops.linear(nr, w), ops.linear(ops._rmsnorm_split(x[:300], lnw, 1e-6), w))
+    assert isinstance(ops.rmsnorm(x, lnw, 1e-6, for_gemm=True), ops.SplitRows)
+
+
+def hip_lib():
+    from mevi_amd import hip
+
+    return hip.lib()
