@@ -39,7 +39,8 @@ def upload_rows(src, device, chunk_rows=1 << 18, threads=8):
     # with pread (one kernel copy, no page-table population of a 27 GB mapping, no intermediate user-space copy); anything
     # else (an array in memory) is copied
     fd = None
-    if isinstance(src, np.memmap) and getattr(src, "filename", None) and src.flags.c_contiguous and src.dtype == np.float32:
+    if isinstance(src, np.memmap) and getattr(src, "filename", None) and src.flags.c_contiguous and src.dtype == np.float32 \
+            and os.environ.get("MEVI_UPLOAD", "pread") != "copy":      # MEVI_UPLOAD=copy: memcpy out of the mapping (A/B)
         try:
             fd = os.open(src.filename, os.O_RDONLY)
             base = int(src.offset)
