@@ -13,7 +13,7 @@ using namespace mevi;
 
 // HOT: every workgroup of an XCD walks the SAME few operand tiles (4 A tiles x 8 W tiles, re-visited forever): the L2-hot
 // ceiling of the loop -- what perfect super-tile locality would give
-template <int SHAPE, bool STORE, bool HOT = false>
+template <int SHAPE, bool STORE, bool HOT = false, int ABL = 0>
 __global__ __launch_bounds__(PP_THREADS, 2) void probe_kernel(const _Float16 *A, const _Float16 *W, int kp, float *C, int ldc,
                                                               float *sink, int n_mtiles, int n_ntiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void probe_kernel(const _Float16 *A,
           for (int ni = 0; ni < 8; ++ni) keep += acc[mi][ni][0] + acc[mi][ni][3];
       }
     };
-    h16_tile_stream<decltype(next), decltype(begin), decltype(emit), H1BlockedUnits>(64, kp / 32, lds, next, begin, emit);
+    h16_tile_stream<decltype(next), decltype(begin), decltype(emit), H1BlockedUnits, ABL>(64, kp / 32, lds, next, begin, emit);
   } else {
     auto emit = [&](f32x16 (&acc)[2][4]) {
       hm = tm, hn = tn, --np;
@@ -94,6 +94,24 @@ float run_batch(const _Float16 *A, int M, const _Float16 *W, int N, int kp, floa
   hipEventRecord(e0);
   for (int i = 0; i < launches; ++i)
     hipLaunchKernelGGL((probe_kernel<SHAPE, false>), dim3(256), dim3(PP_THREADS), h1_lds_bytes(), 0, A, W, kp, nullptr, 0, sink,
+                       M / 256, N / 256);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / launches;
+}
+
+template <int ABL>
+float run_abl(const _Float16 *A, int M, const _Float16 *W, int N, int kp, float *sink, int launches) {
+  hipFuncSetAttribute(reinterpret_cast<const void *>(probe_kernel<16, false, false, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)h1_lds_bytes());
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipEventRecord(e0);
+  for (int i = 0; i < launches; ++i)
+    hipLaunchKernelGGL((probe_kernel<16, false, false, ABL>), dim3(256), dim3(PP_THREADS), h1_lds_bytes(), 0, A, W, kp, nullptr, 0, sink,
                        M / 256, N / 256);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
@@ -198,6 +216,14 @@ int main() {
       const float h32 = run_hot<32>(A, M, W, N, kp, sink, launches), h16 = run_hot<16>(A, M, W, N, kp, sink, launches);
       printf("k %4d L2-hot (every workgroup of an XCD on the same 4 x 8 operand tiles): 32x32x16 %7.1f TFLOP/s | 16x16x32 %7.1f TFLOP/s\n",
              kp, flop / h32 / 1e9, flop / h16 / 1e9);
+    }
+    {
+      const int l2 = launches / 3 + 1;
+      printf("k %4d 16x16x32 ablations (TFLOP/s equivalents): full %7.1f | no barrier %7.1f | no DMA %7.1f | no LDS reads %7.1f | no DMA + no reads %7.1f | MFMA only %7.1f | no MFMA %7.1f\n",
+             kp, flop / run_abl<0>(A, M, W, N, kp, sink, l2) / 1e9, flop / run_abl<1>(A, M, W, N, kp, sink, l2) / 1e9,
+             flop / run_abl<2>(A, M, W, N, kp, sink, l2) / 1e9, flop / run_abl<4>(A, M, W, N, kp, sink, l2) / 1e9,
+             flop / run_abl<6>(A, M, W, N, kp, sink, l2) / 1e9, flop / run_abl<7>(A, M, W, N, kp, sink, l2) / 1e9,
+             flop / run_abl<8>(A, M, W, N, kp, sink, l2) / 1e9);
     }
     hipFree(A); hipFree(W); hipFree(sink);
   }
