@@ -216,6 +216,15 @@ class PrefixTables:
         return cache
 
 
+def default_table_bytes(dev):
+    """Byte budget of the prefix tables when the caller names none: half of the device memory that is free now, at most
+    64 GiB.  On a 288 GB MI355X that tables the head matrices of the 65 536 two-code prefixes of a 3 x 256 codebook (52 GB:
+    the 257-column head GEMM of position 2 becomes a lookup, 315 -> 248 ms per 6980 queries); the scripts' 4 x 32 codebook
+    needs 4.2 GB whatever the budget.  The beams' bits do not depend on it (PrefixTables)."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    return int(min(64 << 30, free // 2))
+
+
 class PrefixTree:
     """The generic decode tree of the reference -- TreeBuilder(share_sons=False).add(tokens of one code path) for every
     existing path (MEVI/main_models.py:50-63, built from the doc -> code mapping at :1707-1728) -- level by level as
@@ -251,10 +260,11 @@ class NCIModel:
     """`generate()` mirrors the reference call; weights use the reference's state_dict names
     (T5ForConditionalGeneration: shared, encoder.*, decoder.*, decode_embeddings, adaptor*, lm_head)."""
 
-    def __init__(self, weights, cfg=None, device=None, prefix_table_bytes=6 << 30, **kw):
+    def __init__(self, weights, cfg=None, device=None, prefix_table_bytes=None, **kw):
         self.dev = torch.device(device if device is not None else "cuda")
         self.cfg = cfg if cfg is not None else NCIConfig(**kw)
-        self.prefix_table_bytes = prefix_table_bytes      # 0: evaluate the adaptor per beam per step
+        # 0: evaluate the adaptor per beam per step; None: sized from the device when the tables are first built
+        self.prefix_table_bytes = prefix_table_bytes
         self._tables = None
         self._graphs = GraphCache()
         c = self.cfg
@@ -278,6 +288,8 @@ class NCIModel:
 
     def tables(self):
         if self._tables is None:
+            if self.prefix_table_bytes is None:
+                self.prefix_table_bytes = default_table_bytes(self.dev)
             self._tables = PrefixTables(self, self.prefix_table_bytes)
         return self._tables
 
@@ -349,7 +361,7 @@ class NCIModel:
         B = ids.shape[0]
         enc = self.encoder.forward(self.shared, ids, mask)
         out = torch.empty((B, K ** M), dtype=torch.float32, device=self.dev)
-        levels = self.tables().levels if self.prefix_table_bytes else 0
+        levels = self.tables().levels if self.prefix_table_bytes != 0 else 0
         for a in range(0, B, max_rows):                      # position 0: one row per query
             m_ = mask[a:a + max_rows]
             xkv = self.decoder.cross_kv(enc[a:a + max_rows], m_, pack=True)
@@ -418,7 +430,7 @@ class NCIModel:
             scores[:, 1:] = -1e9
             node = torch.zeros((B, nb), dtype=torch.int32, device=self.dev)  # every beam starts at the root
         codes = torch.zeros((B, nb, 0), dtype=torch.int64, device=self.dev)
-        levels = self.tables().levels if self.prefix_table_bytes else 0      # positions the prefix tables cover
+        levels = self.tables().levels if self.prefix_table_bytes != 0 else 0      # positions the prefix tables cover
         pidx = torch.zeros(B * nb, dtype=torch.int64, device=self.dev)       # prefix index of every live beam
         # The decoder's K|V caches are never re-ordered (the reference index_selects every layer's cache by the surviving
         # beams' parents after each step, generation_utils.py:927-934): position p of step-p row r stays in cache row r and

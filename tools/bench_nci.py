@@ -1,4 +1,4 @@
-"""NCI generate alone at t5-base shapes (for rocprofv3): python tools/bench_nci.py [nq] [batch]"""
+"""NCI generate alone at t5-base shapes (for rocprofv3): python tools/bench_nci.py [nq] [batch] [M] [K] [table GiB]"""
 import os
 import sys
 import time
@@ -16,7 +16,11 @@ import synth  # noqa: E402
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 dev = torch.device("cuda:0")
-model, tower, g, rn = synth.build(dev, 4, 32, batch)
+M = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+K = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+model, tower, g, rn = synth.build(dev, M, K, batch)
+if len(sys.argv) > 5:
+    model.prefix_table_bytes = int(float(sys.argv[5]) * (1 << 30))
 ids, mask = synth.query_ids(nq, dev, np.random.default_rng(0))
 
 
