@@ -237,7 +237,7 @@ def dense_small_batch(device, index, query, n_docs):
                     "scripts ask, and top-100), mean of 10 calls, inputs and outputs on the device" % TOPK,
             "dtype": "f16 pre-filter (selection) + exact f32 chains (results)",
             "kernel": "ip_filter_h1_small_kernel for batch <= 32 (stationary query tile, every wave streaming its own corpus rows), "
-                      "ip_filter_h1_kernel above",
+                      "ip_filter_h16_kernel above",
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
                          "algorithmic_bytes_per_search": image_bytes,
                          "note": "bytes = the corpus' f16 image (N x 768 x 2), read once per search; the f32 rows of the re-scored "
@@ -717,8 +717,9 @@ def main():
         achieved = filt_flops / (filt_ms * 1e-3) / 1e12 if filt_ms > 0 else None
         if args.exact_f32_path:
             kernel, peak, peak_note = "ip_filter_kernel", PEAK_F32_MFMA_TFLOPS, "f32 MFMA dense peak"
-        else:  # one f16 MFMA per product
-            kernel, peak = "ip_filter_h1_kernel", PEAK_F16_MFMA_TFLOPS
+        else:  # one f16 MFMA per product: v_mfma_f32_16x16x32_f16 (ip_filter_h16_kernel) unless switched back or dim % 64
+            h16 = os.environ.get("MEVI_IP_FILTER_MFMA", "") != "32" and DIM % 64 == 0
+            kernel, peak = ("ip_filter_h16_kernel" if h16 else "ip_filter_h1_kernel"), PEAK_F16_MFMA_TFLOPS
             peak_note = "f16 MFMA dense peak"
         # HBM-side bytes per filter launch: PMC (FETCH_SIZE x 2 on gfx950) of THIS command, recorded by
         # tools/prof_traffic.sh + tools/traffic_summary.py; PMC passes cannot run inside the timed bench.
@@ -734,6 +735,11 @@ def main():
             traffic_note = ("bytes per launch, recorded PMC pass (profiles/%s): L2 memory-side " % os.path.basename(tfile) +
                             "requests incl. Infinity Cache hits; L2 hit rate %.2f; the corpus image itself is %.2f GB per "
                             "launch" % (tj["l2_hit_rate"], n_docs * DIM * 2 / 1e9 / (launches / args.steps)))
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import traffic_summary
+
+            if tj.get("filter_source_sha256") != traffic_summary.filter_source_sha():
+                traffic_note += "; NOTE: the kernel sources changed after this PMC pass (re-run tools/prof_traffic.sh)"
         out = {
             "metric": "queries/sec @ MRR@10-match, MSMARCO dev, 1/2/4/8 MI355X",
             "value": nq * args.steps / elapsed,
