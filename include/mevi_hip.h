@@ -264,6 +264,13 @@ int mevi_attention_varlen_split_f16(const float *q, int64_t q_ts, const float *k
 int mevi_adaptive_logits_f32(const float *s, int64_t lds, const float *t, int64_t ldt, const int64_t *t_index,
                              const float *e, int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream);
 
+/* The same head with lm_head's rows already inside the matrices and the d_model^-0.5 of modeling_t5.py:1607 applied here:
+ * out[row, c] = sum_d (s[row, d] * alpha) * te[trow, c*dim + d],  te[., c*dim + d] = t[., c*dim + d] + e[c, d]  (the bias of the
+ * GEMM that wrote it).  Bit-identical to mevi_scale_f32 + mevi_adaptive_logits_f32; the row's hidden state is read once per 64
+ * columns instead of once per column.  dim <= 1024. */
+int mevi_adaptive_logits_rows_f32(const float *s, int64_t lds, float alpha, const float *te, int64_t ldt, const int64_t *t_index,
+                                  int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream);
+
 /* T5LayerNorm + the ONE projection it feeds (q|k|v, the cross-attention q, wi: MEVI/transformers/modeling_t5.py:155-171 followed by
  * :181, :350-352) in one launch, for the few rows of the latency path (the reference's --timing_infer_step regime): every workgroup
  * normalises its rows itself, with mevi_rmsnorm_split_f16's arithmetic, and multiplies with mevi_gemm_nt_split_*'s accumulation

@@ -1635,6 +1635,67 @@ __global__ __launch_bounds__(256) void adaptive_logits_kernel(const float *__res
   if (lane == 0) out[r * ncol + c] = acc;
 }
 
+// logits[row, c] = sum_d (s[row, d] * alpha) * TE[trow, c*dim + d]: TE = the head matrices with lm_head's rows already in them
+// (the bias of the GEMM that produced them, the same f32 add adaptive_logits_kernel makes), alpha = d_model^-0.5 of
+// modeling_t5.py:1607 applied to the element as scale_kernel would.  One wave per (row, chunk of 64 columns): the row's hidden
+// state is read once and stays in registers (adaptive_logits_kernel reads s, t and e per column: three times the L2 traffic,
+// which is what bounds the table positions -- 32 .. 32768 prefixes shared by 70 k beams).  Per (row, c) the chain is that
+// kernel's: lane l adds its float4 pieces l, l + 64, ... in order, x y z w, then the xor butterfly -- same bits.
+template <int NI>
+__global__ __launch_bounds__(256) void adaptive_logits_rows_kernel(const float *__restrict__ s, long long lds_, float alpha,
+                                                                  const float *__restrict__ TE, long long ldt,
+                                                                  const long long *__restrict__ t_index, long long rows,
+                                                                  int ncol, int dim, int chunks, float *__restrict__ out) {
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= rows * chunks) return;
+  const int lane = threadIdx.x & 63;
+  const long long r = wid / chunks;
+  const int c0 = (int)(wid - r * chunks) * 64;
+  const int c1 = min(ncol, c0 + 64);
+  const int d4 = dim / 4;
+  const long long tr = t_index ? t_index[r] : r;
+  const float4 *sv = reinterpret_cast<const float4 *>(s + r * lds_);
+  float4 a[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int i = lane + 64 * j;
+    a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < d4) {
+      const float4 v = sv[i];
+      a[j] = make_float4(v.x * alpha, v.y * alpha, v.z * alpha, v.w * alpha);
+    }
+  }
+  const float *tb = TE + tr * ldt;
+  float keep = 0.f;
+  for (int c = c0; c < c1; c += 4) {
+    float4 t4[4][NI];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 *tv = reinterpret_cast<const float4 *>(tb + (size_t)min(c + u, c1 - 1) * dim);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int i = lane + 64 * j;
+        t4[u][j] = i < d4 ? tv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        if (lane + 64 * j < d4) {
+          acc = fmaf(a[j].x, t4[u][j].x, acc);
+          acc = fmaf(a[j].y, t4[u][j].y, acc);
+          acc = fmaf(a[j].z, t4[u][j].z, acc);
+          acc = fmaf(a[j].w, t4[u][j].w, acc);
+        }
+      acc = wave_sum(acc);
+      if (lane == c + u - c0) keep = acc;
+    }
+  }
+  if (c0 + lane < c1) out[r * ncol + c0 + lane] = keep;
+}
+
 inline unsigned blocks4(long long waves) { return (unsigned)((waves + 3) / 4); }
 
 }  // namespace
@@ -1963,6 +2024,26 @@ extern "C" int mevi_attention_cached_split_f16(const float *q, int64_t q_bs, con
   return attention_cached_launch(q, q_bs, k, k_bs, k_ts, v, v_bs, v_ts, nullptr, img_bs, nb, tk, heads, dh, key_rows, bias,
                                  bias_rows, bias_ld, q_pos0, causal, scale,
                                  CtxImage{reinterpret_cast<_Float16 *>(out_img), (int)img_np, out_exp}, stream);
+}
+
+extern "C" int mevi_adaptive_logits_rows_f32(const float *s, int64_t lds_, float alpha, const float *te, int64_t ldt,
+                                             const int64_t *t_index, int64_t rows, int64_t ncol, int64_t dim, float *out,
+                                             void *stream) {
+  MEVI_REQUIRE(rows >= 0 && ncol > 0 && dim > 0 && dim % 4 == 0 && dim <= 1024 && lds_ % 4 == 0 && ldt % 4 == 0 && ncol < (1 << 24),
+               MEVI_ERR_INVALID_ARG, "adaptive_logits_rows: bad shape (dim a multiple of 4, at most 1024)");
+  if (rows == 0) return MEVI_OK;
+  MEVI_REQUIRE(s && te && out, MEVI_ERR_INVALID_ARG, "adaptive_logits_rows: null pointer");
+  MEVI_REQUIRE((((uintptr_t)s | (uintptr_t)te) & 15) == 0, MEVI_ERR_INVALID_ARG, "adaptive_logits_rows: s, te 16-byte aligned");
+  const int chunks = (int)((ncol + 63) / 64);
+  const int ni = (int)((dim / 4 + 63) / 64);
+  typedef void (*fn_t)(const float *, long long, float, const float *, long long, const long long *, long long, int, int, int,
+                       float *);
+  static const fn_t table[4] = {adaptive_logits_rows_kernel<1>, adaptive_logits_rows_kernel<2>, adaptive_logits_rows_kernel<3>,
+                                adaptive_logits_rows_kernel<4>};
+  hipLaunchKernelGGL(table[ni - 1], dim3(blocks4(rows * chunks)), dim3(256), 0, (hipStream_t)stream, s, (long long)lds_, alpha, te,
+                     (long long)ldt, reinterpret_cast<const long long *>(t_index), (long long)rows, (int)ncol, (int)dim, chunks, out);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
 }
 
 extern "C" int mevi_adaptive_logits_f32(const float *s, int64_t lds_, const float *t, int64_t ldt,

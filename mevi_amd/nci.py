@@ -15,6 +15,8 @@ adaptive head are evaluated (reference materialises [B*R, t, d, V]), cross K/V o
 adaptor side of the head -- which sees nothing but a beam's code prefix -- is evaluated once per PREFIX
 (PrefixTables) instead of once per beam per step.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -137,14 +139,26 @@ class Adaptor:
                 for _ in self.layers]
 
     def step(self, x, t, cache):
+        """cache: new_cache()'s list of [rows, T, 2d] tensors, or an IndexedPrefixCache (the K|V of positions < t read from
+        the prefix tables in place, position t written behind them)."""
         d = self.cfg.d_model
         n = x.shape[0]
-        for L, kvc in zip(self.layers, cache):
+        indexed = isinstance(cache, IndexedPrefixCache)
+        for li, L in enumerate(self.layers):
             xg = ops.gemm_input(x)
             q = ops.linear(xg, L["wq"], bias=L["bq"])
-            ops.linear(xg, L["wkv"], bias=L["bkv"], out=kvc[:, t, :])
-            ctx = ops.attention(q.view(n, 1, d), kvc[:, :t + 1, :d], kvc[:, :t + 1, d:], self.NHEAD,
-                                q_pos0=t, causal=True, scale=(d // self.NHEAD) ** -0.5)
+            if indexed:
+                buf = cache.bufs[li]
+                ops.linear(xg, L["wkv"], bias=L["bkv"], out=buf[cache.tail:cache.tail + n])
+                rows = buf.shape[0]
+                ctx = ops.attention_cached(q, buf.as_strided((rows, t + 1, d), (2 * d, 0, 1)),
+                                           buf.as_strided((rows, t + 1, d), (2 * d, 0, 1), buf.storage_offset() + d),
+                                           cache.key_rows, self.NHEAD, q_pos0=t, causal=True, scale=(d // self.NHEAD) ** -0.5)
+            else:
+                kvc = cache[li]
+                ops.linear(xg, L["wkv"], bias=L["bkv"], out=kvc[:, t, :])
+                ctx = ops.attention(q.view(n, 1, d), kvc[:, :t + 1, :d], kvc[:, :t + 1, d:], self.NHEAD,
+                                    q_pos0=t, causal=True, scale=(d // self.NHEAD) ** -0.5)
             sa = ops.linear(ctx.view(n, d), L["self_attn.out_proj.weight"], bias=L["self_attn.out_proj.bias"])
             x = ops.add_layernorm(x, sa, L["norm1.weight"], L["norm1.bias"])
             x = ops.add_layernorm(x, None, L["norm2.weight"], L["norm2.bias"], cvec=L["cross_const"])
@@ -154,6 +168,18 @@ class Adaptor:
         return x
 
 
+class IndexedPrefixCache:
+    """The adaptor's K|V cache of n beams at position p WITHOUT assembling it: bufs[l] f32 [tail + n, 2d] holds the prefix
+    tables of positions 0 .. p-1 one after the other (PrefixTables.kv_cat) and, from row `tail`, the K|V the beams write at
+    position p; key_rows i32 [n, p + 1] names the row of every position (mevi_attention_cached_*: same kernel, same bits as
+    on the gathered copy PrefixTables.cache_rows makes)."""
+
+    __slots__ = ("bufs", "tail", "key_rows")
+
+    def __init__(self, bufs, tail, key_rows):
+        self.bufs, self.tail, self.key_rows = bufs, tail, key_rows
+
+
 class PrefixTables:
     """The adaptor half of the PAWA head as tables over code prefixes.
 
@@ -161,7 +187,7 @@ class PrefixTables:
     (0, c1 .. cp) only -- not on the query (modeling_t5.py:1650-1665: the adaptor's memory is one learned vector).
     At position p there are K**p prefixes, shared by every beam of every query: 1, 32, 1024, 32768 for the scripts'
     (M, K) = (4, 32) against 10 beams x thousands of queries per step.  So per level p < `levels`:
-        tmat[p]  f32 [K**p, (K+1)*d]   head matrices  (row = sum_i c_i K**(p-i)), when within the byte budget,
+        tmat[p]  f32 [K**p, (K+1)*d]   head matrices, lm_head's rows added (row = sum_i c_i K**(p-i)), when within the byte budget,
         avec[p]  f32 [K**p, d]         adaptor outputs otherwise (the head GEMM then runs per beam as before),
         kv[l][p] f32 [K**p, 2d]        the adaptor layers' self-attention K|V of position p, so that the first position
                                        beyond the tables continues from a cache assembled by lookup.
@@ -174,6 +200,7 @@ class PrefixTables:
         c, dev = model.cfg, model.dev
         d, K = c.d_model, c.K
         self.levels = 0
+        self._cat, self._retired = None, []
         self.tmat, self.avec, self.kv = [], [], [[] for _ in model.adaptor.layers]
         cache, spent = None, 0
         for p in range(c.T):
@@ -195,7 +222,7 @@ class PrefixTables:
             spent += kv_bytes
             t_bytes = n * (K + 1) * d * 4
             if spent + t_bytes <= table_bytes:
-                self.tmat.append(ops.linear(a, model.head_w[p]))
+                self.tmat.append(ops.linear(a, model.head_w[p], bias=model.head_e[p] if ROW_LOGITS else None))
                 self.avec.append(None)
                 spent += t_bytes
             else:
@@ -204,6 +231,33 @@ class PrefixTables:
                 spent += n * d * 4
             self.levels = p + 1
         self.bytes = spent
+
+    def indexed_cache(self, adaptor, pidx, p):
+        """IndexedPrefixCache of beams whose prefix index at position p = self.levels is `pidx` -- for a position whose cache
+        no later position needs (the final one): 4 layers x p gathers of [n, 2d] rows and the [n, T, 2d] caches not made."""
+        assert p == self.levels and p <= 7
+        K, n = adaptor.cfg.K, pidx.numel()
+        d2 = 2 * adaptor.cfg.d_model
+        offs = [0]
+        for q in range(p):
+            offs.append(offs[-1] + K ** q)
+        tail = offs[p]
+        if self._cat is None or self._cat[0].shape[0] < tail + n:
+            cap = tail + max(n, 0 if self._cat is None else 2 * (self._cat[0].shape[0] - tail))
+            cat = []
+            for l in range(len(self.kv)):
+                buf = torch.empty((cap, d2), dtype=torch.float32, device=pidx.device)
+                for q in range(p):
+                    buf[offs[q]:offs[q + 1]].copy_(self.kv[l][q])
+                    self.kv[l][q] = buf[offs[q]:offs[q + 1]]          # the tables live in the buffer from now on
+                cat.append(buf)
+            if self._cat is not None:
+                self._retired.append(self._cat)     # captured graphs (GraphCache) may still read the old buffers
+            self._cat = cat
+        cols = [(offs[q] + pidx // (K ** (p - q))) for q in range(p)]
+        cols.append(tail + torch.arange(n, device=pidx.device))
+        key_rows = torch.stack(cols, 1).to(torch.int32).contiguous()
+        return IndexedPrefixCache([b[:tail + n] for b in self._cat], tail, key_rows)
 
     def cache_rows(self, adaptor, pidx, p):
         """The adaptor's K|V cache (positions < p filled) of beams whose prefix index at position p is `pidx`."""
@@ -214,6 +268,13 @@ class PrefixTables:
             for l, k in enumerate(cache):
                 ops.gather_rows(self.kv[l][q], idx, out=k[:, q, :])      # straight into the cache slot (row stride T * 2d)
         return cache
+
+
+# MEVI_HEAD_LOGITS=columns: the head as before round 4 (mevi_scale_f32, lm_head's rows added per column inside
+# mevi_adaptive_logits_f32); same bits, three times the cache traffic -- kept for A/B timing
+ROW_LOGITS = os.environ.get("MEVI_HEAD_LOGITS", "rows") != "columns"
+# MEVI_ADAPTOR_CACHE=copy: assemble the adaptor's cache of the final position by gathers (the form before round 4; same bits)
+INDEXED_ADAPTOR_CACHE = os.environ.get("MEVI_ADAPTOR_CACHE", "indexed") != "copy"
 
 
 def default_table_bytes(dev):
@@ -283,7 +344,7 @@ class NCIModel:
             cols = torch.tensor([1] + list(range(2 + p * c.K, 2 + (p + 1) * c.K)), device=self.dev)
             # rows ordered (column, d): W_p[c*d_model + d, e] = adaptor_linear.weight[d*V + v_c, e]
             self.head_w.append(ops.weight(aw[:, cols, :].permute(1, 0, 2).reshape((c.K + 1) * c.d_model, c.d_model).contiguous()))
-            self.head_e.append(lm[cols].contiguous())
+            self.head_e.append(lm[cols].reshape(-1).contiguous())     # [(K+1)*d]: the bias of the head GEMM (lm_head_weight + adaptor_weight, modeling_t5.py:1683)
         del aw
 
     def tables(self):
@@ -299,16 +360,25 @@ class NCIModel:
         key_rows: ancestor-indexed decoder caches (DecoderStack.step)."""
         c = self.cfg
         tok = ops.gather_rows(self.dec_emb, tokens)
-        seq = ops.scale(self.decoder.step(tok, t, dcache, xkv, mask, kv_div, key_rows=key_rows), c.d_model ** -0.5)
+        seq = self.decoder.step(tok, t, dcache, xkv, mask, kv_div, key_rows=key_rows)
+        alpha = c.d_model ** -0.5                                  # modeling_t5.py:1607, applied inside the logits kernel
+        if not ROW_LOGITS:
+            seq = ops.scale(seq, alpha)
+        tmat = None
         if pidx is not None:
             tab = self.tables()
             if tab.tmat[t] is not None:
-                return ops.adaptive_logits(seq, tab.tmat[t], self.head_e[t], t_index=pidx)
-            a = ops.gather_rows(tab.avec[t], pidx)
+                tmat = tab.tmat[t]
+            else:
+                a = ops.gather_rows(tab.avec[t], pidx)
         else:
             a = self.adaptor.step(tok, t, acache)
-        tmat = ops.linear(a, self.head_w[t])                       # [n, (K+1)*d]
-        return ops.adaptive_logits(seq, tmat, self.head_e[t])      # [n, K+1]
+        if tmat is None:
+            pidx = None
+            tmat = ops.linear(a, self.head_w[t], bias=self.head_e[t] if ROW_LOGITS else None)   # [n, (K+1)*d]: adaptor_weight (+ lm_head_weight)
+        if ROW_LOGITS:
+            return ops.adaptive_logits_rows(seq, alpha, tmat, c.K + 1, t_index=pidx)            # [n, K+1]
+        return ops.adaptive_logits(seq, tmat, self.head_e[t].view(c.K + 1, c.d_model), t_index=pidx)
 
     @torch.no_grad()
     def generate(self, input_ids, attention_mask, num_beams=10, num_return_sequences=None, length_penalty=0.8,
@@ -443,7 +513,10 @@ class NCIModel:
         base = torch.arange(B, device=self.dev)[:, None]
         for p in range(c.M + 1):
             if p == levels and p > 0:       # first position beyond the tables: its cache comes from them
-                acache = self.tables().cache_rows(self.adaptor, pidx, p)
+                if p == c.M and INDEXED_ADAPTOR_CACHE:   # ... in place, when no later position continues from it
+                    acache = self.tables().indexed_cache(self.adaptor, pidx, p)
+                else:
+                    acache = self.tables().cache_rows(self.adaptor, pidx, p)
             key_rows = None
             if indexed:
                 key_rows = torch.cat([anc, torch.arange(anc.shape[0], dtype=torch.int32, device=self.dev)[:, None]], 1).contiguous()

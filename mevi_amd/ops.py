@@ -521,6 +521,25 @@ def adaptive_logits(s, t, e, t_index=None):
 
 
 @hip.on_device
+def adaptive_logits_rows(s, alpha, te, ncol, t_index=None):
+    """logits[row, c] = sum_d (s[row, d] * alpha) * te[trow, c*dim + d], trow = row or t_index[row]: adaptive_logits with
+    lm_head's rows already added into `te` (the head GEMM's bias) and the hidden state's scale applied here -- same bits as
+    scale() + adaptive_logits(), a third of the cache traffic."""
+    s, rows, dim, lds = _rows2d(_f32(s))
+    assert te.dim() == 2 and te.shape[1] == ncol * dim and te.stride(1) == 1 and te.dtype == torch.float32
+    if t_index is None:
+        assert te.shape[0] == rows
+    else:
+        assert t_index.dtype == torch.int64 and t_index.is_cuda and t_index.is_contiguous() and t_index.numel() == rows
+    out = torch.empty((rows, ncol), dtype=torch.float32, device=s.device)
+    st = hip.lib().mevi_adaptive_logits_rows_f32(hip.ptr(s), lds, float(alpha), hip.ptr(te), te.stride(0),
+                                                 hip.ptr(t_index) if t_index is not None else None, rows, ncol, dim,
+                                                 hip.ptr(out), hip.stream_ptr())
+    hip.check(st, "mevi_adaptive_logits_rows_f32")
+    return out
+
+
+@hip.on_device
 def beam_step(logits, beam_scores, K, R, final_step=False):
     """logits [nq*nb, K+1] (col 0 eos), beam_scores [nq, nb] -> (scores, parent, code) [nq, R],
     or final scores [nq, nb] when final_step."""

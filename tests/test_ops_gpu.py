@@ -130,6 +130,28 @@ def test_adaptive_logits(cuda):
     assert (got - ref).abs().max() <= 5e-5
 
 
+@pytest.mark.parametrize("rows,ncol,dim,prefixes", [(23, 33, 768, 0), (301, 33, 768, 32), (70, 257, 768, 9), (19, 9, 64, 4),
+                                                     (11, 65, 1000, 0), (5, 128, 256, 3)])
+def test_adaptive_logits_rows_has_the_bits_of_scale_plus_adaptive_logits(cuda, rows, ncol, dim, prefixes):
+    """mevi_adaptive_logits_rows_f32 (lm_head's rows inside the head matrices = the GEMM's bias; the d_model^-0.5 inside the
+    kernel; the hidden state read once per 64 columns) against mevi_scale_f32 + mevi_adaptive_logits_f32: identical bits, with
+    and without a per-row table index, for column counts around the 64-column chunks and dims around the 256-float pieces."""
+    rng = np.random.default_rng(rows + ncol)
+    nt = prefixes if prefixes else rows
+    s = torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32)).to(cuda)
+    t = torch.from_numpy(rng.standard_normal((nt, ncol * dim)).astype(np.float32)).to(cuda)
+    e = torch.from_numpy(rng.standard_normal((ncol, dim)).astype(np.float32)).to(cuda)
+    idx = torch.from_numpy(rng.integers(0, nt, size=rows)).to(cuda) if prefixes else None
+    alpha = dim ** -0.5
+    ref = ops.adaptive_logits(ops.scale(s, alpha), t, e, t_index=idx)
+    te = t + e.reshape(1, -1)
+    got = ops.adaptive_logits_rows(s, alpha, te, ncol, t_index=idx)
+    assert torch.equal(got, ref)
+    f64 = torch.einsum("rd,rcd->rc", s.double().cpu() * alpha,
+                       (t.double().cpu()[idx.cpu()] if prefixes else t.double().cpu()).view(rows, ncol, dim) + e.double().cpu()[None])
+    assert (got.double().cpu() - f64).abs().max() <= 1e-4 * max(1.0, dim / 768)
+
+
 @pytest.mark.parametrize("nq,nb,K,R", [(7, 1, 32, 10), (7, 10, 32, 10), (3, 10, 256, 10), (5, 4, 16, 4)])
 def test_beam_step(cuda, nq, nb, K, R):
     rng = np.random.default_rng(nq + nb + K)
