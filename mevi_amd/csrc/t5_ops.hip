@@ -1405,11 +1405,222 @@ typedef float a16_f4 __attribute__((ext_vector_type(4)));
 constexpr int A16_LD = 68;                               // floats per staged row: 16-byte aligned, 4 banks apart
 constexpr int A16_WAVE_FLOATS = 2 * 32 * A16_LD + 32;    // K | V (Q first) | key mask
 constexpr size_t A16_LDS = (size_t)4 * A16_WAVE_FLOATS * sizeof(float);
+// what a wave of attention_mfma16_kernel works on (all wave-uniform)
+struct A16Work {
+  const float *qg, *kg, *vg;
+  size_t ooff, q_rs, o_rs, k_rs, v_rs;
+  const long long *mrow;
+  float *sk, *sv, *smask;
+  int nq, tk, qstep, h, KB, QB;
+};
+
+// KBM / QBM: key / query blocks of 16 the code is laid out for (1 or 2); a wave whose group needs one of each -- queries of up
+// to 16 tokens, ten beams -- runs the <1, 1> body: no block loops, no wave-uniform branches around them, half the registers
+template <int KBM, int QBM>
+__device__ __forceinline__ void a16_body(const AttnArgs &a, const A16Work &wk) {
+  const int lane = threadIdx.x & 63;
+  const int n = lane & 15, kq = lane >> 4;
+  const float *qg = wk.qg, *kg = wk.kg, *vg = wk.vg;
+  const size_t ooff = wk.ooff, q_rs = wk.q_rs, o_rs = wk.o_rs, k_rs = wk.k_rs, v_rs = wk.v_rs;
+  const long long *mrow = wk.mrow;
+  float *sk = wk.sk, *sv = wk.sv, *smask = wk.smask;
+  const int nq = wk.nq, tk = wk.tk, qstep = wk.qstep, h = wk.h;
+  const int KB = KBM == 1 ? 1 : wk.KB, QB = QBM == 1 ? 1 : wk.QB;
+  const int rows_staged = 16 * (KB > QB ? KB : QB);
+  long long mval = 1;   // the key mask of key `lane` (padded layouts): read here, used after the staging loads are under way
+  if (mrow && lane < tk) mval = mrow[lane];
+  // staging: iteration `it` = rows 4 it .. 4 it + 3, 16 lanes x 16 B per row
+  // (the kernel is bound by the instructions it issues -- 2 waves per SIMD keep it 55 % busy, profiles/r04_attention_pmc.txt --
+  // so registers that are never read are not cleared, x 1.0 is not multiplied and the first product of every block takes the
+  // constant 0 as its C operand)
+  // Every global load first, then the LDS writes: with a row's loads and its writes in one loop body the writes wait for that
+  // row's data before the next row's loads are issued -- four (eight) memory round trips in a row, 58 % of a wave's life.
+  // The loads are unconditional (row index clamped to a real row; offsets in 32 bits from the wave-uniform bases): a K row
+  // past tk only makes scores that are replaced by -inf, a Q row past nq a column that is never stored; V rows past tk are
+  // zeroed when written (their weights are exact zeros).
+  // the bias rows of the lane's query columns with the first loads, not after the score products (one more round trip there)
+  const bool bias4 = a.bias && (a.bias_ld & 3) == 0 && a.bias_ld >= 16 * KB && ((uintptr_t)a.bias & 15) == 0;
+  float4 bpre[QBM][KBM];
+  if (bias4) {
+#pragma unroll
+    for (int qb = 0; qb < QBM; ++qb) {
+      if (qb >= QB) break;
+      const int qpos = a.q_pos0 + qstep * (16 * qb + n);
+      const float *brow = a.bias + ((size_t)h * a.bias_rows + (qpos < a.bias_rows ? qpos : a.bias_rows - 1)) * a.bias_ld;
+#pragma unroll
+      for (int kb = 0; kb < KBM; ++kb) {
+        if (kb >= KB) break;
+        bpre[qb][kb] = *reinterpret_cast<const float4 *>(brow + 16 * kb + 4 * kq);
+      }
+    }
+  }
+  float4 v4[4 * (KBM > QBM ? KBM : QBM)], k4[4 * (KBM > QBM ? KBM : QBM)], q4[4 * (KBM > QBM ? KBM : QBM)];
+  const bool unit_scale = a.scale == 1.0f;   // T5 (no 1/sqrt(d)); x * 1.0f == x bit for bit
+  const int k_rs32 = (int)k_rs, v_rs32 = (int)v_rs, q_rs32 = (int)q_rs;
+#pragma unroll
+  for (int it = 0; it < 4 * (KBM > QBM ? KBM : QBM); ++it) {
+    if (4 * it >= rows_staged) continue;   // wave-uniform; v4[it] is read for 4 it < 16 KB <= rows_staged only
+    const int r = 4 * it + kq;
+    if (tk > 0) {
+      const int rk = min(r, tk - 1);
+      k4[it] = *reinterpret_cast<const float4 *>(kg + (unsigned)(rk * k_rs32 + 4 * n));
+      v4[it] = *reinterpret_cast<const float4 *>(vg + (unsigned)(rk * v_rs32 + 4 * n));
+    } else {
+      k4[it] = v4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    q4[it] = *reinterpret_cast<const float4 *>(qg + (unsigned)(min(r, nq - 1) * q_rs32 + 4 * n));   // nq >= 1 for a live wave
+  }
+  if (lane < 32) smask[lane] = mval == 0 ? -1e9f : 0.f;
+#pragma unroll
+  for (int it = 0; it < 4 * (KBM > QBM ? KBM : QBM); ++it) {
+    if (4 * it >= rows_staged) continue;
+    const int r = 4 * it + kq;
+    float *kr = sk + r * A16_LD + n, *qr = sv + r * A16_LD + n;   // dim 4 n + e -> position e * 16 + n
+    kr[0] = k4[it].x; kr[16] = k4[it].y; kr[32] = k4[it].z; kr[48] = k4[it].w;
+    float4 x = q4[it];
+    if (!unit_scale) x = make_float4(x.x * a.scale, x.y * a.scale, x.z * a.scale, x.w * a.scale);
+    qr[0] = x.x; qr[16] = x.y; qr[32] = x.z; qr[48] = x.w;
+    if (r >= tk) v4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float qf[QBM][16];
+#pragma unroll
+  for (int qb = 0; qb < QBM; ++qb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qb < QB) x = *reinterpret_cast<const float4 *>(sv + (16 * qb + n) * A16_LD + kq * 16 + 4 * j);
+      qf[qb][4 * j] = x.x; qf[qb][4 * j + 1] = x.y; qf[qb][4 * j + 2] = x.z; qf[qb][4 * j + 3] = x.w;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int it = 0; it < 4 * (KBM > QBM ? KBM : QBM); ++it) {
+    if (4 * it >= 16 * KB) continue;
+    *reinterpret_cast<float4 *>(sv + (4 * it + kq) * A16_LD + 4 * n) = v4[it];
+  }
+  // S^T blocks
+  a16_f4 sc[KBM][QBM];   // blocks (kb < KB, qb < QB) only are written and read
+  const a16_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < KBM; ++kb) {
+    if (kb >= KB) break;
+    float kf[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 x = *reinterpret_cast<const float4 *>(sk + (16 * kb + n) * A16_LD + kq * 16 + 4 * j);
+      kf[4 * j] = x.x; kf[4 * j + 1] = x.y; kf[4 * j + 2] = x.z; kf[4 * j + 3] = x.w;
+    }
+#pragma unroll
+    for (int qb = 0; qb < QBM; ++qb) {
+      if (qb >= QB) break;
+      sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0], qf[qb][0], zero4, 0, 0, 0);
+#pragma unroll
+      for (int s = 1; s < 16; ++s) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[qb][s], sc[kb][qb], 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // V is in place for the context phase
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // scores + bias + masks, softmax per query column
+  float sum[QBM];
+#pragma unroll
+  for (int qb = 0; qb < QBM; ++qb) {
+    sum[qb] = 1.f;
+    if (qb >= QB) break;
+    const int qpos = a.q_pos0 + qstep * (16 * qb + n);
+    const float *brow = nullptr;
+    if (a.bias) brow = a.bias + ((size_t)h * a.bias_rows + (qpos < a.bias_rows ? qpos : a.bias_rows - 1)) * a.bias_ld;
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < KBM; ++kb) {
+      if (kb >= KB) break;
+      const int k0 = 16 * kb + 4 * kq;
+      float badd[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+        if (bias4) {
+          const float4 x = bpre[qb][kb];
+          badd[0] = x.x; badd[1] = x.y; badd[2] = x.z; badd[3] = x.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) badd[r] = brow[k0 + r < a.bias_ld ? k0 + r : a.bias_ld - 1];
+        }
+      }
+      const float4 mk = *reinterpret_cast<const float4 *>(smask + k0);
+      const float mk4[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + r;
+        float add = mk4[r] + badd[r];
+        add += (a.causal && key > qpos) ? -1e9f : 0.f;
+        const float v = key < tk ? sc[kb][qb][r] + add : -INFINITY;
+        sc[kb][qb][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sm_ = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KBM; ++kb) {
+      if (kb >= KB) break;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(sc[kb][qb][r] - m);
+        sc[kb][qb][r] = e;
+        sm_ += e;
+      }
+    }
+    sm_ += __shfl_xor(sm_, 16);
+    sm_ += __shfl_xor(sm_, 32);
+    sum[qb] = sm_;
+  }
+  // O^T = V^T . P^T
+  a16_f4 o[QBM][4];    // blocks qb < QB only
+  if (KBM > 1 && KB == 0) {   // a group without keys: the context is zero
+#pragma unroll
+    for (int qb = 0; qb < QBM; ++qb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[qb][c] = zero4;
+  }
+#pragma unroll
+  for (int kb = 0; kb < KBM; ++kb) {
+    if (kb >= KB) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float vf[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vf[c] = sv[(16 * kb + 4 * kq + r) * A16_LD + 16 * c + n];
+#pragma unroll
+      for (int qb = 0; qb < QBM; ++qb) {
+        if (qb >= QB) break;
+        const float p = sc[kb][qb][r] / sum[qb];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          o[qb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c], p, (kb == 0 && r == 0) ? zero4 : o[qb][c], 0, 0, 0);
+      }
+    }
+  }
+  // a lane holds dims 16 c + 4 kq .. + 3 of query 16 qb + n
+#pragma unroll
+  for (int qb = 0; qb < QBM; ++qb) {
+    if (qb >= QB) break;
+    const int qi = 16 * qb + n;
+    if (qi < nq) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        put_ctx4(a, ooff + (size_t)qi * o_rs + 16 * c + 4 * kq, make_float4(o[qb][c][0], o[qb][c][1], o[qb][c][2], o[qb][c][3]));
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void attention_mfma16_kernel(AttnArgs a, int mode) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int D = 64;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int n = lane & 15, kq = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float *sk = sm + (size_t)w * A16_WAVE_FLOATS, *sv = sk + 32 * A16_LD, *smask = sv + 32 * A16_LD;
   const long long ngroups = mode == 0 ? a.nb : a.nb / a.kv_div;
   const long long pair = (long long)blockIdx.x * 4 + w;
@@ -1452,159 +1663,12 @@ __global__ __launch_bounds__(256, 2) void attention_mfma16_kernel(AttnArgs a, in
   const float *qg = a.q + qoff + (size_t)h * D;
   const float *kg = kb_ + (size_t)h * D, *vg = vb_ + (size_t)h * D;
   ooff += (size_t)h * D;
-  const int KB = (tk + 15) >> 4, QB = (nq + 15) >> 4;      // <= 2 each (wave-uniform)
-  const int rows_staged = 16 * (KB > QB ? KB : QB);
-  if (lane < 32) smask[lane] = (mrow && lane < tk && mrow[lane] == 0) ? -1e9f : 0.f;
-  // staging: iteration `it` = rows 4 it .. 4 it + 3, 16 lanes x 16 B per row
-  float4 v4[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    v4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (4 * it >= rows_staged) continue;   // wave-uniform
-    const int r = 4 * it + kq, c4 = n;
-    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4;
-    if (r < tk) {
-      k4 = *reinterpret_cast<const float4 *>(kg + (size_t)r * k_rs + 4 * c4);
-      v4[it] = *reinterpret_cast<const float4 *>(vg + (size_t)r * v_rs + 4 * c4);
-    }
-    if (r < nq) q4 = *reinterpret_cast<const float4 *>(qg + (size_t)r * q_rs + 4 * c4);
-    float *kr = sk + r * A16_LD + c4, *qr = sv + r * A16_LD + c4;   // dim 4 c4 + e -> position e * 16 + c4
-    kr[0] = k4.x; kr[16] = k4.y; kr[32] = k4.z; kr[48] = k4.w;
-    qr[0] = q4.x * a.scale; qr[16] = q4.y * a.scale; qr[32] = q4.z * a.scale; qr[48] = q4.w * a.scale;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float qf[2][16];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (qb < QB) x = *reinterpret_cast<const float4 *>(sv + (16 * qb + n) * A16_LD + kq * 16 + 4 * j);
-      qf[qb][4 * j] = x.x; qf[qb][4 * j + 1] = x.y; qf[qb][4 * j + 2] = x.z; qf[qb][4 * j + 3] = x.w;
-    }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    if (4 * it >= 16 * KB) continue;
-    *reinterpret_cast<float4 *>(sv + (4 * it + kq) * A16_LD + 4 * n) = v4[it];
-  }
-  // S^T blocks
-  a16_f4 sc[2][2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) sc[kb][qb] = a16_f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    if (kb >= KB) break;
-    float kf[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 x = *reinterpret_cast<const float4 *>(sk + (16 * kb + n) * A16_LD + kq * 16 + 4 * j);
-      kf[4 * j] = x.x; kf[4 * j + 1] = x.y; kf[4 * j + 2] = x.z; kf[4 * j + 3] = x.w;
-    }
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      if (qb >= QB) break;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[qb][s], sc[kb][qb], 0, 0, 0);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // V is in place for the context phase
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // scores + bias + masks, softmax per query column
-  const bool bias4 = a.bias && (a.bias_ld & 3) == 0 && a.bias_ld >= 16 * KB && ((uintptr_t)a.bias & 15) == 0;
-  float sum[2];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    sum[qb] = 1.f;
-    if (qb >= QB) break;
-    const int qpos = a.q_pos0 + qstep * (16 * qb + n);
-    const float *brow = nullptr;
-    if (a.bias) brow = a.bias + ((size_t)h * a.bias_rows + (qpos < a.bias_rows ? qpos : a.bias_rows - 1)) * a.bias_ld;
-    float m = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      if (kb >= KB) break;
-      const int k0 = 16 * kb + 4 * kq;
-      float badd[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias) {
-        if (bias4) {
-          const float4 x = *reinterpret_cast<const float4 *>(brow + k0);
-          badd[0] = x.x; badd[1] = x.y; badd[2] = x.z; badd[3] = x.w;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) badd[r] = brow[k0 + r < a.bias_ld ? k0 + r : a.bias_ld - 1];
-        }
-      }
-      const float4 mk = *reinterpret_cast<const float4 *>(smask + k0);
-      const float mk4[4] = {mk.x, mk.y, mk.z, mk.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = k0 + r;
-        float add = mk4[r] + badd[r];
-        add += (a.causal && key > qpos) ? -1e9f : 0.f;
-        const float v = key < tk ? sc[kb][qb][r] + add : -INFINITY;
-        sc[kb][qb][r] = v;
-        m = fmaxf(m, v);
-      }
-    }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float sm_ = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      if (kb >= KB) break;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = expf(sc[kb][qb][r] - m);
-        sc[kb][qb][r] = e;
-        sm_ += e;
-      }
-    }
-    sm_ += __shfl_xor(sm_, 16);
-    sm_ += __shfl_xor(sm_, 32);
-    sum[qb] = sm_;
-  }
-  // O^T = V^T . P^T
-  a16_f4 o[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) o[qb][c] = a16_f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    if (kb >= KB) break;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float vf[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) vf[c] = sv[(16 * kb + 4 * kq + r) * A16_LD + 16 * c + n];
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        if (qb >= QB) break;
-        const float p = sc[kb][qb][r] / sum[qb];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o[qb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c], p, o[qb][c], 0, 0, 0);
-      }
-    }
-  }
-  // a lane holds dims 16 c + 4 kq .. + 3 of query 16 qb + n
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    if (qb >= QB) break;
-    const int qi = 16 * qb + n;
-    if (qi < nq) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        put_ctx4(a, ooff + (size_t)qi * o_rs + 16 * c + 4 * kq, make_float4(o[qb][c][0], o[qb][c][1], o[qb][c][2], o[qb][c][3]));
-    }
-  }
+  A16Work wk;
+  wk.qg = qg, wk.kg = kg, wk.vg = vg, wk.ooff = ooff, wk.q_rs = q_rs, wk.o_rs = o_rs, wk.k_rs = k_rs, wk.v_rs = v_rs;
+  wk.mrow = mrow, wk.sk = sk, wk.sv = sv, wk.smask = smask, wk.nq = nq, wk.tk = tk, wk.qstep = qstep, wk.h = h;
+  wk.KB = (tk + 15) >> 4, wk.QB = (nq + 15) >> 4;      // <= 2 each (wave-uniform)
+  if (wk.KB == 1 && wk.QB == 1) a16_body<1, 1>(a, wk);
+  else if (wk.KB + wk.QB > 0) a16_body<2, 2>(a, wk);
 }
 
 // logits[row, c] = sum_d s[row, d] * (T[trow, c*dim + d] + E[c, d]); one wave per (row, c); trow = row, or
@@ -1798,6 +1862,10 @@ static int launch_passage(const AttnArgs &a, long long pairs, hipStream_t stream
   return MEVI_OK;
 }
 static int launch_mfma16(const AttnArgs &a, int mode, long long pairs, hipStream_t stream) {
+  // row offsets inside a group are formed in 32 bits (at most 32 rows of it)
+  MEVI_REQUIRE(a.k_ts < (1 << 24) && a.v_ts < (1 << 24) && a.q_ts < (1 << 24) && a.q_bs < (1 << 24) && a.k_ts >= 0 && a.v_ts >= 0 &&
+                   a.q_ts >= 0 && a.q_bs >= 0,
+               MEVI_ERR_UNSUPPORTED, "attention: row strides of 2^24 floats or more");
   MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma16_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)A16_LDS));
   hipLaunchKernelGGL(attention_mfma16_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), A16_LDS, stream, a, mode);
