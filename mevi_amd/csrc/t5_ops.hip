@@ -669,18 +669,46 @@ __global__ __launch_bounds__(256, 5) void attention_few_keys_staged_kernel(AttnA
                                    (unsigned int)__shfl((int)(unsigned long long)kr, from);
     sp[it] = reinterpret_cast<const float *>(src) + 4 * piece;
   }
+  // Loads in as few dependent rounds as the registers allow (the waves spend 71 % of their life parked on s_waitcnt,
+  // profiles/r04_attention_pmc.txt): the bias / mask terms and the V rows of the first VB pairs go out with the key rows, both
+  // halves of the key rows together at DH = 64, and every later group of V rows before the previous group's chains.
+  float add = 0.f;
+  if (j < TK) {
+    if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + j];
+    if (a.key_mask && a.key_mask[(size_t)(b / a.kv_div) * TK + j] == 0) add += -1e9f;
+    if (a.causal && j > qpos) add += -1e9f;
+  }
+  constexpr int VB = TK > 5 ? 2 : 4;
+  constexpr int NG = 8 / VB;
+  constexpr bool SMALL = DH == 64 && TK <= 4;   // registers for everything at once (96 per lane at five waves per SIMD)
+  constexpr int NVB = SMALL ? 2 : 1;            // groups of V rows in flight
+  float vv[NVB][VB][TK], vw[NVB][VB][DH > 64 ? TK : 1];   // columns lane and (DH = 96) 64 + lane
+  auto load_v = [&](int g0, int buf) {
+#pragma unroll
+    for (int gi = 0; gi < VB; ++gi)
+#pragma unroll
+      for (int jj = 0; jj < TK; ++jj) {   // a dead pair's pointer is the last live pair's: loaded, not stored
+        const unsigned long long vp = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(vr_hi, 8 * (g0 + gi) + jj) << 32) |
+                                      (unsigned int)__builtin_amdgcn_readlane(vr_lo, 8 * (g0 + gi) + jj);
+        vv[buf][gi][jj] = reinterpret_cast<const float *>(vp)[lane];
+        if constexpr (DH > 64) vw[buf][gi][jj] = lane + 64 < DH ? reinterpret_cast<const float *>(vp)[64 + lane] : 0.f;
+      }
+  };
+  constexpr int NBK = SMALL ? 1 : 2;        // rounds of key-row loads: the whole row at once, or half a row
+  constexpr int NQR = 2 * NQH / NBK;        // 16-float pieces per round
   float acc = 0.f;
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    float4 kf[NQH][N_IT];
+  for (int nb = 0; nb < NBK; ++nb) {
+    float4 kf[NQR][N_IT];
 #pragma unroll
     for (int it = 0; it < N_IT; ++it)
 #pragma unroll
-      for (int qi = 0; qi < NQH; ++qi)
-        kf[qi][it] = srow[it] >= 0 ? *reinterpret_cast<const float4 *>(sp[it] + 16 * (NQH * nb + qi)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int qi = 0; qi < NQR; ++qi)
+        kf[qi][it] = srow[it] >= 0 ? *reinterpret_cast<const float4 *>(sp[it] + 16 * (NQR * nb + qi)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nb == 0) load_v(0, 0);
 #pragma unroll
-    for (int qi = 0; qi < NQH; ++qi) {
-      const int qt = NQH * nb + qi;
+    for (int qi = 0; qi < NQR; ++qi) {
+      const int qt = NQR * nb + qi;
 #pragma unroll
       for (int it = 0; it < N_IT; ++it)
         if (srow[it] >= 0) *reinterpret_cast<float4 *>(&ks[srow[it] * KS + 4 * piece]) = kf[qi][it];
@@ -700,13 +728,7 @@ __global__ __launch_bounds__(256, 5) void attention_few_keys_staged_kernel(AttnA
     }
   }
   float s = -INFINITY;
-  if (j < TK) {
-    float add = 0.f;
-    if (a.bias) add = a.bias[((size_t)h * a.bias_rows + qpos) * a.bias_ld + j];
-    if (a.key_mask && a.key_mask[(size_t)(b / a.kv_div) * TK + j] == 0) add += -1e9f;
-    if (a.causal && j > qpos) add += -1e9f;
-    s = acc + add;
-  }
+  if (j < TK) s = acc + add;
   float m = s;
 #pragma unroll
   for (int off = 4; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -715,22 +737,15 @@ __global__ __launch_bounds__(256, 5) void attention_few_keys_staged_kernel(AttnA
 #pragma unroll
   for (int off = 4; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
   const float p = e / sum;
-  // context: the V loads of VB pairs at a time (VB TK rows of 256 B, one row per instruction; their pointers pass through
-  // SGPRs, which is what limits VB), then the chains
-  constexpr int VB = TK > 5 ? 2 : 4;
+  // context: V rows of VB pairs at a time (VB TK rows of 256 B, one row per instruction; their pointers pass through SGPRs,
+  // which is what limits VB), the next group's loads ahead of this group's chains
 #pragma unroll
-  for (int g0 = 0; g0 < 8; g0 += VB) {
+  for (int gr = 0; gr < NG; ++gr) {
+    const int g0 = gr * VB;
     if (g0 >= ngg) break;
-    float vv[VB][TK], vw[VB][DH > 64 ? TK : 1];   // columns lane and (DH = 96) 64 + lane
-#pragma unroll
-    for (int gi = 0; gi < VB; ++gi)
-#pragma unroll
-      for (int jj = 0; jj < TK; ++jj) {   // a dead pair's pointer is the last live pair's: loaded, not stored
-        const unsigned long long vp = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(vr_hi, 8 * (g0 + gi) + jj) << 32) |
-                                      (unsigned int)__builtin_amdgcn_readlane(vr_lo, 8 * (g0 + gi) + jj);
-        vv[gi][jj] = reinterpret_cast<const float *>(vp)[lane];
-        if constexpr (DH > 64) vw[gi][jj] = lane + 64 < DH ? reinterpret_cast<const float *>(vp)[64 + lane] : 0.f;
-      }
+    if (NVB == 2 && gr + 1 < NG && g0 + VB < ngg) load_v(g0 + VB, (gr + 1) & 1);
+    if (NVB == 1 && gr > 0) load_v(g0, 0);
+    constexpr int one = NVB - 1;
 #pragma unroll
     for (int gi = 0; gi < VB; ++gi) {
       const int gg = g0 + gi;
@@ -739,8 +754,8 @@ __global__ __launch_bounds__(256, 5) void attention_few_keys_staged_kernel(AttnA
 #pragma unroll
       for (int jj = 0; jj < TK; ++jj) {
         const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 8 * gg + jj));
-        acc0 = fmaf(pj, vv[gi][jj], acc0);
-        if constexpr (DH > 64) acc1 = fmaf(pj, vw[gi][jj], acc1);
+        acc0 = fmaf(pj, vv[gr & one][gi][jj], acc0);
+        if constexpr (DH > 64) acc1 = fmaf(pj, vw[gr & one][gi][jj], acc1);
       }
       const size_t o_off = (size_t)bb[gg] * a.o_bs + (size_t)hh[gg] * DH;
       put_ctx(a, o_off + lane, acc0);
