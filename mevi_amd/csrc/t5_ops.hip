@@ -1305,31 +1305,51 @@ __global__ __launch_bounds__(256, 2) void attention_h16_kernel(AttnArgs a) {
   const float *kg = a.k + (a.seq_off ? (size_t)r0 * a.k_ts : (size_t)b * a.k_bs) + (size_t)h * AM_D;
   const float *vg = a.v + (a.seq_off ? (size_t)r0 * a.v_ts : (size_t)b * a.v_bs) + (size_t)h * AM_D;
   const size_t og = (a.seq_off ? (size_t)r0 * a.o_ts : (size_t)b * a.o_bs) + (size_t)h * AM_D;
-  if (t < AM_S) smask[t] = (key_mask && t < tk && key_mask[(size_t)b * tk + t] == 0) ? -1e9f : 0.f;
+  long long mval = 1;   // key t's mask word: asked for here, stored behind the operand loads (not a round trip of its own)
+  if (key_mask && t < tk) mval = key_mask[(size_t)b * tk + t];
   // row-contiguous loads: q / k as (row, dim quad) per thread and pass, v as (four consecutive keys, dim quad)
   float4 q4[8], k4[8], v4[2][4];
   float mq = 0.f, mk_ = 0.f, mv = 0.f;
   auto amax4 = [](float m_, const float4 &x) { return fmaxf(fmaxf(m_, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w))); };
+  // All 24 loads first, unconditional (row index clamped to the last real row, zeroed afterwards): with `if (r < tk)` around a
+  // load and its first use in one loop body every iteration waited for its own data -- nine memory round trips in a row per
+  // workgroup (as attention_mfma16_kernel, profiles/r04_attention_pmc.txt).  Same values, same bits.
+  const float4 zero4f = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tk > 0) {   // uniform
+    const int last = tk - 1;
+    const unsigned q_ts32 = (unsigned)a.q_ts, k_ts32 = (unsigned)a.k_ts, v_ts32 = (unsigned)a.v_ts;   // < 2^24 (checked at launch), rows < 128
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = t + 256 * it, r = min(i >> 4, last), c4 = i & 15;
+      q4[it] = *reinterpret_cast<const float4 *>(qg + ((unsigned)r * q_ts32 + 4u * c4));
+      k4[it] = *reinterpret_cast<const float4 *>(kg + ((unsigned)r * k_ts32 + 4u * c4));
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = t + 256 * it, kg4 = i >> 4, c4 = i & 15;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v4[it][e] = *reinterpret_cast<const float4 *>(vg + ((unsigned)min(4 * kg4 + e, last) * v_ts32 + 4u * c4));
+    }
+  }
+  if (t < AM_S) smask[t] = mval == 0 ? -1e9f : 0.f;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    const int i = t + 256 * it, r = i >> 4, c4 = i & 15;
-    q4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    k4[it] = q4[it];
+    const int r = (t + 256 * it) >> 4;
     if (r < tk) {  // rows past tk are zero
-      const float4 x = *reinterpret_cast<const float4 *>(qg + (size_t)r * a.q_ts + 4 * c4);
+      const float4 x = q4[it];
       q4[it] = make_float4(x.x * a.scale, x.y * a.scale, x.z * a.scale, x.w * a.scale);
-      k4[it] = *reinterpret_cast<const float4 *>(kg + (size_t)r * a.k_ts + 4 * c4);
+    } else {
+      q4[it] = zero4f, k4[it] = zero4f;
     }
     mq = amax4(mq, q4[it]);
     mk_ = amax4(mk_, k4[it]);
   }
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const int i = t + 256 * it, kg4 = i >> 4, c4 = i & 15;
+    const int kg4 = (t + 256 * it) >> 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int r = 4 * kg4 + e;
-      v4[it][e] = r < tk ? *reinterpret_cast<const float4 *>(vg + (size_t)r * a.v_ts + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (4 * kg4 + e >= tk) v4[it][e] = zero4f;
       mv = amax4(mv, v4[it][e]);
     }
   }
@@ -1863,6 +1883,8 @@ static bool short_mfma() {
 // passage-length self-attention: split-precision f16 matrix cores when the context goes out as a split image (= the caller runs
 // the split GEMMs); the f32-MFMA kernel otherwise (MEVI_GEMM=exact) or with MEVI_ATTN_PASSAGE=f32
 static int launch_passage(const AttnArgs &a, long long pairs, hipStream_t stream) {
+  MEVI_REQUIRE(a.q_ts >= 0 && a.k_ts >= 0 && a.v_ts >= 0 && a.q_ts < (1 << 24) && a.k_ts < (1 << 24) && a.v_ts < (1 << 24),
+               MEVI_ERR_UNSUPPORTED, "attention: token strides of 2^24 floats or more");
   static const bool f32only = [] { const char *e = getenv("MEVI_ATTN_PASSAGE"); return e && strcmp(e, "f32") == 0; }();
   if (a.oimg && !f32only) {
     MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_h16_kernel),
