@@ -52,6 +52,36 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
   if (r >= m) return;
   const int lane = threadIdx.x & 63;
   const float *xr = x + (size_t)r * ldx;
+  if (k == 768 && kp == 768) {
+    // the t5-base / bert-base width: the row in registers, its three loads issued together (the loops below make three dependent
+    // trips, then read the row again); same arithmetic in the same order: same bits
+    float4 v[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const float4 *>(xr + 4 * lane + 256 * j);
+    float mx = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+      ss = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, ss))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, off));
+      ss += __shfl_xor(ss, off);
+    }
+    if (lane == 0 && norms) norms[r] = sqrtf(ss) * 1.0001f;
+    const int e = pow2_exp(mx);
+    _Float16 *o = img + (size_t)r * 2 * kp;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      h4 hi, lo;
+      split4(v[j], e, hi, lo);
+      *reinterpret_cast<h4 *>(o + 4 * lane + 256 * j) = hi;
+      *reinterpret_cast<h4 *>(o + kp + 4 * lane + 256 * j) = lo;
+    }
+    if (lane == 0) exps[r] = (signed char)e;
+    return;
+  }
   float mx = 0.f, ss = 0.f;
   for (int c = lane * 4; c < k; c += 256) {
     const float4 v = *reinterpret_cast<const float4 *>(xr + c);

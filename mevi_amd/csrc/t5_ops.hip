@@ -126,7 +126,18 @@ __global__ __launch_bounds__(256) void gather_rows_i64_kernel(const float *__res
   const int lane = threadIdx.x & 63;
   const float4 *s = reinterpret_cast<const float4 *>(table + idx[r] * ldt);
   float4 *d = reinterpret_cast<float4 *>(out + r * ldo);
-  for (int i = lane; i < dim / 4; i += 64) d[i] = s[i];
+  const int d4 = dim / 4;
+  if (d4 <= 256) {   // rows of up to 1024 floats: every load before the first store (a load -> store loop is one round trip per piece)
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < d4) v[j] = s[lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < d4) d[lane + 64 * j] = v[j];
+    return;
+  }
+  for (int i = lane; i < d4; i += 64) d[i] = s[i];
 }
 
 // out[idx[r]] = src[r]: the inverse of gather_rows (padding-free token batches back into the padded layout)
@@ -138,7 +149,18 @@ __global__ __launch_bounds__(256) void scatter_rows_i64_kernel(const float *__re
   const int lane = threadIdx.x & 63;
   const float4 *s = reinterpret_cast<const float4 *>(src + r * lds_);
   float4 *d = reinterpret_cast<float4 *>(out + idx[r] * ldo);
-  for (int i = lane; i < dim / 4; i += 64) d[i] = s[i];
+  const int d4 = dim / 4;
+  if (d4 <= 256) {
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < d4) v[j] = s[lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < d4) d[lane + 64 * j] = v[j];
+    return;
+  }
+  for (int i = lane; i < d4; i += 64) d[i] = s[i];
 }
 
 __global__ __launch_bounds__(256) void scale_kernel(const float *__restrict__ x, float alpha, long long n,
