@@ -195,6 +195,8 @@ class PrefixTables:
     results do not depend on what else is in the batch -- tested), so the beams' logits keep their bits."""
 
     MAX_PREFIXES = 1 << 17
+    MAX_FINAL_PREFIXES = 1 << 20     # the final position: adaptor vectors only, built in chunks (no K|V tables behind it)
+    FINAL_CHUNK = 1 << 17
 
     def __init__(self, model, table_bytes):
         c, dev = model.cfg, model.dev
@@ -207,6 +209,26 @@ class PrefixTables:
             n = K ** p
             kv_bytes = n * 2 * d * 4 * len(model.adaptor.layers)
             if n > self.MAX_PREFIXES or spent + kv_bytes + n * d * 4 > table_bytes:
+                # The final position (eos) of a larger code space -- 32**4 = 1 M prefixes for the scripts' (4, 32): nothing
+                # continues from it, so its adaptor K|V need no table, and its adaptor outputs (3 KB per prefix, 3.2 GB) fit
+                # where its head matrices (101 KB per prefix) do not.  Built in chunks through the indexed cache (the K|V of the
+                # earlier positions read from their tables in place): the adaptor's four layers then run ONCE PER PREFIX instead
+                # of once per beam at the position where every query has its full set of beams (12 ms of a 182 ms pass).
+                if (p == c.M and p == self.levels and 0 < p <= 7 and INDEXED_ADAPTOR_CACHE and n <= self.MAX_FINAL_PREFIXES
+                        and spent + n * d * 4 <= table_bytes):
+                    a = torch.empty((n, d), dtype=torch.float32, device=dev)
+                    for lo in range(0, n, self.FINAL_CHUNK):
+                        rows = torch.arange(lo, min(n, lo + self.FINAL_CHUNK), device=dev)
+                        tokens = 2 + (p - 1) * K + rows % K
+                        a[lo:lo + rows.numel()] = model.adaptor.step(ops.gather_rows(model.dec_emb, tokens), p,
+                                                                     self.indexed_cache(model.adaptor, rows, p))
+                    self.tmat.append(None)
+                    self.avec.append(a)
+                    spent += n * d * 4
+                    self.levels = p + 1
+                    for kl in self.kv:                        # the build's buffers (tables + a chunk's tail) are not needed again
+                        kl[:] = [k.clone() for k in kl]
+                    self._cat, self._retired = None, []
                 break
             if p == 0:
                 tokens = torch.zeros(1, dtype=torch.int64, device=dev)                    # decoder_start_token_id

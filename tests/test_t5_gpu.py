@@ -332,9 +332,15 @@ def test_results_do_not_depend_on_batch_grouping_or_stale_memory_at_base_shapes(
     assert torch.equal(d, d0) and np.array_equal(s, s0) and torch.equal(emb(700), e0)
     # the per-prefix adaptor tables (PrefixTables) against the adaptor evaluated per beam per step: same bits
     tab = model.tables()
-    assert tab.levels == 4 and all(t is not None for t in tab.tmat) and tab.tmat[3].shape == (32 ** 3, 33 * 768)
+    # device-sized budget: head matrices for positions 0-3, and the final position's 32**4 adaptor vectors (3.2 GB, built in chunks)
+    assert tab.levels == 5 and all(t is not None for t in tab.tmat[:4]) and tab.tmat[3].shape == (32 ** 3, 33 * 768)
+    assert tab.tmat[4] is None and tab.avec[4].shape == (32 ** 4, 768)
     model.prefix_table_bytes = 0
     d, s = gen(700)
+    assert torch.equal(d, d0) and np.array_equal(s, s0)
+    model.prefix_table_bytes, model._tables = 6 << 30, None             # round 3's budget: the final position per beam (cache read in place)
+    d, s = gen(nq)
+    assert model.tables().levels == 4
     assert torch.equal(d, d0) and np.array_equal(s, s0)
     model.prefix_table_bytes, model._tables = 60 << 20, None           # tables for positions 0..2 only, adaptor vectors at 2
     d, s = gen(nq)
