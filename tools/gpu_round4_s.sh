@@ -37,4 +37,5 @@ timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $T/
 timeout 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $T/tcc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-seq2seq-legs > $T/tcc.log 2>&1; echo "tcc pass rc=$?"
 python3 $R/tools/traffic_summary.py $T > $O/filter_traffic.json; cat $O/filter_traffic.json
 rm -rf $T/fetch $T/tcc
+python $R/tools/bench_latency.py > $O/latency.txt 2>&1; tail -8 $O/latency.txt
 du -sh $R/gpurun_out
