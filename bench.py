@@ -475,8 +475,9 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
                           "bytes": tab.bytes},
         "flop_per_query_survey_8d_padded": pad2,
         "note": "BASELINE.json configs[2] code shape (3-level RQ-256): prefix tables sized from the device "
-                "(nci.default_table_bytes: half the free memory, <= 64 GiB) hold the head matrices of the 65 536 two-code "
-                "prefixes; the 257-column head GEMM runs per beam at the final position only"}
+                "(nci.default_table_bytes: half the free memory, <= 128 GiB) hold the head matrices of the 65 536 two-code "
+                "prefixes and, memory permitting, the adaptor outputs of the 16.7 M prefixes of the final position; the "
+                "257-column head GEMM runs per beam at the final position only"}
     if with_cpu:
         def agree2():
             from oracle import t5 as ot5

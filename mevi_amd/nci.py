@@ -195,7 +195,7 @@ class PrefixTables:
     results do not depend on what else is in the batch -- tested), so the beams' logits keep their bits."""
 
     MAX_PREFIXES = 1 << 17
-    MAX_FINAL_PREFIXES = 1 << 20     # the final position: adaptor vectors only, built in chunks (no K|V tables behind it)
+    MAX_FINAL_PREFIXES = 1 << 25     # the final position: adaptor vectors only, built in chunks (no K|V tables behind it)
     FINAL_CHUNK = 1 << 17
 
     def __init__(self, model, table_bytes):
@@ -301,11 +301,12 @@ INDEXED_ADAPTOR_CACHE = os.environ.get("MEVI_ADAPTOR_CACHE", "indexed") != "copy
 
 def default_table_bytes(dev):
     """Byte budget of the prefix tables when the caller names none: half of the device memory that is free now, at most
-    64 GiB.  On a 288 GB MI355X that tables the head matrices of the 65 536 two-code prefixes of a 3 x 256 codebook (52 GB:
-    the 257-column head GEMM of position 2 becomes a lookup, 315 -> 248 ms per 6980 queries); the scripts' 4 x 32 codebook
-    needs 4.2 GB whatever the budget.  The beams' bits do not depend on it (PrefixTables)."""
+    128 GiB.  On a 288 GB MI355X that tables, for a 3 x 256 codebook, the head matrices of the 65 536 two-code prefixes (52 GB:
+    the 257-column head GEMM of position 2 becomes a lookup, 315 -> 248 ms per 6980 queries) and the adaptor outputs of the
+    16.7 M three-code prefixes of the final position (51 GB); the scripts' 4 x 32 codebook needs 7.4 GB whatever the budget.
+    The beams' bits do not depend on it (PrefixTables)."""
     free, _ = torch.cuda.mem_get_info(dev)
-    return int(min(64 << 30, free // 2))
+    return int(min(128 << 30, free // 2))
 
 
 class PrefixTree:
