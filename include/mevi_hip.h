@@ -271,6 +271,19 @@ int mevi_adaptive_logits_f32(const float *s, int64_t lds, const float *t, int64_
 int mevi_adaptive_logits_rows_f32(const float *s, int64_t lds, float alpha, const float *te, int64_t ldt, const int64_t *t_index,
                                   int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream);
 
+/* The PAWA head of rows that have no table (the final position of the beam search) in one pass: the head GEMM
+ * te[m, c*dim + d] = a[m, :] . w[c*dim + d, :] + bias[c*dim + d] (split images as mevi_gemm_nt_split_f32) is multiplied with the rows'
+ * hidden states inside its epilogue -- part f32 [n / 256][m][4] holds one partial per (tile, row, wave) -- and mevi_logits_finish_f32
+ * adds the twelve partials of a (row, column): out[m, c] = sum_d (s[m, d] * alpha) * te[m, c*dim + d], in the summation order
+ * mevi_adaptive_logits_rows_f32 uses at dim = 768, so table rows and per-beam rows give the same bits; the [m, n] head matrices
+ * (55 GB for 70 k beams at K = 256) are never written.  mevi_gemm_nt_split_head_supported: dim == 768, n % 768 == 0, a shape of
+ * the tile-stream kernel (not the latency kernels'); elsewhere use mevi_gemm_nt_split_f32 + mevi_adaptive_logits_rows_f32. */
+int mevi_gemm_nt_split_head_supported(int64_t m, int64_t n, int64_t k, int64_t dim);
+int mevi_gemm_nt_split_head_f32(const void *a_img, const int8_t *a_exp, const void *w_img, const int8_t *w_exp, int64_t m, int64_t n,
+                                int64_t k, const float *bias, const float *s, int64_t lds, float alpha, int64_t dim, float *part,
+                                void *stream);
+int mevi_logits_finish_f32(const float *part, int64_t rows, int64_t ncol, float *out, void *stream);
+
 /* T5LayerNorm + the ONE projection it feeds (q|k|v, the cross-attention q, wi: MEVI/transformers/modeling_t5.py:155-171 followed by
  * :181, :350-352) in one launch, for the few rows of the latency path (the reference's --timing_infer_step regime): every workgroup
  * normalises its rows itself, with mevi_rmsnorm_split_f16's arithmetic, and multiplies with mevi_gemm_nt_split_*'s accumulation

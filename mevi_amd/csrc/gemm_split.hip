@@ -210,6 +210,7 @@ struct SplitOut {
   const float *anorm;  // [M] l2 norms of the A rows
   int np;
   float wnorm_max, babs_max, onorm_scale;
+  float alpha;         // OUT = 3 (the fused PAWA head): scale of the hidden states
 };
 
 __device__ __forceinline__ int out_exp(const SplitOut &so, int m) {
@@ -517,12 +518,18 @@ __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
 // ONE output row m = m0 + 128 wn + 16 ni + (lane & 15) and FOUR CONSECUTIVE columns n = n0 + 128 grp + 64 wm + 16 mi + 4 (lane >> 4)
 // + j: 16 bytes per lane and block, 64 contiguous bytes per row and store instruction.  The epilogue walks the 32 blocks in
 // eight steps of four (mi, half of the rows), the residual rows of step i + 1 loaded before the stores of step i.
-template <int ACT, int OUT>   // OUT: 0 = f32 C, 1 = f32 C + residual, 2 = split image
+// OUT = 3, the PAWA head fused (modeling_t5.py:1683-1684: lm_logits = sequence_output . (adaptor_weight + lm_head_weight)): the W
+// rows are (column c, d) pairs, 768 = three tiles per column; instead of storing its 256 x 256 block of head-matrix elements
+// x = acc + bias the epilogue multiplies it with the rows' hidden states (`residual` = s f32 [M, 768], row stride ldr) and
+// writes, per wave, row and tile, ONE partial sum -- C = part f32 [n_ntiles][M][4] (4 = the waves (grp, wm) of a row) -- in
+// the order t5_ops.hip::adaptive_logits_rows768_kernel reproduces for table rows; mevi_logits_finish_f32 adds the twelve
+// partials of a (row, column).  The head matrices of 70 k beams (55 GB at K = 256) are never written.
+template <int ACT, int OUT>   // OUT: 0 = f32 C, 1 = f32 C + residual, 2 = split image, 3 = fused head (above)
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
     const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
     const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
     const float *__restrict__ residual, long long ldr, int n_mtiles, int n_ntiles, SplitOut so) {
-  constexpr bool SPLIT_OUT = OUT == 2, HAS_RES = OUT == 1;
+  constexpr bool SPLIT_OUT = OUT == 2, LOGITS = OUT == 3, HAS_RES = OUT == 1 || OUT == 3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nwg = n_mtiles * n_ntiles;
   const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
@@ -570,8 +577,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
     const bool interior = (mt + 1) * 256 <= M && (nt + 1) * 256 <= N;
     const int ldc4 = (int)ldc * 4, ldr4 = (int)ldr * 4;
     const __amdgpu_buffer_rsrc_t rc = tile_rsrc(SPLIT_OUT ? nullptr : C + (size_t)mt * 256 * ldc + (size_t)nt * 256);
-    const __amdgpu_buffer_rsrc_t rr =
-        tile_rsrc(residual ? residual + (size_t)mt * 256 * ldr + (size_t)nt * 256 : nullptr);
+    const __amdgpu_buffer_rsrc_t rr =   // LOGITS: the hidden states' columns d = 256 (nt mod 3) .. + 255
+        tile_rsrc(residual ? residual + (size_t)mt * 256 * ldr + (size_t)(LOGITS ? nt % 3 : nt) * 256 : nullptr);
     const __amdgpu_buffer_rsrc_t ri =
         tile_rsrc(SPLIT_OUT ? so.img + (size_t)mt * 256 * 2 * so.np + (size_t)nt * 256 : nullptr);
     const __amdgpu_buffer_rsrc_t rw = tile_rsrc(ew + nt * 256);
@@ -624,6 +631,11 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
       }
     };
     load_step(0, bq[0], res[0]);
+    float part[LOGITS ? 8 : 1];   // LOGITS: the lane's chain per row 16 ni + r16, sixteen terms in order (mi, j)
+    if constexpr (LOGITS) {
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) part[ni] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int mi = i >> 2, pr = i & 3;
@@ -641,10 +653,16 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
         for (int j = 0; j < 4; ++j) {
           float x = ldexpf(acc[mi][ni][j], -(em + sx8(wq[mi], j))) + __uint_as_float(bq[mi & 1][j]);
           x = act_fn<ACT>(x);
-          if constexpr (HAS_RES) x += __uint_as_float(res[i & 1][n2][j]);
+          if constexpr (LOGITS) part[ni] = fmaf(__uint_as_float(res[i & 1][n2][j]) * so.alpha, x, part[ni]);
+          else if constexpr (HAS_RES) x += __uint_as_float(res[i & 1][n2][j]);
           v[j] = x;
         }
-        if constexpr (SPLIT_OUT) {
+        if constexpr (LOGITS) {
+          (void)rowt; (void)ok;
+          // pin the step's sums here: with no store to anchor them the compiler sinks all sixteen steps' arithmetic behind the
+          // last step's loads and keeps 32 loaded quads alive (176 bytes of scratch per lane)
+          asm volatile("" : "+v"(part[ni]));
+        } else if constexpr (SPLIT_OUT) {
           const int eo = sx8(eop[ni >> 2], ni & 3);
           h4 hi, lo;
 #pragma unroll
@@ -664,6 +682,20 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
       // keep the steps apart: left alone the scheduler hoists the residual loads of ALL steps to the top (64 registers of
       // loads in flight on top of the 128 accumulators: the residual variants spilled 17-25 registers per lane)
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (LOGITS) {
+      // the wave's partial of each of its rows: (kq 0 + kq 1) + (kq 2 + kq 3); lane kq = 0 stores it
+      int r16b = lane & 15;                   // a second opaque copy: the eight row indices are not kept alive through the steps
+      asm volatile("" : "+v"(r16b));
+      const int mb = mt * 256 + 128 * wn + r16b;
+      float *cp = C + ((size_t)nt * M + mb) * 4 + 2 * grp + wm;
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        float p = part[ni];
+        p += __shfl_xor(p, 16);
+        p += __shfl_xor(p, 32);
+        if (kq == 0 && mb + 16 * ni < mlim) cp[64 * ni] = p;
+      }
     }
   };
   split_tile_stream16(row_bytes, kp * 2, kp / 32, lds, next, begin, emit);
@@ -1097,6 +1129,52 @@ extern "C" int mevi_gemm_nt_split_f32(const void *a_img, const int8_t *a_exp, co
                                       const float *residual, int64_t ldr, int act, void *stream) {
   SplitOut so = {};
   return gemm_split_launch(a_img, a_exp, w_img, w_exp, c, ldc, m, n, k, bias, residual, ldr, act, so, stream);
+}
+
+// The PAWA head fused (gemm_split16_kernel<0, 3>): part f32 [n / 256][m][4], then mevi_logits_finish_f32 (t5_ops.hip).
+// Returns MEVI_ERR_UNSUPPORTED where the unfused pair (this GEMM with bias into f32 + mevi_adaptive_logits_rows_f32) has to
+// be used: the latency kernels' shapes and MEVI_GEMM_MFMA=32 -- the bits are the same either way.
+extern "C" int mevi_gemm_nt_split_head_supported(int64_t m, int64_t n, int64_t k, int64_t dim) {
+  static const long long skinny_max = [] { const char *e = getenv("MEVI_GEMM_SKINNY_MAX"); return e ? atoll(e) : SPLIT_SKINNY_MAX_OUTPUTS; }();
+  static const bool shape32 = [] { const char *e = getenv("MEVI_GEMM_MFMA"); return e && atoi(e) == 32; }();
+  return dim == 768 && n > 0 && n % 768 == 0 && m > 0 && m * n > skinny_max && !shape32 && k > 0;
+}
+
+extern "C" int mevi_gemm_nt_split_head_f32(const void *a_img, const int8_t *a_exp, const void *w_img, const int8_t *w_exp,
+                                           int64_t m, int64_t n, int64_t k, const float *bias, const float *s, int64_t lds_,
+                                           float alpha, int64_t dim, float *part, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(mevi_gemm_nt_split_head_supported(m, n, k, dim), MEVI_ERR_UNSUPPORTED,
+               "gemm_nt_split_head: shape %lld x %lld (dim %lld) not on the fused path", (long long)m, (long long)n, (long long)dim);
+  MEVI_REQUIRE(a_img && a_exp && w_img && w_exp && s && part, MEVI_ERR_INVALID_ARG, "gemm_nt_split_head: null pointer");
+  MEVI_REQUIRE(((uintptr_t)a_img % 16) == 0 && ((uintptr_t)w_img % 16) == 0 && ((uintptr_t)s % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
+                   ((uintptr_t)w_exp % 4) == 0 && lds_ % 4 == 0 && lds_ < (1LL << 20),
+               MEVI_ERR_INVALID_ARG, "gemm_nt_split_head: alignment");
+  MEVI_REQUIRE(m < (1LL << 31) && n < (1LL << 31) && k < (1LL << 20), MEVI_ERR_UNSUPPORTED, "gemm_nt_split_head: too large");
+  const int kp = (int)mevi_split_kp(k);
+  const int64_t n_mtiles = (m + 255) / 256, n_ntiles = n / 256;
+  MEVI_REQUIRE(n_mtiles * n_ntiles <= 0x7fffffffLL, MEVI_ERR_UNSUPPORTED, "gemm_nt_split_head: grid too large");
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  int64_t grid = n_cu / 8 * 8;
+  if (grid < 8) grid = 8;
+  const int64_t tiles = n_mtiles * n_ntiles;
+  if (tiles < grid) grid = (tiles + 7) / 8 * 8;
+  SplitOut so = {};
+  so.alpha = alpha;
+  const size_t lds_bytes = ss_lds_bytes();
+  MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split16_kernel<0, 3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((gemm_split16_kernel<0, 3>), dim3((unsigned)grid), dim3(PP_THREADS), lds_bytes, stream,
+                     reinterpret_cast<const _Float16 *>(a_img), reinterpret_cast<const signed char *>(a_exp), (int)m,
+                     reinterpret_cast<const _Float16 *>(w_img), reinterpret_cast<const signed char *>(w_exp), (int)n, kp, part, 0LL, bias, s,
+                     (long long)lds_, (int)n_mtiles, (int)n_ntiles, so);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
 }
 
 extern "C" int mevi_gemm_nt_split_to_split(const void *a_img, const int8_t *a_exp, const float *a_norm, const void *w_img,

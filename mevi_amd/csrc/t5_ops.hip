@@ -1817,6 +1817,83 @@ __global__ __launch_bounds__(256) void adaptive_logits_rows_kernel(const float *
   if (c0 + lane < c1) out[r * ncol + c0 + lane] = keep;
 }
 
+// The same head at dim = 768 in the summation order of the FUSED form (gemm_split.hip, gemm_split16_kernel<0, 3>: the head GEMM
+// whose epilogue multiplies its 256 x 256 tile with the hidden states instead of storing it), so that a prefix-table row and a
+// row computed per beam give the same bits.  A column's 768 products are summed as that kernel's geometry dictates:
+//   chain   C[third][grp][wm][kq]  = 16 fmaf in order (mi, j) over d = 256 third + 128 grp + 64 wm + 16 mi + 4 kq + j
+//   wave    P[third][grp][wm]      = (C[0] + C[1]) + (C[2] + C[3])             (lanes ^16, ^32 of the MFMA layout)
+//   tile    T[third]               = (P[0][0] + P[0][1]) + (P[1][0] + P[1][1]) (mevi_logits_finish_f32 for the fused form)
+//   logit                          = (T[0] + T[1]) + T[2]
+// Here lane L < 48 is the chain (third, grp, wm, kq) = (L >> 4, (L >> 3) & 1, (L >> 2) & 1, L & 3); the trees are xor 1, 2, 4, 8.
+__global__ __launch_bounds__(256) void adaptive_logits_rows768_kernel(const float *__restrict__ s, long long lds_, float alpha,
+                                                                     const float *__restrict__ TE, long long ldt,
+                                                                     const long long *__restrict__ t_index, long long rows,
+                                                                     int ncol, int chunks, float *__restrict__ out) {
+  constexpr int dim = 768;
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= rows * chunks) return;
+  const int lane = threadIdx.x & 63;
+  const long long r = wid / chunks;
+  const int c0 = (int)(wid - r * chunks) * 64;
+  const int c1 = min(ncol, c0 + 64);
+  const long long tr = t_index ? t_index[r] : r;
+  const bool on = lane < 48;
+  const int d0 = on ? 256 * (lane >> 4) + 128 * ((lane >> 3) & 1) + 64 * ((lane >> 2) & 1) + 4 * (lane & 3) : 0;   // + 16 mi
+  float4 a[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const float4 v = *reinterpret_cast<const float4 *>(s + r * lds_ + d0 + 16 * mi);
+    a[mi] = make_float4(v.x * alpha, v.y * alpha, v.z * alpha, v.w * alpha);
+  }
+  const float *tb = TE + tr * ldt + d0;
+  float keep = 0.f;
+  for (int c = c0; c < c1; c += 4) {
+    float4 t4[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float *tv = tb + (size_t)min(c + u, c1 - 1) * dim;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) t4[u][mi] = *reinterpret_cast<const float4 *>(tv + 16 * mi);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float acc = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        acc = fmaf(a[mi].x, t4[u][mi].x, acc);
+        acc = fmaf(a[mi].y, t4[u][mi].y, acc);
+        acc = fmaf(a[mi].z, t4[u][mi].z, acc);
+        acc = fmaf(a[mi].w, t4[u][mi].w, acc);
+      }
+      if (!on) acc = 0.f;
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 4);
+      acc += __shfl_xor(acc, 8);
+      const float t1 = __shfl(acc, 16), t2 = __shfl(acc, 32), t0 = __shfl(acc, 0);
+      const float z = (t0 + t1) + t2;
+      if (lane == c + u - c0) keep = z;
+    }
+  }
+  if (c0 + lane < c1) out[r * ncol + c0 + lane] = keep;
+}
+
+// The fused form's last step: part [ncol][3][rows][4] wave partials (thirds x (grp, wm)) -> out[row, c], in the order above.
+__global__ __launch_bounds__(256) void logits_finish_kernel(const float *__restrict__ part, long long rows, int ncol,
+                                                           float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // (c, row), row fastest: the reads are contiguous
+  if (i >= rows * ncol) return;
+  const int c = (int)(i / rows);
+  const long long r = i - (long long)c * rows;
+  float t[3];
+#pragma unroll
+  for (int th = 0; th < 3; ++th) {
+    const float4 p = *reinterpret_cast<const float4 *>(part + (((size_t)c * 3 + th) * rows + r) * 4);
+    t[th] = (p.x + p.y) + (p.z + p.w);
+  }
+  out[r * ncol + c] = (t[0] + t[1]) + t[2];
+}
+
 inline unsigned blocks4(long long waves) { return (unsigned)((waves + 3) / 4); }
 
 }  // namespace
@@ -2162,6 +2239,13 @@ extern "C" int mevi_adaptive_logits_rows_f32(const float *s, int64_t lds_, float
   MEVI_REQUIRE(s && te && out, MEVI_ERR_INVALID_ARG, "adaptive_logits_rows: null pointer");
   MEVI_REQUIRE((((uintptr_t)s | (uintptr_t)te) & 15) == 0, MEVI_ERR_INVALID_ARG, "adaptive_logits_rows: s, te 16-byte aligned");
   const int chunks = (int)((ncol + 63) / 64);
+  if (dim == 768) {   // the order of the fused head (see the kernel): a table row and a per-beam row give the same bits
+    hipLaunchKernelGGL(adaptive_logits_rows768_kernel, dim3(blocks4(rows * chunks)), dim3(256), 0, (hipStream_t)stream, s,
+                       (long long)lds_, alpha, te, (long long)ldt, reinterpret_cast<const long long *>(t_index), (long long)rows,
+                       (int)ncol, chunks, out);
+    MEVI_HIP_CHECK(hipGetLastError());
+    return MEVI_OK;
+  }
   const int ni = (int)((dim / 4 + 63) / 64);
   typedef void (*fn_t)(const float *, long long, float, const float *, long long, const long long *, long long, int, int, int,
                        float *);
@@ -2169,6 +2253,16 @@ extern "C" int mevi_adaptive_logits_rows_f32(const float *s, int64_t lds_, float
                                 adaptive_logits_rows_kernel<4>};
   hipLaunchKernelGGL(table[ni - 1], dim3(blocks4(rows * chunks)), dim3(256), 0, (hipStream_t)stream, s, (long long)lds_, alpha, te,
                      (long long)ldt, reinterpret_cast<const long long *>(t_index), (long long)rows, (int)ncol, (int)dim, chunks, out);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_logits_finish_f32(const float *part, int64_t rows, int64_t ncol, float *out, void *stream) {
+  MEVI_REQUIRE(rows >= 0 && ncol > 0 && rows * ncol < (1LL << 40), MEVI_ERR_INVALID_ARG, "logits_finish: bad shape");
+  if (rows == 0) return MEVI_OK;
+  MEVI_REQUIRE(part && out && ((uintptr_t)part & 15) == 0, MEVI_ERR_INVALID_ARG, "logits_finish: null or unaligned pointer");
+  hipLaunchKernelGGL(logits_finish_kernel, dim3((unsigned)((rows * ncol + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     (long long)rows, (int)ncol, out);
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
 }

@@ -90,6 +90,10 @@ _SIGNATURES = {
                                          c_int64, c_void_p, c_void_p]),
     "mevi_adaptive_logits_rows_f32": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                               c_int64, c_void_p, c_void_p]),
+    "mevi_gemm_nt_split_head_supported": (c_int, [c_int64, c_int64, c_int64, c_int64]),
+    "mevi_gemm_nt_split_head_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                            c_int64, c_float, c_int64, c_void_p, c_void_p]),
+    "mevi_logits_finish_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "mevi_beam_step_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
     "mevi_beam_step_tree_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,

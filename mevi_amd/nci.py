@@ -398,7 +398,9 @@ class NCIModel:
             a = self.adaptor.step(tok, t, acache)
         if tmat is None:
             pidx = None
-            tmat = ops.linear(a, self.head_w[t], bias=self.head_e[t] if ROW_LOGITS else None)   # [n, (K+1)*d]: adaptor_weight (+ lm_head_weight)
+            if ROW_LOGITS:     # no table row: the head GEMM and the product with the hidden states in one pass where the shape allows
+                return ops.head_logits(a, self.head_w[t], self.head_e[t], seq, alpha, c.K + 1)
+            tmat = ops.linear(a, self.head_w[t])                   # [n, (K+1)*d]: adaptor_weight
         if ROW_LOGITS:
             return ops.adaptive_logits_rows(seq, alpha, tmat, c.K + 1, t_index=pidx)            # [n, K+1]
         return ops.adaptive_logits(seq, tmat, self.head_e[t].view(c.K + 1, c.d_model), t_index=pidx)

@@ -539,6 +539,36 @@ def adaptive_logits_rows(s, alpha, te, ncol, t_index=None):
     return out
 
 
+FUSED_HEAD = os.environ.get("MEVI_HEAD_FUSED", "1") != "0"     # A/B switch: head GEMM + logits as two kernels (same bits)
+
+
+@hip.on_device
+def head_logits(a, weight, bias, s, alpha, ncol):
+    """The PAWA head of rows without a table: logits[m, c] = sum_d (s[m, d] * alpha) * (a[m] . weight[c*dim + d] + bias[c*dim + d]).
+    With split weights at dim 768 and more rows than the latency kernels take: ONE GEMM whose epilogue multiplies the head
+    matrices with the hidden states instead of storing them (mevi_gemm_nt_split_head_f32) + the 12-partial finish; otherwise
+    linear(bias=) + adaptive_logits_rows -- the same bits either way."""
+    s2, M, dim, lds = _rows2d(_f32(s))
+    N = weight.shape[0]
+    assert N == ncol * dim
+    L = hip.lib()
+    if (FUSED_HEAD and isinstance(weight, SplitRows) and bias is not None and
+            L.mevi_gemm_nt_split_head_supported(M, N, weight.shape[1], dim) and s2.data_ptr() % 16 == 0 and lds % 4 == 0):
+        xs = a if isinstance(a, SplitRows) else split_rows(a)
+        assert xs.shape == (M, weight.shape[1])
+        dev = weight.device
+        part = torch.empty((N // 256, M, 4), dtype=torch.float32, device=dev)
+        st = L.mevi_gemm_nt_split_head_f32(hip.ptr(xs.img), hip.ptr(xs.exp), hip.ptr(weight.img), hip.ptr(weight.exp), M, N,
+                                           weight.shape[1], hip.ptr(bias), hip.ptr(s2), lds, float(alpha), dim, hip.ptr(part),
+                                           hip.stream_ptr())
+        hip.check(st, "mevi_gemm_nt_split_head_f32")
+        out = torch.empty((M, ncol), dtype=torch.float32, device=dev)
+        st = L.mevi_logits_finish_f32(hip.ptr(part), M, ncol, hip.ptr(out), hip.stream_ptr())
+        hip.check(st, "mevi_logits_finish_f32")
+        return out
+    return adaptive_logits_rows(s2, alpha, linear(a, weight, bias=bias), ncol)
+
+
 @hip.on_device
 def beam_step(logits, beam_scores, K, R, final_step=False):
     """logits [nq*nb, K+1] (col 0 eos), beam_scores [nq, nb] -> (scores, parent, code) [nq, R],

@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from mevi_amd import ops
+from mevi_amd.hip import lib as hip_lib
 from oracle import dense as odense
 
 pytestmark = pytest.mark.gpu
@@ -134,8 +135,9 @@ def test_adaptive_logits(cuda):
                                                      (11, 65, 1000, 0), (5, 128, 256, 3)])
 def test_adaptive_logits_rows_has_the_bits_of_scale_plus_adaptive_logits(cuda, rows, ncol, dim, prefixes):
     """mevi_adaptive_logits_rows_f32 (lm_head's rows inside the head matrices = the GEMM's bias; the d_model^-0.5 inside the
-    kernel; the hidden state read once per 64 columns) against mevi_scale_f32 + mevi_adaptive_logits_f32: identical bits, with
-    and without a per-row table index, for column counts around the 64-column chunks and dims around the 256-float pieces."""
+    kernel; the hidden state read once per 64 columns) against mevi_scale_f32 + mevi_adaptive_logits_f32: identical bits (at
+    dim 768: the same products in the fused head's summation order, so within rounding), with and without a per-row table
+    index, for column counts around the 64-column chunks and dims around the 256-float pieces."""
     rng = np.random.default_rng(rows + ncol)
     nt = prefixes if prefixes else rows
     s = torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32)).to(cuda)
@@ -146,10 +148,41 @@ def test_adaptive_logits_rows_has_the_bits_of_scale_plus_adaptive_logits(cuda, r
     ref = ops.adaptive_logits(ops.scale(s, alpha), t, e, t_index=idx)
     te = t + e.reshape(1, -1)
     got = ops.adaptive_logits_rows(s, alpha, te, ncol, t_index=idx)
-    assert torch.equal(got, ref)
+    if dim == 768:      # the summation order of the fused head (test_fused_head_... below): same products, another tree
+        assert (got - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+    else:
+        assert torch.equal(got, ref)
     f64 = torch.einsum("rd,rcd->rc", s.double().cpu() * alpha,
                        (t.double().cpu()[idx.cpu()] if prefixes else t.double().cpu()).view(rows, ncol, dim) + e.double().cpu()[None])
     assert (got.double().cpu() - f64).abs().max() <= 1e-4 * max(1.0, dim / 768)
+
+
+@pytest.mark.parametrize("rows,ncol", [(5000, 33), (777, 9), (300, 257)])
+def test_fused_head_has_the_bits_of_head_gemm_plus_row_logits(cuda, rows, ncol, monkeypatch):
+    """mevi_gemm_nt_split_head_f32 + mevi_logits_finish_f32 (the head matrices multiplied with the hidden states inside the GEMM's
+    epilogue, never written) against mevi_gemm_nt_split_f32 with bias + mevi_adaptive_logits_rows_f32: identical bits -- a beam's
+    logits do not depend on whether its head matrix came from a prefix table or from the fused kernel -- and both within rounding
+    of float64; rows not a multiple of the 256-row tile."""
+    dim = 768
+    g = torch.Generator(device=cuda).manual_seed(rows + ncol)
+    a = torch.randn((rows, dim), device=cuda, generator=g)
+    w = torch.randn((ncol * dim, dim), device=cuda, generator=g) * dim ** -0.5
+    e = torch.randn((ncol * dim,), device=cuda, generator=g)
+    s = torch.randn((rows, dim), device=cuda, generator=g) * 3
+    alpha = dim ** -0.5
+    old = ops.GEMM_MODE
+    try:
+        ops.GEMM_MODE = "split"
+        ws = ops.weight_split(w)
+        assert hip_lib().mevi_gemm_nt_split_head_supported(rows, ncol * dim, dim, dim)
+        fused = ops.head_logits(a, ws, e, s, alpha, ncol)
+        monkeypatch.setattr(ops, "FUSED_HEAD", False)
+        two = ops.head_logits(a, ws, e, s, alpha, ncol)
+    finally:
+        ops.GEMM_MODE = old
+    assert torch.equal(fused, two)
+    ref = torch.einsum("rd,rcd->rc", s.double() * alpha, (a.double() @ w.double().T + e.double()).view(rows, ncol, dim))
+    assert (fused.double() - ref).abs().max() <= 1e-4 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("nq,nb,K,R", [(7, 1, 32, 10), (7, 10, 32, 10), (3, 10, 256, 10), (5, 4, 16, 4)])
