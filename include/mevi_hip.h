@@ -266,8 +266,9 @@ int mevi_adaptive_logits_f32(const float *s, int64_t lds, const float *t, int64_
 
 /* The same head with lm_head's rows already inside the matrices and the d_model^-0.5 of modeling_t5.py:1607 applied here:
  * out[row, c] = sum_d (s[row, d] * alpha) * te[trow, c*dim + d],  te[., c*dim + d] = t[., c*dim + d] + e[c, d]  (the bias of the
- * GEMM that wrote it).  Bit-identical to mevi_scale_f32 + mevi_adaptive_logits_f32; the row's hidden state is read once per 64
- * columns instead of once per column.  dim <= 1024. */
+ * GEMM that wrote it).  The products of mevi_scale_f32 + mevi_adaptive_logits_f32 (bit-identical, except that at dim 768 the sums
+ * follow mevi_gemm_nt_split_head_f32's order); the row's hidden state is read once per 64 columns instead of once per column.
+ * dim <= 1024. */
 int mevi_adaptive_logits_rows_f32(const float *s, int64_t lds, float alpha, const float *te, int64_t ldt, const int64_t *t_index,
                                   int64_t rows, int64_t ncol, int64_t dim, float *out, void *stream);
 
