@@ -289,9 +289,9 @@ def index_build_leg(device, docs, rn, n_docs):
     rq._LAST_ENCODE.clear()
     TW = synth.tower_weights(device) if hasattr(synth, "tower_weights") else None
     if TW is not None:
-        tower = t5.TwinTower(TW, device=device, num_layers=12, num_decoder_layers=12, batch_size=512)
+        tower = t5.TwinTower(TW, device=device, num_layers=12, num_decoder_layers=12)     # device passes of t5.DEVICE_PASS_TOKENS
         rng = np.random.default_rng(0)
-        n = 2048
+        n = 8192
         ids = np.zeros((n, 128), np.int64)
         mask = np.zeros((n, 128), np.int64)
         for i in range(n):

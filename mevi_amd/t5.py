@@ -364,7 +364,9 @@ class DecoderStack:
 # Padded tokens per device pass of a tower (8192 queries x 32, 2048 passages x 128): results do not depend on the
 # grouping (row-wise operators, tested), larger passes fill the GEMM grids (t5-base tower: 19.5 k queries/s at 512 rows
 # per pass, 30.9 k at 2048, 35.4 k at 8192; passages 5.7 k/s at 512, 6.4 k/s at 2048).
-DEVICE_PASS_TOKENS = 262144
+# Round 4: 1 M tokens (8192 passages x 128): 21.0 k passages/s against 19.4 k at 2048 per pass and 17.8 k at 512 (the GEMMs' last,
+# partly filled round of tiles weighs less; 7 GB of FFN image per pass on a 288 GB device).
+DEVICE_PASS_TOKENS = 1048576
 
 
 class TwinTower:
