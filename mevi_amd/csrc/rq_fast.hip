@@ -35,6 +35,7 @@
 #include "mfma_pp_f16.h"
 
 #include <float.h>
+#include <type_traits>
 #include <math.h>
 #include <vector>
 
@@ -85,6 +86,7 @@ struct RfParams {
   float e16, gam;
   int x_row_stride, x_unit_stride;  // bytes between rows / between 32-k units of a row (dim * 4, 128; an experiment sets others)
   long long n_tiles;
+  char *xs;   // XDIR: per-workgroup scratch, [grid][dim / 16 k-steps][512 lanes] x 16 B: the f16 x fragments of the row tile in hand
 };
 
 // SPLIT: both operands as (hi, lo) f16 pairs, three MFMAs per product (hi.hi + hi.lo + lo.hi; lo scaled by 2^11 so that it
@@ -124,9 +126,16 @@ __device__ __forceinline__ float rf_delta(float m, float rho_hat, float E1, floa
 // XSPLIT (the TA = 8 shapes, where a second accumulator set does not fit): x alone as a (hi, lo) pair, the un-scaled lo part
 // accumulated into the SAME accumulator by a second MFMA -- the bound loses x's rounding (e16 x0.58), K = 256 stays bound by
 // its three passes over x.
-template <int TA, int KT, bool SPLIT, bool XSPLIT>
+// XDIR (several groups per row tile, i.e. K = 128 / 256: one level per pass): x crosses HBM, the LDS and the f32 -> f16 conversion
+// ONCE per row tile.  The pass of group 0 stores every lane's converted fragment (16 B per k-step) to the workgroup's scratch
+// (393 KB at dim 768: it stays in L2 / the Infinity Cache); the passes of the later groups load the fragments straight back into
+// registers -- the lane that wrote a fragment is the lane that reads it -- two units ahead, in place of the x LDS-DMA (same
+// look-ahead, same counted waits: stores, loads and LDS-DMA retire in issue order).  Needs dim / 32 divisible by 3 (a ring of
+// three units in registers, indexed at compile time).
+template <int TA, int KT, bool SPLIT, bool XSPLIT, bool XDIR = false>
 __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   static_assert(!(SPLIT && XSPLIT), "one or the other");
+  static_assert(!XDIR || (!SPLIT && !XSPLIT), "XDIR: plain f16 fragments");
   constexpr int NB = (SPLIT || XSPLIT) ? 2 : 1;   // B fragments per k-step: hi (, lo)
   constexpr int AROWS = TA * 32 * (SPLIT ? 2 : 1);   // image rows per unit (hi rows, then lo rows)
   constexpr int AFL = rf_a_floats<TA, SPLIT>();      // floats of a centroid unit
@@ -293,6 +302,58 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     }
   };
 
+  int ra_ = 0, rx_ = 0;  // ring slots of the unit being computed (centroid ring of 3, x ring of XB)
+  // ---- XDIR: the fragment ring in registers, the scratch, the window count -------------------------------------------------------
+  f16x8 xr[XDIR ? 3 : 1][2];   // units u, u + 1, u + 2 of the stream, k-steps 0 | 1; slot = unit mod 3
+  char *xs_t = XDIR ? p.xs + ((size_t)blockIdx.x * (size_t)(U * 2) * 512 + (size_t)t) * 16 : nullptr;   // + k-step * 8192
+  int win = 0;   // vector-memory operations issued since the last counted wait (wave-uniform)
+  // everything issued BEFORE the window has landed; the window's own operations may stay in flight (they retire in issue order)
+  auto wait_window = [&]() {
+    switch (win) {
+      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+    win = 0;
+  };
+  int grp_now = 0;   // group of the tile being computed (set with `grp` below; read by the lambdas)
+  // k-step (u, j) of the tile in hand: group 0 converts it from the x ring (and, XDIR, stores the fragment); later groups (XDIR)
+  // take it from the register ring
+  auto get_x = [&](int u, int j, auto slot_c, f16x8 (&b)[NB]) {
+    if constexpr (XDIR) {
+      if (grp_now != 0) {
+        b[0] = xr[decltype(slot_c)::value][j];
+        return;
+      }
+      read_x(rx_, u, j, b);
+      *reinterpret_cast<f16x8 *>(xs_t + (size_t)(2 * u + j) * 8192) = b[0];
+      ++win;
+    } else {
+      read_x(rx_, u, j, b);
+    }
+  };
+  // half `part` of the x request of a cycle: two LDS-DMA pieces of unit tux of stream tx, or (XDIR, target group > 0) k-step
+  // `part` of that unit straight into the register ring
+  auto issue_x = [&](const Src &tx, int tgrp, int tux, int wbx, int part, auto slot_c) {
+    if constexpr (XDIR) {
+      if (tgrp != 0) {
+        const char *src = xs_t + (size_t)(2 * tux + part) * 8192;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[decltype(slot_c)::value][part]) : "v"(src) : "memory");
+        ++win;
+        return;
+      }
+      win += 2;
+    }
+    dma_x(tx, tux, wbx, 2 * part, 2);
+  };
+
   RfRecord *rec_base = p.rec + (size_t)(blockIdx.x * 8 + w8) * p.region_cap;
   unsigned int rec_n = 0u;  // records of this wave so far (wave-uniform)
   // per-row state carried across the groups of a row tile (this lane's row = 32 w8 + lrow of the tile; both halves agree)
@@ -300,29 +361,33 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   float rho_hat = 0.f, xn = 0.f;
   bool row_bad = false;
 
-  int ra_ = 0, rx_ = 0;  // ring slots of the unit being computed (centroid ring of 3, x ring of XB)
   // One unit (32 k) of the current tile.  On entry alo / bq0 hold k-step (u, 0).  Centroid unit u+2 and x unit u+DX of the
   // stream are requested at the start (their buffers were released by the previous cycle's barrier) -- the centroid pieces
   // FIRST: vmcnt retires in order, and at the barrier everything issued after centroid unit u+1 may stay in flight.  The
   // barrier sits before the LAST half-step: by then every read of unit u has been issued (and, with lgkmcnt(0), completed)
   // and unit u+1 must have landed for the reads of k-step (u+1, 0) that the last half-step issues.
-  auto cycle = [&](int u, bool last) {
+  auto cycle = [&](int u, auto slot_c, bool last) {
+    constexpr int S0 = decltype(slot_c)::value;          // XDIR: ring slot of unit u (= u mod 3); u + 1, u + 2 follow
+    using S1 = std::integral_constant<int, (S0 + 1) % 3>;
+    using S2 = std::integral_constant<int, (S0 + 2) % 3>;
     {
       const bool sp = u + DA >= U;
       dma_a(sp ? nxt : cur, sp ? have_nxt : true, sp ? u + DA - U : u + DA, ra_ == 0 ? AB - 1 : ra_ - 1);
+      if constexpr (XDIR) win += PA_PER_WAVE;
     }
     const bool spx = u + DX >= U;
     const Src &tx = spx ? nxt : cur;
     const int tux = spx ? u + DX - U : u + DX;
+    const int tgrp = spx ? (have_nxt ? grp_n : 0) : grp_now;     // group of the pass unit tux belongs to
     const int wbx = rx_ == 0 ? XB - 1 : rx_ - 1;
     read_a(ra_, 0, H, ahi);
     mma_lo(bq0);
-    dma_x(tx, tux, wbx, 0, 2);
+    issue_x(tx, tgrp, tux, wbx, 0, S2());
     __builtin_amdgcn_sched_barrier(0);
     read_a(ra_, 1, 0, alo);
-    read_x(rx_, u, 1, bq1);
+    get_x(u, 1, slot_c, bq1);
     mma_hi(bq0);
-    dma_x(tx, tux, wbx, 2, 2);
+    issue_x(tx, tgrp, tux, wbx, 1, S2());
     __builtin_amdgcn_sched_barrier(0);
     read_a(ra_, 1, H, ahi);
     mma_lo(bq1);
@@ -331,7 +396,9 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     // x unit u+2: this cycle's centroid unit u+2 and x unit u+2 stay; with DA = 1 it was requested THIS cycle: only x unit u+2
     constexpr int KEEP = DA == 2 ? PA_PER_WAVE + 4 : 4;
     static_assert(DX == 2 && (KEEP == 4 || KEEP == 5 || KEEP == 6), "vmcnt immediates below");
-    if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    static_assert(!XDIR || DA == 2, "XDIR counts its windows for the two-ahead centroid ring");
+    if constexpr (XDIR) wait_window();   // the window: this cycle's requests and fragment stores (the end-of-cycle store of the previous one)
+    else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else if constexpr (KEEP == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -339,7 +406,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     rx_ = rx_ == XB - 1 ? 0 : rx_ + 1;
     if (!last) {
       read_a(ra_, 0, 0, alo);
-      read_x(rx_, u + 1, 0, bq0);
+      get_x(u + 1, 0, S1(), bq0);
     }
     mma_hi(bq1);
     __builtin_amdgcn_sched_barrier(0);
@@ -354,8 +421,10 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   else if constexpr (DA == 2) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  win = 0;
 
   while (true) {
+    grp_now = grp;
 #pragma unroll
     for (int ti = 0; ti < TA; ++ti)
 #pragma unroll
@@ -368,9 +437,23 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     }
     rho_s = 0.f;
     read_a(ra_, 0, 0, alo);     // k-step (0, 0) of the tile: its unit has landed (prologue / the previous tile's last barrier)
-    read_x(rx_, 0, 0, bq0);
-    for (int u = 0; u < U - 1; ++u) cycle(u, false);
-    cycle(U - 1, true);
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    get_x(0, 0, C0(), bq0);
+    if constexpr (XDIR) {       // U is a multiple of 3 (checked by the host): the ring slots are compile-time constants
+      for (int u = 0; u < U - 3; u += 3) {
+        cycle(u, C0(), false);
+        cycle(u + 1, C1(), false);
+        cycle(u + 2, C2(), false);
+      }
+      cycle(U - 3, C0(), false);
+      cycle(U - 2, C1(), false);
+      cycle(U - 1, C2(), true);
+    } else {
+      for (int u = 0; u < U - 1; ++u) cycle(u, C0(), false);
+      cycle(U - 1, C0(), true);
+    }
 
     // ---- epilogue of (row tile rt, group grp): per level argmin of F, candidate test, record ---------------------------------
     if constexpr (SPLIT) {
@@ -524,10 +607,10 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
 
 // (the body lives in a __device__ function: the host pass instantiates a kernel template's own body, and the buffer / LDS
 // builtins above do not exist there)
-template <int TA, int KT, bool SPLIT, bool XSPLIT>
+template <int TA, int KT, bool SPLIT, bool XSPLIT, bool XDIR = false>
 __global__ __launch_bounds__(512, 2) void rq_fast_kernel(const RfParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rq_fast_body<TA, KT, SPLIT, XSPLIT>(p, lds);
+  rq_fast_body<TA, KT, SPLIT, XSPLIT, XDIR>(p, lds);
 }
 
 // ---- prep kernels (codebook only: a few hundred KB) -------------------------------------------------------------------------
@@ -781,10 +864,10 @@ using namespace mevi;
 namespace {
 struct RfPlan {
   int Kp, KT, LPG, ngroups, TA;
-  bool ok, split, xsplit;
+  bool ok, split, xsplit, xdir;
 };
 RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
-  RfPlan pl = {0, 0, 0, 0, 0, false, false, false};
+  RfPlan pl = {0, 0, 0, 0, 0, false, false, false, false};
   if (dim % 32 != 0 || dim < 96 || dim > 8192 || M < 1 || M > 8 || K < 1 || K > 256) return pl;
   int Kp = 32;
   while (Kp < K) Kp <<= 1;
@@ -806,6 +889,11 @@ RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
   // precision (two MFMAs, one accumulator).  At K = 256 it was measured and dropped: main kernel 20.6 -> 26.6 ms for 4.27 ->
   // 2.68 M records (fix-up 5.6 -> 3.6 ms): 28.2 -> 32.9 ms per encode; at K = 128 the variant spills.
   pl.xsplit = !pl.split && pl.KT <= 2 && !getenv("MEVI_RQ_NO_SPLIT");
+  // one level per pass (K = 128 / 256 with several levels): x is converted once per row tile and the later passes take the f16
+  // fragments back from a per-workgroup scratch (rq_fast_body, XDIR); MEVI_RQ_XDIRECT=0: every pass streams x again (A/B)
+  const char *xd = getenv("MEVI_RQ_XDIRECT");
+  pl.xdir = pl.ok && pl.ngroups > 1 && pl.TA == 8 && pl.KT >= 4 && !pl.split && !pl.xsplit && (dim / 32) % 3 == 0 && dim / 32 >= 6 &&
+            !(xd && atoi(xd) == 0);
   return pl;
 }
 constexpr int RF_GRID = 256;  // persistent workgroups (one per CU of the MI355X); 8 record regions each
@@ -817,6 +905,7 @@ struct RfWs {
   unsigned char *row_flag;
   long long *badlist;
   RfRecord *rec;
+  char *xs;
   unsigned int region_cap, n_regions, grid;
 };
 size_t rf_carve(char *base, int64_t n, int64_t dim, int64_t M, int64_t K, const RfPlan &pl, RfWs *ws) {
@@ -845,7 +934,9 @@ size_t rf_carve(char *base, int64_t n, int64_t dim, int64_t M, int64_t K, const 
   char *row_flag = take((size_t)n);
   char *badlist = take((size_t)n * 8);
   char *rec = take((size_t)n_regions * region_cap * sizeof(RfRecord));
+  char *xs = take(pl.xdir ? (size_t)grid * (size_t)(dim / 16) * 512 * 16 : 0);    // XDIR: a row tile's f16 fragments per workgroup
   if (ws) {
+    ws->xs = xs;
     ws->img = reinterpret_cast<_Float16 *>(img);
     ws->mu = reinterpret_cast<float *>(mu), ws->mus = reinterpret_cast<float *>(mus);
     ws->A = reinterpret_cast<float *>(A), ws->G2 = reinterpret_cast<float *>(G2);
@@ -924,6 +1015,7 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   // i.e. 1 KiB-contiguous DMA pieces instead of 128-byte pieces 3 KB apart -- ran 3 % faster: the piece granularity is not what
   // holds the x stream at 4 TB/s)
   p.x_row_stride = d * 4, p.x_unit_stride = 128;
+  p.xs = ws.xs;
   const unsigned grid = ws.grid;
   const void *fn = nullptr;
   size_t lds_bytes = 0;
@@ -936,6 +1028,8 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   MEVI_RF_PICK(8, 1, false, true) MEVI_RF_PICK(8, 2, false, true)
   MEVI_RF_PICK(8, 1, false, false) MEVI_RF_PICK(8, 2, false, false) MEVI_RF_PICK(8, 4, false, false) MEVI_RF_PICK(8, 8, false, false)
 #undef MEVI_RF_PICK
+  if (pl.xdir && pl.KT == 4) fn = reinterpret_cast<const void *>(rq_fast_kernel<8, 4, false, false, true>);
+  if (pl.xdir && pl.KT == 8) fn = reinterpret_cast<const void *>(rq_fast_kernel<8, 8, false, false, true>);
   MEVI_REQUIRE(fn != nullptr, MEVI_ERR_UNSUPPORTED, "rq_encode_fast: no kernel for TA=%d KT=%d", pl.TA, pl.KT);
   MEVI_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   {
