@@ -524,12 +524,16 @@ __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
 // writes, per wave, row and tile, ONE partial sum -- C = part f32 [n_ntiles][M][4] (4 = the waves (grp, wm) of a row) -- in
 // the order t5_ops.hip::adaptive_logits_rows768_kernel reproduces for table rows; mevi_logits_finish_f32 adds the twelve
 // partials of a (row, column).  The head matrices of 70 k beams (55 GB at K = 256) are never written.
-template <int ACT, int OUT>   // OUT: 0 = f32 C, 1 = f32 C + residual, 2 = split image, 3 = fused head (above)
+// NI: 16-row activation blocks per wave -- tiles of TM = 32 NI activation rows x 256 W rows (8: the 256 x 256 tile above; 4 / 2:
+// 128 / 64 activation rows for GEMMs whose 256-row tiles would not fill the device, split_tile_stream16<NI>; same bits per row).
+template <int ACT, int OUT, int NI = 8>   // OUT: 0 = f32 C, 1 = f32 C + residual, 2 = split image, 3 = fused head (above)
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
     const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
     const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
     const float *__restrict__ residual, long long ldr, int n_mtiles, int n_ntiles, SplitOut so) {
   constexpr bool SPLIT_OUT = OUT == 2, LOGITS = OUT == 3, HAS_RES = OUT == 1 || OUT == 3;
+  constexpr int TM = 32 * NI, PR = NI / 2, STEPS = 4 * PR;   // tile height; row-block pairs per block column; epilogue steps
+  static_assert(!LOGITS || NI == 8, "the fused head runs on 256-row tiles");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nwg = n_mtiles * n_ntiles;
   const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
@@ -557,15 +561,16 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
       s.src = reinterpret_cast<const char *>(W) + (size_t)nt * 256 * (size_t)row_bytes;
       rows_left = (long long)N - (long long)nt * 256;
     } else {
-      s.src = reinterpret_cast<const char *>(A) + (size_t)mt * 256 * (size_t)row_bytes;
-      rows_left = (long long)M - (long long)mt * 256;
+      s.src = reinterpret_cast<const char *>(A) + (size_t)mt * TM * (size_t)row_bytes;
+      rows_left = (long long)M - (long long)mt * TM;
+      if (rows_left > TM) rows_left = TM;
     }
     if (rows_left > 256) rows_left = 256;
     s.bytes = (unsigned int)(rows_left * row_bytes);
     return true;
   };
   auto begin = [&]() {};
-  auto emit = [&](f32x4 (&acc)[4][8]) {
+  auto emit = [&](f32x4 (&acc)[4][NI]) {
     const int mt = head_m, nt = head_n;
     head_m = tail_m, head_n = tail_n;
     --n_pend;
@@ -573,23 +578,23 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
     // residual offsets (tile-invariant) out of the tile loop and spills them (17-25 registers per lane in the residual variants)
     int r16 = lane & 15, kq = lane >> 4;
     asm volatile("" : "+v"(r16), "+v"(kq));
-    const int m0 = mt * 256 + 128 * wn + r16;            // + 16 ni
-    const bool interior = (mt + 1) * 256 <= M && (nt + 1) * 256 <= N;
+    const int m0 = mt * TM + 16 * NI * wn + r16;         // + 16 ni
+    const bool interior = (mt + 1) * TM <= M && (nt + 1) * 256 <= N;
     const int ldc4 = (int)ldc * 4, ldr4 = (int)ldr * 4;
-    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(SPLIT_OUT ? nullptr : C + (size_t)mt * 256 * ldc + (size_t)nt * 256);
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(SPLIT_OUT ? nullptr : C + (size_t)mt * TM * ldc + (size_t)nt * 256);
     const __amdgpu_buffer_rsrc_t rr =   // LOGITS: the hidden states' columns d = 256 (nt mod 3) .. + 255
-        tile_rsrc(residual ? residual + (size_t)mt * 256 * ldr + (size_t)(LOGITS ? nt % 3 : nt) * 256 : nullptr);
+        tile_rsrc(residual ? residual + (size_t)mt * TM * ldr + (size_t)(LOGITS ? nt % 3 : nt) * 256 : nullptr);
     const __amdgpu_buffer_rsrc_t ri =
-        tile_rsrc(SPLIT_OUT ? so.img + (size_t)mt * 256 * 2 * so.np + (size_t)nt * 256 : nullptr);
+        tile_rsrc(SPLIT_OUT ? so.img + (size_t)mt * TM * 2 * so.np + (size_t)nt * 256 : nullptr);
     const __amdgpu_buffer_rsrc_t rw = tile_rsrc(ew + nt * 256);
     const __amdgpu_buffer_rsrc_t rb = tile_rsrc(bias ? bias + nt * 256 : nullptr);
     const int ncol = 128 * grp + 64 * wm + 4 * kq;        // column of the lane's quad in block column mi = 0 (+ 16 mi)
     const int nvalid = N - nt * 256;                      // columns of this tile that exist (edge tiles)
-    // per-row scalars of the lane's eight rows, packed four int8 per register: A-row exponents, output exponents (split out)
+    // per-row scalars of the lane's NI rows, packed four int8 per register: A-row exponents, output exponents (split out)
     unsigned int emp[2] = {0u, 0u}, eop[2] = {0u, 0u};
     const int mlim = interior ? 0x7fffffff : M;          // row m exists iff m < mlim
 #pragma unroll
-    for (int ni = 0; ni < 8; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
       const int m = m0 + 16 * ni;
       emp[ni >> 2] |= ((unsigned int)(unsigned char)ea[min(m, M - 1)]) << (8 * (ni & 3));
       if constexpr (SPLIT_OUT) {
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
     auto sx8 = [](unsigned int packed, int i) { return (int)(packed << (24 - 8 * i)) >> 24; };   // sign-extended byte i
     // every load is issued BEFORE the stores it does not depend on (vmcnt retires in issue order): the column exponents of the
     // four block columns up front; bias of block column mi + 1 and the residual rows of step i + 1 before the stores of step i.
-    // A step = two blocks (one block column mi, rows 16 (2 p) and 16 (2 p + 1)): sixteen steps per tile.
+    // A step = two blocks (one block column mi, rows 16 (2 p) and 16 (2 p + 1)): STEPS = 2 NI steps per tile (sixteen at NI = 8).
     unsigned int wq[4];   // four int8 exponents per block column
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
     }
     u32x4 bq[2], res[2][HAS_RES ? 2 : 1];
     auto load_step = [&](int i, u32x4 &b, u32x4 (&r)[HAS_RES ? 2 : 1]) {
-      const int mi = i >> 2, pr = i & 3;
+      const int mi = i / PR, pr = i % PR;
       const int c = ncol + 16 * mi;
       const bool cok = interior || c < nvalid;
       if (pr == 0) {
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
           const int ni = 2 * pr + n2;
-          const int rowt = 128 * wn + 16 * ni + r16;
+          const int rowt = 16 * NI * wn + 16 * ni + r16;
           r[n2] = __builtin_amdgcn_raw_buffer_load_b128(rr, (cok && m0 + 16 * ni < mlim) ? rowt * ldr4 + c * 4 : OOB, 0, 0);
         }
       }
@@ -637,15 +642,15 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
       for (int ni = 0; ni < 8; ++ni) part[ni] = 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int mi = i >> 2, pr = i & 3;
+    for (int i = 0; i < STEPS; ++i) {
+      const int mi = i / PR, pr = i % PR;
       const int c = ncol + 16 * mi;
       const bool cok = interior || c < nvalid;
-      if (i + 1 < 16) load_step(i + 1, bq[((i + 1) >> 2) & 1], res[(i + 1) & 1]);
+      if (i + 1 < STEPS) load_step(i + 1, bq[((i + 1) / PR) & 1], res[(i + 1) & 1]);
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2) {
         const int ni = 2 * pr + n2;
-        const int rowt = 128 * wn + 16 * ni + r16;       // row inside the tile
+        const int rowt = 16 * NI * wn + 16 * ni + r16;   // row inside the tile
         const bool ok = cok && m0 + 16 * ni < mlim;
         const int em = sx8(emp[ni >> 2], ni & 3);
         float v[4];
@@ -687,10 +692,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
       // the wave's partial of each of its rows: (kq 0 + kq 1) + (kq 2 + kq 3); lane kq = 0 stores it
       int r16b = lane & 15;                   // a second opaque copy: the eight row indices are not kept alive through the steps
       asm volatile("" : "+v"(r16b));
-      const int mb = mt * 256 + 128 * wn + r16b;
+      const int mb = mt * TM + 16 * NI * wn + r16b;
       float *cp = C + ((size_t)nt * M + mb) * 4 + 2 * grp + wm;
 #pragma unroll
-      for (int ni = 0; ni < 8; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
         float p = part[ni];
         p += __shfl_xor(p, 16);
         p += __shfl_xor(p, 32);
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
       }
     }
   };
-  split_tile_stream16(row_bytes, kp * 2, kp / 32, lds, next, begin, emit);
+  split_tile_stream16<NI>(row_bytes, kp * 2, kp / 32, lds, next, begin, emit);
 }
 
 // Few outputs (the latency path), 16x16x32 form: one workgroup per 32 x 32 outputs = 2 x 2 blocks, wave 0 multiplies; per 32 k
@@ -1019,6 +1024,26 @@ __global__ __launch_bounds__(1024) void gemm_rmsnorm_split16_kernel(
 // ~13 us (K = 768) per round of 256 workgroups, the tile stream ~50 us for any grid below one wave of tiles
 constexpr long long SPLIT_SKINNY_MAX_OUTPUTS = 1500000;
 
+// Activation blocks per wave (NI) of the tile stream for a GEMM of m rows x n_ntiles 256-column tiles on n_cu CUs: the tile
+// height 32 NI whose rounds x time-per-tile is least.  A 128-row tile costs ~0.61, a 64-row tile ~0.41 of a 256-row tile's time
+// (all W slabs still cross LDS; tools/bench_skinny_crossover.py, profiles/r05_gemm_tile_rows.txt); ties go to the larger tile.
+// The choice changes no bit of any row.  MEVI_GEMM_TILE_ROWS=256|128|64 pins it (A/B).
+inline int split_tile_blocks(int64_t m, int64_t n_ntiles, int n_cu) {
+  static const int pinned = [] { const char *e = getenv("MEVI_GEMM_TILE_ROWS"); return e ? atoi(e) : 0; }();
+  if (pinned == 256 || pinned == 128 || pinned == 64) return pinned / 32;
+  static const double t4 = [] { const char *e = getenv("MEVI_GEMM_TILE_T128"); return e ? atof(e) : 0.61; }();
+  static const double t2 = [] { const char *e = getenv("MEVI_GEMM_TILE_T64"); return e ? atof(e) : 0.41; }();
+  const double cost[3] = {1.0, t4, t2};
+  int best = 8;
+  double best_t = 0.0;
+  for (int i = 0, ni = 8; i < 3; ++i, ni >>= 1) {
+    const int64_t tiles = ((m + 32 * ni - 1) / (32 * ni)) * n_ntiles;
+    const double t = (double)((tiles + n_cu - 1) / n_cu) * cost[i];
+    if (i == 0 || t < best_t * 0.97) best = ni, best_t = t;
+  }
+  return best;
+}
+
 }  // namespace
 }  // namespace mevi
 
@@ -1092,14 +1117,17 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
     MEVI_HIP_CHECK(hipGetLastError());
     return MEVI_OK;
   }
-  const int64_t n_mtiles = (m + 255) / 256, n_ntiles = (n + 255) / 256;
-  MEVI_REQUIRE(n_mtiles * n_ntiles <= 0x7fffffffLL, MEVI_ERR_UNSUPPORTED, "gemm_nt_split: grid too large");
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, v = 0;
     n_cu = (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
+  const int64_t n_ntiles = (n + 255) / 256;
+  const int ni = shape32 ? 8 : split_tile_blocks(m, n_ntiles, n_cu);
+  const int tm = 32 * ni;
+  const int64_t n_mtiles = (m + tm - 1) / tm;
+  MEVI_REQUIRE(n_mtiles * n_ntiles <= 0x7fffffffLL, MEVI_ERR_UNSUPPORTED, "gemm_nt_split: grid too large");
   int64_t grid = n_cu / 8 * 8;  // persistent: one workgroup per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
   const int64_t tiles = n_mtiles * n_ntiles;
@@ -1111,10 +1139,14 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
   static const kern_t table[3][3] = {{gemm_split_kernel<0, 0>, gemm_split_kernel<0, 1>, gemm_split_kernel<0, 2>},
                                      {gemm_split_kernel<1, 0>, gemm_split_kernel<1, 1>, gemm_split_kernel<1, 2>},
                                      {gemm_split_kernel<2, 0>, gemm_split_kernel<2, 1>, gemm_split_kernel<2, 2>}};
-  static const kern_t table16[3][3] = {{gemm_split16_kernel<0, 0>, gemm_split16_kernel<0, 1>, gemm_split16_kernel<0, 2>},
-                                       {gemm_split16_kernel<1, 0>, gemm_split16_kernel<1, 1>, gemm_split16_kernel<1, 2>},
-                                       {gemm_split16_kernel<2, 0>, gemm_split16_kernel<2, 1>, gemm_split16_kernel<2, 2>}};
-  const kern_t fn = (shape32 ? table : table16)[a8][so.img ? 2 : (residual ? 1 : 0)];
+#define MEVI_SPLIT16_TABLE(NI_)                                                                                                  \
+  {{gemm_split16_kernel<0, 0, NI_>, gemm_split16_kernel<0, 1, NI_>, gemm_split16_kernel<0, 2, NI_>},                             \
+   {gemm_split16_kernel<1, 0, NI_>, gemm_split16_kernel<1, 1, NI_>, gemm_split16_kernel<1, 2, NI_>},                             \
+   {gemm_split16_kernel<2, 0, NI_>, gemm_split16_kernel<2, 1, NI_>, gemm_split16_kernel<2, 2, NI_>}}
+  static const kern_t table16[3][3][3] = {MEVI_SPLIT16_TABLE(8), MEVI_SPLIT16_TABLE(4), MEVI_SPLIT16_TABLE(2)};
+#undef MEVI_SPLIT16_TABLE
+  const int o3 = so.img ? 2 : (residual ? 1 : 0);
+  const kern_t fn = shape32 ? table[a8][o3] : table16[ni == 8 ? 0 : (ni == 4 ? 1 : 2)][a8][o3];
   MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(PP_THREADS), lds_bytes, stream, A, reinterpret_cast<const signed char *>(a_exp), (int)m, W,
@@ -1198,8 +1230,15 @@ extern "C" int mevi_gemm_nt_split_to_split(const void *a_img, const int8_t *a_ex
 // ---- norm + projection in one launch (the latency path; see gemm_rmsnorm_split16_kernel) -------------------------------------
 // Supported: k == 768 (the t5-base / bert-base width), m <= 1024 rows, n % 16 == 0 not required (n % 4 == 0); the caller keeps
 // the two-kernel form (mevi_rmsnorm_split_f16 + mevi_gemm_nt_split_*) elsewhere -- same results, bit for bit, either way.
+// The fused kernel multiplies in skinny16_body<1>'s order (16 x 16 x 32 MFMA, 16 x 16 tiles), so it stands in for the two-kernel form
+// only where gemm_split_launch would pick that kernel: not under MEVI_GEMM_MFMA=32 / MEVI_GEMM_SKINNY_TILE=32, and inside
+// MEVI_GEMM_SKINNY_MAX -- the same static switches, read the same way.
 extern "C" int mevi_gemm_rmsnorm_supported(int64_t m, int64_t n, int64_t k) {
-  return k == 768 && m >= 1 && n >= 4 && n % 4 == 0 && ((n + 31) / 32) * ((m + 31) / 32) <= 128 && m * n <= SPLIT_SKINNY_MAX_OUTPUTS;
+  static const long long skinny_max = [] { const char *e = getenv("MEVI_GEMM_SKINNY_MAX"); return e ? atoll(e) : SPLIT_SKINNY_MAX_OUTPUTS; }();
+  static const bool shape32 = [] { const char *e = getenv("MEVI_GEMM_MFMA"); return e && atoi(e) == 32; }();
+  static const bool tile32 = [] { const char *e = getenv("MEVI_GEMM_SKINNY_TILE"); return e && atoi(e) == 32; }();
+  return !shape32 && !tile32 && k == 768 && m >= 1 && n >= 4 && n % 4 == 0 && ((n + 31) / 32) * ((m + 31) / 32) <= 128 &&
+         m * n <= skinny_max;
 }
 
 static int gemm_rmsnorm_launch(const float *x, int64_t ldx, const float *ln_w, float eps, const void *w_img, const int8_t *w_exp,

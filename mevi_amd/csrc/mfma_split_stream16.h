@@ -29,11 +29,22 @@
 
 namespace mevi {
 
-// next(H1Src &) / begin() / emit(acc) as split_tile_stream; emit receives f32x4 acc[4][8]: block (mi, ni) = W rows 16 mi + [0, 16)
-// of the wave's 64, activation rows 16 ni + [0, 16) of the wave's 128.  `U` super-units per tile (>= 2).
-template <class Next, class Begin, class Emit>
+// next(H1Src &) / begin() / emit(acc) as split_tile_stream; emit receives f32x4 acc[4][NI]: block (mi, ni) = W rows 16 mi + [0, 16)
+// of the wave's 64, activation rows 16 ni + [0, 16) of the wave's 16 NI.  `U` super-units per tile (>= 2).
+//
+// NI = 8 is the 256 x 256 tile described above.  NI = 4 / 2 (round 5): tiles of 128 / 64 ACTIVATION rows x 256 W rows for GEMMs
+// whose 256-row tiles would leave most of the 256 CUs idle (a few thousand rows: the 873 queries a rank of the 8-GPU ensemble
+// gets, the reference's own batches of 128) -- the same ring, DMA schedule and barrier; a wave owns 64 W rows x 16 NI activation
+// rows and runs ONE half per window:
+//   window s    P1: read al, wh | M3 of super-unit s-1 (a_hi x w_lo)      P2: read ah | M1 (a_lo x w_hi)      P3: read wl | M2 (a_hi x w_hi)
+// An output block still accumulates, per 32 k, a_lo w_hi, then a_hi w_hi, then a_hi w_lo from a zero-C first product: a row has
+// the bits it has in the 256-row tile (and in the latency kernel).  The a slabs keep their 256-row LDS slots; rows beyond the
+// tile's 32 NI are outside the source descriptor (no traffic; zeros land in LDS and are never read).
+template <int NI = 8, class Next, class Begin, class Emit>
 __device__ __forceinline__ void split_tile_stream16(int row_bytes, int lo_bytes, int U, float *lds, Next next, Begin begin,
                                                     Emit emit, int unit_bytes = 64) {
+  static_assert(NI == 8 || NI == 4 || NI == 2, "activation blocks per wave");
+  constexpr int NA = NI == 8 ? 4 : NI;   // activation fragments per read / product group
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -65,7 +76,7 @@ __device__ __forceinline__ void split_tile_stream16(int row_bytes, int lo_bytes,
 
   const int cj = (kq ^ h16_swz((r16 >> 2) & 3)) * 4;
   const int offw = (grp * BM + 64 * wm + r16) * H1_LD + cj;  // w slabs: the wave's 64 W rows (4 fragments)
-  const int offa = (128 * wn + r16) * H1_LD + cj;            // a slabs: the wave's 128 activation rows (2 x 4 fragments)
+  const int offa = (16 * NI * wn + r16) * H1_LD + cj;        // a slabs: the wave's 16 NI activation rows (NI = 8: 2 x 4 fragments)
   struct Frag4 {
     f16x8 f[4];
   };
@@ -78,13 +89,13 @@ __device__ __forceinline__ void split_tile_stream16(int row_bytes, int lo_bytes,
   auto read_a = [&](int base, int t_, int h, Frag4 &f) {
     const float *p = lds + ring(base + t_) * SS_SLAB + offa + 64 * h * H1_LD;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f.f[i] = *reinterpret_cast<const f16x8 *>(p + 16 * i * H1_LD);
+    for (int i = 0; i < NA; ++i) f.f[i] = *reinterpret_cast<const f16x8 *>(p + 16 * i * H1_LD);
   };
-  f32x4 acc[4][8];
+  f32x4 acc[4][NI];
   auto mma = [&](const Frag4 &w, const Frag4 &a, int h, auto zero) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < NA; ++ni)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
         acc[mi][4 * h + ni] =
@@ -113,11 +124,47 @@ __device__ __forceinline__ void split_tile_stream16(int row_bytes, int lo_bytes,
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // a group of the half windows: `reads` ds_read_b128 (in fours) behind the first of the group's 4 NA MFMAs
+  auto sched_h = [](auto reads) {
+    constexpr int R = decltype(reads)::value, MM = 4 * NA;
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (R > 4) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, R - 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MM - 4, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MM - 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // The six groups of a window, written out (every fragment set has exactly one reader group after its load):
   auto run_window = [&](int u, auto first_) {
     constexpr bool first = decltype(first_)::value;
     dma_slab(ring(base + (is_w ? 7 : 6)), u + 1, is_w);
     dma_slab(ring(base + (is_w ? 9 : 8)), u + 2, !is_w);
+    if constexpr (NI != 8) {
+      // P1: read al, wh | M3 (previous super-unit): a_hi x w_lo
+      read_a(base, 0, 0, AL);
+      read_w(base, 1, WH);
+      if constexpr (!first) {
+        mma(WL, AH, 0, No());
+        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+        sched_h(std::integral_constant<int, 4 + NA>());
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // P2: read ah | M1: a_lo x w_hi
+      read_a(base, 2, 0, AH);
+      mma(WH, AL, 0, first_);
+      sched_h(std::integral_constant<int, NA>());
+      // P3: read wl | M2: a_hi x w_hi
+      read_w(base, 3, WL);
+      mma(WH, AH, 0, No());
+      sched_h(std::integral_constant<int, 4>());
+    } else {
     // P1: read al(h0), wh | M6 (previous super-unit): a_hi(h1) x w_lo
     read_a(base, 0, 0, AL);
     read_w(base, 1, WH);
@@ -147,6 +194,7 @@ __device__ __forceinline__ void split_tile_stream16(int row_bytes, int lo_bytes,
     // P6: -- | M5: a_hi(h1) x w_hi
     mma(WH, AH, 1, No());
     __builtin_amdgcn_sched_barrier(0);
+    }
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     base = ring(base + 4);
@@ -162,7 +210,7 @@ __device__ __forceinline__ void split_tile_stream16(int row_bytes, int lo_bytes,
     begin();
     run_window(0, Yes());
     for (int u = 1; u < U; ++u) run_window(u, No());
-    mma(WL, AH, 1, No());
+    mma(WL, AH, NI == 8 ? 1 : 0, No());
     emit(acc);
     if (!have_nxt) break;
     cur = nxt;

@@ -491,7 +491,6 @@ class EvalRun:
             results.append((text, N, ranks))
         return results
 
-    @torch.no_grad()
     def decode_tree(self):
         """The tree the beams are held to.  `--codebook 1` (every script) = the shared-sons tree of all K codes per level
         (main_models.py:1698-1706): None.  MEVI_DECODE_TREE=clusters (a switch of this build; the reference reaches the same
@@ -507,6 +506,7 @@ class EvalRun:
             self._decode_tree = PrefixTree((keys[:, None] // w) % self.K, self.M, self.K, self.dev)
         return self._decode_tree
 
+    @torch.no_grad()
     def infer(self, texts, doc_ids, rows=None):
         """One batch: returns [(text, ndoc, coarse ranks, fine ranks)] like infer() with recall_level='both'.
         rows: the samples' line numbers in the query file (only read with --query_embedding_path)."""

@@ -293,7 +293,8 @@ class PrefixTables:
 
 
 # MEVI_HEAD_LOGITS=columns: the head as before round 4 (mevi_scale_f32, lm_head's rows added per column inside
-# mevi_adaptive_logits_f32); same bits, three times the cache traffic -- kept for A/B timing
+# mevi_adaptive_logits_f32); three times the cache traffic -- kept for A/B timing.  Same bits at widths other than 768; at 768 the
+# rows kernel follows the fused head's summation order, so the two differ in the last ulps there
 ROW_LOGITS = os.environ.get("MEVI_HEAD_LOGITS", "rows") != "columns"
 # MEVI_ADAPTOR_CACHE=copy: assemble the adaptor's cache of the final position by gathers (the form before round 4; same bits)
 INDEXED_ADAPTOR_CACHE = os.environ.get("MEVI_ADAPTOR_CACHE", "indexed") != "copy"
@@ -538,7 +539,7 @@ class NCIModel:
         base = torch.arange(B, device=self.dev)[:, None]
         for p in range(c.M + 1):
             if p == levels and p > 0:       # first position beyond the tables: its cache comes from them
-                if p == c.M and INDEXED_ADAPTOR_CACHE:   # ... in place, when no later position continues from it
+                if p == c.M and p <= 7 and INDEXED_ADAPTOR_CACHE:   # ... in place, when no later position continues from it (<= 8 keys)
                     acache = self.tables().indexed_cache(self.adaptor, pidx, p)
                 else:
                     acache = self.tables().cache_rows(self.adaptor, pidx, p)

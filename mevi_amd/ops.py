@@ -523,8 +523,9 @@ def adaptive_logits(s, t, e, t_index=None):
 @hip.on_device
 def adaptive_logits_rows(s, alpha, te, ncol, t_index=None):
     """logits[row, c] = sum_d (s[row, d] * alpha) * te[trow, c*dim + d], trow = row or t_index[row]: adaptive_logits with
-    lm_head's rows already added into `te` (the head GEMM's bias) and the hidden state's scale applied here -- same bits as
-    scale() + adaptive_logits(), a third of the cache traffic."""
+    lm_head's rows already added into `te` (the head GEMM's bias) and the hidden state's scale applied here -- a third of the
+    cache traffic of scale() + adaptive_logits(); the same bits as that pair at widths other than 768 (at 768 the kernel sums in the
+    fused head's order, mevi_gemm_nt_split_head_f32, so that table rows and fused rows agree)."""
     s, rows, dim, lds = _rows2d(_f32(s))
     assert te.dim() == 2 and te.shape[1] == ncol * dim and te.stride(1) == 1 and te.dtype == torch.float32
     if t_index is None:
