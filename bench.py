@@ -176,31 +176,47 @@ def gemm_roofline(device, rows):
 
 def cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs):
     """What one `faiss_search.py` process pays around the resident-corpus search: corpus upload (file in the page cache ->
-    HBM: mevi_amd.io.upload_rows preads the mapped file straight into pinned staging buffers, threaded; measured on a 2 GB
-    sample file and scaled), index build, search."""
+    HBM: mevi_amd.io.upload_rows, a ring of pinned staging buffers filled by reader threads ahead of the copy engine; measured
+    on a 2 GB sample file by method and scaled), index build, search."""
+    import shutil
     import tempfile
 
     from mevi_amd import io as mio
 
     rows = min(docs.shape[0], (2 << 30) // (4 * DIM))
-    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    need = rows * DIM * 4 + (64 << 20)
+    tmpdir = tempfile.gettempdir()
+    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > 2 * need:
+        tmpdir = "/dev/shm"
+    elif shutil.disk_usage(tmpdir).free < 2 * need:       # a small box: sample what fits (at least 64 MB)
+        rows = max((64 << 20) // (4 * DIM), min(rows, shutil.disk_usage(tmpdir).free // (8 * DIM * 4)))
     path = os.path.join(tmpdir, "mevi_bench_upload_%d.bin" % os.getpid())
+    by_method = {}
     try:
         docs[:rows].cpu().numpy().tofile(path)
-        m = mio.map_rows(path, DIM)
-        mio.upload_rows(m[: rows // 8], device)
-        t = time.perf_counter()
-        mio.upload_rows(m, device)
-        torch.cuda.synchronize()
-        gbs = rows * DIM * 4 / (time.perf_counter() - t) / 1e9
-        del m
+        for method in ("pread", "copy"):
+            os.environ["MEVI_UPLOAD"] = method
+            m = mio.map_rows(path, DIM)
+            mio.upload_rows(m[: rows // 8], device)
+            best = 0.0
+            for _ in range(2):
+                t = time.perf_counter()
+                mio.upload_rows(m, device)
+                torch.cuda.synchronize()
+                best = max(best, rows * DIM * 4 / (time.perf_counter() - t) / 1e9)
+            by_method[method] = round(best, 2)
+            del m
     finally:
+        os.environ.pop("MEVI_UPLOAD", None)
+        mio.free_staging()
         if os.path.exists(path):
             os.remove(path)
+    gbs = by_method.get("pread") or max(by_method.values())
     upload_s = n_docs * DIM * 4 / 1e9 / gbs
     total = upload_s + index_build_s + search_ms / 1e3
-    return {"upload_gb_per_s": gbs, "upload_frac_of_pcie_gen5_x16": gbs / 63.0, "upload_s": upload_s,
-            "upload_sample": f"{rows} rows ({rows * DIM * 4 / 1e9:.2f} GB) of a mapped file in the page cache ({tmpdir}), pread into pinned buffers",
+    return {"upload_gb_per_s": gbs, "upload_gb_per_s_by_method": by_method, "upload_frac_of_pcie_gen5_x16": gbs / 63.0, "upload_s": upload_s,
+            "upload_sample": f"{rows} rows ({rows * DIM * 4 / 1e9:.2f} GB) of a mapped file in the page cache ({tmpdir}); pread = straight "
+                             "into the pinned ring (the default), copy = memcpy out of the mapping; best of two",
             "host_cpus_granted": len(os.sched_getaffinity(0)),
             "index_build_s": index_build_s, "search_s": search_ms / 1e3, "queries_per_s": nq / total,
             "note": "PCIe-inclusive rate of ONE faiss_search.py invocation (corpus file in the page cache); every further "
@@ -255,6 +271,18 @@ def index_build_leg(device, docs, rn, n_docs):
 
     out = {}
     rq.KEEP_ENCODE_WORKSPACE = True            # the record counters of `stats` below
+    try:
+        _rq_legs(out, device, docs, n_docs)
+    finally:
+        rq.KEEP_ENCODE_WORKSPACE = False
+        rq._LAST_ENCODE.clear()
+    _passage_leg(out, device, n_docs)
+    return out
+
+
+def _rq_legs(out, device, docs, n_docs):
+    from mevi_amd import rq
+
     g = torch.Generator(device=device).manual_seed(5)
     for M_, K_ in ((4, 32), (3, 256)):
         cb = torch.stack([torch.randn((K_, DIM), device=device, generator=g) * (0.05 / (1 + j)) for j in range(M_)])
@@ -285,8 +313,12 @@ def index_build_leg(device, docs, rn, n_docs):
             "achieved": round(mf / ms / 1e9, 1), "frac": round(mf / ms / 1e9 / PEAK_F16_MFMA_TFLOPS, 4),
             "x_stream_gb_per_s": round(4.0 * n_docs * DIM * (1 if K_ <= 32 else M_) / ms / 1e6, 1)}
         del codes, cb
-    rq.KEEP_ENCODE_WORKSPACE = False
-    rq._LAST_ENCODE.clear()
+
+
+def _passage_leg(out, device, n_docs):
+    from mevi_amd import t5
+    import synth
+
     TW = synth.tower_weights(device) if hasattr(synth, "tower_weights") else None
     if TW is not None:
         tower = t5.TwinTower(TW, device=device, num_layers=12, num_decoder_layers=12)     # device passes of t5.DEVICE_PASS_TOKENS
@@ -321,7 +353,6 @@ def index_build_leg(device, docs, rn, n_docs):
                          "peak_note": "f16 MFMA dense peak / 3 (three f16 MFMAs per f32 product); executed = real tokens only "
                                       "(12 encoder layers incl. attention, 12 one-token decoder layers, cross K|V of real tokens)"}}
         del tower, TW
-    return out
 
 
 def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=None, dense_index=None):
@@ -378,8 +409,35 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
     def gen_all(mdl):
         return [mdl.generate(ids[a:a + gen_batch], mask[a:a + gen_batch], num_beams=R) for a in range(0, nq, gen_batch)]
 
+    def nci_policies(mdl):
+        """The beam search under the two prefix-table policies: `one_shot` = tables sized for THIS run's nq
+        queries (what main.py --mode eval does: EvalRun.run -> NCIModel.expect_queries), `steady_state` = a long-lived model
+        (every table that fits the byte budget).  Per policy: table build ms, the first pass (build + search) and the steady
+        pass; break_even_queries = the workload above which the larger tables repay their build."""
+        mdl.prefix_table_bytes, mdl._tables = 0, None
+        mdl.generate(ids[:256], mask[:256], num_beams=R)          # kernels and allocator warm, no table built yet
+        mdl.prefix_table_bytes = None
+        res, gen = {}, None
+        for policy, q in (("one_shot", nq), ("steady_state", None)):
+            mdl.prefix_table_queries, mdl._tables = q, None
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            gen_all(mdl)
+            torch.cuda.synchronize()
+            first = (time.perf_counter() - t) * 1e3
+            steady, gen = timed(lambda: gen_all(mdl), 2)
+            res[policy] = dict(mdl.tables().describe(), first_pass_ms=round(first, 2), steady_ms=round(steady, 2))
+        o, s_ = res["one_shot"], res["steady_state"]
+        gain = (o["steady_ms"] - s_["steady_ms"]) / nq                       # ms per query the larger tables save
+        extra = s_["build_ms"] - o["build_ms"]
+        res["break_even_queries"] = int(extra / gain) if gain > 1e-9 and extra > 0 else (0 if extra <= 0 else None)
+        res["note"] = ("one_shot is what a drop-in `main.py --mode eval` over these %d queries pays (first_pass_ms includes build_ms); "
+                       "steady_state is a resident model; break_even_queries = extra build / per-query saving" % nq)
+        return res, gen
+
     tower_ms, qemb = timed(lambda: tower.encode_query({"input_ids": ids, "attention_mask": mask}), 3)
-    nci_ms, gen = timed(lambda: gen_all(model), 2)
+    tabs, gen = nci_policies(model)
+    nci_ms = tabs["steady_state"]["steady_ms"]
     pad, exe = seq2seq_flops(M, K, R, real_tokens / nq)
     peak3 = PEAK_F16_MFMA_TFLOPS / 3
     out["dense_arm_with_tower"] = {
@@ -389,7 +447,8 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
         "note": "generate.py --gen_query (T5-ANCE tower, t5-base shapes, synthetic weights) + faiss_search.py"}
     out["seq2seq_arm"] = {
         "nci_generate_ms": nci_ms, "nci_generate_queries_per_s": nq / nci_ms * 1e3, "beams": R, "rq": [M, K],
-        "queries_per_pass": gen_batch, "dtype": SPLIT_DTYPE,
+        "queries_per_pass": gen_batch, "dtype": SPLIT_DTYPE, "prefix_table_policies": tabs,
+        "one_shot_queries_per_s": nq / tabs["one_shot"]["first_pass_ms"] * 1e3,
         "roofline": {
             "bound": "mfma", "unit": "TFLOP/s", "flop_per_query_survey_8d_padded": pad, "flop_per_query_executed": exe,
             "achieved": exe * nq / nci_ms / 1e9, "achieved_padded_equivalent": pad * nq / nci_ms / 1e9,
@@ -398,6 +457,19 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
                          "counts the arithmetic executed (real tokens, per-prefix adaptor tables), not the padded budget"},
         "note": "main.py --mode eval beam search (t5-base NCI model, synthetic weights), all queries resident"}
     guarded("gemm_roofline", lambda: dict(gemm_roofline(device, real_tokens), dtype=SPLIT_DTYPE))
+
+    def sweep_leg():
+        """Tower and beam search by queries per call (tools/batch_sweep.py): 873 = what each rank of the 8-GPU ensemble runs
+        (6980 / 8, MEVI/main.py:318-322); 128 / 8 = the reference's own batch regimes (generate.py:289, marco_eval_nci_rq.sh:12)."""
+        import batch_sweep
+
+        rows = batch_sweep.sweep(model, tower, ids, mask, M, K, R, seq2seq_flops=seq2seq_flops, tower_flops=tower_flops)
+        return {"what": "one tower.encode_query / model.generate call of <queries> queries (median of 3-5 after a warm-up call; resident "
+                        "model, steady-state prefix tables); frac = executed f32 products x 3 / time / f16 MFMA peak",
+                "at_873": next((r for r in rows if r["queries"] == 873), None),
+                "at_128": next((r for r in rows if r["queries"] == 128), None), "per_size": rows}
+
+    guarded("seq2seq_batch_sweep", sweep_leg)
 
     # ---- C4, timed directly on the resident corpus ---------------------------------------------------------------------
     chain, dindex = chain_c4.run(model, tower, docs, ids, mask, planted_ids(nq, n_docs), rn, M, K, R, TOPK, gen_batch, rng)
@@ -412,6 +484,11 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
                          "flop_split": {"tower_x2_f32_products": 2 * tw, "nci_f32_products": exe * nq,
                                         "dense_filter_f16_products": 2.0 * nq * float(n_docs) * DIM},
                          "peak_note": "f16 MFMA dense peak; f32 products of the split GEMMs counted three times (three f16 MFMAs each)"}
+    chain["prefix_tables"] = dict(model.tables().describe(), policy="steady_state (resident model; the 3 timed repeats never build)",
+                                  one_shot_chain_ms=round(chain["chain_ms"] - nci_ms + tabs["one_shot"]["first_pass_ms"], 2),
+                                  one_shot_queries_per_s=round(nq / (chain["chain_ms"] - nci_ms + tabs["one_shot"]["first_pass_ms"]) * 1e3, 1),
+                                  one_shot_note="chain_ms with the beam-search stage replaced by the one_shot policy's first pass (table build "
+                                                "included): what ONE MS MARCO dev run of main.py pays")
     out["chain_c4"] = chain
     guarded("faiss_search_cli_inclusive", lambda: cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs))
     del dindex
@@ -464,15 +541,13 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
     cpu_w2 = {k: v.cpu() for k, v in W2.items()} if with_cpu else None
     model2 = nci.NCIModel(W2, device=device, M=M2, K=K2, adaptor_layer_num=4, num_layers=12, num_decoder_layers=6)
     del W2
-    nci2_ms, gen2 = timed(lambda: gen_all(model2), 1)
+    tabs2, gen2 = nci_policies(model2)
+    nci2_ms = tabs2["steady_state"]["steady_ms"]
     pad2, exe2 = seq2seq_flops(M2, K2, R, real_tokens / nq)
-    tab = model2.tables()
     out["seq2seq_arm_rq_3x256"] = {
         "nci_generate_ms": nci2_ms, "nci_generate_queries_per_s": nq / nci2_ms * 1e3, "beams": R, "rq": [M2, K2],
-        "queries_per_pass": gen_batch, "dtype": SPLIT_DTYPE,
-        "prefix_tables": {"levels": tab.levels, "head_matrices_at": [p for p in range(tab.levels) if tab.tmat[p] is not None],
-                          "adaptor_vectors_only_at": [p for p in range(tab.levels) if tab.tmat[p] is None],
-                          "bytes": tab.bytes},
+        "queries_per_pass": gen_batch, "dtype": SPLIT_DTYPE, "prefix_table_policies": tabs2,
+        "one_shot_queries_per_s": nq / tabs2["one_shot"]["first_pass_ms"] * 1e3,
         "flop_per_query_survey_8d_padded": pad2,
         "note": "BASELINE.json configs[2] code shape (3-level RQ-256): prefix tables sized from the device "
                 "(nci.default_table_bytes: half the free memory, <= 128 GiB) hold the head matrices of the 65 536 two-code "
@@ -504,11 +579,11 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
 
 # ---- the ONE line ---------------------------------------------------------------------------------------------------------
 LINE_BUDGET = 7600      # bytes: the driver keeps the last 8 KB of stdout beside `parsed`; the whole line must fit in it
-_DROP = ("note", "sample_detail", "what", "slice", "per_rank", "per_batch", "layers", "checksums", "statistic", "stats",
-         "prefix_tables", "flop_split", "setup_untimed_ms", "recall1000", "loadavg", "cgroup_cpu_max", "backend", "faiss",
+_DROP = ("note", "sample_detail", "per_size", "what", "slice", "per_rank", "per_batch", "layers", "checksums", "statistic", "stats",
+         "flop_split", "head_matrices_at", "adaptor_vectors_only_at", "one_shot_note", "setup_untimed_ms", "recall1000", "loadavg", "cgroup_cpu_max", "backend", "faiss",
          "upload_sample", "seconds", "cpu_seconds", "oracle_seconds", "algorithmic_bytes", "flop_executed",
          "flop_per_query_survey_8d_padded", "flop_per_query_executed", "executed_f16_mfma_flop", "algorithmic_bytes_per_search")
-_DROP_ORDER = ("faiss_search_cli_inclusive", "seq2seq_cpu_sample", "dense_small_batch", "gemm_roofline", "dense_arm_with_tower",
+_DROP_ORDER = ("seq2seq_cpu_sample", "dense_small_batch", "gemm_roofline", "faiss_search_cli_inclusive", "dense_arm_with_tower", "seq2seq_batch_sweep",
                "seq2seq_arm_rq_3x256", "index_build", "multi_gpu")      # least important first, should the line still be long
 
 
@@ -519,7 +594,7 @@ def _compact(v, path=()):
     if isinstance(v, dict):
         return {k: _compact(x, path + (k,)) for k, x in v.items()
                 if path + (k,) in _KEEP_PATHS
-                or not (any(d in k for d in _DROP) or k in ("dtype", "workload", "cpu", "kernel", "sweep"))}
+                or not (k in _DROP or k.endswith("_note") or k in ("dtype", "workload", "cpu", "kernel", "sweep"))}
     if isinstance(v, (list, tuple)):
         return [_compact(x, path) for x in v]
     if isinstance(v, float):

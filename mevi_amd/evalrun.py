@@ -604,6 +604,11 @@ class EvalRun:
         bs = max(1, a.eval_batch_size, getattr(a, "device_batch_size", None) or 1)
         if self.timer is not None:      # latency of the script's own step: eval_batch_size queries, replayed HIP graphs
             bs = max(1, a.eval_batch_size)
+        # the prefix tables of the PAWA head are sized for THIS run: a position is tabled only when this rank's queries x beams
+        # outnumber its prefixes (nci.PrefixTables.WORTH_MARGIN) -- a one-shot eval does not pay seconds of table build for
+        # prefixes it never visits.  MEVI_PREFIX_TABLES=all keeps the long-lived-model policy (every table that fits).
+        if not self.eval_all and os.environ.get("MEVI_PREFIX_TABLES", "workload") != "all":
+            self.nci.expect_queries(len(idx))
         for s in range(0, len(idx), bs):
             rows = df.iloc[idx[s:s + bs]]
             cache += self.infer(rows["query"].tolist(), rows["oldid"].tolist(), idx[s:s + bs])

@@ -15,11 +15,52 @@ import pickle
 import numpy as np
 
 
-def upload_rows(src, device, chunk_rows=1 << 18, threads=8):
-    """f32 [rows, dim] host array or memmap -> CUDA tensor through two pinned staging buffers (page-locked copies run
-    at PCIe rate and overlap the next chunk's read; a pageable 27 GB `tensor.to(device)` is several times slower).
-    The host-side copy into the staging buffer is split over `threads` threads (numpy releases the GIL while copying;
-    one thread moves ~10 GB/s, which would otherwise bound the upload)."""
+_STAGING = {}      # (buffers, bytes each) -> pinned uint8 tensors, kept for the life of the process (hipHostMalloc is slow)
+
+
+def _staging(nbuf, nbytes):
+    import torch
+
+    key = (nbuf, nbytes)
+    if key not in _STAGING:
+        for k in [k for k in _STAGING if k[0] == nbuf and k[1] < nbytes]:     # superseded smaller set
+            del _STAGING[k]
+        _STAGING[key] = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
+    return _STAGING[key]
+
+
+def free_staging():
+    """Release the pinned staging buffers upload_rows keeps between calls."""
+    _STAGING.clear()
+
+
+def file_range(src):
+    """(path, byte offset of src[0, 0] in the file) when `src` is a C-contiguous f32 view of a file-backed np.memmap, else None.
+    The offset comes from ADDRESSES -- a sliced memmap keeps the root's `.offset` (numpy does not adjust it), so
+    `root.offset + (address of the view - address of the root)` is the only reading that is right for `m[a:b]` too."""
+    if not isinstance(src, np.memmap) or not getattr(src, "filename", None) or not src.flags.c_contiguous or src.dtype != np.float32:
+        return None
+    root = src
+    while isinstance(root.base, np.memmap):
+        root = root.base
+    if not isinstance(root, np.memmap) or root.size == 0:
+        return None
+    delta = src.__array_interface__["data"][0] - root.__array_interface__["data"][0]
+    if delta < 0 or delta + src.nbytes > root.nbytes:
+        return None
+    return str(src.filename), int(root.offset) + int(delta)
+
+
+def upload_rows(src, device, chunk_rows=None, threads=8, buffers=4):
+    """f32 [rows, dim] host array or memmap -> CUDA tensor through a ring of pinned staging buffers (64 MiB each unless
+    `chunk_rows` says otherwise): reader threads fill the buffers AHEAD of the copy engine -- a buffer is refilled as soon as
+    its own copy has finished, while the copies of the other buffers are queued -- so host reads and DMA overlap instead of
+    alternating.  A file-backed memmap (faiss_search.read / map_rows) is pread straight from the page cache into the pinned
+    buffer (one kernel copy, no page-table population of a 27 GB mapping); anything else is copied out of memory.
+    Measured on the pool's boxes (16-CPU cgroup, tools/probe_upload2.py): fills 77-100 GB/s with 8-16 threads, pinned -> device
+    DMA 57 GB/s; the round-4 form (two 800 MB buffers allocated per call, fill and copy in turns) delivered 5.8 GB/s.
+    MEVI_UPLOAD=copy: memcpy out of the mapping instead of pread (A/B)."""
+    from collections import deque
     from concurrent.futures import ThreadPoolExecutor
 
     import torch
@@ -28,52 +69,72 @@ def upload_rows(src, device, chunk_rows=1 << 18, threads=8):
     out = torch.empty((rows, dim), dtype=torch.float32, device=device)
     if rows == 0:
         return out
+    row_bytes = dim * 4
+    if chunk_rows is None:
+        chunk_rows = max(1, (64 << 20) // row_bytes)
     chunk_rows = max(1, min(chunk_rows, rows))
-    stage = [torch.empty((chunk_rows, dim), dtype=torch.float32).pin_memory() for _ in range(2)]
+    nchunks = (rows + chunk_rows - 1) // chunk_rows
+    buffers = max(2, min(buffers, nchunks + 1))
+    stage = _staging(buffers, chunk_rows * row_bytes)
     views = [b.numpy() for b in stage]
-    done = [torch.cuda.Event() for _ in range(2)]
-    stream = torch.cuda.current_stream(device)
+    done = [torch.cuda.Event() for _ in range(buffers)]
     threads = max(1, min(threads, os.cpu_count() or 1))
-
-    # a file-backed memmap (faiss_search.read / map_rows): the bytes go from the page cache STRAIGHT into the pinned buffer
-    # with pread (one kernel copy, no page-table population of a 27 GB mapping, no intermediate user-space copy); anything
-    # else (an array in memory) is copied
+    fr = file_range(src) if os.environ.get("MEVI_UPLOAD", "pread") != "copy" else None
     fd = None
-    if isinstance(src, np.memmap) and getattr(src, "filename", None) and src.flags.c_contiguous and src.dtype == np.float32 \
-            and os.environ.get("MEVI_UPLOAD", "pread") != "copy":      # MEVI_UPLOAD=copy: memcpy out of the mapping (A/B)
+    if fr is not None:
         try:
-            fd = os.open(src.filename, os.O_RDONLY)
-            base = int(src.offset)
+            fd = os.open(fr[0], os.O_RDONLY)
         except OSError:
             fd = None
+    src_bytes = None if fd is not None else np.ascontiguousarray(src).view(np.uint8).reshape(rows, row_bytes) \
+        if not src.flags.c_contiguous else src.view(np.uint8).reshape(rows, row_bytes)
+    piece = max(1 << 20, (chunk_rows * row_bytes + threads - 1) // threads)      # bytes per reader task
 
-    def fill(dst, a, b):
-        if b <= a:
-            return
+    def fill(b, byte0, lo, hi):
+        """bytes [lo, hi) of the chunk that starts at byte `byte0` of the matrix -> staging buffer b."""
+        dst = memoryview(views[b])[lo:hi]
         if fd is None:
-            np.copyto(dst, src[a:b])
+            flat = src_bytes.reshape(-1)
+            np.copyto(np.frombuffer(dst, np.uint8), flat[byte0 + lo:byte0 + hi])
             return
-        mv = memoryview(dst).cast("B")
-        off, got = base + a * dim * 4, 0
-        while got < len(mv):
-            n = os.preadv(fd, [mv[got:]], off + got)
+        off, got = fr[1] + byte0 + lo, 0
+        while got < len(dst):
+            n = os.preadv(fd, [dst[got:]], off + got)
             if n <= 0:
-                raise OSError(f"short read of {src.filename} at byte {off + got}")
+                raise OSError(f"short read of {fr[0]} at byte {off + got}")
             got += n
 
-    with ThreadPoolExecutor(threads) as pool:
-        for i, a in enumerate(range(0, rows, chunk_rows)):
-            b = min(a + chunk_rows, rows)
-            if i >= 2:
-                done[i & 1].synchronize()              # the copy that last used this buffer has finished
-            n = b - a
-            cuts = [a + n * j // threads for j in range(threads + 1)]
-            list(pool.map(lambda j: fill(views[i & 1][cuts[j] - a:cuts[j + 1] - a], cuts[j], cuts[j + 1]), range(threads)))
-            out[a:b].copy_(stage[i & 1][:n], non_blocking=True)
-            done[i & 1].record(stream)
-    stream.synchronize()
-    if fd is not None:
-        os.close(fd)
+    out_bytes = out.view(torch.uint8).view(-1)
+    try:
+        with torch.cuda.device(out.device), ThreadPoolExecutor(threads) as pool:
+            stream = torch.cuda.current_stream()
+            fills = deque()
+
+            def submit(i):
+                a = i * chunk_rows
+                n = (min(a + chunk_rows, rows) - a) * row_bytes
+                fills.append((i, n, [pool.submit(fill, i % buffers, a * row_bytes, lo, min(lo + piece, n)) for lo in range(0, n, piece)]))
+
+            nxt = 0
+            while nxt < min(nchunks, buffers - 1):
+                submit(nxt)
+                nxt += 1
+            while fills:
+                i, n, futs = fills.popleft()
+                for f in futs:
+                    f.result()
+                a = i * chunk_rows * row_bytes
+                out_bytes[a:a + n].copy_(stage[i % buffers][:n], non_blocking=True)
+                done[i % buffers].record(stream)
+                if nxt < nchunks:        # the buffer chunk `nxt` takes was last read by the copy of chunk nxt - buffers
+                    if nxt >= buffers:
+                        done[nxt % buffers].synchronize()
+                    submit(nxt)
+                    nxt += 1
+            stream.synchronize()
+    finally:
+        if fd is not None:
+            os.close(fd)
     return out
 
 

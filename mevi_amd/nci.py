@@ -197,17 +197,36 @@ class PrefixTables:
     MAX_PREFIXES = 1 << 17
     MAX_FINAL_PREFIXES = 1 << 25     # the final position: adaptor vectors only, built in chunks (no K|V tables behind it)
     FINAL_CHUNK = 1 << 17
+    # A position is tabled only when its K**p prefixes, with this margin, are fewer than the beam rows the caller is about to
+    # run at it (`expected_queries` x live beams): building a row and running it for a beam cost the same adaptor step / head
+    # GEMM, so below that the table is pure overhead -- the (3, 256) final position is 16.7 M prefixes (a 3 s build) of which
+    # one MS MARCO dev run touches 69 800.  expected_queries None = a long-lived model (every table that fits the budget).
+    WORTH_MARGIN = 1.25
 
-    def __init__(self, model, table_bytes):
+    def __init__(self, model, table_bytes, expected_queries=None, beams=None):
+        import time
+
         c, dev = model.cfg, model.dev
         d, K = c.d_model, c.K
         self.levels = 0
         self._cat, self._retired = None, []
         self.tmat, self.avec, self.kv = [], [], [[] for _ in model.adaptor.layers]
+        self.expected_queries, self.beams = expected_queries, beams
         cache, spent = None, 0
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+
+        def worth(n, p):
+            if expected_queries is None:
+                return True
+            live = n if beams is None else min(beams, n)                  # beams alive at position p (1, then min(R, K**p))
+            return n * self.WORTH_MARGIN <= expected_queries * live or n == 1
+
         for p in range(c.T):
             n = K ** p
             kv_bytes = n * 2 * d * 4 * len(model.adaptor.layers)
+            if not worth(n, p):
+                break
             if n > self.MAX_PREFIXES or spent + kv_bytes + n * d * 4 > table_bytes:
                 # The final position (eos) of a larger code space -- 32**4 = 1 M prefixes for the scripts' (4, 32): nothing
                 # continues from it, so its adaptor K|V need no table, and its adaptor outputs (3 KB per prefix, 3.2 GB) fit
@@ -253,6 +272,14 @@ class PrefixTables:
                 spent += n * d * 4
             self.levels = p + 1
         self.bytes = spent
+        torch.cuda.synchronize(dev)
+        self.build_ms = (time.perf_counter() - t0) * 1e3
+
+    def describe(self):
+        """What was tabled, for the bench line / logs."""
+        return {"levels": self.levels, "head_matrices_at": [p for p in range(self.levels) if self.tmat[p] is not None],
+                "adaptor_vectors_only_at": [p for p in range(self.levels) if self.tmat[p] is None], "bytes": self.bytes,
+                "build_ms": round(self.build_ms, 2), "expected_queries": self.expected_queries, "beams": self.beams}
 
     def indexed_cache(self, adaptor, pidx, p):
         """IndexedPrefixCache of beams whose prefix index at position p = self.levels is `pidx` -- for a position whose cache
@@ -345,11 +372,14 @@ class NCIModel:
     """`generate()` mirrors the reference call; weights use the reference's state_dict names
     (T5ForConditionalGeneration: shared, encoder.*, decoder.*, decode_embeddings, adaptor*, lm_head)."""
 
-    def __init__(self, weights, cfg=None, device=None, prefix_table_bytes=None, **kw):
+    def __init__(self, weights, cfg=None, device=None, prefix_table_bytes=None, prefix_table_queries=None, **kw):
         self.dev = torch.device(device if device is not None else "cuda")
         self.cfg = cfg if cfg is not None else NCIConfig(**kw)
         # 0: evaluate the adaptor per beam per step; None: sized from the device when the tables are first built
         self.prefix_table_bytes = prefix_table_bytes
+        # how many queries this model is about to serve (EvalRun passes its run's count): positions whose prefix count exceeds
+        # the beam rows of that workload are not tabled (PrefixTables.WORTH_MARGIN); None = long-lived, table what fits
+        self.prefix_table_queries = prefix_table_queries
         self._tables = None
         self._graphs = GraphCache()
         c = self.cfg
@@ -371,12 +401,20 @@ class NCIModel:
             self.head_e.append(lm[cols].reshape(-1).contiguous())     # [(K+1)*d]: the bias of the head GEMM (lm_head_weight + adaptor_weight, modeling_t5.py:1683)
         del aw
 
-    def tables(self):
+    def tables(self, beams=None):
         if self._tables is None:
             if self.prefix_table_bytes is None:
                 self.prefix_table_bytes = default_table_bytes(self.dev)
-            self._tables = PrefixTables(self, self.prefix_table_bytes)
+            self._tables = PrefixTables(self, self.prefix_table_bytes, self.prefix_table_queries, beams)
         return self._tables
+
+    def expect_queries(self, n):
+        """The caller is about to run `n` queries through generate() (None: no limit known).  Tables already built for a
+        smaller or equal workload stay; a larger one rebuilds them on the next call (they may now pay for more positions)."""
+        old = self.prefix_table_queries
+        self.prefix_table_queries = n
+        if self._tables is not None and old is not None and (n is None or n > old):
+            self._tables = None
 
     # -- one decoding position for all live beams -----------------------------------------------
     def _logits(self, tokens, t, dcache, acache, xkv, mask, kv_div, pidx=None, key_rows=None):
@@ -434,7 +472,7 @@ class NCIModel:
         mask = attention_mask.to(self.dev, torch.int64).contiguous()
         if graph and 0 < ids.shape[0] <= GRAPH_MAX_ROWS:
             if self.prefix_table_bytes:
-                self.tables()
+                self.tables(R)
             decoded, hyp, enc = self._graphs.run(("generate", R, float(length_penalty), id(tree)) + tuple(ids.shape),
                                                  lambda i, m: self._search(i, m, R, length_penalty, pack=False, tree=tree), ids, mask)
         else:
@@ -526,7 +564,7 @@ class NCIModel:
             scores[:, 1:] = -1e9
             node = torch.zeros((B, nb), dtype=torch.int32, device=self.dev)  # every beam starts at the root
         codes = torch.zeros((B, nb, 0), dtype=torch.int64, device=self.dev)
-        levels = self.tables().levels if self.prefix_table_bytes != 0 else 0      # positions the prefix tables cover
+        levels = self.tables(R).levels if self.prefix_table_bytes != 0 else 0     # positions the prefix tables cover
         pidx = torch.zeros(B * nb, dtype=torch.int64, device=self.dev)       # prefix index of every live beam
         # The decoder's K|V caches are never re-ordered (the reference index_selects every layer's cache by the surviving
         # beams' parents after each step, generation_utils.py:927-934): position p of step-p row r stays in cache row r and

@@ -922,6 +922,14 @@ def test_pinned_upload_of_a_mapped_file_reads_straight_into_the_staging_buffers(
         m = map_rows(str(tmp_path / "rows.bin"), 24, rows=rows, first_row=first)
         want = a[first:first + (rows if rows is not None else len(a))]
         assert isinstance(m, np.memmap) and torch.equal(upload_rows(m, cuda, chunk_rows=chunk).cpu(), torch.from_numpy(want))
+    # SLICES of a mapping (numpy keeps the root's .offset on them: the file position has to come from the addresses), more chunks
+    # than staging buffers, fewer, and the default chunk size
+    whole = map_rows(str(tmp_path / "rows.bin"), 24)
+    inner = map_rows(str(tmp_path / "rows.bin"), 24, first_row=3)
+    for view, want, chunk in ((whole[17:517], a[17:517], 64), (inner[5:9], a[8:12], 8), (whole[1:], a[1:], 100), (whole[900:], a[900:], None),
+                              (np.memmap(str(tmp_path / "rows.bin"), dtype=np.float32, mode="r").reshape(-1, 24)[10:20], a[10:20], 3)):
+        assert torch.equal(upload_rows(view, cuda, chunk_rows=chunk).cpu(), torch.from_numpy(np.ascontiguousarray(want)))
+        assert torch.equal(upload_rows(view, cuda, chunk_rows=chunk, buffers=2, threads=3).cpu(), torch.from_numpy(np.ascontiguousarray(want)))
 
 
 def _two_rank_eval_worker(rank, world, port, args_dict, ret):

@@ -422,6 +422,28 @@ def test_tower_directory_with_safetensors_only(tmp_path):
         load_tower_weights(str(tmp_path / "none"))
 
 
+def test_file_position_of_memmap_views(tmp_path):
+    """io.file_range: where a C-contiguous view of a mapped file starts IN THE FILE (upload_rows preads from there).  A sliced
+    np.memmap reports its root's `.offset`: the position must follow the view."""
+    from mevi_amd import io as mio
+
+    a = np.arange(1000 * 8, dtype=np.float32).reshape(1000, 8)
+    path = str(tmp_path / "x.bin")
+    a.tofile(path)
+    m = mio.map_rows(path, 8)
+    assert m[10:20].offset == 0                                   # the numpy behaviour the function must not trust
+    assert mio.file_range(m) == (path, 0)
+    assert mio.file_range(m[17:517]) == (path, 17 * 32)
+    assert mio.file_range(mio.map_rows(path, 8, first_row=3)[5:9]) == (path, 8 * 32)
+    assert mio.file_range(np.memmap(path, dtype=np.float32, mode="r").reshape(-1, 8)[10:20]) == (path, 320)
+    assert mio.file_range(a) is None and mio.file_range(m[:, :4]) is None and mio.file_range(m[::2]) is None
+    for view in (m[17:517], mio.map_rows(path, 8, first_row=3)[5:9]):       # the bytes at that position are the view's bytes
+        _, off = mio.file_range(view)
+        with open(path, "rb") as f:
+            f.seek(off)
+            assert f.read(view.nbytes) == view.tobytes()
+
+
 def test_context_image_exponent_and_bounds():
     """Host side of the split-image attention contexts (mevi_amd/ops.py): the exponent of a bound puts it in [2^14, 2^15) as
     pow2_exp of csrc/gemm_split.hip does for a row maximum, and the |V| bound is a true bound for rmsnorm / layernorm inputs."""
