@@ -415,7 +415,7 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
         (every table that fits the byte budget).  Per policy: table build ms, the first pass (build + search) and the steady
         pass; break_even_queries = the workload above which the larger tables repay their build."""
         mdl.prefix_table_bytes, mdl._tables = 0, None
-        mdl.generate(ids[:256], mask[:256], num_beams=R)          # kernels and allocator warm, no table built yet
+        gen_all(mdl)                                              # kernels warm and the allocator grown to a full pass, no table built yet
         mdl.prefix_table_bytes = None
         res, gen = {}, None
         for policy, q in (("one_shot", nq), ("steady_state", None)):

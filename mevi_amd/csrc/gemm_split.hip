@@ -1028,20 +1028,47 @@ constexpr long long SPLIT_SKINNY_MAX_OUTPUTS = 1500000;
 // height 32 NI whose rounds x time-per-tile is least.  A 128-row tile costs ~0.61, a 64-row tile ~0.41 of a 256-row tile's time
 // (all W slabs still cross LDS; tools/bench_skinny_crossover.py, profiles/r05_gemm_tile_rows.txt); ties go to the larger tile.
 // The choice changes no bit of any row.  MEVI_GEMM_TILE_ROWS=256|128|64 pins it (A/B).
-inline int split_tile_blocks(int64_t m, int64_t n_ntiles, int n_cu) {
+inline int split_tile_blocks(int64_t m, int64_t n_ntiles, int n_cu, double *cost_out = nullptr) {
   static const int pinned = [] { const char *e = getenv("MEVI_GEMM_TILE_ROWS"); return e ? atoi(e) : 0; }();
-  if (pinned == 256 || pinned == 128 || pinned == 64) return pinned / 32;
   static const double t4 = [] { const char *e = getenv("MEVI_GEMM_TILE_T128"); return e ? atof(e) : 0.61; }();
   static const double t2 = [] { const char *e = getenv("MEVI_GEMM_TILE_T64"); return e ? atof(e) : 0.41; }();
   const double cost[3] = {1.0, t4, t2};
   int best = 8;
   double best_t = 0.0;
   for (int i = 0, ni = 8; i < 3; ++i, ni >>= 1) {
+    if ((pinned == 256 || pinned == 128 || pinned == 64) && pinned != 32 * ni) continue;
     const int64_t tiles = ((m + 32 * ni - 1) / (32 * ni)) * n_ntiles;
     const double t = (double)((tiles + n_cu - 1) / n_cu) * cost[i];
-    if (i == 0 || t < best_t * 0.97) best = ni, best_t = t;
+    if (best_t == 0.0 || t < best_t * 0.97) best = ni, best_t = t;
   }
+  if (cost_out) *cost_out = best_t;
   return best;
+}
+
+// Rows [0, m1) in 256-row tiles that fill WHOLE rounds of the device, the remaining rows as a GEMM of their own (with the tile
+// height that suits them): 819 tiles of a 69 800 x 768 projection are 3.2 rounds of 256 CUs -- four rounds' time -- where three
+// full rounds + 102 half-height tiles take 3.6.  Returns m1 (0: one launch).  A second launch costs ~6 us (launch + its
+// prologue), 0.065 of a K = 768 tile; rows keep their bits (the tile heights agree bit for bit).  MEVI_GEMM_SPLIT_M=0: off (A/B).
+inline int64_t split_rows_plan(int64_t m, int64_t n_ntiles, int n_cu, int kp) {
+  static const bool off = [] { const char *e = getenv("MEVI_GEMM_SPLIT_M"); return (e && atoi(e) == 0) || getenv("MEVI_GEMM_TILE_ROWS"); }();
+  if (off) return 0;
+  const int64_t tiles8 = ((m + 255) / 256) * n_ntiles;
+  const int64_t r8 = (tiles8 + n_cu - 1) / n_cu;
+  if (r8 < 2) return 0;
+  double single;
+  (void)split_tile_blocks(m, n_ntiles, n_cu, &single);
+  const double launch = 0.065 * 768.0 / (double)kp;
+  int64_t best_m1 = 0;
+  double best = single;
+  for (int64_t R = r8 - 1; R >= 1 && R >= r8 - 2; --R) {
+    const int64_t m1_tiles = R * n_cu / n_ntiles;
+    if (m1_tiles == 0 || m1_tiles * 256 >= m) continue;
+    double rest;
+    (void)split_tile_blocks(m - m1_tiles * 256, n_ntiles, n_cu, &rest);
+    const double t = (double)R + rest + launch;
+    if (t < best * 0.97) best = t, best_m1 = m1_tiles * 256;
+  }
+  return best_m1;
 }
 
 }  // namespace
@@ -1082,7 +1109,7 @@ extern "C" int mevi_rmsnorm_split_f16(const float *x, int64_t ldx, const float *
 
 static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void *w_img, const int8_t *w_exp,
                              float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias,
-                             const float *residual, int64_t ldr, int act, SplitOut so, void *stream_) {
+                             const float *residual, int64_t ldr, int act, SplitOut so, void *stream_, int force_ni = 0) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   MEVI_REQUIRE(m >= 0 && n >= 0 && k > 0, MEVI_ERR_INVALID_ARG, "gemm_nt_split: bad shape");
   if (m == 0 || n == 0) return MEVI_OK;
@@ -1124,7 +1151,20 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
   const int64_t n_ntiles = (n + 255) / 256;
-  const int ni = shape32 ? 8 : split_tile_blocks(m, n_ntiles, n_cu);
+  if (!shape32 && force_ni == 0) {
+    const int64_t m1 = split_rows_plan(m, n_ntiles, n_cu, kp);
+    if (m1 > 0) {       // whole rounds of 256-row tiles, then the remaining rows on their own (every row-indexed pointer moves on by m1)
+      const int st = gemm_split_launch(a_img, a_exp, w_img, w_exp, c, ldc, m1, n, k, bias, residual, ldr, act, so, stream_, 8);
+      if (st != MEVI_OK) return st;
+      SplitOut so2 = so;
+      if (so.img) so2.img = so.img + (size_t)m1 * 2 * so.np, so2.exps = so.exps + m1;
+      if (so.norms) so2.norms = so.norms + m1;
+      if (so.anorm) so2.anorm = so.anorm + m1;
+      return gemm_split_launch(A + (size_t)m1 * 2 * kp, a_exp + m1, w_img, w_exp, c ? c + (size_t)m1 * ldc : nullptr, ldc, m - m1, n, k, bias,
+                               residual ? residual + (size_t)m1 * ldr : nullptr, ldr, act, so2, stream_, -1);
+    }
+  }
+  const int ni = shape32 ? 8 : (force_ni > 0 ? force_ni : split_tile_blocks(m, n_ntiles, n_cu));
   const int tm = 32 * ni;
   const int64_t n_mtiles = (m + tm - 1) / tm;
   MEVI_REQUIRE(n_mtiles * n_ntiles <= 0x7fffffffLL, MEVI_ERR_UNSUPPORTED, "gemm_nt_split: grid too large");

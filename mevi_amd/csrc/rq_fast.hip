@@ -132,10 +132,24 @@ __device__ __forceinline__ float rf_delta(float m, float rho_hat, float E1, floa
 // registers -- the lane that wrote a fragment is the lane that reads it -- two units ahead, in place of the x LDS-DMA (same
 // look-ahead, same counted waits: stores, loads and LDS-DMA retire in issue order).  Needs dim / 32 divisible by 3 (a ring of
 // three units in registers, indexed at compile time).
-template <int TA, int KT, bool SPLIT, bool XSPLIT, bool XDIR = false>
+//
+// XDEEP (round 5; XDIR shapes with dim / 32 divisible by 12): the passes of groups >= 1 run a DEEPER look-ahead.  PMC of the XDIR
+// kernel (profiles/r04_rq_xdir.txt) showed its waves parked 63 % of their life at the per-unit wait: a unit's centroid slab and x
+// fragments were requested about one cycle (~0.6 us of MFMA) before their use, an L2 round trip of 1-2 us.  In those passes the
+// f32 x ring (96 of the 160 KiB) is dead, so its space is re-cut into 16-KiB slots (slot s = floats [s AFL, (s + 1) AFL)):
+//   pass 0           slots 0 1 2 = centroid ring (unit u in slot u mod 3)      3+4 | 5+6 | 7+8 = x ring X0 X1 X2 (f32, 32 KiB each)
+//   passes >= 1      deep unit v = (g - 1) U + u:  centroid slab in slot {0, 1, 2, 8}[v mod 4],
+//                    its f16 x fragments (LDS-DMA from the scratch: [k-step][thread] x 16 B) in slot {3, 4, 5, 7}[v mod 4]
+// Deep unit v + 3 is requested in cycle v (three cycles ahead, both operands through LDS: no register ring), and the counted
+// wait lets the requests of the last TWO windows fly.  The hand-overs reuse the XDIR kernel's request times: pass 0's last two
+// cycles request deep units 0 and 1 (slots 0 / 3 and 1 / 4 are free by then), deep cycle 0 requests units 2 AND 3, the last two
+// deep cycles request the next row tile's centroid units 0, 1 (slots 0, 1) and x units 0, 1 (X0, X1) -- every target slot's
+// previous tenant has been read by then (checked case by case in DESIGN 4.3b).  Same MFMA sequence per row: same codes.
+template <int TA, int KT, bool SPLIT, bool XSPLIT, bool XDIR = false, bool XDEEP = false>
 __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   static_assert(!(SPLIT && XSPLIT), "one or the other");
   static_assert(!XDIR || (!SPLIT && !XSPLIT), "XDIR: plain f16 fragments");
+  static_assert(!XDEEP || (XDIR && TA == 8), "XDEEP: a refinement of the XDIR kernels (16-KiB centroid units)");
   constexpr int NB = (SPLIT || XSPLIT) ? 2 : 1;   // B fragments per k-step: hi (, lo)
   constexpr int AROWS = TA * 32 * (SPLIT ? 2 : 1);   // image rows per unit (hi rows, then lo rows)
   constexpr int AFL = rf_a_floats<TA, SPLIT>();      // floats of a centroid unit
@@ -168,18 +182,20 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   // ---- DMA duties ---------------------------------------------------------------------------------------------------
   // x: piece q (8 rows x 128 B) of this wave's own 32 rows; lane (r8 = lane >> 3, slot = lane & 7) fetches logical piece
   // slot ^ g(row), g(row) = (row >> 1) & 7, so that the b128 fragment reads below are bank-conflict free
-  int voff_x[4];
+  // (two lane patterns serve the four pieces -- the swizzle key of piece q is (4 q + (r8 >> 1)) & 7: even | odd q -- and one serves
+  // every centroid piece; the rest of a piece's address is wave-uniform and rides in the instruction's scalar offset: per-lane
+  // invariants are what pass 0 has no registers for)
+  int voff_x[2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < 2; ++q) {
     const int r8 = lane >> 3, row = 32 * w8 + 8 * q + r8;
     voff_x[q] = row * p.x_row_stride + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
   }
   // centroid image: piece (16 rows x 64 B); lane (r16 = lane >> 2, slot = lane & 3) fetches piece slot ^ ((row >> 2) & 3)
-  int voff_a[PA_PER_WAVE];
-#pragma unroll
-  for (int i = 0; i < PA_PER_WAVE; ++i) {
-    const int row = 16 * (w8 * PA_PER_WAVE + i) + (lane >> 2);
-    voff_a[i] = row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+  int voff_a0;
+  {
+    const int row = 16 * (w8 * PA_PER_WAVE) + (lane >> 2);
+    voff_a0 = row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
   }
   const unsigned int a_block_bytes = (unsigned int)(AROWS * 64);  // one unit of one group's image
 
@@ -224,7 +240,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
 #pragma unroll
     for (int ia = 0; ia < PA_PER_WAVE; ++ia)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void *)(lds + ab * AFL + (16 * (w8 * PA_PER_WAVE + ia)) * 16),
-                                               16, voff_a[ia], u * (int)a_block_bytes, 0, 0);
+                                               16, voff_a0, u * (int)a_block_bytes + ia * 1024, 0, 0);
   };
   auto dma_x = [&](const Src &s, int u, int xb, int first, int count) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.x), 0, (int)s.xbytes, 0x00020000);
@@ -232,7 +248,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     for (int i = 0; i < 4; ++i) {
       if (i < first || i >= first + count) continue;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(lds + XBASE + xb * RF_XFL + (32 * w8 + 8 * i) * 32), 16,
-                                               voff_x[i], u * p.x_unit_stride, 0, 0);
+                                               voff_x[i & 1], u * p.x_unit_stride + (i >> 1) * 16 * p.x_row_stride, 0, 0);
     }
   };
 
@@ -265,8 +281,10 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     const int c0 = 4 * j + 2 * half;
     const float4 x0 = *reinterpret_cast<const float4 *>(ub + offb + ((c0 ^ b_sw) << 2));
     const float4 x1 = *reinterpret_cast<const float4 *>(ub + offb + (((c0 + 1) ^ b_sw) << 2));
-    const float4 m0 = *reinterpret_cast<const float4 *>(mus_l + 32 * u + 16 * j + 8 * half);
-    const float4 m1 = *reinterpret_cast<const float4 *>(mus_l + 32 * u + 16 * j + 8 * half + 4);
+    int h8 = 8 * half;
+    if constexpr (XDEEP) asm volatile("" : "+v"(h8));   // (not an invariant to keep: the unrolled cycles each held their own copy of this address)
+    const float4 m0 = *reinterpret_cast<const float4 *>(mus_l + 32 * u + 16 * j + h8);
+    const float4 m1 = *reinterpret_cast<const float4 *>(mus_l + 32 * u + 16 * j + h8 + 4);
     float v[8];
     v[0] = fmaf(x0.x, sx, -m0.x); v[1] = fmaf(x0.y, sx, -m0.y); v[2] = fmaf(x0.z, sx, -m0.z); v[3] = fmaf(x0.w, sx, -m0.w);
     v[4] = fmaf(x1.x, sx, -m1.x); v[5] = fmaf(x1.y, sx, -m1.y); v[6] = fmaf(x1.z, sx, -m1.z); v[7] = fmaf(x1.w, sx, -m1.w);
@@ -304,24 +322,41 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
 
   int ra_ = 0, rx_ = 0;  // ring slots of the unit being computed (centroid ring of 3, x ring of XB)
   // ---- XDIR: the fragment ring in registers, the scratch, the window count -------------------------------------------------------
-  f16x8 xr[XDIR ? 3 : 1][2];   // units u, u + 1, u + 2 of the stream, k-steps 0 | 1; slot = unit mod 3
+  f16x8 xr[XDIR && !XDEEP ? 3 : 1][2];   // units u, u + 1, u + 2 of the stream, k-steps 0 | 1; slot = unit mod 3 (XDEEP: through LDS)
   char *xs_t = XDIR ? p.xs + ((size_t)blockIdx.x * (size_t)(U * 2) * 512 + (size_t)t) * 16 : nullptr;   // + k-step * 8192
   int win = 0;   // vector-memory operations issued since the last counted wait (wave-uniform)
   // everything issued BEFORE the window has landed; the window's own operations may stay in flight (they retire in issue order)
-  auto wait_window = [&]() {
-    switch (win) {
-      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  int win_prev = 0;   // XDEEP: operations of the previous window (they too may stay in flight in the deep cycles)
+  auto wait_count = [&](int keep) {
+    switch (keep) {
+#define MEVI_RF_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      MEVI_RF_W(1) MEVI_RF_W(2) MEVI_RF_W(3) MEVI_RF_W(4) MEVI_RF_W(5) MEVI_RF_W(6) MEVI_RF_W(7) MEVI_RF_W(8) MEVI_RF_W(9)
+      MEVI_RF_W(10) MEVI_RF_W(11) MEVI_RF_W(12) MEVI_RF_W(13) MEVI_RF_W(14) MEVI_RF_W(15) MEVI_RF_W(16)
+#undef MEVI_RF_W
       default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     }
+  };
+  auto wait_window = [&]() {
+    wait_count(win);
+    win_prev = win;
     win = 0;
+  };
+  // XDEEP: k-step `part` of x16 unit uq (this wave's 64 fragments = 1 KiB of the scratch, [k-step][thread] x 16 B) -> LDS slot
+  // (the lane's thread index goes through an opaque copy at every use: left visible, the compiler hoists these addresses out of
+  // the tile loop, and pass 0 -- 128 accumulators + the conversion -- then spills into its cycles: scratch loads there are
+  // vector-memory operations whose `s_waitcnt vmcnt(0)` drains the whole DMA look-ahead; measured 26 -> 47 ms per encode)
+  auto dma_x16 = [&](int uq, int part, int slot) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xs + (size_t)blockIdx.x * (size_t)(U * 2) * 8192, 0, (int)(U * 2 * 8192), 0x00020000);
+    int tt = threadIdx.x;
+    asm volatile("" : "+v"(tt));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(lds + slot * AFL + (part * 512 + 64 * w8) * 4), 16,
+                                             tt * 16, (2 * uq + part) * 8192, 0, 0);
+  };
+  auto read_x16 = [&](int slot, int j, f16x8 (&b)[NB]) {
+    int tt = threadIdx.x;
+    asm volatile("" : "+v"(tt));
+    b[0] = *reinterpret_cast<const f16x8 *>(lds + slot * AFL + j * 2048 + tt * 4);
   };
   int grp_now = 0;   // group of the tile being computed (set with `grp` below; read by the lambdas)
   // k-step (u, j) of the tile in hand: group 0 converts it from the x ring (and, XDIR, stores the fragment); later groups (XDIR)
@@ -329,11 +364,22 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   auto get_x = [&](int u, int j, auto slot_c, f16x8 (&b)[NB]) {
     if constexpr (XDIR) {
       if (grp_now != 0) {
-        b[0] = xr[decltype(slot_c)::value][j];
+        if constexpr (XDEEP) read_x16(3, j, b);          // only the top-of-pass read of deep unit (g - 1) U: slot {3,4,5,7}[0]
+        else b[0] = xr[decltype(slot_c)::value][j];
         return;
       }
       read_x(rx_, u, j, b);
-      *reinterpret_cast<f16x8 *>(xs_t + (size_t)(2 * u + j) * 8192) = b[0];
+      if constexpr (XDEEP) {   // a buffer store (scalar base + 32-bit lane offset): the 64-bit store addresses of the unrolled cycles
+                               // were loop invariants the compiler kept -- and spilled into pass 0's cycles (see dma_x16)
+        typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            p.xs + (size_t)blockIdx.x * (size_t)(U * 2) * 8192, 0, (int)(U * 2 * 8192), 0x00020000);
+        int tt = threadIdx.x;
+        asm volatile("" : "+v"(tt));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, b[0]), rs, tt * 16, (2 * u + j) * 8192, 0);
+      } else {
+        *reinterpret_cast<f16x8 *>(xs_t + (size_t)(2 * u + j) * 8192) = b[0];
+      }
       ++win;
     } else {
       read_x(rx_, u, j, b);
@@ -344,8 +390,12 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   auto issue_x = [&](const Src &tx, int tgrp, int tux, int wbx, int part, auto slot_c) {
     if constexpr (XDIR) {
       if (tgrp != 0) {
-        const char *src = xs_t + (size_t)(2 * tux + part) * 8192;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[decltype(slot_c)::value][part]) : "v"(src) : "memory");
+        if constexpr (XDEEP) {     // the first deep units (0, 1), requested by pass 0's last two cycles: slots 3, 4
+          dma_x16(tux, part, 3 + tux);
+        } else {
+          const char *src = xs_t + (size_t)(2 * tux + part) * 8192;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[decltype(slot_c)::value][part]) : "v"(src) : "memory");
+        }
         ++win;
         return;
       }
@@ -412,6 +462,68 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // ---- XDEEP: one unit of a pass of group >= 1 (deep unit v, v mod 4 = I), look-ahead of three units through LDS ------------------
+  auto dma_a_grp = [&](int gq, int uq, int slot) {
+    Src s;
+    s.x = nullptr, s.xbytes = 0u;
+    s.a = reinterpret_cast<const char *>(p.img) + (size_t)gq * U * a_block_bytes;
+    dma_a(s, true, uq, slot);
+  };
+  auto cycle_deep = [&](int v, auto i4, bool last) {
+    constexpr int I = decltype(i4)::value;
+    constexpr int CS[4] = {0, 1, 2, 8}, XS[4] = {3, 4, 5, 7};
+    const int V = (p.ngroups - 1) * U;        // deep units of a row tile
+    const int w = v + 3;
+    int x_uq = -1, nx = -1;                   // this cycle's x16 request (deep unit w) | the next row tile's f32 x unit (stream end)
+    if (w < V) {
+      if (v == 0) {                           // the ramp: units 0, 1 came from pass 0's last cycles, unit 2 is requested here too
+        dma_a_grp(1, 2, CS[2]);
+        win += PA_PER_WAVE;
+      }
+      int gq = 1, uq = w;
+      while (uq >= U) uq -= U, ++gq;
+      dma_a_grp(gq, uq, CS[(I + 3) & 3]);
+      win += PA_PER_WAVE;
+      x_uq = uq;
+    } else if (v >= V - 2) {                  // next row tile's pass 0 (its prologue state), at the XDIR kernel's request times
+      nx = v - (V - 2);
+      dma_a(nxt, have_nxt, nx, nx);
+      win += PA_PER_WAVE;
+    }
+    auto x_half = [&](int part) {
+      if (x_uq >= 0) {
+        if (v == 0) dma_x16(2, part, XS[2]), ++win;
+        dma_x16(x_uq, part, XS[(I + 3) & 3]), ++win;
+      } else if (nx >= 0) {
+        dma_x(nxt, nx, nx, 2 * part, 2), win += 2;
+      }
+    };
+    read_a(CS[I], 0, H, ahi);
+    mma_lo(bq0);
+    x_half(0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(CS[I], 1, 0, alo);
+    read_x16(XS[I], 1, bq1);
+    mma_hi(bq0);
+    x_half(1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(CS[I], 1, H, ahi);
+    mma_lo(bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    // unit v + 1 must have landed: it was requested three windows ago, so the requests of the last TWO windows may stay in flight --
+    // except on the ramp (units 1, 2 were requested in the previous window) and in the stream's last cycle (the next tile's unit 0 was)
+    const bool one = v < 2 || v == V - 1;
+    wait_count(one ? win : win_prev + win);
+    win_prev = win, win = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last) {
+      read_a(CS[(I + 1) & 3], 0, 0, alo);
+      read_x16(XS[(I + 1) & 3], 0, bq0);
+    }
+    mma_hi(bq1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // prologue: unit 0 (waited for); centroid units up to DA - 1 and x unit 1 stay in flight
   dma_a(cur, true, 0, 0);
   dma_x(cur, 0, 0, 0, 4);
@@ -441,7 +553,16 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
     using C1 = std::integral_constant<int, 1>;
     using C2 = std::integral_constant<int, 2>;
     get_x(0, 0, C0(), bq0);
-    if constexpr (XDIR) {       // U is a multiple of 3 (checked by the host): the ring slots are compile-time constants
+    using C3 = std::integral_constant<int, 3>;
+    if (XDEEP && grp != 0) {    // U is a multiple of 12 (host): deep unit (grp - 1) U + u sits in the slots of u mod 4
+      const int v0 = (grp - 1) * U;
+      for (int u = 0; u < U; u += 4) {
+        cycle_deep(v0 + u, C0(), false);
+        cycle_deep(v0 + u + 1, C1(), false);
+        cycle_deep(v0 + u + 2, C2(), false);
+        cycle_deep(v0 + u + 3, C3(), u + 4 >= U);
+      }
+    } else if constexpr (XDIR) {       // U is a multiple of 3 (checked by the host): the ring slots are compile-time constants
       for (int u = 0; u < U - 3; u += 3) {
         cycle(u, C0(), false);
         cycle(u + 1, C1(), false);
@@ -607,10 +728,10 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
 
 // (the body lives in a __device__ function: the host pass instantiates a kernel template's own body, and the buffer / LDS
 // builtins above do not exist there)
-template <int TA, int KT, bool SPLIT, bool XSPLIT, bool XDIR = false>
+template <int TA, int KT, bool SPLIT, bool XSPLIT, bool XDIR = false, bool XDEEP = false>
 __global__ __launch_bounds__(512, 2) void rq_fast_kernel(const RfParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rq_fast_body<TA, KT, SPLIT, XSPLIT, XDIR>(p, lds);
+  rq_fast_body<TA, KT, SPLIT, XSPLIT, XDIR, XDEEP>(p, lds);
 }
 
 // ---- prep kernels (codebook only: a few hundred KB) -------------------------------------------------------------------------
@@ -864,10 +985,10 @@ using namespace mevi;
 namespace {
 struct RfPlan {
   int Kp, KT, LPG, ngroups, TA;
-  bool ok, split, xsplit, xdir;
+  bool ok, split, xsplit, xdir, xdeep;
 };
 RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
-  RfPlan pl = {0, 0, 0, 0, 0, false, false, false, false};
+  RfPlan pl = {0, 0, 0, 0, 0, false, false, false, false, false};
   if (dim % 32 != 0 || dim < 96 || dim > 8192 || M < 1 || M > 8 || K < 1 || K > 256) return pl;
   int Kp = 32;
   while (Kp < K) Kp <<= 1;
@@ -894,6 +1015,10 @@ RfPlan rf_plan(int64_t dim, int64_t M, int64_t K) {
   const char *xd = getenv("MEVI_RQ_XDIRECT");
   pl.xdir = pl.ok && pl.ngroups > 1 && pl.TA == 8 && pl.KT >= 4 && !pl.split && !pl.xsplit && (dim / 32) % 3 == 0 && dim / 32 >= 6 &&
             !(xd && atoi(xd) == 0);
+  // ... and, where the unit count allows (a ring of three in pass 0, of four in the later passes), those later passes three units
+  // ahead through the dead x ring (rq_fast_body, XDEEP); MEVI_RQ_XDEEP=0: the XDIR kernel of round 4 (A/B)
+  const char *xe = getenv("MEVI_RQ_XDEEP");
+  pl.xdeep = pl.xdir && (dim / 32) % 12 == 0 && !(xe && atoi(xe) == 0);
   return pl;
 }
 constexpr int RF_GRID = 256;  // persistent workgroups (one per CU of the MI355X); 8 record regions each
@@ -1030,6 +1155,8 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
 #undef MEVI_RF_PICK
   if (pl.xdir && pl.KT == 4) fn = reinterpret_cast<const void *>(rq_fast_kernel<8, 4, false, false, true>);
   if (pl.xdir && pl.KT == 8) fn = reinterpret_cast<const void *>(rq_fast_kernel<8, 8, false, false, true>);
+  if (pl.xdeep && pl.KT == 4) fn = reinterpret_cast<const void *>(rq_fast_kernel<8, 4, false, false, true, true>);
+  if (pl.xdeep && pl.KT == 8) fn = reinterpret_cast<const void *>(rq_fast_kernel<8, 8, false, false, true, true>);
   MEVI_REQUIRE(fn != nullptr, MEVI_ERR_UNSUPPORTED, "rq_encode_fast: no kernel for TA=%d KT=%d", pl.TA, pl.KT);
   MEVI_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   {

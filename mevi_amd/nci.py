@@ -215,6 +215,11 @@ class PrefixTables:
         cache, spent = None, 0
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
+        self.level_ms = []                      # build time per position (a synchronisation per level: the build is rare)
+
+        def lap():
+            torch.cuda.synchronize(dev)
+            self.level_ms.append(round((time.perf_counter() - t0) * 1e3 - sum(self.level_ms), 2))
 
         def worth(n, p):
             if expected_queries is None:
@@ -248,6 +253,7 @@ class PrefixTables:
                     for kl in self.kv:                        # the build's buffers (tables + a chunk's tail) are not needed again
                         kl[:] = [k.clone() for k in kl]
                     self._cat, self._retired = None, []
+                    lap()
                 break
             if p == 0:
                 tokens = torch.zeros(1, dtype=torch.int64, device=dev)                    # decoder_start_token_id
@@ -271,6 +277,7 @@ class PrefixTables:
                 self.avec.append(a)
                 spent += n * d * 4
             self.levels = p + 1
+            lap()
         self.bytes = spent
         torch.cuda.synchronize(dev)
         self.build_ms = (time.perf_counter() - t0) * 1e3
@@ -279,7 +286,7 @@ class PrefixTables:
         """What was tabled, for the bench line / logs."""
         return {"levels": self.levels, "head_matrices_at": [p for p in range(self.levels) if self.tmat[p] is not None],
                 "adaptor_vectors_only_at": [p for p in range(self.levels) if self.tmat[p] is None], "bytes": self.bytes,
-                "build_ms": round(self.build_ms, 2), "expected_queries": self.expected_queries, "beams": self.beams}
+                "build_ms": round(self.build_ms, 2), "level_ms": self.level_ms, "expected_queries": self.expected_queries, "beams": self.beams}
 
     def indexed_cache(self, adaptor, pidx, p):
         """IndexedPrefixCache of beams whose prefix index at position p = self.levels is `pidx` -- for a position whose cache

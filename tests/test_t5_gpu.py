@@ -380,6 +380,70 @@ def test_device_sized_prefix_tables_for_the_3x256_codebook_keep_the_bits(cuda):
     assert torch.equal(d0, d1) and np.array_equal(np.asarray(s0), np.asarray(s1))
 
 
+def test_prefix_tables_sized_for_the_workload_cost_a_one_shot_eval_nothing(cuda):
+    """a one-shot `main.py --mode eval` over MS MARCO dev (6980 queries) must not pay seconds of table build
+    for prefixes it never visits.  With the run's query count passed (EvalRun.run -> NCIModel.expect_queries) a position is
+    tabled only when queries x beams outnumber its prefixes: at (3, 256) that leaves positions 0 and 1 (the 65 536 two-code
+    prefixes and the 16.7 M of the final position are not worth 69 800 beam rows) -- the first pass, build included, is not
+    slower than with the former 6 GiB budget, which the device-sized default of a long-lived model loses to by seconds; same
+    beams, same score bits under every policy.  (4, 32): positions 0..3 tabled, the 1 M prefixes of the final position not."""
+    import sys
+    import time
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+
+    free, _ = torch.cuda.mem_get_info(cuda)
+    if free < (220 << 30):
+        pytest.skip("needs a 288 GB device (the long-lived policy tables 103 GB)")
+    nq = 6980
+    ids, mask = synth.query_ids(nq, cuda, np.random.default_rng(3))
+
+    def first_pass(model):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        d, s = model.generate(ids, mask, num_beams=10)[:2]
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) * 1e3, d, np.asarray(s)
+
+    model, _, _, _ = synth.build(cuda, 3, 256, None)
+    del _
+    model.prefix_table_bytes = 0
+    model.generate(ids[:256], mask[:256], num_beams=10)               # kernels warm, allocator grown, no table yet
+    model.prefix_table_bytes = None
+    model.expect_queries(nq)
+    t_work, d0, s0 = first_pass(model)
+    tab = model.tables()
+    assert tab.levels == 2 and tab.expected_queries == nq and tab.build_ms < 200, tab.describe()
+    model.prefix_table_queries, model.prefix_table_bytes, model._tables = None, 6 << 30, None
+    t_6g, d1, s1 = first_pass(model)
+    assert model.tables().levels == 3
+    assert torch.equal(d0, d1) and np.array_equal(s0, s1)
+    assert t_work <= t_6g * 1.10, (t_work, t_6g)
+    model.prefix_table_queries, model.prefix_table_bytes, model._tables = None, None, None
+    t_all, d2, s2 = first_pass(model)                                   # the long-lived policy: every table that fits
+    assert model.tables().levels == 4 and model.tables().build_ms > 500
+    assert torch.equal(d0, d2) and np.array_equal(s0, s2)
+    assert t_work < t_all, (t_work, t_all)
+    # a larger workload announced later rebuilds (more positions pay); a smaller one keeps what exists
+    model._tables = None
+    model.expect_queries(1000)
+    assert model.tables(10).levels == 2
+    model.expect_queries(100000)
+    assert model._tables is None and model.tables(10).levels == 3
+    del model
+    torch.cuda.empty_cache()
+    model, _, _, _ = synth.build(cuda, 4, 32, None)
+    del _
+    model.expect_queries(nq)
+    d0, s0 = model.generate(ids[:500], mask[:500], num_beams=10)[:2]
+    assert model.tables().levels == 4 and model.tables().tmat[3] is not None
+    model.prefix_table_queries, model._tables = None, None
+    d1, s1 = model.generate(ids[:500], mask[:500], num_beams=10)[:2]
+    assert model.tables().levels == 5
+    assert torch.equal(d0, d1) and np.array_equal(np.asarray(s0), np.asarray(s1))
+
+
 def test_graph_replay_of_small_batches_equals_the_eager_pass(cuda):
     """graph=True: batches of <= GRAPH_MAX_ROWS queries replay one captured HIP graph of the whole tower forward / beam
     search; first call eager, second captures, later ones replay with new inputs -- all bit-identical to the eager,

@@ -42,7 +42,7 @@ while [ $# -gt 0 ]; do
       name=${rest%%:*}; cmd=$(plus "${rest#*:}"); OUT=$O/trace_$name; rm -rf $OUT; mkdir -p $OUT
       (cd /tmp && TRACE_GAP=1 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/$cmd > $OUT/log.txt 2>&1)
       grep -v "^[EW]20" $OUT/log.txt | tail -n 2
-      python3 tools/trace_tail.py $OUT $O/${name}_timed_pass_kernel_stats.csv; rm -rf $OUT;;
+      python3 tools/trace_tail.py $OUT $O/${name}_timed_pass_kernel_stats.csv > $O/${name}_timed_pass.txt; head -40 $O/${name}_timed_pass.txt; rm -rf $OUT;;
     stats_bench)
       OUT=$O/stats_bench; rm -rf $OUT; mkdir -p $OUT
       (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-seq2seq-legs > $OUT/bench.log 2>&1)

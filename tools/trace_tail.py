@@ -16,6 +16,12 @@ for i in range(1, len(rows)):
     if rows[i][0] - rows[i - 1][1] >= gap:
         cut = i
 rows = rows[cut:]
+if os.environ.get("TIMELINE"):       # every launch of the phase: start offset, duration, idle gap before it
+    t0, prev = rows[0][0], rows[0][0]
+    for s_, e_, n_ in rows:
+        print("%10.1f us  +%9.1f us  (gap %7.1f)  %s" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, (s_ - prev) / 1e3,
+                                                     n_.replace("mevi::(anonymous namespace)::", "")[:90]))
+        prev = e_
 agg = {}
 for s, e, n in rows:
     n = n.replace("mevi::(anonymous namespace)::", "").replace("void ", "")
