@@ -47,7 +47,7 @@ def ip_topk(query, docs, k, id_offset=0):
     if ws_bytes == 0:
         raise hip.MeviHipError(f"ip_topk: unsupported shape nq={nq} dim={dim} k={k}")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=query.device)
-    with torch.cuda.device(query.device):
+    with hip.device_guard(query.device):
         st = L.mevi_ip_topk_f32(hip.ptr(query), nq, hip.ptr(docs), nd, dim, k, id_offset,
                                 hip.ptr(out_s), hip.ptr(out_i), hip.ptr(ws), ws_bytes, hip.stream_ptr())
     hip.check(st, "mevi_ip_topk_f32")
@@ -68,7 +68,7 @@ class DenseIndex:
         L = hip.lib()
         nbytes = L.mevi_ip_index_bytes(nd, dim)
         self.index = torch.empty(nbytes, dtype=torch.uint8, device=docs.device)
-        with torch.cuda.device(docs.device):
+        with hip.device_guard(docs.device):
             st = L.mevi_ip_index_build_f32(hip.ptr(self.docs), nd, dim, hip.ptr(self.index), nbytes, hip.stream_ptr())
         hip.check(st, "mevi_ip_index_build_f32")
 
@@ -86,7 +86,7 @@ class DenseIndex:
         if ws_bytes == 0:
             raise hip.MeviHipError(f"ip_topk_indexed: unsupported shape nq={nq} dim={dim} k={k}")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=query.device)
-        with torch.cuda.device(query.device):
+        with hip.device_guard(query.device):
             st = L.mevi_ip_topk_indexed_f32(hip.ptr(query), nq, hip.ptr(self.docs), hip.ptr(self.index), nd, dim, k,
                                             id_offset, hip.ptr(out_s), hip.ptr(out_i), hip.ptr(ws), ws_bytes,
                                             hip.stream_ptr())
@@ -114,7 +114,7 @@ def topk_merge(scores, ids, k_out):
         scores, ids, nlists = torch.stack(parts_s), torch.stack(parts_i), half
     out_s = torch.empty((nq, k_out), dtype=torch.float32, device=scores.device)
     out_i = torch.empty((nq, k_out), dtype=torch.int64, device=scores.device)
-    with torch.cuda.device(scores.device):
+    with hip.device_guard(scores.device):
         st = L.mevi_topk_merge_f32(hip.ptr(scores), hip.ptr(ids), nlists, nq, k_in, k_out,
                                    hip.ptr(out_s), hip.ptr(out_i), None, 0, hip.stream_ptr())
     hip.check(st, "mevi_topk_merge_f32")
@@ -169,7 +169,7 @@ def pack_lists(scores, ids):
     if not scores.is_cuda:       # the gloo CPU tests inject their own search / merge; same format
         return (scores.view(torch.int32).to(torch.int64) << 32) | (ids & 0xFFFFFFFF)
     out = torch.empty(scores.shape, dtype=torch.int64, device=scores.device)
-    with torch.cuda.device(scores.device):
+    with hip.device_guard(scores.device):
         hip.check(hip.lib().mevi_pack_lists_i64(hip.ptr(scores), hip.ptr(ids), scores.numel(), hip.ptr(out), hip.stream_ptr()),
                   "mevi_pack_lists_i64")
     return out
@@ -188,7 +188,7 @@ def merge_packed(gathered, k):
     out_s = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
     out_i = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
     unproven = torch.zeros(nq, dtype=torch.uint8, device=gathered.device)
-    with torch.cuda.device(gathered.device):
+    with hip.device_guard(gathered.device):
         st = hip.lib().mevi_topk_merge_packed_f32(hip.ptr(gathered), world, nq, kl, k, 1 if kl < k else 0, hip.ptr(out_s),
                                                   hip.ptr(out_i), hip.ptr(unproven), hip.stream_ptr())
     hip.check(st, "mevi_topk_merge_packed_f32")
@@ -372,7 +372,7 @@ def profile(query, doc, dim, topk, param, bs=[1, 2, 4, 8], device=None):
     print(f"Param {param} trained: {is_trained_before_train(param)}.")
     query = np.asarray(query, dtype=np.float32).reshape(-1, dim)
     nlist = ivf.parse_factory(param)
-    with torch.cuda.device(device):
+    with hip.device_guard(device):
         t = time.time()
         d = _as_device_f32(np.asarray(doc).reshape(-1, dim) if isinstance(doc, np.ndarray) else doc, device)
         torch.cuda.synchronize()

@@ -160,8 +160,39 @@ def require_gpu():
                            "mevi_amd has no CPU fallback")
 
 
+# Host cost of a launch: the small-batch passes (the reference's own batch sizes) are ~250-550 launches during which the GPU
+# mostly waits for Python.  cProfile of a 128-query tower pass (tools/prof_host.py, 4.5 ms for 247 launches): the public
+# `torch.cuda.current_stream()` took 7.7 us per call and `with torch.cuda.device(...)` 4-8 us -- more than the ctypes call
+# itself.  The raw hooks below are what torch's own Python wrappers end in.
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
 def stream_ptr():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current device's current stream as an integer handle (ctypes passes it as void *); the capturing stream inside
+    `torch.cuda.graph`."""
+    return _raw_stream(_cur_device())
+
+
+class _NoGuard:
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(dev):
+    """`with device_guard(t.device):` = `with torch.cuda.device(t.device):`, for free when that device is already current."""
+    idx = dev.index
+    if idx is None or idx == _cur_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def on_device(fn):
@@ -172,7 +203,7 @@ def on_device(fn):
     @functools.wraps(fn)
     def run(*args, **kw):
         t = next((a for a in args if torch.is_tensor(a)), None)
-        if t is None or not t.is_cuda or t.device.index == torch.cuda.current_device():
+        if t is None or not t.is_cuda or t.device.index == _cur_device():
             return fn(*args, **kw)
         with torch.cuda.device(t.device):
             return fn(*args, **kw)
@@ -181,4 +212,5 @@ def on_device(fn):
 
 
 def ptr(t):
-    return c_void_p(t.data_ptr())
+    """Device address of a tensor's first element, as the integer ctypes passes for a void * argument."""
+    return t.data_ptr()

@@ -103,8 +103,13 @@ def gemm_input(x):
     return split_rows(x) if GEMM_MODE == "split" and not isinstance(x, SplitRows) else x
 
 
+def split_kp(k):
+    """mevi_split_kp (csrc/gemm_split.hip) without the foreign call: whole 32-wide slabs, at least two."""
+    return 64 if k <= 64 else (k + 31) // 32 * 32
+
+
 def _split_buffers(M, K, dev, zero=False):
-    kp = int(hip.lib().mevi_split_kp(K))
+    kp = split_kp(K)
     img = (torch.zeros if zero and kp != K else torch.empty)((M, 2 * kp), dtype=torch.int16, device=dev)
     return img, torch.empty((M,), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev)
 
@@ -144,7 +149,7 @@ def _pow2_exp(m):
 
 def _ctx_image(rows, k, bound, dev):
     """SplitRows for `rows` context rows of width k, all with the exponent of `bound`; returns (image, np, exponent)."""
-    kp = int(hip.lib().mevi_split_kp(k))
+    kp = split_kp(k)
     img = (torch.zeros if kp != k else torch.empty)((rows, 2 * kp), dtype=torch.int16, device=dev)
     e = _pow2_exp(bound * 1.001)
     fill = _EXP_FILL.get((dev, e))
@@ -160,7 +165,7 @@ def _ctx_image(rows, k, bound, dev):
 def split_rows(x):
     """SplitRows image of x f32 [m, k] (last dim contiguous)."""
     x, M, K, ldx = _rows2d(_f32(x))
-    with torch.cuda.device(x.device):
+    with hip.device_guard(x.device):
         img, exp, norm = _split_buffers(M, K, x.device)
         st = hip.lib().mevi_split_rows_f16(hip.ptr(x), ldx, M, K, hip.ptr(img), hip.ptr(exp), hip.ptr(norm), hip.stream_ptr())
     hip.check(st, "mevi_split_rows_f16")
@@ -179,7 +184,7 @@ def _linear_normed(nr, weight, bias, residual, act, out, for_gemm):
             (bias is not None and bias.data_ptr() % 16):
         return None
     dev = weight.device
-    with torch.cuda.device(dev):
+    with hip.device_guard(dev):
         if for_gemm:
             if residual is not None or out is not None or weight.norm_max is None:
                 return None
@@ -222,7 +227,7 @@ def _linear_split(x, weight, bias, residual, act, out, for_gemm):
     if for_gemm:       # act(x W^T + b) as the next GEMM's operand
         assert residual is None and out is None and xs.norm is not None and weight.norm_max is not None
         babs = _abs_max(bias) if bias is not None else 0.0
-        with torch.cuda.device(dev):
+        with hip.device_guard(dev):
             img, exp, norm = _split_buffers(M, N, dev, zero=True)
             st = L.mevi_gemm_nt_split_to_split(hip.ptr(xs.img), hip.ptr(xs.exp), hip.ptr(xs.norm), hip.ptr(weight.img),
                                                hip.ptr(weight.exp), weight.norm_max, M, N, K,
@@ -237,7 +242,7 @@ def _linear_split(x, weight, bias, residual, act, out, for_gemm):
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
         ldr = residual.stride(0)
-    with torch.cuda.device(dev):
+    with hip.device_guard(dev):
         st = L.mevi_gemm_nt_split_f32(hip.ptr(xs.img), hip.ptr(xs.exp), hip.ptr(weight.img), hip.ptr(weight.exp),
                                       hip.ptr(out), out.stride(0), M, N, K,
                                       hip.ptr(bias) if bias is not None else None,

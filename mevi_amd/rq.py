@@ -32,7 +32,7 @@ def last_encode_stats():
         import ctypes
 
         out = (ctypes.c_int64 * 3)()
-        with torch.cuda.device(ws.device):
+        with hip.device_guard(ws.device):
             hip.check(hip.lib().mevi_rq_encode_fast_stats(hip.ptr(ws), st["n"], st["dim"], st["M"], st["K"], out, hip.stream_ptr()),
                       "mevi_rq_encode_fast_stats")
         st.update(records=int(out[0]), rows_reencoded_exactly=int(out[1]), ambiguous_row_levels=int(out[2]))
@@ -61,7 +61,7 @@ def rq_encode(x, codebook, mode=None):
     codes = torch.empty((n, M), dtype=torch.int32, device=x.device)
     L = hip.lib()
     _LAST_ENCODE.clear()
-    with torch.cuda.device(x.device):
+    with hip.device_guard(x.device):
         nbytes = L.mevi_rq_encode_fast_workspace_bytes(n, dim, M, K) if mode == "fast" and n > 0 else 0
         if nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -91,7 +91,7 @@ def cluster_means(x, labels, K, old=None):
     L = hip.lib()
     nbytes = L.mevi_cluster_means_workspace_bytes(n, dim, K)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with hip.device_guard(x.device):
         st = L.mevi_cluster_means_f32(hip.ptr(x), n, dim, hip.ptr(labels), 1, K,
                                       hip.ptr(old.contiguous()) if old is not None else None, hip.ptr(cent),
                                       hip.ptr(counts), hip.ptr(sumsq), hip.ptr(ws), nbytes, hip.stream_ptr())
@@ -174,7 +174,7 @@ def train_rq_codebook(x, M, K, seed=0, **kw):
         book.append(centers)
         codes.append(labels)
         if level != M - 1:
-            with torch.cuda.device(x.device):   # res -= centers[labels], row by row in place
+            with hip.device_guard(x.device):   # res -= centers[labels], row by row in place
                 st = L.mevi_gather_sub_f32(hip.ptr(res), hip.ptr(src), hip.ptr(centers), hip.ptr(labels), n, dim,
                                            hip.ptr(res), hip.stream_ptr())
             hip.check(st, "mevi_gather_sub_f32")
@@ -365,7 +365,7 @@ class ProductQuantization:
         softmax(-distance) times the running beam probability, top-R over beams x K.  Returns labels
         i32[bs, R, M] (and probabilities f32[bs, R])."""
         assert not do_sample and num_beams in (None, num_return_sequences)
-        with torch.cuda.device(self.device):          # stream_ptr() and the launches below refer to the codebook's GPU
+        with hip.device_guard(self.device):          # stream_ptr() and the launches below refer to the codebook's GPU
             return self._beam_search(doc_emb, num_return_sequences, return_proba)
 
     def _beam_search(self, doc_emb, num_return_sequences, return_proba):

@@ -37,6 +37,11 @@ def test_workspace_queries_are_pure_host_arithmetic():
     assert a > 2 * 6980 * 4096 * 8
     assert L.mevi_ip_topk_workspace_bytes(6980, 768, 5000) == 0   # k > 4096 unsupported
     assert L.mevi_ip_topk_workspace_bytes(0, 768, 10) == 0
+    # the image width the host computes without a foreign call is the library's
+    from mevi_amd import ops
+
+    for k in list(range(1, 300)) + [767, 768, 769, 2048, 3072, 3073, 100000]:
+        assert ops.split_kp(k) == L.mevi_split_kp(k), k
 
 
 def test_product_path_fails_loudly_without_gpu():
