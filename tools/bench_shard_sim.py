@@ -6,6 +6,10 @@ its proof (the real payload shape: W x nq x k_local packed i64; rank 0's own lis
 
     python tools/bench_shard_sim.py [out.json]            # W in {1, 2, 4, 8}; efficiency = T(1) / (W x (search + post))
     SWEEP=1 python tools/bench_shard_sim.py               # also sweeps the chunk schedule knobs at W = 8 and W = 1
+    python tools/bench_shard_sim.py out.json --layout sorted   # + the adversarial layout: the corpus sorted by its score against
+                                                          #   the mean query, so that shard 0 holds most of every top-k and the
+                                                          #   truncated first round fails (second round: full-k lists)
+    python tools/bench_shard_sim.py out.json --predict-c5 # + the seq2seq legs at 6980 / 873 queries: predicted 8-GPU chain
 
 The all-gather itself cannot be measured on a 1-GPU box: `allgather_payload_bytes` / (7 links x ~153 GB/s) is quoted as the
 xGMI floor.  VERDICT r2 #1 target: efficiency >= 0.94 at W = 8."""
@@ -90,6 +94,76 @@ for world in (1, 2, 4, 8):
     del index, docs
     torch.cuda.empty_cache()
 
+def all_shards(world, corpus=None, tag="bench"):
+    """The W-way search with EVERY shard searched in turn on this device (one resident at a time): the true first-round lists
+    of all ranks, the merge's proof, the second round it asks for -- per-rank times of both rounds, max over ranks."""
+    per_rank, lists = [], []
+    kl = dense.truncated_list_len(k, world)
+    for r in range(world):
+        a, b = dense.shard_range(bench.N_DOCS, r, world)
+        docs = corpus[a:b] if corpus is not None else bench.gen_shard(a, b, dev, bench.N_DOCS)
+        index = dense.DenseIndex(docs)
+        ms, (s, i) = timed(lambda: index.search(query, kl, id_offset=a), 3)
+        lists.append(dense.pack_lists(s, i))
+        per_rank.append({"rank": r, "round1_search_ms": round(ms, 3)})
+        del index, docs
+    gathered = torch.stack(lists)
+    post_ms, (ms_, mi_, unproven) = timed(lambda: dense.merge_packed(gathered, k), 3)
+    q2 = torch.nonzero(unproven).view(-1)
+    out = {"layout": tag, "world": world, "k_local": kl, "round1_search_ms_max": max(p["round1_search_ms"] for p in per_rank),
+           "round1_post_ms": round(post_ms, 3), "second_round_queries": int(q2.numel())}
+    if q2.numel():
+        qq = query[q2].contiguous()
+        lists2 = []
+        for r in range(world):
+            a, b = dense.shard_range(bench.N_DOCS, r, world)
+            docs = corpus[a:b] if corpus is not None else bench.gen_shard(a, b, dev, bench.N_DOCS)
+            index = dense.DenseIndex(docs)
+            ms, (s, i) = timed(lambda: index.search(qq, k, id_offset=a), 3)
+            lists2.append(dense.pack_lists(s, i))
+            per_rank[r]["round2_search_ms"] = round(ms, 3)
+            del index, docs
+        g2 = torch.stack(lists2)
+        post2, (ms2, mi2, un2) = timed(lambda: dense.merge_packed(g2, k), 3)
+        out["round2_search_ms_max"] = max(p["round2_search_ms"] for p in per_rank)
+        out["round2_post_ms"] = round(post2, 3)
+        out["round2_queries_per_s_per_rank"] = round(q2.numel() / out["round2_search_ms_max"] * 1e3, 1)
+        out["unproven_after_round2"] = int(un2.sum().item())
+        out["allgather_round2_bytes_per_rank"] = int(q2.numel()) * k * 8
+        ms_[q2], mi_[q2] = ms2, mi2
+    out["per_rank_total_ms"] = out["round1_search_ms_max"] + out["round1_post_ms"] + out.get("round2_search_ms_max", 0.0) + out.get("round2_post_ms", 0.0)
+    out["per_rank"] = per_rank
+    return out, (ms_, mi_)
+
+
+extra = {}
+if "--layout" in sys.argv and sys.argv[sys.argv.index("--layout") + 1] == "sorted":
+    corpus = bench.gen_shard(0, bench.N_DOCS, dev, bench.N_DOCS)
+    ref_s, ref_i = dense.DenseIndex(corpus).search(query, k)                       # the un-sharded answer (ids of the ORIGINAL layout)
+    order = torch.argsort(corpus @ query.mean(0), descending=True)                # rows most like the mean query first: shard 0 is hot
+    corpus = corpus[order].contiguous()
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel(), device=dev)
+    lay = []
+    for world in (2, 4, 8):
+        o, (ms_, mi_) = all_shards(world, corpus, "sorted by score against the mean query (shard 0 holds most of every top-k)")
+        got = torch.sort(order[mi_.clamp_min(0)], 1)[0]                        # ids mapped back to the original layout
+        o["same_documents_as_unsharded"] = bool(torch.equal(got, torch.sort(ref_i, 1)[0]))
+        o["rows_with_other_documents"] = int((got != torch.sort(ref_i, 1)[0]).any(1).sum().item())
+        o["scores_bit_equal_to_unsharded"] = bool(torch.equal(ms_.view(torch.int32), ref_s.view(torch.int32)))
+        o["note"] = ("rows_with_other_documents: exact score ties at the k-th position -- a tie goes to the lower id, and ids are "
+                     "positions in the layout; the score lists are bit-equal")
+        o["efficiency_vs_w1_bench_layout"] = rows[0]["per_rank_total_ms"] / (world * o["per_rank_total_ms"])
+        lay.append(o)
+        print(json.dumps({k_: v for k_, v in o.items() if k_ != "per_rank"}), flush=True)
+    extra["sorted_layout"] = lay
+    del corpus, order, inv
+    torch.cuda.empty_cache()
+if "--all-shards" in sys.argv or "--predict-c5" in sys.argv:
+    o, _ = all_shards(8)
+    extra["bench_layout_all_8_shards"] = o
+    print(json.dumps({k_: v for k_, v in o.items() if k_ != "per_rank"}), flush=True)
+
 t1 = rows[0]["per_rank_total_ms"]
 for r in rows:
     r["ideal_ms"] = t1 / r["world"]
@@ -98,6 +172,40 @@ summary = {"what": "per-rank cost of dense.sharded_ip_topk on one MI355X simulat
                    "8,841,823 x 768 docs, top-1000); efficiency = T(W=1) / (W x (local search + pack/unpack/merge/proof)); the "
                    "all-gather's wire time is not included (1-GPU box): see allgather_xgmi_floor_ms",
            "device": torch.cuda.get_device_name(0), "reps": REPS, "rows": rows}
+summary.update(extra)
+if "--predict-c5" in sys.argv:
+    # BASELINE.json configs[4] predicted from one GPU: what a rank of 8 runs is the dense arm on its shard (above) and the seq2seq
+    # arm + both tower passes + the fine stage on ITS 873 queries (DistributedSampler, MEVI/main.py:318-322)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import numpy as np
+    import batch_sweep
+    import synth
+
+    torch.cuda.empty_cache()
+    model, tower, _, _ = synth.build(dev, 4, 32, None)
+    ids, mask = synth.query_ids(nq, dev, np.random.default_rng(0))
+    model.generate(ids, mask, num_beams=10)
+    sw = {r["queries"]: r for r in batch_sweep.sweep(model, tower, ids, mask, 4, 32, 10, (873, nq), bench.seq2seq_flops, bench.tower_flops)}
+    fine_ms_1 = float(os.environ.get("FINE_MS", "2.7"))               # fine stage of 6980 queries (chain_c4.stage_ms.fine_stage)
+    w8 = next(r for r in rows if r["world"] == 8)
+    dense8 = extra.get("bench_layout_all_8_shards", {}).get("per_rank_total_ms", w8["per_rank_total_ms"]) + w8["allgather_xgmi_floor_ms"]
+    one = 2 * sw[nq]["tower_ms"] + rows[0]["per_rank_total_ms"] + sw[nq]["nci_ms"] + fine_ms_1
+    eight = 2 * sw[873]["tower_ms"] + dense8 + sw[873]["nci_ms"] + fine_ms_1 / 8
+    summary["predicted_c5"] = {
+        "what": "chain per rank at 8 GPUs = 2 x tower(873 queries) + sharded dense search of all 6980 queries on 1/8 of the corpus "
+                "(+ the all-gather's xGMI floor) + beam search(873) + fine stage / 8, against the same sum at 1 GPU; all legs measured "
+                "in this process on one MI355X.  To be falsified by the first SCALE run.",
+        "one_gpu": {"tower_ms": sw[nq]["tower_ms"], "dense_ms": rows[0]["per_rank_total_ms"], "nci_ms": sw[nq]["nci_ms"], "fine_ms": fine_ms_1,
+                    "chain_ms": round(one, 2), "queries_per_s": round(nq / one * 1e3, 1)},
+        "eight_gpus_per_rank": {"tower_ms": sw[873]["tower_ms"], "dense_ms": round(dense8, 3), "nci_ms": sw[873]["nci_ms"],
+                                "nci_frac": sw[873].get("nci_frac"), "tower_frac": sw[873].get("tower_frac"),
+                                "fine_ms": round(fine_ms_1 / 8, 3), "chain_ms": round(eight, 2), "queries_per_s": round(nq / eight * 1e3, 1)},
+        "predicted_efficiency": {"dense_arm": round(rows[0]["per_rank_total_ms"] / (8 * dense8), 4),
+                                 "target_dense_arm": "within 15 % of linear (north_star): >= 0.85",
+                                 "tower": round(sw[nq]["tower_ms"] / (8 * sw[873]["tower_ms"]), 4),
+                                 "beam_search": round(sw[nq]["nci_ms"] / (8 * sw[873]["nci_ms"]), 4),
+                                 "whole_chain": round(one / (8 * eight), 4)}}
+    print(json.dumps(summary["predicted_c5"]), flush=True)
 if sweep:
     summary["schedule_sweep"] = sweep
 print(json.dumps({"efficiency": {r["world"]: round(r["efficiency"], 4) for r in rows}}), flush=True)
