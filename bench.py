@@ -232,7 +232,7 @@ def dense_small_batch(device, index, query, n_docs):
     ("at query micro-batch <= 64 it flips to HBM"): ms per search on resident tensors, HBM rate of the image."""
     image_bytes = float(n_docs) * DIM * 2
     per = []
-    for bs in (1, 2, 4, 8, 64):
+    for bs in (1, 2, 4, 8, 32, 64, 128, 255):
         row = {"batch": bs}
         for kk in (TOPK, 100):
             q = query[:bs].contiguous()
@@ -253,7 +253,7 @@ def dense_small_batch(device, index, query, n_docs):
                     "scripts ask, and top-100), mean of 10 calls, inputs and outputs on the device" % TOPK,
             "dtype": "f16 pre-filter (selection) + exact f32 chains (results)",
             "kernel": "ip_filter_h1_small_kernel for batch <= 32 (stationary query tile, every wave streaming its own corpus rows), "
-                      "ip_filter_h16_kernel above",
+                      "ip_filter_h16_kernel<2> / <4> (query tiles of 64 / 128) up to 128 queries, the 256-query tile above",
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
                          "algorithmic_bytes_per_search": image_bytes,
                          "note": "bytes = the corpus' f16 image (N x 768 x 2), read once per search; the f32 rows of the re-scored "

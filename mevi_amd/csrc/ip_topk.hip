@@ -293,10 +293,11 @@ struct RecStash {
   int n;             // wave-uniform
 };
 
-__device__ __forceinline__ void load_tq16(float (&tq)[8], const float *__restrict__ tau, int q0, int nq) {
+template <int NI>
+__device__ __forceinline__ void load_tq16(float (&tq)[NI], const float *__restrict__ tau, int q0, int nq) {
   const int r16 = threadIdx.x & 15;
 #pragma unroll
-  for (int ni = 0; ni < 8; ++ni) {
+  for (int ni = 0; ni < NI; ++ni) {
     const int qi = q0 + 16 * ni + r16;
     tq[ni] = tau[qi < nq ? qi : nq - 1];     // branch-free (the caller masks columns >= nq to +inf)
   }
@@ -332,7 +333,8 @@ __device__ __forceinline__ void rec_flush(RecStash &st, const float *__restrict_
   st.n = 0;
 }
 
-__device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq)[8], int q0, long long d0, long long doc_end,
+template <int NI>
+__device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][NI], const float (&tq)[NI], int q0, long long d0, long long doc_end,
                                             const float *__restrict__ tau, unsigned long long *__restrict__ buf,
                                             unsigned int *__restrict__ count, int S, int k, int cap, unsigned int id_base,
                                             RecStash &st, bool flush_now) {
@@ -346,7 +348,7 @@ __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq
       for (int j = 0; j < 4; ++j)
         if (d0 + 16 * mi + 4 * kq + j >= doc_end) {
 #pragma unroll
-          for (int ni = 0; ni < 8; ++ni) acc[mi][ni][j] = -INFINITY;
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni][j] = -INFINITY;
         }
   }
   if (st.n >= H16_FLUSH_AT || (flush_now && st.n > 0)) rec_flush(st, tau, buf, count, S, k, cap);
@@ -357,7 +359,7 @@ __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 8; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
       const f32x4 a = acc[mi][ni];
       // v_max3 + v_max through asm: fmaxf() makes the compiler canonicalise every input first (five vector instructions per
       // block instead of two); a NaN accumulator cannot pass either way
@@ -383,9 +385,9 @@ __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq
   // counts and lane kq = 0 takes the slots -- the eight columns' atomics are issued together (one round trip, not eight)
   st.n = n0;
   rec_flush(st, tau, buf, count, S, k, cap);
-  unsigned int before[8], base[8];
+  unsigned int before[NI], base[NI];
 #pragma unroll
-  for (int ni = 0; ni < 8; ++ni) {
+  for (int ni = 0; ni < NI; ++ni) {
     unsigned int c = 0u;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -399,7 +401,7 @@ __device__ __forceinline__ void emit_tile16(f32x4 (&acc)[4][8], const float (&tq
     before[ni] = ((kq & 1) ? c1 : 0u) + ((kq & 2) ? s23 : 0u);    // lanes in kq order: the lower lane of the own pair, the whole lower pair
   }
 #pragma unroll
-  for (int ni = 0; ni < 8; ++ni) {
+  for (int ni = 0; ni < NI; ++ni) {
     unsigned int slot = __shfl(base[ni], r16) + before[ni];
     unsigned long long *dst = buf + (size_t)(q0 + 16 * ni + r16) * S + k;
 #pragma unroll
@@ -1071,6 +1073,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h1_kernel(
 
 // The same kernel on v_mfma_f32_16x16x32_f16 (mfma_pp_f16x16.h; the default: +10 % sustained rate of the tile loop on this
 // part, tools/probes/mfma16_probe.hip) with the 16 x 16 epilogue.  dimp must be a multiple of 64 (pad_k).
+template <int NI>   // query blocks per wave: query tiles of QT = 32 NI (h16_tile_stream<NI>)
 __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h16_kernel(
     const float *__restrict__ Qh, int nq, const float *__restrict__ Dh, long long doc_begin, long long doc_end,
     int dimp, const float *__restrict__ tau, unsigned long long *__restrict__ buf,
@@ -1087,6 +1090,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h16_kernel(
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
   const int grp = w8 >> 2, wm = (w8 >> 1) & 1, wn = w8 & 1;
   const size_t block_bytes = (size_t)256 * dimp * 2;
+  constexpr int QT = 32 * NI;
   int head_d = 0, head_q = 0, tail_d = 0, tail_q = 0, n_pend = 0;
 
   auto next = [&](H1Src &s) -> bool {
@@ -1101,12 +1105,13 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h16_kernel(
       const long long first = doc_begin + (long long)dpair * 2 * BM;
       s.src = reinterpret_cast<const char *>(Dh) + (size_t)(first >> 8) * block_bytes;
     } else {
-      s.src = reinterpret_cast<const char *>(Qh) + (size_t)qtile * block_bytes;
+      // (the query image is cut in blocks of 256 rows: query tile `qtile` of 32 NI rows starts at row qtile * QT of its block)
+      s.src = reinterpret_cast<const char *>(Qh) + (size_t)((qtile * QT) >> 8) * block_bytes + (size_t)((qtile * QT) & 255) * 64;
     }
     s.bytes = (unsigned int)block_bytes;
     return true;
   };
-  float tq[8];
+  float tq[NI];
   RecStash stash;
   {
     char *sb = reinterpret_cast<char *>(lds) + h1_lds_bytes() + (size_t)w8 * STASH_BYTES_PER_WAVE;
@@ -1116,23 +1121,23 @@ __global__ __launch_bounds__(PP_THREADS, 2) void ip_filter_h16_kernel(
   }
   int tiles_done = 0;
   auto begin = [&]() {
-    load_tq16(tq, tau, head_q * H1_QT + 128 * wn, nq);
+    load_tq16<NI>(tq, tau, head_q * QT + 16 * NI * wn, nq);
   };
-  auto emit = [&](f32x4 (&acc)[4][8]) {
+  auto emit = [&](f32x4 (&acc)[4][NI]) {
     const int dpair = head_d, qtile = head_q;
     head_d = tail_d, head_q = tail_q;
     --n_pend;
     const long long drow0 = doc_begin + ((long long)dpair * 2 + grp) * BM;
-    const int qb = qtile * H1_QT + 128 * wn;
-    if (qb + 128 > nq) {   // the last query tile (wave-uniform): columns past nq never pass
+    const int qb = qtile * QT + 16 * NI * wn;
+    if (qb + 16 * NI > nq) {   // the last query tile (wave-uniform): columns past nq never pass
 #pragma unroll
-      for (int ni = 0; ni < 8; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
         if (qb + 16 * ni + (t & 15) >= nq) tq[ni] = INFINITY;
     }
     ++tiles_done;
-    emit_tile16(acc, tq, qb, drow0 + 64 * wm, doc_end, tau, buf, count, S, k, cap, id_base, stash, (tiles_done & flush_mask) == 0);
+    emit_tile16<NI>(acc, tq, qb, drow0 + 64 * wm, doc_end, tau, buf, count, S, k, cap, id_base, stash, (tiles_done & flush_mask) == 0);
   };
-  h16_tile_stream(64, dimp / 32, lds, next, begin, emit, H1BlockedUnits());
+  h16_tile_stream<NI>(64, dimp / 32, lds, next, begin, emit, H1BlockedUnits());
   rec_flush(stash, tau, buf, count, S, k, cap);
 }
 
@@ -1421,7 +1426,18 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   // MFMAs per phase) was measured at the same MFMA-pipe utilisation (85.6 % vs 85.4 %)
   // and pads nq further, so only NI = 2 is instantiated.
   const int ni = 2;
-  const int qt = h1 ? H1_QT : 64 * ni;
+  // the 16x16x32 pre-filter's query tile: 256 queries, or 128 / 64 when the whole search is that small (33 .. 128 queries:
+  // faiss_search.profile's larger batches -- HBM-bound, and a 256-query tile multiplies mostly rows that do not exist).
+  // MEVI_IP_FILTER_QT=256 pins the large tile (A/B; same lists)
+  static const bool shape32_f = [] { const char *e = getenv("MEVI_IP_FILTER_MFMA"); return e && atoi(e) == 32; }();
+  static const int qt_pin = [] { const char *e = getenv("MEVI_IP_FILTER_QT"); return e ? atoi(e) : 0; }();
+  const bool k16shape = h1 && !shape32_f && dim % 64 == 0;
+  int ni16 = 8;
+  if (k16shape) {
+    ni16 = nq <= 64 ? 2 : (nq <= 128 ? 4 : 8);
+    if (qt_pin == 256 || qt_pin == 128 || qt_pin == 64) ni16 = qt_pin / 32;
+  }
+  const int qt = h1 ? (k16shape ? 32 * ni16 : H1_QT) : 64 * ni;
   const int n_qtiles = (int)((nq + qt - 1) / qt);
   // expected survivors per chunk = k * growth = cap / growth_div (default 3: 3x head-room over the mean, tens of standard
   // deviations for exchangeable row order; a query that still overflows takes the guaranteed path)
@@ -1442,9 +1458,10 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
                      !getenv("MEVI_IP_TOPK_NO_SMALL");
   if (small) fn = reinterpret_cast<const void *>(ip_filter_h1_small_kernel);
   else if (h1) {  // Q, D = f16 images, dim = padded dim.  MEVI_IP_FILTER_MFMA=32: the 32x32x16 form (A/B; same lists)
-    static const bool shape32 = [] { const char *e = getenv("MEVI_IP_FILTER_MFMA"); return e && atoi(e) == 32; }();
-    fn = (shape32 || dim % 64 != 0) ? reinterpret_cast<const void *>(ip_filter_h1_kernel)
-                                    : reinterpret_cast<const void *>(ip_filter_h16_kernel);
+    fn = !k16shape ? reinterpret_cast<const void *>(ip_filter_h1_kernel)
+         : ni16 == 8 ? reinterpret_cast<const void *>(ip_filter_h16_kernel<8>)
+         : ni16 == 4 ? reinterpret_cast<const void *>(ip_filter_h16_kernel<4>)
+                     : reinterpret_cast<const void *>(ip_filter_h16_kernel<2>);
   }
   else if (ktail) MEVI_PICK(2, true);
   else MEVI_PICK(2, false);
@@ -1495,7 +1512,7 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       int flush_mask = H16_FLUSH_EVERY - 1;
       {
         const double per_q = seen >= g.k ? (double)g.k * (double)chunk / (double)seen : (double)chunk;
-        const double r = per_q / (double)chunk * 64.0 * 128.0;
+        const double r = per_q / (double)chunk * 64.0 * 16.0 * (double)ni16;     // records per wave tile (64 rows x 16 NI queries)
         int T = H16_FLUSH_EVERY;
         while (T > 1 && T * r > 56.0) T >>= 1;
         flush_mask = T - 1;
@@ -1508,7 +1525,7 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
         const int64_t nb = (chunk + 255) / 256;
         grid = (unsigned)(nb < n_cu ? nb : n_cu);
       }
-      const bool k16 = fn == reinterpret_cast<const void *>(ip_filter_h16_kernel);
+      const bool k16 = k16shape && !small;
       if (hipLaunchKernel(fn, dim3(grid), dim3(PP_THREADS), small ? args_small : (k16 ? args16 : args), pp_lds, stream) != hipSuccess) {
         set_error("ip_topk: filter kernel launch failed");
         return -1;

@@ -38,12 +38,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int h16_swz(int quad) { return (quad & 2) ? 3 : 0; }
 
-// next / begin / emit / uoff as h1_tile_stream (begin() is called two windows before the tile's emit, not at its start); emit receives f32x4 acc[4][8]: block (mi, ni) = corpus rows 16 mi + [0, 16)
-// of the wave's 64, queries 16 ni + [0, 16) of the wave's 128.  nunits even, >= 4.
-template <class Next, class Begin, class Emit, class UOff = H1PlainUnits, int ABL = 0>
+// next / begin / emit / uoff as h1_tile_stream (begin() is called two windows before the tile's emit, not at its start); emit receives f32x4 acc[4][NI]: block (mi, ni) = corpus rows 16 mi + [0, 16)
+// of the wave's 64, queries 16 ni + [0, 16) of the wave's 16 NI.  nunits even, >= 4.
+//
+// NI = 8: the 256-query tile above.  NI = 4 / 2 (round 5): query tiles of 128 / 64 for searches of 33 .. 128 queries
+// (faiss_search.profile's larger batches): such a search is bound by streaming the corpus image, and in the 256-query tile
+// three quarters of its matrix work, fragment reads and query staging multiply rows that do not exist.  Same ring, same unit
+// images; a wave owns 64 corpus rows x 16 NI queries and a window is ONE product group:
+//   window g:  ds_read A[g & 1], B[g & 1] <- unit g (4 + NI reads) | 4 NI MFMA  A[(g-1) & 1] x B[(g-1) & 1] | 4 DMA pieces of unit g+3
+// Of the query-side waves only those whose 64 rows exist in the tile stage anything.  An accumulator sums its 32-k products in
+// the same order from a zero-C first product, so the raw scores -- the keys -- are the 256-query tile's, bit for bit.
+template <int NI = 8, class Next, class Begin, class Emit, class UOff = H1PlainUnits, int ABL = 0>
 __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float *lds, Next next, Begin begin, Emit emit,
                                                 UOff uoff = UOff()) {
-  constexpr int NBUF = H1_NBUF, DEPTH = NBUF - 1;
+  static_assert(NI == 8 || NI == 4 || NI == 2, "query blocks per wave");
+  constexpr int NA = NI == 8 ? 4 : NI;   // query fragments per read / product group
+  // NI < 8: a unit holds the 256 corpus rows + the tile's 32 NI query rows only (20 / 24 KiB instead of 32), so the same 128 KiB
+  // take six / five units: five / four in flight instead of three -- what a search bound by the corpus stream is short of
+  constexpr int UNIT = NI == 8 ? H1_UNIT : (256 + 32 * NI) * H1_LD;
+  constexpr int NBUF = NI == 8 ? H1_NBUF : (NI == 4 ? 5 : 6), DEPTH = NBUF - 1;
+  static_assert((size_t)NBUF * UNIT * 4 <= h1_lds_bytes(), "ring inside the kernel's LDS");
+  auto wait_units = [](auto barrier) {       // all but the last DEPTH - 1 units' pieces (four per unit and wave) have landed
+    constexpr bool B = decltype(barrier)::value;
+    if constexpr (DEPTH == 3) { if constexpr (B) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); }
+    else if constexpr (DEPTH == 4) { if constexpr (B) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory"); }
+    else { if constexpr (B) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); }
+  };
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -61,11 +81,13 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
   bool have_nxt = next(nxt);
   if (!have_nxt) nxt.bytes = 0u, nxt.src = cur.src;
 
+  const bool stages = w8 < 4 || 64 * (w8 & 3) < 32 * NI;   // query-side waves beyond the tile's 32 NI rows stage nothing
   auto dma2 = [&](const H1Src &s, int u, int gb, int p0) {
     if constexpr (ABL & 2) return;
+    if (NI != 8 && !stages) return;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.src), 0, (int)s.bytes, 0x00020000);
-    float *base = lds + gb * H1_UNIT + (64 * w8) * H1_LD;
+    float *base = lds + gb * UNIT + (64 * w8) * H1_LD;
 #pragma unroll
     for (int i = p0; i < p0 + 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(base + 16 * i * H1_LD), 16,
@@ -74,7 +96,7 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
 
   const int cj = (kq ^ h16_swz((r16 >> 2) & 3)) * 4;  // float offset of this lane's piece inside its row
   const int offa = (grp * BM + 64 * wm + r16) * H1_LD + cj;
-  const int offb = (2 * BM + 128 * wn + r16) * H1_LD + cj;
+  const int offb = (2 * BM + 16 * NI * wn + r16) * H1_LD + cj;
   struct FragA {
     f16x8 a[4];
   };
@@ -83,24 +105,24 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
   };
   auto read_a = [&](int gb, FragA &f) {
     if constexpr (ABL & 4) return;
-    const float *p = lds + gb * H1_UNIT + offa;
+    const float *p = lds + gb * UNIT + offa;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) f.a[mi] = *reinterpret_cast<const f16x8 *>(p + 16 * mi * H1_LD);
   };
   auto read_b = [&](int gb, int hi, FragB &f) {
     if constexpr (ABL & 4) return;
-    const float *p = lds + gb * H1_UNIT + offb + 64 * hi * H1_LD;
+    const float *p = lds + gb * UNIT + offb + 64 * hi * H1_LD;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) f.b[ni] = *reinterpret_cast<const f16x8 *>(p + 16 * ni * H1_LD);
+    for (int ni = 0; ni < NA; ++ni) f.b[ni] = *reinterpret_cast<const f16x8 *>(p + 16 * ni * H1_LD);
   };
-  f32x4 acc[4][8];
+  f32x4 acc[4][NI];
   // zero: the first product of a tile into these sixteen blocks -- the instruction's C operand is the constant 0, so the 128
   // accumulator registers are never cleared by vector moves (128 v_mov per wave and tile otherwise)
   auto mma = [&](const FragA &fa, const FragB &fb, int hi, auto zero) {
     if constexpr (ABL & 8) return;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < NA; ++ni)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
         acc[mi][4 * hi + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.a[mi], fb.b[ni], decltype(zero)::value ? z : acc[mi][4 * hi + ni], 0, 0, 0);
@@ -161,20 +183,60 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
     rb = rb == NBUF - 1 ? 0 : rb + 1;
   };
 
+  // NI < 8: one product group per window -- unit u's fragments into (An, Bn) while the previous unit's (Ap, Bp) multiply
+  auto window_h = [&](int u, auto first_, auto zero_, FragA &An, const FragA &Ap, FragB &Bn, const FragB &Bp) {
+    constexpr bool first = decltype(first_)::value;
+    const bool spill = u + DEPTH >= nunits;
+    H1Src tgt;
+    tgt.src = spill ? nxt.src : cur.src;
+    tgt.bytes = spill ? nxt.bytes : cur.bytes;
+    const int tu = spill ? u + DEPTH - nunits : u + DEPTH;
+    const int wb = rb == 0 ? NBUF - 1 : rb - 1;
+    read_a(rb, An);
+    read_b(rb, 0, Bn);
+    if constexpr (!first) mma(Ap, Bp, 0, zero_);
+    dma2(tgt, tu, wb, 0);
+    dma2(tgt, tu, wb, 2);
+    if constexpr (!first) {   // the reads in fours behind the first MFMAs, the DMA pieces after them
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NA - 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_units(std::integral_constant<bool, true>());
+    __builtin_amdgcn_sched_barrier(0);
+    rb = rb == NBUF - 1 ? 0 : rb + 1;
+  };
+
 #pragma unroll
   for (int u = 0; u < DEPTH; ++u) {
     dma2(cur, u, u, 0);
     dma2(cur, u, u, 2);
   }
-  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // unit 0 landed
+  wait_units(std::integral_constant<bool, false>());  // unit 0 landed
   __builtin_amdgcn_sched_barrier(0);
   while (true) {
     if constexpr (ABL & 8) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if constexpr (NI != 8) {
+      using Yes = std::integral_constant<bool, true>;
+      window_h(0, Yes(), No(), A0, A1, BL, BH);           // (BL, BH serve as the two alternating query fragment sets)
+      window_h(1, No(), Yes(), A1, A0, BH, BL);           // unit 0's product: the first into the blocks
+      for (int u = 2; u < nunits; u += 2) {
+        if (u + 2 >= nunits) begin();
+        window_h(u, No(), No(), A0, A1, BL, BH);
+        window_h(u + 1, No(), No(), A1, A0, BH, BL);
+      }
+      mma(A1, BH, 0, No());
+    } else {
     window(0, std::integral_constant<int, 0>(), A0, A1);
     window(1, std::integral_constant<int, 1>(), A1, A0);
     for (int u = 2; u < nunits; u += 2) {
@@ -183,6 +245,7 @@ __device__ __forceinline__ void h16_tile_stream(int row_bytes, int nunits, float
       window(u + 1, std::integral_constant<int, 2>(), A1, A0);
     }
     mma(A1, BH, 1, No());
+    }
     emit(acc);
     if (!have_nxt) break;
     cur = nxt;

@@ -1,12 +1,16 @@
 """GPU parity of the dense arm (mevi_ip_topk_f32 / mevi_topk_merge_f32 through the C ABI)
 against oracle/mevi_oracle.c.  Bar: BIT-EXACT scores and identical ids -- both sides
 compute the same sequential fmaf chain and order by (score desc, id asc)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from mevi_amd import dense, hip
 from oracle import dense as odense
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -83,6 +87,42 @@ def test_few_queries_take_the_streaming_kernel_with_the_same_bits(cuda, nq, nd, 
         np.testing.assert_array_equal(i_, ei)
         np.testing.assert_array_equal(s_.view(np.uint32), es.view(np.uint32))
     assert st.n_failed_queries == 0 or nd < 1000
+
+
+@pytest.mark.parametrize("nq,nd,dim,k", [
+    (33, 40000, 768, 100), (64, 70001, 768, 1000), (65, 30000, 768, 300), (100, 25000, 768, 1000), (128, 50000, 768, 100),
+    (129, 20000, 768, 100), (255, 30000, 768, 1000), (48, 9000, 128, 50), (90, 12345, 192, 64),
+])
+def test_medium_batches_take_the_narrow_query_tiles_with_the_same_bits(cuda, nq, nd, dim, k):
+    """33 .. 128 queries (faiss_search.profile's larger batches, MEVI/faiss_search.py:32-68): ip_filter_h16_kernel<2> / <4> --
+    query tiles of 64 / 128 instead of 256 -- must return the oracle's lists bit for bit, like the 256-query tile it
+    replaces there (MEVI_IP_FILTER_QT=256 pins that one: same result); 129 .. 255 queries keep the wide tile."""
+    import os
+
+    rng = np.random.default_rng(nq * 131 + nd + dim)
+    q = rng.standard_normal((nq, dim), dtype=np.float32)
+    d = rng.standard_normal((nd, dim), dtype=np.float32)
+    es, ei = odense.ip_topk_exact(q, d, k)
+    s1, i1 = _run_indexed(q, d, k, cuda)
+    st = _stats()
+    np.testing.assert_array_equal(i1, ei)
+    np.testing.assert_array_equal(s1.view(np.uint32), es.view(np.uint32))
+    assert st.n_failed_queries == 0
+    code = ("import os, sys, numpy as np, torch; sys.path.insert(0, %r); from mevi_amd import dense; "
+            "q = np.load(sys.argv[1]); d = np.load(sys.argv[2]); dev = torch.device('cuda:0'); "
+            "s, i = dense.DenseIndex(torch.from_numpy(d).to(dev)).search(torch.from_numpy(q).to(dev), int(sys.argv[3])); "
+            "np.save(sys.argv[4], i.cpu().numpy()); np.save(sys.argv[5], s.cpu().numpy())" % ROOT)
+    import subprocess
+    import sys
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:      # the switch is read once per process: the pinned tile runs in a child
+        np.save(tmp + "/q.npy", q), np.save(tmp + "/d.npy", d)
+        r = subprocess.run([sys.executable, "-c", code, tmp + "/q.npy", tmp + "/d.npy", str(k), tmp + "/i.npy", tmp + "/s.npy"],
+                           env=dict(os.environ, MEVI_IP_FILTER_QT="256"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        np.testing.assert_array_equal(np.load(tmp + "/i.npy"), ei)
+        np.testing.assert_array_equal(np.load(tmp + "/s.npy").view(np.uint32), es.view(np.uint32))
 
 
 def test_k_larger_than_corpus_pads_like_faiss(cuda):
