@@ -482,6 +482,10 @@ def test_captured_graphs_survive_a_larger_eager_pass(cuda):
     import synth
     from mevi_amd import ops
 
+    # (the fills are per process: an earlier test with a whole MS MARCO-sized pass has grown them -- start from fresh ones, the old
+    # arrays retired as the product retires them)
+    ops._EXP_FILL_RETIRED.extend(ops._EXP_FILL.values())
+    ops._EXP_FILL.clear()
     model, tower, _, _ = synth.build(cuda, 4, 32, None)
     ids, mask = synth.query_ids(2400, cuda, np.random.default_rng(5))
     q = {"input_ids": ids[:2], "attention_mask": mask[:2]}
