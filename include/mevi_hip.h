@@ -184,6 +184,49 @@ int mevi_gemm_nt_split_f32(const void *a_img, const int8_t *a_exp, const void *w
                            const float *residual, int64_t ldr, int act, void *stream);
 
 /* ------------------------------------------------------------------------
+ * T5LayerNorm folded into the linear layers around it (round 5).  The reference normalises the residual stream before every
+ * projection (T5LayerSelfAttention / T5LayerCrossAttention / T5LayerFF: `self.layer_norm(hidden_states)` then q|k|v / q / wi,
+ * MEVI/transformers/modeling_t5.py:155-171, 189-201, 421-445, 452-480); a T5LayerNorm is a per-row scale times a per-column
+ * weight, so   rmsnorm(x) W^T = rsqrt(mean(x^2) + eps) * (x (W (.) w_ln)^T):
+ *   - the weights are held as W (.) w_ln (the caller folds them at load),
+ *   - the residual stream travels as f32 rows + their split image + a bound on max |row| + the sums of squares of every row's
+ *     16-column blocks (ssq f32 [m, n / 16]), written by the GEMM that produces it (mevi_gemm_nt_split_residual_stream: the
+ *     o / wo projections' `hidden_states + dropout(y)`, :200, :444, :479) or, where it starts, by mevi_split_rows_ssq_f16,
+ *   - the consuming projection multiplies the image and scales each row of the product (mevi_gemm_nt_split_normed_*): the
+ *     scale comes from the block sums, blocks added in index order (mevi_row_rscale_f32 states the formula; GEMMs on the
+ *     latency kernels compute it themselves, the tile stream takes it from `rscale_ws`, filled by one small launch).
+ * No pass over the rows exists any more just to normalise them (mevi_rmsnorm_split_f16 read and wrote 4 B per element).
+ * Same value up to f32 rounding (the scale is applied after the product instead of before); a row's result has the same
+ * bits in any batch and on either kernel family.  n of the stream: multiple of 16, <= 1024 (mevi_gemm_norm_fold_supported).
+ * ---------------------------------------------------------------------- */
+int mevi_gemm_norm_fold_supported(int64_t n_stream);
+/* x f32 [m, k] -> image + exponents, bound[r] >= max |x_r| (the l2 norm, rounded up), ssq [m, k / 16] */
+int mevi_split_rows_ssq_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int8_t *exps, float *bound,
+                            float *ssq, void *stream);
+/* out[r] = 1 / sqrt(sum(parts[r, :]) / dim + eps) */
+int mevi_row_rscale_f32(const float *parts, int64_t m, int64_t nparts, float dim, float eps, float *out, void *stream);
+/* C = act(rs (.) (A.W^T) + bias) (+ residual), rs[r] from parts [m, nparts]; rscale_ws f32 [m] (scratch of the call) */
+int mevi_gemm_nt_split_normed_f32(const void *a_img, const int8_t *a_exp, const float *parts, int64_t nparts, float rs_dim,
+                                  float rs_eps, float *rscale_ws, const void *w_img, const int8_t *w_exp, float *c,
+                                  int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias, const float *residual,
+                                  int64_t ldr, int act, void *stream);
+/* ... written as a split image (mevi_gemm_nt_split_to_split); a_norm_bound >= ||rs_r A_r|| for every row (sqrt(d)) */
+int mevi_gemm_nt_split_normed_to_split(const void *a_img, const int8_t *a_exp, const float *parts, int64_t nparts,
+                                       float rs_dim, float rs_eps, float *rscale_ws, float a_norm_bound, const void *w_img,
+                                       const int8_t *w_exp, float w_norm_max, int64_t m, int64_t n, int64_t k,
+                                       const float *bias, float bias_abs_max, int act, void *out_img, int8_t *out_exp,
+                                       float *out_norm, void *stream);
+/* c = residual + A.W^T (f32 [m, n]) AND its image / exponents / bound / block sums.  a_norm [m] (or NULL: a_norm_const for
+ * every row) bounds ||A_r||; the image's exponent comes from x_bound[r] + a_norm * w_norm_max.  parts != NULL: A is itself a
+ * normed stream (c = residual + rs (.) (A.W^T): the one-position decoder's o(v(norm x)) projection), a_norm_const = sqrt(d). */
+int mevi_gemm_nt_split_residual_stream(const void *a_img, const int8_t *a_exp, const float *a_norm, float a_norm_const,
+                                       const float *parts, int64_t nparts, float rs_dim, float rs_eps, float *rscale_ws,
+                                       const void *w_img, const int8_t *w_exp, float w_norm_max, float *c, int64_t ldc,
+                                       int64_t m, int64_t n, int64_t k, const float *residual, int64_t ldr,
+                                       const float *x_bound, void *out_img, int8_t *out_exp, float *out_bound,
+                                       float *out_ssq, void *stream);
+
+/* ------------------------------------------------------------------------
  * Small-shape T5 / adaptor operators (wave-per-row kernels).  Stream-ordered, no workspace.
  * ---------------------------------------------------------------------- */
 /* T5LayerNorm: out = w * (x / sqrt(mean(x^2) + eps))  (MEVI/transformers/modeling_t5.py:155-171) */

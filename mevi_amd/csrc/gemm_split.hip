@@ -211,7 +211,41 @@ struct SplitOut {
   int np;
   float wnorm_max, babs_max, onorm_scale;
   float alpha;         // OUT = 3 (the fused PAWA head): scale of the hidden states
+  // ---- round 5: T5LayerNorm folded into the linear layers around it (modeling_t5.py:155-171 feeds exactly one projection) ----
+  // rmsnorm(x) W^T = rsqrt(mean x^2 + eps) * (x (W (.) w_ln)^T): the CONSUMER multiplies the raw residual row (its split image) with
+  // the weight that carries w_ln and scales the product per row; the PRODUCER of the residual stream (the GEMM that adds its result
+  // to it) writes, next to the f32 rows, their split image and the sums of squares of their 16-column blocks.
+  const float *rscale;  // consumer: [M] row scale, applied to the product before bias / activation (tile stream; nullptr: none)
+  const float *rparts;  // consumer, latency kernels: [M][nparts] block sums of squares -> the scale is computed in the kernel
+  int nparts;           //   (same formula, same order as mevi_row_rscale_f32)
+  float rs_dim, rs_eps;
+  float anorm_const;    // split output without per-row norms (anorm == nullptr): ||A row|| bound, e.g. sqrt(d) of a normed row
+  float *ssq;           // producer: [M][N / 16] sum of squares of the OUTPUT row's 16-column blocks (N % 16 == 0)
+  const float *xbound;  // producer with image: [M] bound on max |residual row|; the image's exponent = that of xbound + ||a|| wnorm_max
+  float *obound;        // producer with image: [M] the new bound
 };
+
+// sum of squares of a row's 16-column block: the lane's four columns as an fma chain, then (kq0 + kq1) + (kq2 + kq3) -- the ONE
+// order every producer (tile stream, latency kernels) and mevi_split_rows_ssq use, so a row's scale has the same bits in any batch
+__device__ __forceinline__ float block_ssq(float v0, float v1, float v2, float v3) {
+  float q = fmaf(v3, v3, fmaf(v2, v2, fmaf(v1, v1, v0 * v0)));
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  return q;
+}
+// the row scale from its block sums: blocks added in index order
+__device__ __forceinline__ float row_rscale(const float *__restrict__ parts, int nparts, float dim, float eps) {
+  float ss = 0.f;
+  if (nparts & 3) {       // narrow streams (the miniature models of the tests): rows of the table are not 16-byte aligned
+    for (int i = 0; i < nparts; ++i) ss += parts[i];
+  } else {
+    for (int i = 0; i < nparts; i += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(parts + i);
+      ss += v.x, ss += v.y, ss += v.z, ss += v.w;
+    }
+  }
+  return 1.0f / sqrtf(ss / dim + eps);
+}
 
 __device__ __forceinline__ int out_exp(const SplitOut &so, int m) {
   return pow2_exp(fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * 1.001f);
@@ -526,12 +560,14 @@ __global__ __launch_bounds__(256) void gemm_split_skinny_kernel(
 // partials of a (row, column).  The head matrices of 70 k beams (55 GB at K = 256) are never written.
 // NI: 16-row activation blocks per wave -- tiles of TM = 32 NI activation rows x 256 W rows (8: the 256 x 256 tile above; 4 / 2:
 // 128 / 64 activation rows for GEMMs whose 256-row tiles would not fill the device, split_tile_stream16<NI>; same bits per row).
-template <int ACT, int OUT, int NI = 8>   // OUT: 0 = f32 C, 1 = f32 C + residual, 2 = split image, 3 = fused head (above)
+// OUT = 4 (round 5): f32 C + residual AND the split image of the result (exponent from so.xbound + ||a|| wnorm_max) AND the sums of
+// squares of its 16-column blocks (so.ssq) -- the producer side of the folded T5LayerNorm (SplitOut).
+template <int ACT, int OUT, int NI = 8>   // OUT: 0 = f32 C, 1 = f32 C + residual, 2 = split image, 3 = fused head (above), 4 = f32 + residual + image + block sums
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
     const _Float16 *__restrict__ A, const signed char *__restrict__ ea, int M, const _Float16 *__restrict__ W,
     const signed char *__restrict__ ew, int N, int kp, float *__restrict__ C, long long ldc, const float *__restrict__ bias,
     const float *__restrict__ residual, long long ldr, int n_mtiles, int n_ntiles, SplitOut so) {
-  constexpr bool SPLIT_OUT = OUT == 2, LOGITS = OUT == 3, HAS_RES = OUT == 1 || OUT == 3;
+  constexpr bool SPLIT_OUT = OUT == 2, LOGITS = OUT == 3, BOTH = OUT == 4, HAS_RES = OUT == 1 || OUT == 3 || OUT == 4;
   constexpr int TM = 32 * NI, PR = NI / 2, STEPS = 4 * PR;   // tile height; row-block pairs per block column; epilogue steps
   static_assert(!LOGITS || NI == 8, "the fused head runs on 256-row tiles");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -585,20 +621,31 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
     const __amdgpu_buffer_rsrc_t rr =   // LOGITS: the hidden states' columns d = 256 (nt mod 3) .. + 255
         tile_rsrc(residual ? residual + (size_t)mt * TM * ldr + (size_t)(LOGITS ? nt % 3 : nt) * 256 : nullptr);
     const __amdgpu_buffer_rsrc_t ri =
-        tile_rsrc(SPLIT_OUT ? so.img + (size_t)mt * TM * 2 * so.np + (size_t)nt * 256 : nullptr);
+        tile_rsrc((SPLIT_OUT || BOTH) ? so.img + (size_t)mt * TM * 2 * so.np + (size_t)nt * 256 : nullptr);
     const __amdgpu_buffer_rsrc_t rw = tile_rsrc(ew + nt * 256);
     const __amdgpu_buffer_rsrc_t rb = tile_rsrc(bias ? bias + nt * 256 : nullptr);
     const int ncol = 128 * grp + 64 * wm + 4 * kq;        // column of the lane's quad in block column mi = 0 (+ 16 mi)
     const int nvalid = N - nt * 256;                      // columns of this tile that exist (edge tiles)
     // per-row scalars of the lane's NI rows, packed four int8 per register: A-row exponents, output exponents (split out)
     unsigned int emp[2] = {0u, 0u}, eop[2] = {0u, 0u};
+    float rsv[NI];                                       // the rows' scales (folded norm: so.rscale), 1 otherwise
     const int mlim = interior ? 0x7fffffff : M;          // row m exists iff m < mlim
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int m = m0 + 16 * ni;
       emp[ni >> 2] |= ((unsigned int)(unsigned char)ea[min(m, M - 1)]) << (8 * (ni & 3));
+      rsv[ni] = so.rscale ? so.rscale[min(m, M - 1)] : 1.0f;
+      if constexpr (BOTH) {
+        const float bound = fmaf(so.anorm ? so.anorm[min(m, M - 1)] : so.anorm_const, so.wnorm_max, so.xbound[min(m, M - 1)]);
+        const int e = pow2_exp(bound * 1.001f);
+        eop[ni >> 2] |= ((unsigned int)(unsigned char)(signed char)e) << (8 * (ni & 3));
+        if (nt == 0 && grp == 0 && wm == 0 && kq == 0 && m < mlim) {  // one writer per row
+          so.exps[m] = (signed char)e;
+          so.obound[m] = bound * 1.0001f;
+        }
+      }
       if constexpr (SPLIT_OUT) {
-        const float bound = fmaf(so.anorm[min(m, M - 1)], so.wnorm_max, so.babs_max);
+        const float bound = fmaf(so.anorm ? so.anorm[min(m, M - 1)] : so.anorm_const, so.wnorm_max, so.babs_max);
         const int e = pow2_exp(bound * 1.001f);
         eop[ni >> 2] |= ((unsigned int)(unsigned char)(signed char)e) << (8 * (ni & 3));
         if (nt == 0 && grp == 0 && wm == 0 && kq == 0 && m < mlim) {  // one writer per row
@@ -656,7 +703,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float x = ldexpf(acc[mi][ni][j], -(em + sx8(wq[mi], j))) + __uint_as_float(bq[mi & 1][j]);
+          float x = __fmul_rn(ldexpf(acc[mi][ni][j], -(em + sx8(wq[mi], j))), rsv[ni]) + __uint_as_float(bq[mi & 1][j]);   // (no fma with the bias: the latency kernels round the product too)
           x = act_fn<ACT>(x);
           if constexpr (LOGITS) part[ni] = fmaf(__uint_as_float(res[i & 1][n2][j]) * so.alpha, x, part[ni]);
           else if constexpr (HAS_RES) x += __uint_as_float(res[i & 1][n2][j]);
@@ -667,6 +714,22 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
           // pin the step's sums here: with no store to anchor them the compiler sinks all sixteen steps' arithmetic behind the
           // last step's loads and keeps 32 loaded quads alive (176 bytes of scratch per lane)
           asm volatile("" : "+v"(part[ni]));
+        } else if constexpr (BOTH) {
+          const int eo = sx8(eop[ni >> 2], ni & 3);
+          h4 hi, lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xs = ldexpf(v[j], eo);
+            hi[j] = (_Float16)xs;
+            lo[j] = (_Float16)(xs - (float)hi[j]);
+          }
+          const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rc, ok ? rowt * ldc4 + c * 4 : OOB, 0, 0);
+          const int off = ok ? rowt * (so.np * 4) + c * 2 : OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), ri, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), ri, off, so.np * 2, 0);
+          const float q = block_ssq(v[0], v[1], v[2], v[3]);
+          if (kq == 0 && ok) so.ssq[(size_t)(mt * TM + rowt) * (size_t)(N >> 4) + (size_t)(nt * 16 + 8 * grp + 4 * wm + mi)] = q;
         } else if constexpr (SPLIT_OUT) {
           const int eo = sx8(eop[ni >> 2], ni & 3);
           h4 hi, lo;
@@ -757,11 +820,18 @@ __device__ __forceinline__ void skinny16_body(
   const int mc = min(m, M - 1);
   const int em = ea[mc];
   int eo = 0;
+  // folded T5LayerNorm (SplitOut): the row's scale, given or from its block sums; a producer of the residual stream (C AND image)
+  // takes the image's exponent from the bound it carries forward
+  const float rs = so.rscale ? so.rscale[mc] : (so.rparts ? row_rscale(so.rparts + (size_t)mc * so.nparts, so.nparts, so.rs_dim, so.rs_eps) : 1.0f);
+  const bool both = so.img && C;
   if (so.img) {
-    eo = out_exp(so, mc);
+    const float an = so.anorm ? so.anorm[mc] : so.anorm_const;
+    const float bound = both ? fmaf(an, so.wnorm_max, so.xbound[mc]) : fmaf(an, so.wnorm_max, so.babs_max);
+    eo = pow2_exp(bound * 1.001f);
     if (storer && mi == 0 && mok && n0 == 0 && kq == 0) {   // one writer per row
       so.exps[m] = (signed char)eo;
-      if (so.norms) so.norms[m] = fmaf(so.anorm[m], so.wnorm_max, so.babs_max) * so.onorm_scale;
+      if (both) so.obound[m] = bound * 1.0001f;
+      else if (so.norms) so.norms[m] = bound * so.onorm_scale;
     }
   }
   const int nq_ = min(n0 + 16 * mi + 4 * kq, N - 4);
@@ -817,16 +887,32 @@ __device__ __forceinline__ void skinny16_body(
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the empty tail pieces: nothing may target LDS past the loop
   const int n = n0 + 16 * mi + 4 * kq;         // n, N, ldc multiples of 4: a quad is whole or absent, and 16-byte aligned
+  if (so.ssq && storer) {   // block sums of the OUTPUT rows (producer of the residual stream): all 64 lanes take part in the shuffles
+    float w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = __fmul_rn(ldexpf(acc[j], -(em + (int)(signed char)(pw >> (8 * j)))), rs);
+      if (bias) x += pb[j];
+      x = act == 1 ? act_fn<1>(x) : (act == 2 ? act_fn<2>(x) : x);
+      if (residual) x += pr[j];
+      w4[j] = x;
+    }
+    const float q = block_ssq(w4[0], w4[1], w4[2], w4[3]);
+    if (kq == 0 && mok && n < N) so.ssq[(size_t)m * (size_t)(N >> 4) + (size_t)((n0 >> 4) + mi)] = q;
+  }
   if (!storer || n >= N || !mok) return;
   const int a8 = act;
   f32x4 v;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float x = ldexpf(acc[j], -(em + (int)(signed char)(pw >> (8 * j))));
+    float x = __fmul_rn(ldexpf(acc[j], -(em + (int)(signed char)(pw >> (8 * j)))), rs);
     if (bias) x += pb[j];
     x = a8 == 1 ? act_fn<1>(x) : (a8 == 2 ? act_fn<2>(x) : x);
     if (residual) x += pr[j];
     v[j] = x;
+  }
+  if (both) {      // every lane of the block is here (storer waves only; rows / column quads past the edge left above): see below
+    *reinterpret_cast<f32x4 *>(C + (size_t)m * ldc + n) = v;
   }
   if (so.img) {
     f16x4 hi, lo;
@@ -1020,6 +1106,59 @@ __global__ __launch_bounds__(1024) void gemm_rmsnorm_split16_kernel(
   }
 }
 
+// rs[m] = rsqrt(mean(x_m^2) + eps) from the row's block sums (folded T5LayerNorm, SplitOut): one lane per row
+__global__ __launch_bounds__(256) void row_rscale_kernel(const float *__restrict__ parts, long long m, int nparts, float dim, float eps,
+                                                        float *__restrict__ out) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r < m) out[r] = row_rscale(parts + (size_t)r * nparts, nparts, dim, eps);
+}
+
+// Where the residual stream STARTS (token embeddings): rows of x f32 [m, k] -> split image with the row's own exponent, its bound
+// (the l2 norm, rounded up: >= max |x|) and the block sums of squares in block_ssq's order (a 16-column block = four lanes of the
+// wave: lane & 3 plays kq).  k % 16 == 0, k <= 1024 here (one float4 per lane and 256 columns).  One wave per row.
+__global__ __launch_bounds__(256) void split_rows_ssq_kernel(const float *__restrict__ x, long long ldx, long long m, int k, int kp,
+                                                            _Float16 *__restrict__ img, signed char *__restrict__ exps,
+                                                            float *__restrict__ bound, float *__restrict__ ssq) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= m) return;
+  const int lane = threadIdx.x & 63;
+  const float *xr = x + (size_t)r * ldx;
+  float4 v[4];
+  float mx = 0.f, ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * lane + 256 * j;
+    v[j] = c < k ? *reinterpret_cast<const float4 *>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+    float q = fmaf(v[j].w, v[j].w, fmaf(v[j].z, v[j].z, fmaf(v[j].y, v[j].y, v[j].x * v[j].x)));
+    q += __shfl_xor(q, 1);
+    q += __shfl_xor(q, 2);
+    if ((lane & 3) == 0 && c < k) ssq[(size_t)r * (k >> 4) + (c >> 4)] = q;
+    ss += q;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, off));
+    ss += __shfl_xor(ss, off);
+  }
+  const int e = pow2_exp(mx);
+  _Float16 *o = img + (size_t)r * 2 * kp;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * lane + 256 * j;
+    if (c < kp) {
+      h4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+      if (c < k) split4(v[j], e, hi, lo);
+      *reinterpret_cast<h4 *>(o + c) = hi;
+      *reinterpret_cast<h4 *>(o + kp + c) = lo;
+    }
+  }
+  if (lane == 0) {
+    exps[r] = (signed char)e;
+    bound[r] = sqrtf(ss * 0.25f) * 1.001f + mx * 1e-6f;   // ss counts every block four times (all four lanes add the block's sum)
+  }
+}
+
 // crossover measured with tools/bench_skinny_crossover.py (profiles/r02_skinny_crossover.txt): the latency kernel takes
 // ~13 us (K = 768) per round of 256 workgroups, the tile stream ~50 us for any grid below one wave of tiles
 constexpr long long SPLIT_SKINNY_MAX_OUTPUTS = 1500000;
@@ -1129,6 +1268,16 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
   // MEVI_GEMM_MFMA=32: the 32x32x16 kernels (A/B switch; BOTH kernels change together -- a row's bits are the same in the
   // tile stream and in the latency kernel of one shape, not across shapes)
   static const bool shape32 = [] { const char *e = getenv("MEVI_GEMM_MFMA"); return e && atoi(e) == 32; }();
+  if (so.rparts && so.rscale && m * n > skinny_max && force_ni == 0) {
+    // the tile stream takes one scale per row (its lanes hold eight rows each): from the block sums, one launch for the whole GEMM
+    hipLaunchKernelGGL(row_rscale_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, so.rparts, (long long)m, so.nparts, so.rs_dim,
+                       so.rs_eps, const_cast<float *>(so.rscale));
+    so.rparts = nullptr;
+  } else if (so.rparts && m * n <= skinny_max) {
+    so.rscale = nullptr;      // the latency kernels compute it themselves (no extra launch)
+  } else if (so.rparts && force_ni != 0) {
+    so.rparts = nullptr;      // a part of a GEMM whose scales the first call has computed
+  }
   if (m * n <= skinny_max) {
     // fewer 32 x 32 tiles than half the CUs: 16 x 16 tiles (MEVI_GEMM_SKINNY_TILE=32 keeps the large tile; same bits)
     static const bool tile32 = [] { const char *e = getenv("MEVI_GEMM_SKINNY_TILE"); return e && atoi(e) == 32; }();
@@ -1160,6 +1309,10 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
       if (so.img) so2.img = so.img + (size_t)m1 * 2 * so.np, so2.exps = so.exps + m1;
       if (so.norms) so2.norms = so.norms + m1;
       if (so.anorm) so2.anorm = so.anorm + m1;
+      if (so.rscale) so2.rscale = so.rscale + m1;
+      if (so.rparts) so2.rparts = so.rparts + (size_t)m1 * so.nparts;
+      if (so.ssq) so2.ssq = so.ssq + (size_t)m1 * (size_t)(n >> 4);
+      if (so.xbound) so2.xbound = so.xbound + m1, so2.obound = so.obound + m1;
       return gemm_split_launch(A + (size_t)m1 * 2 * kp, a_exp + m1, w_img, w_exp, c ? c + (size_t)m1 * ldc : nullptr, ldc, m - m1, n, k, bias,
                                residual ? residual + (size_t)m1 * ldr : nullptr, ldr, act, so2, stream_, -1);
     }
@@ -1185,8 +1338,13 @@ static int gemm_split_launch(const void *a_img, const int8_t *a_exp, const void 
    {gemm_split16_kernel<2, 0, NI_>, gemm_split16_kernel<2, 1, NI_>, gemm_split16_kernel<2, 2, NI_>}}
   static const kern_t table16[3][3][3] = {MEVI_SPLIT16_TABLE(8), MEVI_SPLIT16_TABLE(4), MEVI_SPLIT16_TABLE(2)};
 #undef MEVI_SPLIT16_TABLE
+  static const kern_t both16[3] = {gemm_split16_kernel<0, 4, 8>, gemm_split16_kernel<0, 4, 4>, gemm_split16_kernel<0, 4, 2>};
+  const bool both = so.img && c;     // the producer of the residual stream: f32 rows + their image + block sums
+  MEVI_REQUIRE(!both || (!shape32 && a8 == 0 && residual && so.ssq && so.xbound && so.obound && n % 16 == 0), MEVI_ERR_INVALID_ARG,
+               "gemm_nt_split: residual-stream output needs the 16x16x32 kernels, no activation, a residual, n %% 16 == 0");
+  MEVI_REQUIRE(!(shape32 && (so.rscale || so.rparts)), MEVI_ERR_UNSUPPORTED, "gemm_nt_split: row scales need the 16x16x32 kernels");
   const int o3 = so.img ? 2 : (residual ? 1 : 0);
-  const kern_t fn = shape32 ? table[a8][o3] : table16[ni == 8 ? 0 : (ni == 4 ? 1 : 2)][a8][o3];
+  const kern_t fn = shape32 ? table[a8][o3] : (both ? both16[ni == 8 ? 0 : (ni == 4 ? 1 : 2)] : table16[ni == 8 ? 0 : (ni == 4 ? 1 : 2)][a8][o3]);
   MEVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(PP_THREADS), lds_bytes, stream, A, reinterpret_cast<const signed char *>(a_exp), (int)m, W,
@@ -1265,6 +1423,97 @@ extern "C" int mevi_gemm_nt_split_to_split(const void *a_img, const int8_t *a_ex
   so.babs_max = bias_abs_max;
   so.onorm_scale = sqrtf((float)n) * 1.0001f;  // ||row||_2 <= sqrt(n) * max|element|
   return gemm_split_launch(a_img, a_exp, w_img, w_exp, nullptr, 0, m, n, k, bias, nullptr, 0, act, so, stream);
+}
+
+// ---- T5LayerNorm folded into the linear layers around it (round 5; SplitOut) ------------------------------------------------------
+// The residual stream travels as (f32 rows, split image, bound on max |row|, block sums of squares [M][N / 16]):
+//   mevi_split_rows_ssq_f16             where it starts (token embeddings)
+//   mevi_gemm_nt_split_residual_stream  x' = x + a W^T: the f32 rows AND their image, bound, block sums, in the GEMM's epilogue
+//   mevi_gemm_nt_split_normed_*         act(rsqrt(mean x^2 + eps) (x W'^T) + b): W' = W (.) w_ln, x = the stream's image
+// mevi_rmsnorm_split_f16 (one pass over the rows per norm: read 4 B, write 4 B per element) is not launched on this path.
+extern "C" int mevi_gemm_norm_fold_supported(int64_t n_stream) {
+  static const bool shape32 = [] { const char *e = getenv("MEVI_GEMM_MFMA"); return e && atoi(e) == 32; }();
+  return !shape32 && n_stream >= 16 && n_stream % 16 == 0 && n_stream <= 1024;
+}
+
+extern "C" int mevi_split_rows_ssq_f16(const float *x, int64_t ldx, int64_t m, int64_t k, void *img, int8_t *exps, float *bound,
+                                       float *ssq, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(m >= 0 && mevi_gemm_norm_fold_supported(k), MEVI_ERR_UNSUPPORTED, "split_rows_ssq: k must be a multiple of 16, <= 1024");
+  if (m == 0) return MEVI_OK;
+  MEVI_REQUIRE(x && img && exps && bound && ssq, MEVI_ERR_INVALID_ARG, "split_rows_ssq: null pointer");
+  MEVI_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)img % 16) == 0, MEVI_ERR_UNSUPPORTED, "split_rows_ssq: alignment");
+  hipLaunchKernelGGL(split_rows_ssq_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, x, (long long)ldx, (long long)m, (int)k,
+                     (int)mevi_split_kp(k), reinterpret_cast<_Float16 *>(img), reinterpret_cast<signed char *>(exps), bound, ssq);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" int mevi_row_rscale_f32(const float *parts, int64_t m, int64_t nparts, float dim, float eps, float *out, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(m >= 0 && nparts > 0, MEVI_ERR_INVALID_ARG, "row_rscale: bad shape");
+  if (m == 0) return MEVI_OK;
+  MEVI_REQUIRE(parts && out && ((uintptr_t)parts % 16) == 0, MEVI_ERR_INVALID_ARG, "row_rscale: null / unaligned pointer");
+  hipLaunchKernelGGL(row_rscale_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, parts, (long long)m, (int)nparts, dim, eps, out);
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+static int fold_consumer(SplitOut &so, const float *parts, int64_t nparts, float rs_dim, float rs_eps, float *rscale_ws) {
+  MEVI_REQUIRE(parts && rscale_ws && nparts > 0 && ((uintptr_t)parts % 16) == 0, MEVI_ERR_INVALID_ARG,
+               "gemm_nt_split_normed: block sums [m][nparts] (16-byte aligned) and a [m] scale buffer are required");
+  so.rparts = parts, so.nparts = (int)nparts, so.rs_dim = rs_dim, so.rs_eps = rs_eps, so.rscale = rscale_ws;
+  return MEVI_OK;
+}
+
+extern "C" int mevi_gemm_nt_split_normed_f32(const void *a_img, const int8_t *a_exp, const float *parts, int64_t nparts, float rs_dim,
+                                             float rs_eps, float *rscale_ws, const void *w_img, const int8_t *w_exp, float *c,
+                                             int64_t ldc, int64_t m, int64_t n, int64_t k, const float *bias, const float *residual,
+                                             int64_t ldr, int act, void *stream) {
+  SplitOut so = {};
+  if (m > 0) { const int st = fold_consumer(so, parts, nparts, rs_dim, rs_eps, rscale_ws); if (st != MEVI_OK) return st; }
+  return gemm_split_launch(a_img, a_exp, w_img, w_exp, c, ldc, m, n, k, bias, residual, ldr, act, so, stream);
+}
+
+extern "C" int mevi_gemm_nt_split_normed_to_split(const void *a_img, const int8_t *a_exp, const float *parts, int64_t nparts,
+                                                  float rs_dim, float rs_eps, float *rscale_ws, float a_norm_bound, const void *w_img,
+                                                  const int8_t *w_exp, float w_norm_max, int64_t m, int64_t n, int64_t k,
+                                                  const float *bias, float bias_abs_max, int act, void *out_img, int8_t *out_exp,
+                                                  float *out_norm, void *stream) {
+  MEVI_REQUIRE(m == 0 || (out_img && out_exp), MEVI_ERR_INVALID_ARG, "gemm_nt_split_normed_to_split: null pointer");
+  MEVI_REQUIRE(w_norm_max >= 0.f && bias_abs_max >= 0.f && a_norm_bound >= 0.f, MEVI_ERR_INVALID_ARG, "gemm_nt_split_normed_to_split: negative bound");
+  SplitOut so = {};
+  if (m > 0) { const int st = fold_consumer(so, parts, nparts, rs_dim, rs_eps, rscale_ws); if (st != MEVI_OK) return st; }
+  so.img = reinterpret_cast<_Float16 *>(out_img);
+  so.exps = reinterpret_cast<signed char *>(out_exp);
+  so.norms = out_norm;
+  so.anorm = nullptr, so.anorm_const = a_norm_bound;     // ||rsqrt(.) x|| <= sqrt(d): the same bound for every row
+  so.np = (int)mevi_split_kp(n);
+  so.wnorm_max = w_norm_max;
+  so.babs_max = bias_abs_max;
+  so.onorm_scale = sqrtf((float)n) * 1.0001f;
+  return gemm_split_launch(a_img, a_exp, w_img, w_exp, nullptr, 0, m, n, k, bias, nullptr, 0, act, so, stream);
+}
+
+extern "C" int mevi_gemm_nt_split_residual_stream(const void *a_img, const int8_t *a_exp, const float *a_norm, float a_norm_const,
+                                                  const float *parts, int64_t nparts, float rs_dim, float rs_eps, float *rscale_ws,
+                                                  const void *w_img, const int8_t *w_exp, float w_norm_max, float *c, int64_t ldc,
+                                                  int64_t m, int64_t n, int64_t k, const float *residual, int64_t ldr,
+                                                  const float *x_bound, void *out_img, int8_t *out_exp, float *out_bound,
+                                                  float *out_ssq, void *stream) {
+  MEVI_REQUIRE(mevi_gemm_norm_fold_supported(n), MEVI_ERR_UNSUPPORTED, "gemm_nt_split_residual_stream: n must be a multiple of 16, <= 1024");
+  MEVI_REQUIRE(m == 0 || (c && residual && x_bound && out_img && out_exp && out_bound && out_ssq), MEVI_ERR_INVALID_ARG,
+               "gemm_nt_split_residual_stream: null pointer");
+  MEVI_REQUIRE(w_norm_max >= 0.f && a_norm_const >= 0.f, MEVI_ERR_INVALID_ARG, "gemm_nt_split_residual_stream: negative bound");
+  SplitOut so = {};
+  if (m > 0 && parts) { const int st = fold_consumer(so, parts, nparts, rs_dim, rs_eps, rscale_ws); if (st != MEVI_OK) return st; }
+  so.img = reinterpret_cast<_Float16 *>(out_img);
+  so.exps = reinterpret_cast<signed char *>(out_exp);
+  so.anorm = a_norm, so.anorm_const = a_norm_const;
+  so.np = (int)mevi_split_kp(n);
+  so.wnorm_max = w_norm_max;
+  so.ssq = out_ssq, so.xbound = x_bound, so.obound = out_bound;
+  return gemm_split_launch(a_img, a_exp, w_img, w_exp, c, ldc, m, n, k, nullptr, residual, ldr, 0, so, stream);
 }
 
 // ---- norm + projection in one launch (the latency path; see gemm_rmsnorm_split16_kernel) -------------------------------------

@@ -57,6 +57,18 @@ _SIGNATURES = {
     "mevi_gemm_nt_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                        c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mevi_gemm_rmsnorm_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "mevi_gemm_norm_fold_supported": (c_int, [c_int64]),
+    "mevi_split_rows_ssq_f16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mevi_row_rscale_f32": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p]),
+    "mevi_gemm_nt_split_normed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int,
+                                              c_void_p]),
+    "mevi_gemm_nt_split_normed_to_split": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_float,
+                                                   c_void_p, c_void_p, c_float, c_int64, c_int64, c_int64, c_void_p, c_float, c_int,
+                                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mevi_gemm_nt_split_residual_stream": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_float, c_float, c_void_p,
+                                                   c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                                   c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mevi_gemm_nt_rmsnorm_split_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                                c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mevi_gemm_nt_rmsnorm_split_to_split": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_float, c_int64, c_int64,

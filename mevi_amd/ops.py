@@ -159,7 +159,9 @@ def _ctx_image(rows, k, bound, dev):
             # exponent array of its o-projection GEMM and does not keep it alive: a superseded fill is retired, never freed
             _EXP_FILL_RETIRED.append(fill)
         fill = _EXP_FILL[(dev, e)] = torch.full((max(rows, 1 << 16),), e, dtype=torch.int8, device=dev)
-    return SplitRows(img, fill[:rows], k, None), kp, e
+    # (norm_max of an ACTIVATION image: one bound on every row's l2 norm -- sqrt(k) |element| <= sqrt(k) bound -- for the GEMM
+    # that adds this context to the residual stream, linear_residual)
+    return SplitRows(img, fill[:rows], k, None, math.sqrt(k) * bound * 1.001), kp, e
 
 
 def split_rows(x):
@@ -277,6 +279,130 @@ def linear(x, weight, bias=None, residual=None, relu=False, out=None, gelu=False
                                     hip.stream_ptr())
     hip.check(st, "mevi_gemm_nt_f32")
     return out
+
+
+# ---- T5LayerNorm folded into the linear layers around it (include/mevi_hip.h, "T5LayerNorm folded ...") ---------------------------
+# Built in round 5, every golden and oracle comparison holds with it, and it is OFF by default because it measured
+# SLOWER where it was meant to pay: NCI generate 166.9 -> 174.7 ms per 6980 queries, tower 60.0 -> 62.0 ms, 873 queries 27.2 -> 28.3 ms
+# (one box, profiles/r05_fold_norm.txt).  The separate pass streams at 6 TB/s (60 us per 76.9 k rows); writing the stream's image in
+# the producing GEMM's epilogue -- 64-byte store segments, behind the f32 rows the next residual add still needs -- costs as much,
+# and the block sums (48 scattered 4-byte stores per row) and the scale launch come on top.  Only the batch-1 graphs gain (launches:
+# tower 1.33 -> 1.29 ms, NCI 3.11 -> 3.05 ms), and a row must have the same bits in any batch, so there is no folding small batches
+# only.  MEVI_FOLD_NORM=1 turns it on (A/B; tests/test_t5_gpu.py runs the goldens both ways).
+FOLD_NORM = os.environ.get("MEVI_FOLD_NORM", "0") == "1"
+
+
+def fold_norm_ok(d_model):
+    """Whether the T5 stacks of width d_model run with their norms folded: split GEMM, a width the stream kernels take."""
+    return bool(FOLD_NORM and GEMM_MODE == "split" and hip.lib().mevi_gemm_norm_fold_supported(int(d_model)))
+
+
+def fold_weight(w, ln):
+    """W (.) w_ln: the [out, in] weight of the projection a T5LayerNorm with weight `ln` feeds, with the norm's weight folded in."""
+    return (w * ln[None, :]).contiguous()
+
+
+class ResidualRows:
+    """A T5 stack's residual stream with its norms folded away: x f32 [M, D], the split image of x (img, exp), bound f32 [M]
+    >= max |row| and ssq f32 [M, D / 16] = sums of squares of the rows' 16-column blocks.  The projections that follow a
+    T5LayerNorm read the image and scale their product per row (linear_normed); the projections that add to the stream write
+    all five next to each other (linear_residual)."""
+
+    __slots__ = ("x", "img", "exp", "bound", "ssq")
+
+    def __init__(self, x, img, exp, bound, ssq):
+        self.x, self.img, self.exp, self.bound, self.ssq = x, img, exp, bound, ssq
+
+    @property
+    def shape(self):
+        return tuple(self.x.shape)
+
+    @property
+    def device(self):
+        return self.x.device
+
+
+def _stream_buffers(M, D, dev):
+    kp = split_kp(D)
+    img = (torch.zeros if kp != D else torch.empty)((M, 2 * kp), dtype=torch.int16, device=dev)
+    return (img, torch.empty((M,), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev),
+            torch.empty((M, D // 16), dtype=torch.float32, device=dev))
+
+
+@hip.on_device
+def residual_start(x):
+    """Where a stack's residual stream starts (the token embeddings): x f32 [M, D] -> ResidualRows."""
+    x, M, D, ldx = _rows2d(_f32(x))
+    img, exp, bound, ssq = _stream_buffers(M, D, x.device)
+    st = hip.lib().mevi_split_rows_ssq_f16(hip.ptr(x), ldx, M, D, hip.ptr(img), hip.ptr(exp), hip.ptr(bound), hip.ptr(ssq), hip.stream_ptr())
+    hip.check(st, "mevi_split_rows_ssq_f16")
+    return ResidualRows(x, img, exp, bound, ssq)
+
+
+def linear_normed(r, weight, eps, bias=None, relu=False, out=None, for_gemm=False):
+    """act(rmsnorm(x) W^T + b) for the stream r, `weight` = split image of W (.) w_ln: the image of the RAW rows is multiplied and
+    every row of the product scaled by rsqrt(mean x^2 + eps) (mevi_gemm_nt_split_normed_*)."""
+    M, K = r.shape
+    N = weight.shape[0]
+    assert isinstance(weight, SplitRows) and weight.shape[1] == K
+    dev = weight.device
+    L = hip.lib()
+    act = 1 if relu else 0
+    with hip.device_guard(dev):
+        ws = torch.empty((M,), dtype=torch.float32, device=dev)
+        np_ = r.ssq.shape[1]
+        if for_gemm:
+            assert out is None and weight.norm_max is not None
+            babs = _abs_max(bias) if bias is not None else 0.0
+            img, exp, norm = _split_buffers(M, N, dev, zero=True)
+            st = L.mevi_gemm_nt_split_normed_to_split(hip.ptr(r.img), hip.ptr(r.exp), hip.ptr(r.ssq), np_, float(K), eps, hip.ptr(ws),
+                                                      math.sqrt(K) * 1.0001, hip.ptr(weight.img), hip.ptr(weight.exp), weight.norm_max,
+                                                      M, N, K, hip.ptr(bias) if bias is not None else None, babs, act, hip.ptr(img),
+                                                      hip.ptr(exp), hip.ptr(norm), hip.stream_ptr())
+            hip.check(st, "mevi_gemm_nt_split_normed_to_split")
+            return SplitRows(img, exp, N, norm)
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=dev)
+        assert out.shape == (M, N) and out.stride(1) == 1
+        st = L.mevi_gemm_nt_split_normed_f32(hip.ptr(r.img), hip.ptr(r.exp), hip.ptr(r.ssq), np_, float(K), eps, hip.ptr(ws),
+                                             hip.ptr(weight.img), hip.ptr(weight.exp), hip.ptr(out), out.stride(0), M, N, K,
+                                             hip.ptr(bias) if bias is not None else None, None, 0, act, hip.stream_ptr())
+    hip.check(st, "mevi_gemm_nt_split_normed_f32")
+    return out
+
+
+def linear_residual(a, weight, r, normed_eps=None):
+    """The stream's next state x + a W^T (T5's `hidden_states + dropout(y)`), as ResidualRows: f32 rows, image, bound and block sums
+    from the GEMM's epilogue.  `a`: a SplitRows with per-row norms (`norm`) or one bound for all rows (`norm_max`: attention
+    contexts) -- or, with `normed_eps`, the stream itself (x + rmsnorm(x) W^T: the one-position decoder's folded o(v(.)))."""
+    assert isinstance(weight, SplitRows) and weight.norm_max is not None
+    if torch.is_tensor(a):        # an f32 operand (attention contexts with MEVI_ATTN_CTX=f32): its image, with the rows' norms
+        a = split_rows(a)
+    M, D = r.shape
+    N, K = weight.shape
+    assert N == D
+    dev = weight.device
+    L = hip.lib()
+    with hip.device_guard(dev):
+        x = torch.empty((M, D), dtype=torch.float32, device=dev)
+        img, exp, bound, ssq = _stream_buffers(M, D, dev)
+        if normed_eps is not None:
+            assert a is r and K == D
+            ws = torch.empty((M,), dtype=torch.float32, device=dev)
+            a_img, a_exp, a_norm, a_const = r.img, r.exp, None, math.sqrt(K) * 1.0001
+            parts, np_, rd, re, wsp = hip.ptr(r.ssq), r.ssq.shape[1], float(K), normed_eps, hip.ptr(ws)
+        else:
+            assert isinstance(a, SplitRows) and a.shape == (M, K)
+            a_img, a_exp = a.img, a.exp
+            a_norm, a_const = (a.norm, 0.0) if a.norm is not None else (None, float(a.norm_max))
+            assert a_norm is not None or a.norm_max is not None
+            parts, np_, rd, re, wsp = None, 0, 0.0, 0.0, None
+        st = L.mevi_gemm_nt_split_residual_stream(hip.ptr(a_img), hip.ptr(a_exp), hip.ptr(a_norm) if a_norm is not None else None, a_const,
+                                                  parts, np_, rd, re, wsp, hip.ptr(weight.img), hip.ptr(weight.exp), weight.norm_max,
+                                                  hip.ptr(x), D, M, N, K, hip.ptr(r.x), r.x.stride(0), hip.ptr(r.bound), hip.ptr(img),
+                                                  hip.ptr(exp), hip.ptr(bound), hip.ptr(ssq), hip.stream_ptr())
+    hip.check(st, "mevi_gemm_nt_split_residual_stream")
+    return ResidualRows(x, img, exp, bound, ssq)
 
 
 class NormedRows:

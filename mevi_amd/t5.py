@@ -59,7 +59,30 @@ def _dev(w, key, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
-class EncoderStack:
+class _PreNormBlocks:
+    """The linear layers of T5's pre-norm residual blocks in their two forms: with the T5LayerNorm folded into the projection
+    it feeds (self.fold: the residual stream is an ops.ResidualRows) or as its own pass (an f32 tensor)."""
+
+    def _nl(self, x, L, ln, wk, **kw):
+        """act(rmsnorm(x) W^T)"""
+        if self.fold:
+            return ops.linear_normed(x, L[wk], self.d.eps, **kw)
+        return ops.linear(ops.rmsnorm(x, L[ln], self.d.eps, for_gemm=True), L[wk], **kw)
+
+    def _rl(self, a, L, wk, x):
+        """x + a W^T"""
+        if self.fold:
+            return ops.linear_residual(a, L[wk], x)
+        return ops.linear(a, L[wk], residual=x)
+
+    def _start(self, x):
+        return ops.residual_start(x) if self.fold else x
+
+    def _final(self, x):
+        return ops.rmsnorm(x.x if self.fold else x, self.final_ln, self.d.eps)
+
+
+class EncoderStack(_PreNormBlocks):
     """T5Stack(is_decoder=False).  Weights: the reference's state_dict names under `prefix`."""
 
     def __init__(self, w, dims, device, prefix="encoder", max_len=64):
@@ -75,9 +98,14 @@ class EncoderStack:
                 ln1=_dev(w, f"{p}.1.layer_norm.weight", device),
                 wi=_dev(w, f"{p}.1.DenseReluDense.wi.weight", device),
                 wo2=_dev(w, f"{p}.1.DenseReluDense.wo.weight", device)))
+        # round 5: the T5LayerNorms folded into the projections they feed (ops.ResidualRows; MEVI_FOLD_NORM=0: separate passes)
+        self.fold = ops.fold_norm_ok(dims.d_model)
+        if self.fold:
+            for L in self.layers:
+                L["wqkv"], L["wi"] = ops.fold_weight(L["wqkv"], L["ln0"]), ops.fold_weight(L["wi"], L["ln1"])
         ops.prepare_weights(self.layers, ("wqkv", "wo", "wi", "wo2"))
         for L in self.layers:   # |V| bound: the self-attention context goes to `o` as its split image (ops.ctx_bound)
-            L["vb"] = ops.ctx_bound(ops.norm_out_bound(L["ln0"], dims.d_model), L["wqkv"])
+            L["vb"] = ops.ctx_bound(math.sqrt(dims.d_model) * 1.0001 if self.fold else ops.norm_out_bound(L["ln0"], dims.d_model), L["wqkv"])
         self.final_ln = _dev(w, f"{prefix}.final_layer_norm.weight", device)
         self.out_norm = ops.norm_out_bound(self.final_ln, dims.d_model)     # l2 bound of a returned state row
         self.rel = _dev(w, f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight", device)
@@ -109,41 +137,35 @@ class EncoderStack:
                 idx = None
         bias = self.bias(S)
         if idx is None:
-            x = ops.gather_rows(embeddings, input_ids.reshape(-1))
+            x = self._start(ops.gather_rows(embeddings, input_ids.reshape(-1)))
             for L in self.layers:
-                h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
-                qkv = ops.linear(h, L["wqkv"]).view(B, S, 3 * d.inner)
+                qkv = self._nl(x, L, "ln0", "wqkv").view(B, S, 3 * d.inner)
                 ctx = ops.attention(qkv[:, :, :d.inner], qkv[:, :, d.inner:2 * d.inner], qkv[:, :, 2 * d.inner:],
                                     d.num_heads, bias=bias, key_mask=attention_mask, split_bound=L["vb"])
-                x = ops.linear(ctx if L["vb"] is not None else ctx.view(B * S, d.inner), L["wo"], residual=x)
-                h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
-                x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
-            return ops.rmsnorm(x, self.final_ln, d.eps).view(B, S, d.d_model)
-        x = ops.gather_rows(embeddings, input_ids.reshape(-1)[idx])            # [T, d_model], T real tokens
+                x = self._rl(ctx if L["vb"] is not None else ctx.view(B * S, d.inner), L, "wo", x)
+                x = self._rl(self._nl(x, L, "ln1", "wi", relu=True, for_gemm=True), L, "wo2", x)
+            return self._final(x).view(B, S, d.d_model)
+        x = self._start(ops.gather_rows(embeddings, input_ids.reshape(-1)[idx]))            # [T, d_model], T real tokens
         seq_off, longest = packed_offsets(attention_mask)
         if seq_off is not None and varlen_ok(longest, d.d_kv):
             # right-padded sequences (what the tokenizers produce): attention runs on the packed rows too
             for L in self.layers:
-                h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
-                qkv = ops.linear(h, L["wqkv"])
+                qkv = self._nl(x, L, "ln0", "wqkv")
                 ctx = ops.attention_varlen(qkv[:, :d.inner], qkv[:, d.inner:2 * d.inner], qkv[:, 2 * d.inner:], seq_off,
                                            longest, d.num_heads, bias=bias, split_bound=L["vb"])
-                x = ops.linear(ctx, L["wo"], residual=x)
-                h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
-                x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
+                x = self._rl(ctx, L, "wo", x)
+                x = self._rl(self._nl(x, L, "ln1", "wi", relu=True, for_gemm=True), L, "wo2", x)
         else:
             qkv = torch.zeros((B * S, 3 * d.inner), dtype=torch.float32, device=x.device)   # padded rows stay 0 (finite)
             for L in self.layers:
-                h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
-                ops.scatter_rows(ops.linear(h, L["wqkv"]), idx, qkv)
+                ops.scatter_rows(self._nl(x, L, "ln0", "wqkv"), idx, qkv)
                 q3 = qkv.view(B, S, 3 * d.inner)
                 ctx = ops.attention(q3[:, :, :d.inner], q3[:, :, d.inner:2 * d.inner], q3[:, :, 2 * d.inner:],
                                     d.num_heads, bias=bias, key_mask=attention_mask)
-                x = ops.linear(ops.gather_rows(ctx.view(B * S, d.inner), idx), L["wo"], residual=x)
-                h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
-                x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
+                x = self._rl(ops.gather_rows(ctx.view(B * S, d.inner), idx), L, "wo", x)
+                x = self._rl(self._nl(x, L, "ln1", "wi", relu=True, for_gemm=True), L, "wo2", x)
         out = torch.zeros((B * S, d.d_model), dtype=torch.float32, device=x.device)
-        ops.scatter_rows(ops.rmsnorm(x, self.final_ln, d.eps), idx, out)
+        ops.scatter_rows(self._final(x), idx, out)
         return out.view(B, S, d.d_model)
 
 
@@ -217,7 +239,7 @@ class CrossKV:
         self.layers, self.mask, self.kv_off, self.longest = layers, mask, kv_off, longest
 
 
-class DecoderStack:
+class DecoderStack(_PreNormBlocks):
     """T5Stack(is_decoder=True) evaluated one position at a time with a KV cache.
 
     The reference runs use_cache=False and recomputes the whole prefix for every beam at every
@@ -245,13 +267,20 @@ class DecoderStack:
                 wi=_dev(w, f"{p}.2.DenseReluDense.wi.weight", device),
                 wo2=_dev(w, f"{p}.2.DenseReluDense.wo.weight", device)))
         keys = ("wqkv", "wo", "xq", "xo", "wi", "wo2")
+        self.fold = ops.fold_norm_ok(dims.d_model)      # the T5LayerNorms folded into wqkv / (wov) / xq / wi (ops.ResidualRows)
         if max_len == 1 and ops.GEMM_MODE == "split" and WOV_FUSE:
             # A single-position decoder (the towers) attends to ONE key: the softmax weight is exactly 1, the context is v, and
             # o(v(h)) = h (Wo Wv)^T -- one projection instead of two (the product is taken once, in f64).  MEVI_GEMM=exact keeps
             # the two sequential-chain GEMMs of the reference.
             for L in self.layers:
                 L["wov"] = (L["wo"].double() @ L["wqkv"][2 * dims.inner:].double()).float().contiguous()
+                if self.fold:
+                    L["wov"] = ops.fold_weight(L["wov"], L["ln0"])
             keys += ("wov",)
+        if self.fold:
+            for L in self.layers:
+                L["wqkv"], L["xq"], L["wi"] = (ops.fold_weight(L["wqkv"], L["ln0"]), ops.fold_weight(L["xq"], L["ln1"]),
+                                               ops.fold_weight(L["wi"], L["ln2"]))
         # the cross-attention K|V of ALL layers read the same encoder states: one GEMM of n_layers * 6 column tiles (12 layers:
         # 85 tile rounds on 256 CUs instead of 12 x 8)
         self.xkv_all = ops.weight(torch.cat([L["xkv"] for L in self.layers]).contiguous(), keep_norm=True)
@@ -261,7 +290,7 @@ class DecoderStack:
             self.xkv_all.norm = None
         ops.prepare_weights(self.layers, keys)
         for L in self.layers:
-            L["vb"] = ops.ctx_bound(ops.norm_out_bound(L["ln0"], dims.d_model), L["wqkv"])
+            L["vb"] = ops.ctx_bound(math.sqrt(dims.d_model) * 1.0001 if self.fold else ops.norm_out_bound(L["ln0"], dims.d_model), L["wqkv"])
             L["xvb"] = None          # cross-attention: needs the encoder's output norm (set_encoder_norm)
         self.final_ln = _dev(w, f"{prefix}.final_layer_norm.weight", device)
         rel = _dev(w, f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight", device)
@@ -321,21 +350,23 @@ class DecoderStack:
         n = x.shape[0]
         if key_rows is not None:
             cache = [kvc[:n] if t == 0 else kvc for kvc in cache]
+        x = self._start(x)
         for L, kvc, xc in zip(self.layers, cache, xkv.layers):
-            h = ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True)
             ctx = None
             if t == 0 and "wov" in L:
-                x = ops.linear(h, L["wov"], residual=x)          # o(v(h)) in one projection (see __init__)
+                # o(v(norm x)) in one projection (see __init__)
+                x = ops.linear_residual(x, L["wov"], x, normed_eps=d.eps) if self.fold else \
+                    ops.linear(ops.rmsnorm(x, L["ln0"], d.eps, for_gemm=True), L["wov"], residual=x)
             elif t == 0:
                 # one key: its softmax weight is exp(0) / exp(0) = 1 exactly, so the attention output IS v -- no query
                 # projection, no attention kernel; a single-position decoder (the towers) never needs k either
                 if self.max_len == 1:
-                    ctx = ops.linear(h, L["wqkv"][2 * d.inner:])
+                    ctx = self._nl(x, dict(L, wv=L["wqkv"][2 * d.inner:]), "ln0", "wv")
                 else:
-                    ops.linear(h, L["wqkv"][d.inner:], out=kvc[:, 0, d.inner:])
+                    self._nl(x, dict(L, wkv=L["wqkv"][d.inner:]), "ln0", "wkv", out=kvc[:, 0, d.inner:])
                     ctx = kvc[:, 0, 2 * d.inner:]
             else:
-                ops.linear(h, L["wqkv"], out=kvc[:n, t, :])
+                self._nl(x, L, "ln0", "wqkv", out=kvc[:n, t, :])
                 q = kvc[:n, t, :d.inner]
                 if key_rows is not None:
                     ctx = ops.attention_cached(q, kvc[:, :, d.inner:2 * d.inner], kvc[:, :, 2 * d.inner:], key_rows, d.num_heads,
@@ -346,19 +377,17 @@ class DecoderStack:
                     if L["vb"] is None:
                         ctx = ctx.view(n, d.inner)
             if ctx is not None:
-                x = ops.linear(ctx, L["wo"], residual=x)
-            h = ops.rmsnorm(x, L["ln1"], d.eps, for_gemm=True)
-            q = ops.linear(h, L["xq"])
+                x = self._rl(ctx, L, "wo", x)
+            q = self._nl(x, L, "ln1", "xq")
             if xkv.kv_off is None:
                 ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :, :d.inner], xc[:, :, d.inner:], d.num_heads,
                                     kv_div=kv_div, key_mask=xkv.mask, split_bound=L["xvb"])
             else:
                 ctx = ops.attention(q.view(n, 1, d.inner), xc[:, :d.inner], xc[:, d.inner:], d.num_heads, kv_div=kv_div,
                                     kv_off=xkv.kv_off, kv_longest=xkv.longest, split_bound=L["xvb"])
-            x = ops.linear(ctx if L["xvb"] is not None else ctx.view(n, d.inner), L["xo"], residual=x)
-            h = ops.rmsnorm(x, L["ln2"], d.eps, for_gemm=True)
-            x = ops.linear(ops.linear(h, L["wi"], relu=True, for_gemm=True), L["wo2"], residual=x)
-        return ops.rmsnorm(x, self.final_ln, d.eps)
+            x = self._rl(ctx if L["xvb"] is not None else ctx.view(n, d.inner), L, "xo", x)
+            x = self._rl(self._nl(x, L, "ln2", "wi", relu=True, for_gemm=True), L, "wo2", x)
+        return self._final(x)
 
 
 # Padded tokens per device pass of a tower (8192 queries x 32, 2048 passages x 128): results do not depend on the

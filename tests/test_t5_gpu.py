@@ -108,6 +108,48 @@ def test_nci_generate_matches_reference_golden(cuda, path):
     assert np.array_equal(codes.cpu().numpy(), ot5.decode_token(torch.from_numpy(g["decoded"]), cfg["K"]).numpy())
 
 
+def test_goldens_hold_with_the_layer_norms_folded_into_the_projections(cuda, monkeypatch):
+    """MEVI_FOLD_NORM=1 (round 5; off by default because it measured slower, profiles/r05_fold_norm.txt): T5LayerNorm as a row scale
+    behind the projection it feeds -- rmsnorm(x) W^T = rsqrt(mean x^2 + eps) (x (W (.) w_ln)^T) -- with the residual stream's image and
+    block sums of squares written by the GEMM that produces it (mevi_gemm_nt_split_residual_stream / _normed_*).  The reference
+    goldens hold at their tolerances, a row keeps its bits whether it travels alone (graph replay, latency kernels) or in a
+    batch (tile stream), and the packed encoder equals the padded one."""
+    from mevi_amd import ops
+
+    monkeypatch.setattr(ops, "FOLD_NORM", True)
+    g = np.load(os.path.join(GOLD, "g2_t5_tower.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    tower = t5.TwinTower(nci.load_npz_weights(g), device=cuda, **cfg)
+    assert tower.encoder.fold and tower.decoder.fold
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    enc = tower.encoder.forward(tower.shared, ids.to(cuda), mask.to(cuda), pack=False)
+    assert np.abs(enc.cpu().numpy() - g["enc_last"]).max() <= 5e-5
+    packed = tower.encoder.forward(tower.shared, ids.to(cuda), mask.to(cuda), pack=True)
+    valid = g["attention_mask"].astype(bool)
+    assert np.array_equal(packed.cpu().numpy()[valid], enc.cpu().numpy()[valid])
+    reps = tower.encode_query({"input_ids": ids, "attention_mask": mask})
+    assert np.abs(reps.cpu().numpy() - g["reps"]).max() <= 5e-5
+    for a in (0, 3):                                                     # eager, capture, replay: one query alone
+        for _ in range(3):
+            one = tower.encode_query({"input_ids": ids[a:a + 1], "attention_mask": mask[a:a + 1]}, graph=True)
+            assert torch.equal(one, reps[a:a + 1])
+    for path in sorted(glob.glob(os.path.join(GOLD, "g1_nci_*.npz"))):
+        g = np.load(path)
+        cfg = json.loads(str(g["cfg"]))
+        beams = cfg.pop("beams")
+        model = nci.NCIModel(nci.load_npz_weights(g), device=cuda, **cfg)
+        assert model.encoder.fold and model.decoder.fold
+        ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+        dec, scores, enc, _ = model.generate(ids, mask, num_beams=beams, num_return_sequences=beams, max_length=cfg["M"] + 2)
+        valid = g["attention_mask"].astype(bool)
+        assert np.abs(enc.cpu().numpy() - g["enc_hidden"])[valid].max() <= 5e-5
+        assert np.array_equal(dec.cpu().numpy(), g["decoded"])
+        assert np.abs(np.array(scores) - g["scores"]).max() <= 1e-5
+        for _ in range(3):
+            d1, s1, _, _ = model.generate(ids[:1], mask[:1], num_beams=beams, graph=True)
+            assert torch.equal(d1, dec[:beams]) and s1 == scores[:beams]
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1t_nci_tree_*.npz"))))
 def test_nci_generate_under_a_generic_prefix_tree_matches_reference_golden(cuda, path):
     """Golden G1T: generate(decode_tree = the trie of the existing code paths, TreeBuilder(share_sons=False),
