@@ -664,15 +664,22 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
       const int c = ncol + 16 * mi;
       wq[mi] = __builtin_amdgcn_raw_buffer_load_b32(rw, (interior || c < nvalid) ? c : OOB, 0, 0);
     }
-    u32x4 bq[2], res[2][HAS_RES ? 2 : 1];
-    auto load_step = [&](int i, u32x4 &b, u32x4 (&r)[HAS_RES ? 2 : 1]) {
-      const int mi = i / PR, pr = i % PR;
+    // Step order (round 5): ROW-block major -- step i = (row pair pr = i / 4, block column mi = i % 4) -- so that the four 64-byte
+    // pieces of a row's 256 bytes in this wave's columns leave in four consecutive store instructions (block-column major had
+    // them a quarter of the epilogue apart: half-written 128-byte lines waiting in L2 while 32 CUs of the XCD write 8 MB).
+    // The bias quads of the four block columns are held for the whole tile (all four loaded up front).
+    constexpr int RD = 1;                      // residual rows are requested RD steps ahead of their use (a ring of RD + 1 steps)
+    u32x4 bq[4], res[RD + 1][HAS_RES ? 2 : 1];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int c = ncol + 16 * mi;
+      bq[mi] = u32x4{0u, 0u, 0u, 0u};
+      if (bias) bq[mi] = __builtin_amdgcn_raw_buffer_load_b128(rb, (interior || c < nvalid) ? c * 4 : OOB, 0, 0);
+    }
+    auto load_step = [&](int i, u32x4 (&r)[HAS_RES ? 2 : 1]) {
+      const int mi = i & 3, pr = i >> 2;
       const int c = ncol + 16 * mi;
       const bool cok = interior || c < nvalid;
-      if (pr == 0) {
-        b = u32x4{0u, 0u, 0u, 0u};
-        if (bias) b = __builtin_amdgcn_raw_buffer_load_b128(rb, cok ? c * 4 : OOB, 0, 0);
-      }
       if constexpr (HAS_RES) {
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
@@ -682,7 +689,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
         }
       }
     };
-    load_step(0, bq[0], res[0]);
+#pragma unroll
+    for (int i = 0; i < RD && i < STEPS; ++i) load_step(i, res[i]);
     float part[LOGITS ? 8 : 1];   // LOGITS: the lane's chain per row 16 ni + r16, sixteen terms in order (mi, j)
     if constexpr (LOGITS) {
 #pragma unroll
@@ -690,10 +698,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
     }
 #pragma unroll
     for (int i = 0; i < STEPS; ++i) {
-      const int mi = i / PR, pr = i % PR;
+      const int mi = i & 3, pr = i >> 2;
       const int c = ncol + 16 * mi;
       const bool cok = interior || c < nvalid;
-      if (i + 1 < STEPS) load_step(i + 1, bq[((i + 1) / PR) & 1], res[(i + 1) & 1]);
+      if (i + RD < STEPS) load_step(i + RD, res[(i + RD) & RD]);
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2) {
         const int ni = 2 * pr + n2;
@@ -703,10 +711,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_split16_kernel(
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float x = __fmul_rn(ldexpf(acc[mi][ni][j], -(em + sx8(wq[mi], j))), rsv[ni]) + __uint_as_float(bq[mi & 1][j]);   // (no fma with the bias: the latency kernels round the product too)
+          float x = __fmul_rn(ldexpf(acc[mi][ni][j], -(em + sx8(wq[mi], j))), rsv[ni]) + __uint_as_float(bq[mi][j]);   // (no fma with the bias: the latency kernels round the product too)
           x = act_fn<ACT>(x);
-          if constexpr (LOGITS) part[ni] = fmaf(__uint_as_float(res[i & 1][n2][j]) * so.alpha, x, part[ni]);
-          else if constexpr (HAS_RES) x += __uint_as_float(res[i & 1][n2][j]);
+          if constexpr (LOGITS) part[ni] = fmaf(__uint_as_float(res[i & RD][n2][j]) * so.alpha, x, part[ni]);
+          else if constexpr (HAS_RES) x += __uint_as_float(res[i & RD][n2][j]);
           v[j] = x;
         }
         if constexpr (LOGITS) {

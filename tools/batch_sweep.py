@@ -60,6 +60,9 @@ def sweep(model, tower, ids, mask, M, K, R, sizes=SIZES, seq2seq_flops=None, tow
 
 
 if __name__ == "__main__":
+    from mevi_amd import hip as _hip
+    if os.environ.get("MEVI_PROBE_LIB"):
+        _hip.LIB = os.path.abspath(os.environ["MEVI_PROBE_LIB"])
     import synth
     import bench
 

@@ -22,6 +22,9 @@ def child():
     import torch
 
     sys.path.insert(0, ROOT)
+    from mevi_amd import hip as _hip
+    if os.environ.get("MEVI_PROBE_LIB"):
+        _hip.LIB = os.path.abspath(os.environ["MEVI_PROBE_LIB"])
     from mevi_amd import ops
 
     dev = torch.device("cuda:0")
