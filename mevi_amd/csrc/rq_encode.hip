@@ -191,6 +191,138 @@ __global__ __launch_bounds__(256, 2) void rq_level_kernel(const float *__restric
   }
 }
 
+// The same level for a LIST of rows (the exact re-encode of the rows the matrix-core encoder could not decide, rq_fast.hip) --
+// typically ten thousand of 8.8 M.  rq_level_kernel's 128-row workgroups left most of the device idle there (79 workgroups of
+// ~0.45 ms each per level, behind 69 000 empty ones launched to cover a count only the device knows): here a workgroup takes
+// 32 rows and its four waves split the centroid chunks (wave w: centroids 128 g + 32 w .. + 31 of group g), staged together
+// (one float4 of the residual slab and four of the centroid slabs per thread), the waves' (distance, index) minima combined
+// through LDS; the grid is fixed and walks the list.  Every distance is the same sequential fmaf chain, ties go to the lowest
+// centroid: same codes.
+template <int LEVEL>
+__global__ __launch_bounds__(256, 2) void rq_rows32_kernel(const float *__restrict__ X, int dim, const float *__restrict__ C, int M, int K,
+                                                          int *__restrict__ codes, const long long *__restrict__ rows,
+                                                          const unsigned int *__restrict__ nrows) {
+  constexpr int level = LEVEL;
+  __shared__ __attribute__((aligned(16))) float xs[2][32 * RQ_LD];
+  __shared__ __attribute__((aligned(16))) float cs[2][128 * RQ_LD];
+  __shared__ float sbd[4][32];
+  __shared__ int sbc[4][32];
+  const long long n = (long long)*nrows;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ld = lane >> 3, lc = lane & 7;
+  const int srow = t >> 3, skq = (t & 7) * 4;
+  const size_t level_stride = (size_t)K * dim;
+  const int nslab = (dim + RQ_KS - 1) / RQ_KS;
+  const int ngroup = (K + 127) / 128;
+  for (long long blk = blockIdx.x; blk * 32 < n; blk += gridDim.x) {
+    const long long row0 = blk * 32;
+    long long r = row0 + srow;
+    if (r > n - 1) r = n - 1;
+    r = rows[r];
+    const float *xptr = X + (size_t)r * dim + skq;
+    int prev[LEVEL > 0 ? LEVEL : 1];
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j) prev[j] = codes[(size_t)r * M + j];
+    float4 rx, rc[4];
+    auto gload = [&](int g, int s) {
+      const int kk = s * RQ_KS + skq;
+      const bool in = kk < dim;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) {
+        v = *reinterpret_cast<const float4 *>(xptr + s * RQ_KS);
+#pragma unroll
+        for (int j = 0; j < LEVEL; ++j) {  // residual with the reference's operation order
+          const float4 c = *reinterpret_cast<const float4 *>(C + j * level_stride + (size_t)prev[j] * dim + kk);
+          v.x -= c.x; v.y -= c.y; v.z -= c.z; v.w -= c.w;
+        }
+      }
+      rx = v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cent = g * 128 + srow + 32 * i;
+        rc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in && cent < K) rc[i] = *reinterpret_cast<const float4 *>(C + level * level_stride + (size_t)cent * dim + kk);
+      }
+    };
+    auto lstore = [&](int b) {
+      *reinterpret_cast<float4 *>(&xs[b][srow * RQ_LD + skq]) = rx;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&cs[b][(srow + 32 * i) * RQ_LD + skq]) = rc[i];
+    };
+    float best_d[4];
+    int best_c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) best_d[i] = INFINITY, best_c[i] = 0;
+    for (int g = 0; g < ngroup; ++g) {
+      float acc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+      __syncthreads();  // the previous group's (and block's) readers are done with both buffers
+      gload(g, 0);
+      lstore(0);
+      __syncthreads();
+      for (int s = 0; s < nslab; ++s) {
+        if (s + 1 < nslab) gload(g, s + 1);
+        const float *px = &xs[s & 1][ld * RQ_LD];
+        const float *pc = &cs[s & 1][(32 * wave + lc) * RQ_LD];
+#pragma unroll 2
+        for (int k4 = 0; k4 < RQ_KS; k4 += 4) {
+          float4 xv[4], cv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(px + 8 * i * RQ_LD + k4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cv[j] = *reinterpret_cast<const float4 *>(pc + 8 * j * RQ_LD + k4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float d;
+              d = xv[i].x - cv[j].x; acc[i][j] = fmaf(d, d, acc[i][j]);
+              d = xv[i].y - cv[j].y; acc[i][j] = fmaf(d, d, acc[i][j]);
+              d = xv[i].z - cv[j].z; acc[i][j] = fmaf(d, d, acc[i][j]);
+              d = xv[i].w - cv[j].w; acc[i][j] = fmaf(d, d, acc[i][j]);
+            }
+        }
+        if (s + 1 < nslab) lstore((s + 1) & 1);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = g * 128 + 32 * wave + lc + 8 * j;
+          const float d = acc[i][j];
+          if (c < K && (d < best_d[i] || (d == best_d[i] && c < best_c[i]))) best_d[i] = d, best_c[i] = c;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) {
+        const float od = __shfl_xor(best_d[i], off);
+        const int oc = __shfl_xor(best_c[i], off);
+        if (od < best_d[i] || (od == best_d[i] && oc < best_c[i])) best_d[i] = od, best_c[i] = oc;
+      }
+      if (lc == 0) sbd[wave][ld + 8 * i] = best_d[i], sbc[wave][ld + 8 * i] = best_c[i];
+    }
+    __syncthreads();
+    if (t < 32) {
+      float d = sbd[0][t];
+      int c = sbc[0][t];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float od = sbd[w][t];
+        const int oc = sbc[w][t];
+        if (od < d || (od == d && oc < c)) d = od, c = oc;
+      }
+      if (row0 + t < n) codes[(size_t)rows[row0 + t] * M + level] = c;
+    }
+    // (the next block's first __syncthreads orders these reads before its stores)
+  }
+}
+
 // out[r] = X[src[r]] - C[code[r]]: the residual hand-down of pq.beam_search (pq.py:690-693). One wave per row.
 __global__ __launch_bounds__(256) void gather_sub_kernel(const float *__restrict__ X, const long long *__restrict__ src,
                                                         const float *__restrict__ C, const int *__restrict__ code,
@@ -212,14 +344,15 @@ __global__ __launch_bounds__(256) void gather_sub_kernel(const float *__restrict
 // exact encode of the rows listed in `rows[0, *nrows)` (device-side count; the grid covers max_rows): rq_fast.hip's fallback
 int rq_encode_exact_rows(const float *x, int64_t dim, const float *codebook, int64_t M, int64_t K, int32_t *codes,
                          const long long *rows, const unsigned int *nrows, int64_t max_rows, hipStream_t stream) {
-  const int64_t nblk = (max_rows + RQ_ROWS - 1) / RQ_ROWS;
-  MEVI_REQUIRE(nblk <= 0x7fffffffLL && M <= RQ_MAXM && dim % 4 == 0, MEVI_ERR_UNSUPPORTED, "rq_encode_exact_rows: shape");
+  MEVI_REQUIRE(M <= RQ_MAXM && dim % 4 == 0, MEVI_ERR_UNSUPPORTED, "rq_encode_exact_rows: shape");
+  // a fixed grid walks the list (its length lives on the device): enough workgroups for ~64 k rows in one round
+  int64_t grid = (max_rows + 31) / 32;
+  if (grid > 2048) grid = 2048;
   for (int level = 0; level < (int)M; ++level) {
-#define MEVI_RQ_LEVEL(L)                                                                                   \
-  case L:                                                                                                  \
-    hipLaunchKernelGGL((rq_level_kernel<L, false>), dim3((unsigned)nblk), dim3(256), 0, stream, x,         \
-                       (long long)max_rows, (int)dim, codebook, (int)M, (int)K, codes, (float *)nullptr,   \
-                       rows, nrows);                                                                       \
+#define MEVI_RQ_LEVEL(L)                                                                                             \
+  case L:                                                                                                            \
+    hipLaunchKernelGGL((rq_rows32_kernel<L>), dim3((unsigned)grid), dim3(256), 0, stream, x, (int)dim, codebook, (int)M, \
+                       (int)K, codes, rows, nrows);                                                                  \
     break;
     switch (level) {
       MEVI_RQ_LEVEL(0) MEVI_RQ_LEVEL(1) MEVI_RQ_LEVEL(2) MEVI_RQ_LEVEL(3)
