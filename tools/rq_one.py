@@ -7,6 +7,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mevi_amd import hip as _hip  # noqa: E402
+if os.environ.get("MEVI_PROBE_LIB"):  # A/B timing of another build of the library on the same device
+    _hip.LIB = os.path.abspath(os.environ["MEVI_PROBE_LIB"])
 import bench  # noqa: E402
 from mevi_amd import rq  # noqa: E402
 
