@@ -63,7 +63,9 @@ struct RfLevel {
   float und_c;   // 2 * 2^-25 sqrt(dim) / S_c,j   (x ||x'||: products lost to f16 underflow of the centroids)
   float und_x;   // 2 * 2^-25 sqrt(dim) cnmax_j / S_x
   float sc;      // S_c,j
-  float pad[2];
+  float dc2;     // 2 (1 + 2u) max_c ||c'_j - image row / S_c,j||: what the centroids' ONE rounding to f16 really moved them (x ||x'||);
+                 // written by rf_image_kernel (atomic max of the bits); 0 with the split image, whose term stays in e16
+  float pad;
 };
 
 struct RfParams {
@@ -665,7 +667,7 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
       const float q = xn + L.qpre;
       // roundings between F and F*: the table entries (A, j of G), the j adds and the fma, each relative to <= cnmax^2 + 2 q cnmax
       const float e24 = (2.f * (float)j + 3.f) * 5.97e-8f;
-      const float E1 = (p.e16 * xn * L.cnmax + e24 * (L.cnmax * L.cnmax + 2.f * q * L.cnmax) + L.und_c * xn + L.und_x) * 1.01f;
+      const float E1 = (p.e16 * xn * L.cnmax + L.dc2 * xn + e24 * (L.cnmax * L.cnmax + 2.f * q * L.cnmax) + L.und_c * xn + L.und_x) * 1.01f;
       const float dl = (float)j * 5.97e-8f * q * 1.01f;
       float dpos;
       float delta = rf_delta(m, rho_hat, E1, p.gam, dl, dpos);
@@ -795,7 +797,7 @@ __global__ void rf_levels_kernel(const float *__restrict__ stat, int M, int dim,
     L.qpre = qpre;
     L.und_c = 2.f * 2.98e-8f * 1.01f * sq / sc;
     L.und_x = 2.f * 2.98e-8f * 1.01f * sq * L.cnmax / sx;
-    L.pad[0] = L.pad[1] = 0.f;
+    L.dc2 = 0.f, L.pad = 0.f;
     lev[j] = L;
     qpre += L.cnmax * 1.00001f;
   }
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(256) void rf_mus_kernel(const float *__restrict__ m
 
 // image + A: one wave per (level, centroid incl. padding)
 __global__ __launch_bounds__(256) void rf_image_kernel(const float *__restrict__ C, int M, int K, int Kp, int dim, int LPG, int TA,
-                                                      int split, const float *__restrict__ mu, const RfLevel *__restrict__ lev,
+                                                      int split, const float *__restrict__ mu, RfLevel *__restrict__ lev,
                                                       _Float16 *__restrict__ img, float *__restrict__ A) {
   const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (wv >= M * Kp) return;
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(256) void rf_image_kernel(const float *__restrict__
   const int U = dim >> 5;
   const bool real = c < K;
   const float sc = lev[j].sc;
-  double ss = 0.0;
+  double ss = 0.0, dd = 0.0;
   for (int k = lane; k < dim; k += 64) {
     float v = 0.f;
     if (real) {
@@ -828,11 +830,19 @@ __global__ __launch_bounds__(256) void rf_image_kernel(const float *__restrict__
     }
     const int arows = TA * 32 * (split ? 2 : 1);
     const _Float16 h = (_Float16)(v * sc);
+    {
+      const double d = (double)v - (double)(float)h / (double)sc;   // S_c is a power of two: exact
+      dd += d * d;
+    }
     img[(((size_t)g * U + (k >> 5)) * arows + rowi) * 32 + (k & 31)] = h;
     if (split) img[(((size_t)g * U + (k >> 5)) * arows + TA * 32 + rowi) * 32 + (k & 31)] = (_Float16)((v * sc - (float)h) * 2048.f);
   }
-  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off), dd += __shfl_xor(dd, off);
   if (lane == 0) A[(size_t)j * Kp + c] = real ? (float)ss : INFINITY;
+  if (lane == 0 && real && !split) {   // non-negative floats order like their bits
+    const float v = (float)(2.0 * (1.0 + 2.0 / 2048.0) * sqrt(dd) * 1.0001);
+    atomicMax(reinterpret_cast<unsigned int *>(&lev[j].dc2), __float_as_uint(v));
+  }
 }
 
 // G2[(i K + a)][j][c] = 2 c'_i[a] . c'_j[c] for i < j (f64 accumulation, rounded once), 0 elsewhere.  One 16 x 16 output tile
@@ -1121,19 +1131,22 @@ extern "C" int mevi_rq_encode_fast_f32(const float *x, int64_t n, int64_t dim, c
   p.M = Mi, p.K = Ki, p.Kp = pl.Kp, p.LPG = pl.LPG, p.ngroups = pl.ngroups;
   p.codes = codes, p.row_flag = ws.row_flag, p.rec = ws.rec, p.counters = ws.counters, p.region_n = ws.region_n;
   p.region_cap = ws.region_cap;
-  // |x~.c~ / (S_x S_c) - x'.c'| <= ((2u + u^2) + 4 dim 2^-24 + 2^-22) ||x'|| ||c'||  (both operands rounded once to f16, u = 2^-11;
-  // f16 x f16 products exact in f32; 4 x 2^-24 per accumulation step lets the matrix core truncate; 2^-22 covers the f32
-  // roundings of x S_x - mu S_x and c' S_c); it enters F twice
-  // plain: both operands rounded once to f16 (u = 2^-11), f16 x f16 products exact in f32, 4 x 2^-24 per accumulation step lets
-  // the matrix core truncate, 2^-22 covers the f32 roundings of x S_x - mu S_x and c' S_c:
-  //   |x~.c~ / (S_x S_c) - x'.c'| <= ((2u + u^2) + 4 dim 2^-24 + 2^-22) ||x'|| ||c'||
+  // The product's error, both operands rounded once to f16 (u = 2^-11), f16 x f16 products exact in f32:
+  //   |x~.c~ / (S_x S_c) - x'.c'| <= ||dx|| ||c'|| + ||x'|| ||dc|| + ||dx|| ||dc|| + acc ||x~|| ||c~|| / (S_x S_c)
+  // with ||dx|| <= (u + 2^-22) ||x'|| (worst case) and ||dc|| the MEASURED distance of a centroid to its image row
+  // (rf_image_kernel -> RfLevel::dc2, the level's maximum; round 5: a vector's roundings do not all go the same way -- ||dc||
+  // comes out at ~0.4 u ||c'||: a fifth off the whole bound, 4.29 -> 3.41 M ambiguous row-levels at (3, 256), same codes);
+  // acc = 4 x 2^-24 per accumulation step (lets the matrix core truncate); 2^-22 covers the f32 roundings of x S_x - mu S_x and
+  // c' S_c.  Everything enters F twice (the factor -2).  e16 multiplies ||x'|| cnmax, dc2 multiplies ||x'||.
+  // (The row's own ||dx||, summed beside ||x'||^2 while pass 0 converts, takes another 28 % off the records -- and was measured
+  // slower at K = 256 either way: a second running sum in a register spills (K = 128: 19.2 -> 24.1 ms), the same sum by
+  // ds_add_f32 into LDS costs pass 0 1.8 ms for 1.9 ms less fix-up.  Not kept.)
   // split: (hi, lo) pairs carry 22 bits (3 x 2^-22 for the two roundings of lo and the dropped lo.lo term); the cross terms'
-  // own accumulation is 2^-10 of the main chain's.  Either enters F twice (the factor -2).
+  // own accumulation is 2^-10 of the main chain's; no dc2.  x-split: x carries 22 bits (2^-22 + the f32 rounding), two MFMAs per step.
   const double acc_step = 4.0 * (double)dim / 16777216.0;
-  // x-split: x carries 22 bits (2^-22 + the f32 rounding), the centroids are rounded once (u): u + 2 x 2^-22, two MFMAs per step.
   p.e16 = pl.split ? (float)(2.0 * (3.0 / 4194304.0 + acc_step * (1.0 + 1.0 / 512.0) + 1.0 / 4194304.0) * 1.001)
-          : pl.xsplit ? (float)(2.0 * ((1.0 / 2048.0) * (1.0 + 1.0 / 1048576.0) + 2.0 / 4194304.0 + acc_step * (1.0 + 1.0 / 1024.0) + 1.0 / 4194304.0) * 1.001)
-                      : (float)(2.0 * ((2.0 / 2048.0 + 1.0 / (2048.0 * 2048.0)) + acc_step + 1.0 / 4194304.0) * 1.001);
+          : pl.xsplit ? (float)(2.0 * (2.0 / 4194304.0 + acc_step * (1.0 + 1.0 / 1024.0) + 1.0 / 4194304.0) * 1.001)
+                      : (float)(2.0 * ((1.0 / 2048.0 + 1.0 / 4194304.0) + acc_step * (1.0 + 1.0 / 512.0) + 1.0 / 4194304.0) * 1.001);
   p.gam = (float)((double)(dim + 2) / 16777216.0 * 1.01);   // the oracle's chain: dim fma + the subtraction, relative
   p.n_tiles = (n + RF_ROWS - 1) / RF_ROWS;
   // (experiment, round 3: reading every 256-row tile as if it were stored unit-major -- row stride 128, unit stride 32 KiB,
