@@ -99,6 +99,29 @@ def test_rows_keep_their_bits_in_any_batch(cuda):
         assert torch.equal(ops.linear(xs[:m], wi, bias=b, relu=True), ops.linear(xs, wi, bias=b, relu=True)[:m])
 
 
+def test_rows_keep_their_bits_across_tile_heights_and_the_row_split(cuda):
+    """Round 5: the tile stream runs 256 / 128 / 64 activation rows per tile (chosen per GEMM by its tile rounds) and cuts GEMMs of
+    several rounds into whole rounds + a remainder launch.  Whatever batch a row travels in -- 600 ... 20 000 rows from the head
+    or the middle of a 70 000-row batch -- it has the bits it has in the big batch: f32 + residual, plain f32, and the image."""
+    g = torch.Generator(device=cuda).manual_seed(11)
+    M = 70000
+    x = torch.randn((M, 768), device=cuda, generator=g)
+    r = torch.randn((M, 768), device=cuda, generator=g)
+    b = torch.randn((2304,), device=cuda, generator=g)
+    wo = ops.weight_split(torch.randn((768, 768), device=cuda, generator=g) * 768 ** -0.5)
+    wq = ops.weight_split(torch.randn((2304, 768), device=cuda, generator=g) * 768 ** -0.5)
+    xs = ops.split_rows(x)
+    y = ops.linear(xs, wo, residual=r)
+    q = ops.linear(xs, wq, bias=b)
+    h = ops.linear(xs, wq, bias=b, relu=True, for_gemm=True)
+    for lo, m in ((0, 600), (0, 873), (0, 1418), (0, 2048), (0, 4096), (0, 9600), (0, 20000), (30000, 873), (41111, 5000), (69000, 1000)):
+        sub = xs[lo:lo + m]
+        assert torch.equal(ops.linear(sub, wo, residual=r[lo:lo + m]), y[lo:lo + m]), (lo, m)
+        assert torch.equal(ops.linear(sub, wq, bias=b), q[lo:lo + m]), (lo, m)
+        hm = ops.linear(sub, wq, bias=b, relu=True, for_gemm=True)
+        assert torch.equal(hm.img, h.img[lo:lo + m]) and torch.equal(hm.exp, h.exp[lo:lo + m]), (lo, m)
+
+
 def test_strided_output_and_fused_rmsnorm(cuda):
     g = torch.Generator(device=cuda).manual_seed(9)
     x = torch.randn((1500, 768), device=cuda, generator=g) * 30
