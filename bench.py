@@ -634,7 +634,9 @@ def summaries_into_config(out):
     c5 = out.get("chain_c5")
     if c5:
         cfg["chain_c5"] = {"queries_per_s": c5["queries_per_s"], "chain_ms": c5["chain_ms"], "mrr10": c5.get("mrr10"),
-                           "dense_lists_identical_on_all_ranks": c5.get("dense_lists_identical_on_all_ranks")}
+                           "dense_lists_identical_on_all_ranks": c5.get("dense_lists_identical_on_all_ranks"),
+                           "stage_ms_max_over_ranks": c5.get("stage_ms_max_over_ranks"),
+                           "seq2seq_frac_per_rank": c5.get("seq2seq_frac_per_rank")}
 
 
 def print_line(out):
@@ -681,7 +683,21 @@ def chain_c5(device, rank, world, backend, n_docs, nq, start, end, limit_s):
     allr = [None] * world
     dist.all_gather_object(allr, rec)
     if rank == 0:
-        return chain_c4.aggregate_sharded(allr, nq, world, TOPK, R, M, K, backend)
+        out = chain_c4.aggregate_sharded(allr, nq, world, TOPK, R, M, K, backend)
+        try:        # each rank's share of the seq2seq arm against the f16 matrix peak / 3 (the 873-query regime)
+            lens = mask.sum(1).cpu().numpy()
+            for r in out["per_rank"]:
+                mine = lens[r["rank"]::world]
+                sm = r["stage_ms"]
+                if sm.get("nci_beam_search"):
+                    r["nci_frac"] = round(seq2seq_flops(M, K, R, float(mine.mean()))[1] * len(mine) / sm["nci_beam_search"] / 1e9 / (2500.0 / 3), 4)
+                if sm.get("tower"):
+                    r["tower_frac"] = round(tower_flops(mine) / sm["tower"] / 1e9 / (2500.0 / 3), 4)
+            out["seq2seq_frac_per_rank"] = {"nci": [r.get("nci_frac") for r in out["per_rank"]],
+                                            "tower": [r.get("tower_frac") for r in out["per_rank"]]}
+        except Exception as e:
+            out["seq2seq_frac_per_rank"] = f"{type(e).__name__}: {e}"
+        return out
     return None
 
 

@@ -150,6 +150,9 @@ def test_bench_c5_chain_rehearsal_with_two_ranks_sharing_the_device():
                                                  "tower_again", "fine_stage"}
     assert set(c["mrr10"]) == {"dense", "fine", "ensemble", "ensemble_alpha20"} and 0.0 <= c["mrr10"]["ensemble"] <= 1.0
     assert "REHEARSAL" in c["workload"]
+    f = c["seq2seq_frac_per_rank"]                                  # each rank's share of the seq2seq arm against the matrix peak
+    assert len(f["nci"]) == 2 and len(f["tower"]) == 2 and all(0.0 < v < 1.0 for v in f["nci"] + f["tower"])
+    assert d["config"]["chain_c5"]["seq2seq_frac_per_rank"] == f
 
 
 def test_bench_starts_its_own_ranks_from_the_plain_command():
