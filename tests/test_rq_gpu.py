@@ -105,6 +105,30 @@ def test_matrix_core_encoder_on_adversarial_inputs(cuda):
     assert 2 <= st["rows_reencoded_exactly"] <= 0.1 * len(x), st          # the two overflow rows, few others
 
 
+def test_centroids_whose_f16_roundings_all_go_the_same_way(cuda):
+    """Round 5: the candidate bound takes the centroids' MEASURED distance to their f16 image (RfLevel::dc2) instead of the worst
+    case u ||c||.  Here the measurement IS the worst case: every centroid entry sits just below the midpoint of two f16 values
+    (mantissa 1 + 0.98 x 2^-11), so every rounding moves it by ~u in the direction of -c, and rows that are sums of centroids + a
+    little noise are as parallel to those displacements as rows get.  Codes == the exact kernel's == the oracle's."""
+    rng = np.random.default_rng(21)
+    M, K, dim, n = 3, 256, 768, 20000
+    e = rng.integers(-6, -3, size=(M, K, dim))
+    sgn = rng.choice([-1.0, 1.0], size=(M, K, dim))
+    cb = (sgn * np.exp2(e) * (1.0 + 0.98 * 2.0 ** -11)).astype(np.float32)
+    cb[0, K // 2:] = -cb[0, :K // 2]                                   # level 0 is centred by its mean: exactly zero here
+    cb[1] *= 0.5
+    cb[2] *= 0.25
+    pick = rng.integers(0, K, size=(n, M))
+    x = sum(cb[j][pick[:, j]] for j in range(M)) + 0.01 * rng.standard_normal((n, dim)).astype(np.float32)
+    x[::7] = 0.5 * (cb[0][pick[::7, 0]] + cb[0][(pick[::7, 0] + 1) % K]) + 0.002 * rng.standard_normal((len(x[::7]), dim)).astype(np.float32)
+    x = x.astype(np.float32)
+    fast, exact, st = _both(x, cb, cuda)
+    assert st["path"] == "fast"
+    assert np.array_equal(fast, exact), (st, int((fast != exact).any(1).sum()))
+    assert np.array_equal(exact[:3000], orq.rq_encode(x[:3000], cb))
+    assert st["rows_reencoded_exactly"] <= 0.2 * n, st
+
+
 def test_matrix_core_encoder_large(cuda):
     """300 k rows at both script shapes against the oracle, 2 M rows fast vs the exact kernel."""
     g = torch.Generator(device=cuda).manual_seed(3)
