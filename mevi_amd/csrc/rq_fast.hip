@@ -281,12 +281,26 @@ __device__ __forceinline__ void rq_fast_body(const RfParams &p, float *lds) {
   auto read_x = [&](int gb, int u, int j, f16x8 (&b)[NB]) {
     const float *ub = lds + gb * RF_XFL;
     const int c0 = 4 * j + 2 * half;
-    const float4 x0 = *reinterpret_cast<const float4 *>(ub + offb + ((c0 ^ b_sw) << 2));
-    const float4 x1 = *reinterpret_cast<const float4 *>(ub + offb + (((c0 + 1) ^ b_sw) << 2));
     int h8 = 8 * half;
     if constexpr (XDEEP) asm volatile("" : "+v"(h8));   // (not an invariant to keep: the unrolled cycles each held their own copy of this address)
-    const float4 m0 = *reinterpret_cast<const float4 *>(mus_l + 32 * u + 16 * j + h8);
-    const float4 m1 = *reinterpret_cast<const float4 *>(mus_l + 32 * u + 16 * j + h8 + 4);
+    // The four LDS reads of a conversion as inline assembly (round 5, found in the ISA).  Written as C++ loads they made the
+    // compiler put `s_waitcnt vmcnt(0)` in front of them in every cycle of pass 0: it sees LDS-DMA requests in flight (the counted
+    // waits of this kernel are inline assembly, invisible to its bookkeeping) and cannot tell their targets from the x rows and mu
+    // read here, so the whole look-ahead -- the unit requested a moment ago included -- was drained twice per cycle.  The data
+    // read here landed before the barrier of the previous cycle (wait_window / the counted vmcnt).  (Measured: nothing at K = 256,
+    // whose cycle is bound elsewhere -- profiles/r05_rq_ablation.txt --, -2 % at (4, 32).  Reads kept in flight under the next MFMA
+    // block -- a second statement for the wait -- need 16 registers pass 0 does not have at TA = 8: 8 -> 700 B of scratch.)
+    float4 x0, x1, m0, m1;
+    {
+      typedef __attribute__((address_space(3))) const float *lp_t;
+      const unsigned int ax0 = (unsigned int)(unsigned long long)(lp_t)(ub + offb + ((c0 ^ b_sw) << 2));
+      const unsigned int ax1 = (unsigned int)(unsigned long long)(lp_t)(ub + offb + (((c0 + 1) ^ b_sw) << 2));
+      const unsigned int am0 = (unsigned int)(unsigned long long)(lp_t)(mus_l + 32 * u + 16 * j + h8);
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(x0), "=&v"(x1), "=&v"(m0), "=&v"(m1)
+                   : "v"(ax0), "v"(ax1), "v"(am0)
+                   : "memory");
+    }
     float v[8];
     v[0] = fmaf(x0.x, sx, -m0.x); v[1] = fmaf(x0.y, sx, -m0.y); v[2] = fmaf(x0.z, sx, -m0.z); v[3] = fmaf(x0.w, sx, -m0.w);
     v[4] = fmaf(x1.x, sx, -m1.x); v[5] = fmaf(x1.y, sx, -m1.y); v[6] = fmaf(x1.z, sx, -m1.z); v[7] = fmaf(x1.w, sx, -m1.w);
