@@ -472,7 +472,9 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
     guarded("seq2seq_batch_sweep", sweep_leg)
 
     # ---- C4, timed directly on the resident corpus ---------------------------------------------------------------------
-    chain, dindex = chain_c4.run(model, tower, docs, ids, mask, planted_ids(nq, n_docs), rn, M, K, R, TOPK, gen_batch, rng)
+    chain, dindex = chain_c4.run(model, tower, docs, ids, mask, planted_ids(nq, n_docs), rn, M, K, R, TOPK, gen_batch, rng,
+                                 with_latency=True)
+    out["latency_b1"] = chain.pop("latency_b1", None)         # VERDICT r5 #4a: ONE query through the chain, stage by stage
     chain["dtype"] = "tower / NCI: " + SPLIT_DTYPE + "; dense: f16 pre-filter + exact f32 chains; fine stage: f32 chains; ensemble: f64"
     # the chain's own roofline: f16 matrix-core FLOP executed by its stages (three per product of the split GEMMs of both tower
     # passes and the beam search, one per product of the dense pre-filter) over the chain's wall clock
@@ -493,11 +495,21 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
     guarded("faiss_search_cli_inclusive", lambda: cli_inclusive(device, docs, index_build_s, search_ms, nq, n_docs))
     del dindex
 
+    def chain_trained():
+        """The same chain ONCE more on a TRAINED codebook (the random centroids above leave skewed cells -- the
+        fine stage's candidates per query move toward SURVEY 8 a18's ~84 with balanced ones).  One timed pass after a warm-up."""
+        c, di2 = chain_c4.run(model, tower, docs, ids, mask, planted_ids(nq, n_docs), rn, M, K, R, TOPK, gen_batch, rng, repeats=1,
+                              codebook="trained", plant=False)
+        del di2
+        return {k_: c[k_] for k_ in ("codebook", "chain_ms", "queries_per_s", "ms", "fine_candidates_per_query", "fine_candidates_max",
+                                     "mrr10", "setup_untimed_ms", "planted_top1_ok")}
+
+
     if with_cpu:
         from oracle import t5 as ot5
 
         ncfg, tcfg = synth.oracle_cfgs(M, K)
-        n_t, n_g = min(nq, 64), min(nq, 8)
+        n_t, n_g = min(nq, 64), min(nq, int(os.environ.get("MEVI_BENCH_CERT_QUERIES", "32")))     # VERDICT r5 #5: 8 -> 32 chain queries
         ci, cm = ids.cpu(), mask.cpu()
         with torch.no_grad():
             t = time.time()
@@ -532,6 +544,8 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
             out.setdefault("mrr10_match", {})["chain_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc()[-500:]}"
         del cpu_w
     chain_c4.LAST.clear()
+    guarded("chain_c4_trained_codebook", chain_trained)      # after the certificate: it re-writes chain_c4.LAST's index artefacts
+    chain_c4.LAST.clear()
 
     # ---- BASELINE.json configs[2]: 3 levels x 256 codes ------------------------------------------------------------------
     del model, gen
@@ -558,7 +572,7 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
             from oracle import t5 as ot5
 
             ncfg2, _ = synth.oracle_cfgs(M2, K2)
-            n2 = min(nq, 4)
+            n2 = min(nq, 16)
             with torch.no_grad():
                 t = time.time()
                 rd, rs, _ = ot5.nci_generate(cpu_w2, ncfg2, ids[:n2].cpu(), mask[:n2].cpu(), R)
@@ -574,16 +588,26 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
     del model2, gen2, cpu_w2, tower
     torch.cuda.empty_cache()
     guarded("index_build", lambda: index_build_leg(device, docs, rn, n_docs))
+
+    def sensitivity():
+        """the headline's two data-dependent fast paths on corpora shaped like a dense retriever's output, at
+        full C2 size (tools/data_sensitivity.py; per-kind records in the detail file, min / max here)."""
+        import data_sensitivity
+
+        return data_sensitivity.sweep(device, n_docs, nq)
+
+    if n_docs >= 1_000_000 or os.environ.get("MEVI_BENCH_SENSITIVITY") == "1":
+        guarded("data_sensitivity", sensitivity)
     return out
 
 
 # ---- the ONE line ---------------------------------------------------------------------------------------------------------
 LINE_BUDGET = 7600      # bytes: the driver keeps the last 8 KB of stdout beside `parsed`; the whole line must fit in it
-_DROP = ("note", "sample_detail", "per_size", "what", "slice", "per_rank", "per_batch", "layers", "checksums", "statistic", "stats",
+_DROP = ("note", "sample_detail", "per_size", "per_kind", "what", "slice", "per_rank", "per_batch", "layers", "checksums", "statistic", "stats",
          "flop_split", "head_matrices_at", "adaptor_vectors_only_at", "one_shot_note", "setup_untimed_ms", "recall1000", "loadavg", "cgroup_cpu_max", "backend", "faiss",
          "upload_sample", "seconds", "cpu_seconds", "oracle_seconds", "algorithmic_bytes", "flop_executed",
          "flop_per_query_survey_8d_padded", "flop_per_query_executed", "executed_f16_mfma_flop", "algorithmic_bytes_per_search")
-_DROP_ORDER = ("seq2seq_cpu_sample", "dense_small_batch", "gemm_roofline", "faiss_search_cli_inclusive", "dense_arm_with_tower", "seq2seq_batch_sweep",
+_DROP_ORDER = ("seq2seq_cpu_sample", "chain_c4_trained_codebook", "dense_small_batch", "gemm_roofline", "faiss_search_cli_inclusive", "dense_arm_with_tower", "seq2seq_batch_sweep",
                "seq2seq_arm_rq_3x256", "index_build", "multi_gpu")      # least important first, should the line still be long
 
 
@@ -617,7 +641,8 @@ def summaries_into_config(out):
     if ch:
         diffs = [v["abs_diff"] for v in ch.values() if isinstance(v, dict) and "abs_diff" in v]
         same = [v["top10_identical"] for v in ch.values() if isinstance(v, dict) and "top10_identical" in v]
-        cert.update(beams_identical=ch.get("beams_identical"), chain_mrr10_abs_diff=max(diffs) if diffs else None,
+        cert.update(chain_queries=ch.get("queries"), beams_identical=ch.get("beams_identical"),
+                    beams_differing=ch.get("beams_differing_from_oracle"), chain_mrr10_abs_diff=max(diffs) if diffs else None,
                     chain_top10_identical_frac=min(same) if same else None, tower_max_abs_diff=ch.get("tower_max_abs_diff"),
                     rq_codes_identical_on_sample=ch.get("rq_codes_identical_on_sample"),
                     within_1e_4=ch.get("mrr10_within_1e-4"))

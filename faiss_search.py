@@ -15,6 +15,7 @@ import numpy as np
 
 from mevi_amd.dense import is_trained_before_train, profile, search, shard_range, sharded_ip_topk  # noqa: F401  (API parity: search, profile)
 from mevi_amd.io import map_rows, read, to_file  # noqa: F401
+from mevi_amd.phases import mark
 
 
 def _distributed_search(query, doc_path, dim, topk):
@@ -45,6 +46,7 @@ if __name__ == "__main__":
     parser.add_argument("--topk", type=int, default=1000)
     parser.add_argument("--param", type=str, default="IVF100,Flat")
     args = parser.parse_args()
+    mark("start-up + imports")
     query = read(args.query_path, args.dim)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
@@ -65,5 +67,7 @@ if __name__ == "__main__":
     else:
         doc = read(args.doc_path, args.dim)
         dists, indices = search(query, doc, args.dim, args.topk, args.param)
+        mark("read + upload + index build + search")
         print(indices.dtype, indices.shape, dists.dtype, dists.shape)
         to_file(args.raw_query_path, args.output_path, dists, indices)
+        mark("ranked TSV written")

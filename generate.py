@@ -16,6 +16,7 @@ import numpy as np
 import pandas as pd
 
 from mevi_amd.io import encode_batch, flush_rows, map_rows
+from mevi_amd.phases import mark
 
 
 # padded tokens per device pass (= mevi_amd.t5.DEVICE_PASS_TOKENS); --batch_size only raises it: the embeddings do not
@@ -80,9 +81,12 @@ def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path,
                                 timeout=DIST_TIMEOUT)
     device = torch.device(f"cuda:{gpus[rank]}")
     torch.cuda.set_device(device)
+    mark("start-up + imports (torch, GPU context)")
     encoder = encoder or load_document_encoder(model_path, ckpt_path, device)
+    mark("tower weights -> HBM", sync=True)
     tokenizer = tokenizer or get_tokenizer(tokenizer_path)
     df = pd.read_csv(query_file, names=["query", "oldid"], encoding="utf-8", header=None, sep="\t")["query"]
+    mark("tokenizer + query file")
     start, end = rank_range(len(df), rank, nrank)
     cur_path = output_path[:-4] + f"_{rank}.bin" if nrank > 1 else output_path
     out = map_rows(cur_path, dim, "w+", rows=end - start)
@@ -92,6 +96,7 @@ def gen_query_embedding(rank, query_file, model_path, ckpt_path, tokenizer_path,
         tok = encode_batch(tokenizer, df[s:e], query_length)
         out[s - start:e - start] = encoder.encode_query(tok).cpu().numpy()
     flush_rows(out)
+    mark("tokenise + tower + write embeddings")
     if nrank > 1:
         dist.barrier()
         if rank == 0:

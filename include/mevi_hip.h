@@ -433,9 +433,16 @@ typedef struct mevi_ip_topk_stats {
   double max_err_ratio;      /* indexed search: largest observed |f16 approx - exact| / proven bound among survivors */
   double err_bound;          /* indexed search: 1.0 (max_err_ratio is relative to the bound the proof uses) */
   int64_t n_second_pass_queries; /* indexed search: unproven queries retried with a 2x wider survivor list */
+  /* indexed search, mevi_ip_topk_set_profiling(2) only (one small counting launch per filter launch; 0 otherwise): what the
+   * DATA decides about the pre-filter's cost -- keys appended by the filter launches of the main pass (sum over queries and
+   * launches), the largest per-query count of one launch, and (query, launch) pairs that filled their list (those queries
+   * take the guaranteed path) */
+  int64_t n_filter_candidates;
+  int64_t max_launch_candidates;
+  int64_t n_list_overflows;
 } mevi_ip_topk_stats;
 void mevi_ip_topk_set_growth(double growth);
-void mevi_ip_topk_set_profiling(int enable); /* record HIP events around every filter/compact launch */
+void mevi_ip_topk_set_profiling(int enable); /* 1: record HIP events around every filter/compact launch; 2: also count candidates */
 void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out);
 
 /* ---- host-side text output (no device work) --------------------------------------------------------------------

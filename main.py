@@ -232,10 +232,14 @@ def partial_inference(rank, args):
     if args.time_str is None:
         args.time_str = time.strftime("%Y%m%d%H%M%S")
     args.metric_path = default_metric_path(args)
+    from mevi_amd.phases import mark
+
+    mark("start-up + imports (torch, GPU context)")
     run = EvalRun(args, rank=rank, nrank=nrank, barrier=barrier, device=torch.device("cuda", gpu))
     df = (load_nq_queries if args.dataset == "nq_dpr" else load_queries)(args.data_dir, args.n_test)
     print("Inference start...")
     run.run(df)
+    mark("EvalRun.run: beam search + tower + fine stage + logs + metrics", sync=True)
     if nrank > 1:
         dist.destroy_process_group()
 

@@ -39,7 +39,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int h16_swz(int quad) { return (quad & 2) ? 3 : 0; }
 
 // next / begin / emit / uoff as h1_tile_stream (begin() is called two windows before the tile's emit, not at its start); emit receives f32x4 acc[4][NI]: block (mi, ni) = corpus rows 16 mi + [0, 16)
-// of the wave's 64, queries 16 ni + [0, 16) of the wave's 16 NI.  nunits even, >= 4.
+// of the wave's 64, queries 16 ni + [0, 16) of the wave's 16 NI.  nunits even, >= 4, and >= DEPTH (= NBUF - 1: 3 / 4 / 5 at
+// NI = 8 / 4 / 2): a window's look-ahead reaches into the NEXT tile only, never past it -- the host picks NI accordingly
+// (ip_topk.hip::run_pass; a 128-k image has four units, so NI = 2 is not offered there).
 //
 // NI = 8: the 256-query tile above.  NI = 4 / 2 (round 5): query tiles of 128 / 64 for searches of 33 .. 128 queries
 // (faiss_search.profile's larger batches): such a search is bound by streaming the corpus image, and in the 256-query tile

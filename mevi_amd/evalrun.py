@@ -245,6 +245,7 @@ class EvalRun:
         d_model = self.cfg.d_model
         self.nci = NCIModel(nci_w, cfg=self.cfg, device=self.dev)
         del nci_w
+        mark("NCI checkpoint -> model in HBM", sync=True)
         # the tower and its tokenizer (init_document_encoder, MEVI/main_models.py:1643-1681)
         enc = getattr(a, "document_encoder", None) or "ance"
         tower_dir = os.path.join(a.ckpt_dir, "t5-ance")       # NCI shares the T5-ANCE vocabulary in every configuration
@@ -264,6 +265,7 @@ class EvalRun:
 
             tokenizer = AutoTokenizer.from_pretrained(tower_dir)
         self.tokenizer = tokenizer
+        mark("tower weights + tokenizer", sync=True)
         # BERT-family towers read the query through their own tokenizer (`qenc_source_ids`, main_models.py:853-856):
         # bert-base-uncased, special tokens only for 'ar2' (main_models.py:359-360)
         self.tower_tokenizer = tower_tokenizer
@@ -279,6 +281,7 @@ class EvalRun:
         n_docs = os.path.getsize(a.embedding_path) // (4 * d_model)
         emb = np.memmap(a.embedding_path, dtype=np.float32, mode="r", shape=(n_docs, d_model))
         self.emb = upload_rows(emb, self.dev)
+        mark("corpus embeddings file -> HBM")
         # RQ codebook + cluster index (pickles if present, else encode on the GPU and write them)
         self.pq = ProductQuantization("rq", self.M, a.subvector_bits, "l2", d_model, device=self.dev)
         if ckpt_codebook is not None:             # --infer_ckpt carries pq.codebook: pq.initialize is skipped (main_models.py:4252)
@@ -309,6 +312,7 @@ class EvalRun:
                 write_mapping_sidecar(map_path, self.index.doc_codes(n_docs))   # the same mapping as an array (ensemble scripts)
         self.barrier()
         self.mapping = CodeMap(self.index.doc_codes(n_docs))
+        mark("RQ codebook + cluster index (%s)" % ("pickle read" if have_clusters else "encode on the GPU + pickles written"), sync=True)
         print("Number of all pq document clusters:", len(self.index.keys))
         # --doc_multiclus C > 1 (gen_pq_doc_topk, main_models.py:3222-3262): every document also belongs to the clusters of
         # its top-C code paths; rqtopk<C>*.pt holds the paths, rqmulticlus<C>*.pkl the code -> documents dict

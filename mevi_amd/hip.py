@@ -21,7 +21,8 @@ class MeviHipError(RuntimeError):
 class IpTopkStats(ctypes.Structure):
     _fields_ = [("n_chunks", c_int64), ("n_failed_queries", c_int64), ("n_fallback_chunks", c_int64),
                 ("filter_ms", c_double), ("compact_ms", c_double), ("filter_flops", c_double),
-                ("max_err_ratio", c_double), ("err_bound", c_double), ("n_second_pass_queries", c_int64)]
+                ("max_err_ratio", c_double), ("err_bound", c_double), ("n_second_pass_queries", c_int64),
+                ("n_filter_candidates", c_int64), ("max_launch_candidates", c_int64), ("n_list_overflows", c_int64)]
 
 
 _SIGNATURES = {
@@ -176,8 +177,10 @@ def require_gpu():
 # mostly waits for Python.  cProfile of a 128-query tower pass (tools/prof_host.py, 4.5 ms for 247 launches): the public
 # `torch.cuda.current_stream()` took 7.7 us per call and `with torch.cuda.device(...)` 4-8 us -- more than the ctypes call
 # itself.  The raw hooks below are what torch's own Python wrappers end in.
-_raw_stream = torch._C._cuda_getCurrentRawStream
-_cur_device = torch._C._cuda_getDevice
+# They are private: a torch build without them (CPU-only wheel, a rename) falls back to the public calls instead of failing
+# the import -- `require_gpu()` / MeviHipError stay the way a missing GPU is reported.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
 def stream_ptr():

@@ -15,23 +15,28 @@ import pickle
 import numpy as np
 
 
-_STAGING = {}      # (buffers, bytes each) -> pinned uint8 tensors, kept for the life of the process (hipHostMalloc is slow)
+import threading
+
+_STAGING = {}      # (buffers, bytes each) -> pinned uint8 tensors, kept between calls (hipHostMalloc is slow)
+_STAGING_LOCK = threading.Lock()       # one upload at a time owns the ring: two concurrent callers would fill the same buffers
+_STAGING_KEEP_BYTES = 512 << 20        # rings larger than this (an explicit, large chunk_rows) are released after the call
 
 
 def _staging(nbuf, nbytes):
+    """The ring for this shape; any other cached ring is dropped first (one set of pinned buffers per process)."""
     import torch
 
     key = (nbuf, nbytes)
     if key not in _STAGING:
-        for k in [k for k in _STAGING if k[0] == nbuf and k[1] < nbytes]:     # superseded smaller set
-            del _STAGING[k]
+        _STAGING.clear()
         _STAGING[key] = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
     return _STAGING[key]
 
 
 def free_staging():
     """Release the pinned staging buffers upload_rows keeps between calls."""
-    _STAGING.clear()
+    with _STAGING_LOCK:
+        _STAGING.clear()
 
 
 def file_range(src):
@@ -60,15 +65,29 @@ def upload_rows(src, device, chunk_rows=None, threads=8, buffers=4):
     Measured on the pool's boxes (16-CPU cgroup, tools/probe_upload2.py): fills 77-100 GB/s with 8-16 threads, pinned -> device
     DMA 57 GB/s; the round-4 form (two 800 MB buffers allocated per call, fill and copy in turns) delivered 5.8 GB/s.
     MEVI_UPLOAD=copy: memcpy out of the mapping instead of pread (A/B)."""
+    import torch
+
+    if src.dtype != np.float32:
+        raise TypeError(f"upload_rows: f32 rows expected, got {src.dtype} (the staging ring moves raw bytes)")
+    rows, dim = src.shape
+    out = torch.empty((rows, dim), dtype=torch.float32, device=device)
+    if rows == 0:
+        return out
+    with _STAGING_LOCK:          # the ring is shared state: concurrent uploads (threads, devices) take turns (ADVICE r5)
+        try:
+            return _upload_rows_locked(src, out, chunk_rows, threads, buffers)
+        finally:
+            if sum(k[0] * k[1] for k in _STAGING) > _STAGING_KEEP_BYTES:
+                _STAGING.clear()
+
+
+def _upload_rows_locked(src, out, chunk_rows, threads, buffers):
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
 
     import torch
 
     rows, dim = src.shape
-    out = torch.empty((rows, dim), dtype=torch.float32, device=device)
-    if rows == 0:
-        return out
     row_bytes = dim * 4
     if chunk_rows is None:
         chunk_rows = max(1, (64 << 20) // row_bytes)

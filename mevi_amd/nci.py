@@ -409,6 +409,11 @@ class NCIModel:
         del aw
 
     def tables(self, beams=None):
+        # the policy is sized for the widest search seen: a later generate() with more beams rebuilds (and drops the graphs
+        # captured over the old tables); beams=None (describe / tools) reads whatever is there
+        if self._tables is not None and beams is not None and self._tables.beams is not None and beams > self._tables.beams:
+            self._tables = None
+            self._graphs = GraphCache()
         if self._tables is None:
             if self.prefix_table_bytes is None:
                 self.prefix_table_bytes = default_table_bytes(self.dev)
@@ -422,6 +427,7 @@ class NCIModel:
         self.prefix_table_queries = n
         if self._tables is not None and old is not None and (n is None or n > old):
             self._tables = None
+            self._graphs = GraphCache()     # captured generate() graphs hold the old tables' addresses and level structure
 
     # -- one decoding position for all live beams -----------------------------------------------
     def _logits(self, tokens, t, dcache, acache, xkv, mask, kv_div, pidx=None, key_rows=None):

@@ -92,6 +92,9 @@ def test_few_queries_take_the_streaming_kernel_with_the_same_bits(cuda, nq, nd, 
 @pytest.mark.parametrize("nq,nd,dim,k", [
     (33, 40000, 768, 100), (64, 70001, 768, 1000), (65, 30000, 768, 300), (100, 25000, 768, 1000), (128, 50000, 768, 100),
     (129, 20000, 768, 100), (255, 30000, 768, 1000), (48, 9000, 128, 50), (90, 12345, 192, 64),
+    # persistent workgroups streaming SEVERAL tiles of a four-unit (dim <= 128) image: the 64-query tile's five-unit
+    # look-ahead does not fit such a tile -- these take the 128-query tile
+    (48, 300000, 128, 50), (64, 400000, 64, 100), (40, 350000, 192, 30),
 ])
 def test_medium_batches_take_the_narrow_query_tiles_with_the_same_bits(cuda, nq, nd, dim, k):
     """33 .. 128 queries (faiss_search.profile's larger batches, MEVI/faiss_search.py:32-68): ip_filter_h16_kernel<2> / <4> --
@@ -230,7 +233,7 @@ def test_centred_image_proves_queries_on_mean_shifted_embeddings(cuda):
     np.testing.assert_array_equal(i, ei)
     np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
     assert st.n_failed_queries == 0, st.n_failed_queries
-    assert st.max_err_ratio <= 0.25
+    assert st.max_err_ratio <= 0.5            # round 6: the bound is the MEASURED rounding (about half the worst case of rounds 1-5)
 
 
 def test_heavy_tailed_magnitudes_keep_the_f16_bound_honest(cuda):
@@ -251,7 +254,7 @@ def test_heavy_tailed_magnitudes_keep_the_f16_bound_honest(cuda):
     es, ei = odense.ip_topk_exact(q, d, k)
     np.testing.assert_array_equal(i, ei)
     np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
-    assert 0 < st.max_err_ratio <= 0.5, st.max_err_ratio
+    assert 0 < st.max_err_ratio <= 1.0, st.max_err_ratio      # a rigorous bound: few large coordinates may come close to it, never past it
 
 
 def test_adversarial_row_order_takes_guaranteed_path(cuda):
@@ -312,7 +315,7 @@ def test_indexed_prefilter_proves_most_queries_and_falls_back_for_the_rest(cuda)
     st = _stats()
     assert st.n_failed_queries <= 3
     # the proof's error bound must dominate what is actually observed, with a wide margin
-    assert 0 < st.max_err_ratio <= st.err_bound / 8, (st.max_err_ratio, st.err_bound)
+    assert 0 < st.max_err_ratio <= st.err_bound / 4, (st.max_err_ratio, st.err_bound)
     # 5000 copies of one row + noise far below the error bound: the top-50 cannot be proven from 256 survivors
     base = rng.standard_normal((1, 64), dtype=np.float32)
     d2 = np.concatenate([base + 1e-6 * rng.standard_normal((5000, 64)).astype(np.float32),
@@ -495,3 +498,57 @@ def test_packed_merge_equals_merge_truncated(cuda, world, nq, kl, k):
     os_, oi_ = odense.topk_merge(np.stack(ls), np.stack(li), k)
     np.testing.assert_array_equal(got_i.cpu().numpy(), oi_)
     np.testing.assert_array_equal(got_s.cpu().numpy().view(np.uint32), os_.view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", ["iid", "clustered", "ance_scale", "duplicates"])
+def test_realistic_corpus_distributions_bit_exact(cuda, kind):
+    """the corpora of the bench's `data_sensitivity` leg (tools/synth.py: clustered rows in document runs, a
+    T5-ANCE-like scale with a common component of norm ~11 and outlier dimensions, 1 % exact + 1 % near duplicates with
+    queries planted ON duplicated rows) at a size the oracle finishes: exact-f32 path and f16-pre-filtered path both return
+    the oracle's lists bit for bit, whatever the proof sends to the second pass or the fallback."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+
+    nd, nq, k = 70_000, 64, 100
+    docs, info = synth.corpus(kind, cuda, nd, 768, block=16384, n_clusters=40)
+    q, planted = synth.corpus_queries(kind, docs, nq, info)
+    d_h, q_h = docs.cpu().numpy(), q.cpu().numpy()
+    _check(q_h, d_h, k, cuda)
+    st = _stats()                                            # of the indexed search _check ran last
+    es, ei = odense.ip_topk_exact(q_h, d_h, k)
+    if kind == "duplicates":                                 # queries on duplicated rows: the copy pair ties, lower id first
+        tied = (es[:, 0] == es[:, 1]).sum()
+        assert tied >= nq // 4, tied
+        assert (ei[es[:, 0] == es[:, 1], 0] < ei[es[:, 0] == es[:, 1], 1]).all()
+    elif kind != "ance_scale":                               # (un-normalised rows of norm 8-16: the inner product prefers the long ones)
+        assert (ei[:, :10] == planted.cpu().numpy()[:, None]).any(1).mean() > 0.9
+    assert st.max_err_ratio <= 1.0, st.max_err_ratio         # the proof's bound dominates what was observed
+    # k = 1000 over a cluster-sized neighbourhood (the whole top-k inside one cluster: dense scores at rank k)
+    s2, i2 = _run_indexed(q_h[:16], d_h, 1000, cuda)
+    es2, ei2 = odense.ip_topk_exact(q_h[:16], d_h, 1000)
+    np.testing.assert_array_equal(i2, ei2)
+    np.testing.assert_array_equal(s2.view(np.uint32), es2.view(np.uint32))
+
+
+def test_candidate_counters_of_profiling_level_two(cuda):
+    """mevi_ip_topk_set_profiling(2): the indexed search also reports how many keys its filter launches appended (what the
+    data decides about its cost); level 0 / 1 leave the counters at zero and the results never change."""
+    rng = np.random.default_rng(11)
+    q = rng.standard_normal((40, 768), dtype=np.float32)
+    d = rng.standard_normal((30000, 768), dtype=np.float32)
+    s0, i0 = _run_indexed(q, d, 100, cuda)
+    assert _stats().n_filter_candidates == 0
+    L = hip.lib()
+    L.mevi_ip_topk_set_profiling(2)
+    try:
+        s1, i1 = _run_indexed(q, d, 100, cuda)
+        st = _stats()
+    finally:
+        L.mevi_ip_topk_set_profiling(0)
+    np.testing.assert_array_equal(i0, i1)
+    np.testing.assert_array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    kp = 100 + 48                                            # h1_kprime: every query keeps at least K' keys of the first launch
+    assert st.n_filter_candidates >= 40 * kp and st.max_launch_candidates >= kp and st.n_list_overflows == 0, \
+        (st.n_filter_candidates, st.max_launch_candidates, st.n_list_overflows)

@@ -69,7 +69,7 @@ def test_indexed_prefilter_equals_exact_path_at_full_size(c2):
     hip.lib().mevi_ip_topk_get_stats(st)
     assert torch.equal(i2, i) and torch.equal(s2.view(torch.int32), s.view(torch.int32))
     assert st.n_failed_queries <= 0.01 * bench.N_QUERIES
-    assert st.max_err_ratio <= st.err_bound / 8
+    assert st.max_err_ratio <= st.err_bound / 4      # the measured-rounding bound of round 6 (observed 0.06 of the old worst-case bound)
 
 
 def test_scores_are_exact_chains_and_lists_are_complete(c2):

@@ -251,3 +251,24 @@ def test_rq_training_matches_scikit_learn_quality(cuda):
     pq = rq.ProductQuantization("rq", M, int(np.log2(K)), "l2", dim, device=cuda)
     pq.unsupervised_update_codebook_manually(x, 3)
     assert torch.equal(pq.get_codebook(), book) and np.array_equal(pq.last_preds, codes.cpu().numpy())
+
+
+@pytest.mark.parametrize("kind", ["iid", "clustered", "ance_scale"])
+@pytest.mark.parametrize("M,K", [(4, 32), (3, 256)])
+def test_trained_codebook_on_realistic_corpora_equals_oracle(cuda, kind, M, K):
+    """the RQ encode with a TRAINED codebook (rq.train_rq_codebook = residual k-means, what MEVI/pq.py:550-598
+    produces: cells meet where the data is dense, so more row-levels are ambiguous than against a random codebook) on the
+    corpora of tools/synth.py -- codes equal the oracle's and the exact kernel's, bit for bit."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "tools"))
+    import synth
+
+    n = 12_000
+    docs, _ = synth.corpus(kind, cuda, n, 768, block=4096, n_clusters=60)
+    book, _ = rq.train_rq_codebook(docs, M, K, seed=2, n_init=2, max_iter=15)
+    fast, exact, st = _both(docs.cpu().numpy(), book.cpu().numpy(), cuda)
+    want = orq.rq_encode(docs.cpu().numpy(), book.cpu().numpy())
+    assert st["path"] == "fast"
+    assert np.array_equal(exact, want)
+    assert np.array_equal(fast, want), (st, int((fast != want).any(1).sum()))

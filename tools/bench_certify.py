@@ -4,7 +4,7 @@ MEVI/ensemble_marco.py:221-240).
 
   * dense_certificate: a fixed slice of the bench's own data (first 64 queries x first 500 000 corpus rows, which hold
     the planted neighbours) through oracle.dense.ip_topk_exact (CPU, sequential fmaf chains) and through the HIP search;
-  * chain_certificate: 8 queries of the C4 chain on a 500 000-row sub-corpus -- tower, dense top-k, NCI beam search,
+  * chain_certificate: 32 queries of the C4 chain on a 500 000-row sub-corpus -- tower, dense top-k, NCI beam search,
     fine stage, ensemble -- CPU (oracle/, the host dict path of the ensemble pinned to golden G6) against GPU.
 
 Only bench.py calls this (oracle/ as the checker, never as the thing measured)."""
@@ -130,6 +130,8 @@ def chain_certificate(model, tower, cpu_w, cfgs, docs, codes_h, codebook, ids, m
         "seconds": round(time.perf_counter() - t0, 1),
         "tower_max_abs_diff": float((qe.cpu() - ce).abs().max()),
         "beams_identical": bool(np.array_equal(bc, obc)),
+        "queries": n_q, "beams": int(n_q * R),
+        "beams_differing_from_oracle": int((bc != obc).any(-1).sum()),     # near-tie swaps (0 when beams_identical)
         "beam_score_max_abs_diff": float(np.abs(np.asarray(gsc[:n_q * R]) - osc[:n_q * R].numpy()).max()),
         "rq_codes_identical_on_sample": rq_same,
         "dense": both(ci.tolist(), gi_h.tolist()),

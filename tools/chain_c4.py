@@ -42,10 +42,62 @@ def sync_time(fn):
     return time.perf_counter() - t, out
 
 
-def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, quiet=True, repeats=3):
+def latency_b1(model, tower, dindex, fs, ids, mask, M, K, R, topk, n=24):
+    """ONE query through the chain (VERDICT r5 #4a) -- the regime the reference's own hooks time (MEVI/generate.py:247-280
+    and MEVI/faiss_search.py:32-68 at batch 1, --timing_infer_step MEVI/main_models.py:3729-3732,4091-4096): query tower
+    (HIP-graph replay) -> dense top-k over the resident corpus -> NCI beam search (graph replay) -> fine stage on the beam
+    clusters, each stage alone (median of `n` different queries, device synchronised per call) and the four in sequence."""
+    def med(fn):
+        fn(0)
+        fn(1)                                       # graphs are captured on a key's second call
+        torch.cuda.synchronize()
+        ts = []
+        for i in range(n):
+            t = time.perf_counter()
+            fn(2 + i)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t) * 1e3)
+        return float(np.median(ts))
+
+    nq = ids.shape[0]
+    one = lambda i: (ids[i % nq:i % nq + 1], mask[i % nq:i % nq + 1])       # noqa: E731
+
+    def tower_q(i):
+        a, m = one(i)
+        return tower.encode_query({"input_ids": a, "attention_mask": m}, graph=True)
+
+    def beams(i):
+        a, m = one(i)
+        return nci.decode_token(model.generate(a, m, num_beams=R, graph=True)[0], K).view(-1, R, M).cpu().numpy()
+
+    qs = [tower_q(i).clone() for i in range(n + 2)]
+    bs = [beams(i) for i in range(n + 2)]
+
+    def whole(i):
+        q = tower_q(i)
+        dindex.search(q, topk)
+        return fs.rerank(q, beams(i))
+
+    out = {"tower": med(tower_q), "dense_top%d" % topk: med(lambda i: dindex.search(qs[i], topk)),
+           "nci_beam_search": med(beams), "fine_stage": med(lambda i: fs.rerank(qs[i], bs[i]))}
+    out = {k_: round(v, 3) for k_, v in out.items()}
+    out["sum_of_stages_ms"] = round(sum(out.values()), 3)
+    out["chain_in_sequence_ms"] = round(med(whole), 3)
+    out["note"] = ("one query, resident model / corpus / index, tower and beam search as HIP-graph replays (same bits as the batched "
+                   "path); the beam search's figure includes the 10 x M token read-back and decode_token, the fine stage its host-side "
+                   "cluster look-up; weight-streaming floors: tower 0.89 GB, NCI 1.25 GB, dense 13.6 GB of f16 image per query")
+    return out
+
+
+def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, quiet=True, repeats=3, codebook=None, plant=True,
+        with_latency=False):
     """`docs` f32 [N, d] resident corpus (MODIFIED: one planted neighbour per query at a 3.8-6.5 sigma margin);
     `planted` the planted document of every query.  Returns a dict with per-stage milliseconds, the chain rates, the
-    ensemble metrics and checksums of the intermediate results."""
+    ensemble metrics and checksums of the intermediate results.
+    `codebook`: None = random N(0, 0.05 / (1 + level)) centroids (the bench's index artefact since round 1); 'trained' = residual
+    k-means on a strided 1 M-row sample of `docs` (rq.train_rq_codebook: what MEVI/pq.py:550-598 produces -- balanced cells, so
+    the fine stage sees ~N / K^M x R candidates per query); or a tensor.  `plant=False`: `docs` already carries
+    the planted neighbours of an earlier run() on the same queries."""
     nq, d = ids.shape[0], docs.shape[1]
     dev = docs.device
 
@@ -59,8 +111,15 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
     c = c / c.norm(dim=1, keepdim=True)
     z = torch.from_numpy(rng.uniform(3.8, 6.5, nq).astype(np.float32)).to(dev)     # margin in sigmas of the corpus noise
     strength = z * 0.05 * qemb.norm(dim=1) / (qemb * c).sum(1).clamp_min(1e-6)
-    docs[torch.from_numpy(planted).to(dev)] += strength[:, None] * c
-    codebook = torch.stack([rn(K, d, s=0.05 / (1 + j)) for j in range(M)])
+    if plant:
+        docs[torch.from_numpy(planted).to(dev)] += strength[:, None] * c
+    codebook_kind = "random" if codebook is None else ("trained" if isinstance(codebook, str) else "given")
+    if codebook is None:
+        codebook = torch.stack([rn(K, d, s=0.05 / (1 + j)) for j in range(M)])
+    elif isinstance(codebook, str):
+        assert codebook == "trained", codebook
+        step = max(1, docs.shape[0] // 1_000_000)
+        codebook, _ = rq.train_rq_codebook(docs[::step][:1_000_000].contiguous(), M, K, seed=1, n_init=3, max_iter=40)
     t_rq, codes = sync_time(lambda: rq.rq_encode(docs, codebook))
     codes_h = codes.cpu().numpy()
     LAST.update(codebook=codebook, codes_h=codes_h)
@@ -102,6 +161,13 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
     stages = passes[int(order[len(order) // 2])]
     total = sum(stages.values())
     reuse = total - stages["tower_again"]
+
+    lat = None
+    if with_latency:
+        try:
+            lat = latency_b1(model, tower, dindex, fs, ids, mask, M, K, R, topk)
+        except Exception as e:
+            lat = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- metrics as marco_ensemble.sh computes them: ensemble_marco.py's cluster ranks, combination, ranking and gt look-up
     # on the device (mevi_amd/consumers.py; the lists of a live chain are already arrays), Recall / MRR accumulated by the
@@ -172,7 +238,7 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
     return {
         "workload": f"C4: {nq} queries, corpus {docs.shape[0]} x {d}, beams {R}, RQ ({M},{K}), top-{topk}; tower -> dense "
                     f"search -> NCI beam search -> tower again -> fine stage, inputs in HBM, timed directly",
-        "device_batch": batch,
+        "device_batch": batch, "codebook": codebook_kind,
         "ms": {k_: round(v * 1e3, 2) for k_, v in stages.items()},
         "chain_ms": round(total * 1e3, 2), "queries_per_s": round(nq / total, 1),
         "repeats": len(totals), "chain_ms_all": [round(t_ * 1e3, 2) for t_ in totals], "chain_ms_min": round(min(totals) * 1e3, 2),
@@ -187,7 +253,7 @@ def run(model, tower, docs, ids, mask, planted, rn, M, K, R, topk, batch, rng, q
         "fine_candidates_per_query": float(ndoc.mean()), "fine_candidates_max": int(ndoc.max()),
         "mrr10": {k_: v[1][10] for k_, v in res.items()}, "recall1000": {k_: v[0][1000] for k_, v in res.items()},
         "ensemble_with_planted_beam_cluster": planted_beam,
-        "planted_top1_ok": planted_top1,
+        "planted_top1_ok": planted_top1, "latency_b1": lat,
         "checksums": {n_: zlib.crc32(np.ascontiguousarray(a_).tobytes()) for n_, a_ in
                       (("qemb", qemb.cpu().numpy()), ("doc_codes", codes_h), ("beam_codes", bcodes), ("dense_ids", di_h),
                        ("ndoc", ndoc))},

@@ -102,3 +102,116 @@ def query_ids(nq, dev, rng):
         ids[i, L - 1] = 1
         mask[i, :L] = 1
     return torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+
+
+# ---- corpus distributions for the data-sensitivity sweep -------------------------------------------------------
+# The headline corpus (bench.gen_block) is i.i.d. 0.05 N(0,1) + 0.02.  The two data-dependent fast paths -- the f16 pre-filter
+# of the dense search (how many rows pass the running threshold, how many queries the proof sends to the second pass) and the
+# matrix-core RQ shortlist (how many row-levels are ambiguous) -- are also timed on corpora shaped like what the reference's
+# towers emit: clustered, un-normalised with a large common component (MEVI/document_encoder.py:118,139 returns
+# last_hidden_state[:, 0, :] as is), and with duplicated passages (MS MARCO has exact and near duplicates).  Every generator
+# is seeded per 65536-row block, on the device, like bench.gen_block.
+CORPUS_KINDS = ("iid", "clustered", "ance_scale", "duplicates")
+CORPUS_BLOCK = 65536
+N_CLUSTERS = 10_000
+
+
+def _cluster_tables(dev, dim, n_clusters, sigma_between, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    centres = sigma_between * torch.randn((n_clusters, dim), device=dev, generator=g)
+    # cluster popularity ~ 1 / (rank + 10)^0.7: the largest clusters hold several thousand rows of an 8.8 M corpus, the median
+    # a few hundred -- a query planted in a large cluster has its whole top-1000 inside ONE cluster (dense scores at rank k)
+    w = 1.0 / (torch.arange(n_clusters, device=dev, dtype=torch.float32) + 10.0) ** 0.7
+    return centres, w / w.sum()
+
+
+def _assign_runs(rows, weights, g, mean_run=8):
+    """Cluster of every row of a block: constant over runs of geometric length (mean `mean_run`) -- the passages of one web
+    document sit next to each other in MS MARCO's collection -- each run's cluster drawn by popularity."""
+    dev = weights.device
+    new_run = torch.rand((rows,), device=dev, generator=g) < 1.0 / mean_run
+    new_run[0] = True
+    run_id = torch.cumsum(new_run.to(torch.int64), 0) - 1
+    n_runs = int(run_id[-1].item()) + 1
+    cl = torch.multinomial(weights, n_runs, replacement=True, generator=g)
+    return cl[run_id]
+
+
+def corpus_spec(kind, dev, dim=d, n_clusters=N_CLUSTERS):
+    """What every block of corpus `kind` shares (cluster centres, popularity, the common component, per-dimension scales)."""
+    if kind not in CORPUS_KINDS:
+        raise ValueError(f"unknown corpus kind {kind!r} (one of {CORPUS_KINDS})")
+    spec = {"kind": kind, "dim": dim}
+    if kind == "clustered":
+        spec["centres"], spec["weights"] = _cluster_tables(dev, dim, n_clusters, 0.05, 77)
+        spec.update(sigma_within=0.012, shift=0.02)
+    elif kind == "ance_scale":
+        # row norms 10-14: a common component of norm ~11 (+-0.4 per dimension), a clustered residual of norm ~3.7, a per-row
+        # scale jitter of 8 %, and four outlier dimensions with 10x the spread (dense retrievers' embeddings have such)
+        spec["centres"], spec["weights"] = _cluster_tables(dev, dim, n_clusters, 0.12, 78)
+        g = torch.Generator(device=dev).manual_seed(79)
+        spec["common"] = 0.4 * (2.0 * (torch.rand((dim,), device=dev, generator=g) < 0.5).float() - 1.0)
+        dscale = torch.ones((dim,), device=dev)
+        dscale[torch.randperm(dim, device=dev, generator=g)[:4]] = 10.0
+        spec.update(sigma_within=0.06, dim_scale=dscale, row_jitter=0.08)
+    return spec
+
+
+def corpus_block(spec, b, n_docs, block=CORPUS_BLOCK):
+    """Rows [b * block, ...) of the corpus described by `spec` (f32 [rows, dim] on the spec's device)."""
+    kind, dim = spec["kind"], spec["dim"]
+    rows = min(block, n_docs - b * block)
+    if kind in ("iid", "duplicates"):
+        dev = spec.get("device")
+        g = torch.Generator(device=dev).manual_seed(10_000 + b)           # bench.gen_block's stream
+        return 0.05 * torch.randn((rows, dim), device=dev, generator=g) + 0.02
+    dev = spec["centres"].device
+    g = torch.Generator(device=dev).manual_seed(20_000 + b + (1_000_000 if kind == "ance_scale" else 0))
+    cl = _assign_runs(rows, spec["weights"], g)
+    x = spec["centres"][cl] + spec["sigma_within"] * torch.randn((rows, dim), device=dev, generator=g)
+    if kind == "clustered":
+        return x + spec["shift"]
+    x = x * spec["dim_scale"] + spec["common"]
+    return x * (1.0 + spec["row_jitter"] * torch.randn((rows, 1), device=dev, generator=g))
+
+
+def corpus(kind, dev, n_docs, dim=d, block=CORPUS_BLOCK, n_clusters=N_CLUSTERS):
+    """(docs f32 [n_docs, dim] on `dev`, info) -- the whole corpus of `kind`.  'duplicates': the i.i.d. corpus with 1 % of the
+    rows overwritten by exact copies of other rows and another 1 % by near copies (relative noise 1e-3)."""
+    spec = corpus_spec(kind, dev, dim, n_clusters)
+    spec["device"] = dev
+    out = torch.empty((n_docs, dim), dtype=torch.float32, device=dev)
+    for b in range((n_docs + block - 1) // block):
+        blk = corpus_block(spec, b, n_docs, block)
+        out[b * block:b * block + blk.shape[0]] = blk
+    info = {"kind": kind, "rows": n_docs, "dim": dim}
+    if kind == "duplicates":
+        g = torch.Generator(device=dev).manual_seed(4242)
+        n_dup = max(1, n_docs // 100)
+        perm = torch.randperm(n_docs, device=dev, generator=g)
+        dst_exact, dst_near, src = perm[:n_dup], perm[n_dup:2 * n_dup], perm[2 * n_dup:4 * n_dup]
+        out[dst_exact] = out[src[:n_dup]]
+        out[dst_near] = out[src[n_dup:]] * (1.0 + 1e-3 * torch.randn((n_dup, dim), device=dev, generator=g))
+        info.update(exact_duplicates=n_dup, near_duplicates=n_dup, dup_src=src[:n_dup], dup_dst=dst_exact)
+    if kind in ("clustered", "ance_scale"):
+        info.update(clusters=n_clusters, sigma_within=spec["sigma_within"])
+    nr = out[:: max(1, n_docs // 4096)].norm(dim=1)
+    info["row_norm"] = {"mean": float(nr.mean()), "min": float(nr.min()), "max": float(nr.max())}
+    return out, info
+
+
+def corpus_queries(kind, docs, nq, info=None, seed=1234):
+    """(queries f32 [nq, dim], planted row of every query): a query is a corpus row spread over the WHOLE corpus plus noise
+    of half the within-cluster spread -- inside its cluster, not on top of its row.  'duplicates': every other query is planted
+    on a row that has an exact copy (its top ranks then hold a tie run: order by ascending id)."""
+    n_docs, dim = docs.shape
+    dev = docs.device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ids = (torch.arange(nq, device=dev, dtype=torch.int64) * max(1, n_docs // max(nq, 1)) + 17) % n_docs
+    if kind == "duplicates" and info is not None and "dup_src" in info:
+        src = info["dup_src"]
+        pick = src[(torch.arange((nq + 1) // 2, device=dev) * 7919) % src.shape[0]]
+        ids[::2] = pick[: ids[::2].shape[0]]
+    noise = {"iid": 0.005, "duplicates": 0.005, "clustered": 0.006, "ance_scale": 0.03}[kind]
+    q = docs[ids] + noise * torch.randn((nq, dim), device=dev, generator=g)
+    return q.contiguous(), ids
