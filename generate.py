@@ -31,9 +31,9 @@ DIST_TIMEOUT = datetime.timedelta(hours=24)
 
 
 def get_tokenizer(model_path):
-    from transformers import AutoTokenizer
+    from mevi_amd.io import load_tokenizer
 
-    return AutoTokenizer.from_pretrained(model_path)
+    return load_tokenizer(model_path)
 
 
 def rank_range(n, rank, nrank):

@@ -1558,6 +1558,10 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
         hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8)
       n_cu = v;
   }
+  // MEVI_IP_FILTER_CUS=<n> (probe, profiles/r06_dense_overlap_probe.txt): the persistent filter takes n CUs instead of all,
+  // leaving the rest to whatever else is in flight (a second search's re-scoring on another stream)
+  static const int cu_cap = [] { const char *e = getenv("MEVI_IP_FILTER_CUS"); return e ? atoi(e) : 0; }();
+  if (cu_cap >= 8 && cu_cap < n_cu) n_cu = cu_cap / 8 * 8;
   int64_t seen = 0, launches = 0;
   while (seen < nd) {
     int64_t chunk = cap_docs;

@@ -19,6 +19,7 @@ from . import dense as mdense
 from . import fine as mfine
 from . import hip
 from .io import RankLog, encode_batch, join_i64, upload_rows
+from .phases import mark
 from .nci import MODEL_INFO, NCIModel, check_weights, config_from_weights, decode_token
 from .rq import ClusterIndex, ProductQuantization
 from .t5 import T5Dims, TwinTower
@@ -261,9 +262,9 @@ class EvalRun:
         else:
             raise NotImplementedError(enc)
         if tokenizer is None:
-            from transformers import AutoTokenizer  # host-side tokenisation stays an HF call (boundary)
+            from .io import load_tokenizer      # host-side tokenisation: the HF tokenizer, or SentencePiece itself for T5 directories
 
-            tokenizer = AutoTokenizer.from_pretrained(tower_dir)
+            tokenizer = load_tokenizer(tower_dir)
         self.tokenizer = tokenizer
         mark("tower weights + tokenizer", sync=True)
         # BERT-family towers read the query through their own tokenizer (`qenc_source_ids`, main_models.py:853-856):

@@ -189,6 +189,77 @@ def encode_batch(tokenizer, texts, max_length, **kw):
     return fn(list(texts), max_length=max_length, padding="max_length", truncation=True, return_tensors="pt", **kw)
 
 
+class SpmT5Tokenizer:
+    """The T5 SentencePiece tokenizer of a checkpoint directory WITHOUT importing `transformers` (whose import costs a CLI
+    process about a second -- tools/e2e_cli.py: generate.py and main.py each paid it for 6980 short strings).
+
+    What the reference's tokenizer does to a plain string (vendored transformers 3.4 `T5Tokenizer`: `_tokenize` =
+    `sp_model.EncodeAsPieces(text)`, `build_inputs_with_special_tokens` appends `</s>`; MEVI/generate.py:85-87,
+    MEVI/main_models.py:445-455 call it with `max_length=L, padding='max_length', truncation=True`) is: SentencePiece ids,
+    cut to L - 1, eos, pad to L; attention mask 1 on the real tokens.  That is computed here with the `sentencepiece` package
+    itself.  A text that contains a special-token spelling (`</s>`, `<pad>`, `<unk>`, `<extra_id_N>`: split out by the HF
+    tokenizer before SentencePiece sees the rest) is handed, together with its whole batch, to the HF tokenizer, imported at
+    that moment.  `MEVI_TOKENIZER=hf` always uses the HF object."""
+
+    SPECIAL = ("</s>", "<pad>", "<unk>", "<extra_id_")
+
+    def __init__(self, path):
+        import sentencepiece
+
+        self.path = path
+        self.sp = sentencepiece.SentencePieceProcessor(model_file=os.path.join(path, "spiece.model"))
+        self.eos_id, self.pad_id = self.sp.piece_to_id("</s>"), self.sp.piece_to_id("<pad>")
+        if self.sp.id_to_piece(self.eos_id) != "</s>" or self.sp.id_to_piece(self.pad_id) != "<pad>":
+            raise ValueError("spiece.model without </s> / <pad> pieces")
+        self._hf = None
+
+    def hf(self):
+        if self._hf is None:
+            from transformers import AutoTokenizer
+
+            self._hf = AutoTokenizer.from_pretrained(self.path)
+        return self._hf
+
+    def __call__(self, texts, max_length=None, padding=False, truncation=False, return_tensors=None, **kw):
+        import torch
+
+        texts = [texts] if isinstance(texts, str) else list(texts)
+        plain = (padding == "max_length" and truncation is True and return_tensors == "pt" and max_length and not kw
+                 and all(isinstance(t, str) and not any(sp in t for sp in self.SPECIAL) for t in texts))
+        if not plain:
+            return self.hf()(texts, max_length=max_length, padding=padding, truncation=truncation, return_tensors=return_tensors, **kw)
+        ids = np.full((len(texts), max_length), self.pad_id, np.int64)
+        mask = np.zeros((len(texts), max_length), np.int64)
+        for i, row in enumerate(self.sp.encode(texts)):
+            row = row[:max_length - 1] + [self.eos_id]
+            ids[i, :len(row)] = row
+            mask[i, :len(row)] = 1
+        return {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+
+    batch_encode_plus = __call__
+
+
+def load_tokenizer(path):
+    """The tokenizer of a checkpoint directory: `AutoTokenizer.from_pretrained(path)` (host-side tokenisation stays an HF call,
+    SURVEY 8b) -- except for T5 SentencePiece directories, which get SpmT5Tokenizer (same ids, no `transformers` import)."""
+    if os.environ.get("MEVI_TOKENIZER", "") != "hf" and os.path.isfile(os.path.join(path, "spiece.model")):
+        cls = None
+        cfg = os.path.join(path, "tokenizer_config.json")
+        if os.path.isfile(cfg):
+            import json
+
+            with open(cfg) as f:
+                cls = json.load(f).get("tokenizer_class")
+        if cls in (None, "T5Tokenizer", "T5TokenizerFast"):
+            try:
+                return SpmT5Tokenizer(path)
+            except Exception:           # no sentencepiece package, a model without the T5 special pieces, ...
+                pass
+    from transformers import AutoTokenizer
+
+    return AutoTokenizer.from_pretrained(path)
+
+
 def read(path, dim):
     """Raw f32 file -> [rows, dim] (raises like numpy if the size does not divide).  Large files (the 27 GB corpus) come
     back as a read-only memory map -- an ndarray too -- so that the only copy made is the one into the upload's staging

@@ -248,6 +248,9 @@ def ensemble_main(dir_path, gt_file, ance_file, fine_file, coarse_file, mapping_
                   alphas="0.6", betas="0.03", gammas="0.02", recall_num="10,50,1000", ofile=None):
     if mapping_file is None or not os.path.exists(mapping_file):
         raise AssertionError(f"mapping file {mapping_file} does not exist")
+    from .phases import mark
+
+    mark("start-up + imports")
     alphas, betas, gammas = ([float(x) for x in v.split(",")] for v in (alphas, betas, gammas))
     cutoffs = [int(x) for x in recall_num.split(",")]
     gts, _, _ = mio.load_parsed(resolve(gt_file, dir_path), GT_TEMPLATE)
@@ -256,11 +259,13 @@ def ensemble_main(dir_path, gt_file, ance_file, fine_file, coarse_file, mapping_
     have_fine = fine_path is not None and os.path.exists(fine_path)
     _, _, clusters = mio.load_parsed(resolve(coarse_file, dir_path), COARSE_TEMPLATE)
     mapping = load_mapping(mapping_file)
+    mark("gt + coarse TSV + doc -> code mapping read")
     from . import consumers
 
     fast = consumers.ensemble_main(gts, ance_path, fine_path if have_fine else None, clusters, mapping, alphas, betas, gammas,
                                    cutoffs, ofile)            # the big lists as flat arrays, the arithmetic on the device
     if fast is not None:
+        mark("dense + fine TSV parsed, ranks / combination / metrics (device path)")
         return fast
     dense_p, dense_s, _ = mio.load_parsed(ance_path, RANKED_TEMPLATE)
     if have_fine:

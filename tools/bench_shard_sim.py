@@ -185,7 +185,13 @@ if "--predict-c5" in sys.argv:
     model, tower, _, _ = synth.build(dev, 4, 32, None)
     ids, mask = synth.query_ids(nq, dev, np.random.default_rng(0))
     model.generate(ids, mask, num_beams=10)
-    sw = {r["queries"]: r for r in batch_sweep.sweep(model, tower, ids, mask, 4, 32, 10, (873, nq), bench.seq2seq_flops, bench.tower_flops)}
+    # per-rank query counts of the replica layout (8 x 873) and of the ARM-SPLIT layouts: the beam search on `a`
+    # ranks (ceil(nq / a) queries each), both tower passes on the other 8 - a, concurrently
+    W8 = 8
+    per = lambda parts: (nq + parts - 1) // parts       # noqa: E731
+    split_sizes = sorted({per(a) for a in range(2, W8 - 1)} | {per(W8 - a) for a in range(2, W8 - 1)})
+    sw = {r["queries"]: r for r in batch_sweep.sweep(model, tower, ids, mask, 4, 32, 10, tuple(sorted(set(split_sizes) | {873, nq})),
+                                                    bench.seq2seq_flops, bench.tower_flops)}
     fine_ms_1 = float(os.environ.get("FINE_MS", "2.7"))               # fine stage of 6980 queries (chain_c4.stage_ms.fine_stage)
     w8 = next(r for r in rows if r["world"] == 8)
     dense8 = extra.get("bench_layout_all_8_shards", {}).get("per_rank_total_ms", w8["per_rank_total_ms"]) + w8["allgather_xgmi_floor_ms"]
@@ -205,6 +211,26 @@ if "--predict-c5" in sys.argv:
                                  "tower": round(sw[nq]["tower_ms"] / (8 * sw[873]["tower_ms"]), 4),
                                  "beam_search": round(sw[nq]["nci_ms"] / (8 * sw[873]["nci_ms"]), 4),
                                  "whole_chain": round(one / (8 * eight), 4)}}
+    # ---- arm-split layouts: every rank searches its corpus shard for all queries (as above); the `a` beam-search ranks start the
+    # search at t = 0 (it needs no embedding), the 8 - a tower ranks run the first tower pass, all ranks exchange the embeddings
+    # (all-gather, 21 MB) and search their shards, the tower ranks run the second pass; beams (nq x R x M ints) and embeddings
+    # meet on the tower ranks for the fine stage.  A rank's time = its own arm + the dense search; the layout's = the slowest rank.
+    layouts = [{"layout": "replicas 8 x %d queries (MEVI/main.py:318-322: what chain_c5 runs)" % per(W8), "nci_ranks": W8, "tower_ranks": W8,
+                "nci_rank_ms": round(eight, 2), "tower_rank_ms": round(eight, 2), "chain_ms": round(eight, 2)}]
+    for a in range(2, W8 - 1):
+        nn, tt = per(a), per(W8 - a)
+        nci_rank = sw[nn]["nci_ms"] + dense8
+        tower_rank = 2 * sw[tt]["tower_ms"] + dense8 + fine_ms_1 / (W8 - a)
+        layouts.append({"layout": "arm split: beam search on %d ranks x %d queries, both tower passes on %d ranks x %d" % (a, nn, W8 - a, tt),
+                        "nci_ranks": a, "tower_ranks": W8 - a, "nci_ms": sw[nn]["nci_ms"], "nci_frac": sw[nn].get("nci_frac"),
+                        "tower_ms": sw[tt]["tower_ms"], "tower_frac": sw[tt].get("tower_frac"),
+                        "nci_rank_ms": round(nci_rank, 2), "tower_rank_ms": round(tower_rank, 2), "chain_ms": round(max(nci_rank, tower_rank), 2)})
+    best = min(layouts, key=lambda l: l["chain_ms"])
+    summary["predicted_c5"]["layouts"] = layouts
+    summary["predicted_c5"]["best_layout"] = {"layout": best["layout"], "chain_ms": best["chain_ms"],
+                                              "queries_per_s": round(nq / best["chain_ms"] * 1e3, 1),
+                                              "gain_over_replicas": round(eight / best["chain_ms"], 4),
+                                              "whole_chain_efficiency": round(one / (8 * best["chain_ms"]), 4)}
     print(json.dumps(summary["predicted_c5"]), flush=True)
 if sweep:
     summary["schedule_sweep"] = sweep
