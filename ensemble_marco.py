@@ -21,3 +21,6 @@ if __name__ == "__main__":
     a = parser.parse_args()
     ensemble_main(a.dir_path, a.gt_file, a.ance_file, a.fine_file, a.coarse_file, a.mapping_file,
                   a.alphas, a.betas, a.gammas, a.recall_num, a.ofile)
+    from mevi_amd.phases import finish
+
+    finish()

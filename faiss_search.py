@@ -15,7 +15,7 @@ import numpy as np
 
 from mevi_amd.dense import is_trained_before_train, profile, search, shard_range, sharded_ip_topk  # noqa: F401  (API parity: search, profile)
 from mevi_amd.io import map_rows, read, to_file  # noqa: F401
-from mevi_amd.phases import mark
+from mevi_amd.phases import finish, mark
 
 
 def _distributed_search(query, doc_path, dim, topk):
@@ -71,3 +71,4 @@ if __name__ == "__main__":
         print(indices.dtype, indices.shape, dists.dtype, dists.shape)
         to_file(args.raw_query_path, args.output_path, dists, indices)
         mark("ranked TSV written")
+        finish()

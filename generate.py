@@ -16,7 +16,7 @@ import numpy as np
 import pandas as pd
 
 from mevi_amd.io import encode_batch, flush_rows, map_rows
-from mevi_amd.phases import mark
+from mevi_amd.phases import finish, mark
 
 
 # padded tokens per device pass (= mevi_amd.t5.DEVICE_PASS_TOKENS); --batch_size only raises it: the embeddings do not
@@ -63,7 +63,9 @@ def load_document_encoder(model_path, ckpt_path, device):
         return load_bert_tower(model_path, device)
     weights, dims = load_tower_weights(model_path)
     if ckpt_path is not None:  # fine-tuned tower inside a training checkpoint (generate.py:200-211)
-        sd = torch.load(ckpt_path, map_location="cpu")
+        from mevi_amd.io import load_checkpoint
+
+        sd = load_checkpoint(ckpt_path)
         sd = sd.get("state_dict", sd)
         pre = "document_encoder.lm_q."
         weights.update({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
@@ -245,3 +247,4 @@ if __name__ == "__main__":
         mp.spawn(gen_query_embedding, nprocs=len(gpus), args=common)
     else:
         gen_query_embedding(0, *common)
+        finish()

@@ -451,6 +451,11 @@ void mevi_ip_topk_get_stats(mevi_ip_topk_stats *out);
  * bytes: comma-joined values into `out` (cap >= 26 n / 21 n bytes), returning the byte count or a negative status. */
 int64_t mevi_format_f32_list(const float *v, int64_t n, char *out, int64_t cap);
 int64_t mevi_format_i64_list(const int64_t *v, int64_t n, char *out, int64_t cap);
+/* both list columns of a whole ranked TSV in one call (faiss_search.to_file writes 6980 x 1000 ids and scores per dense file,
+ * MEVI/faiss_search.py:71-77): row r -> `id,id,...<TAB>score,score,...` at out + r * row_cap (row_cap >= 47 k + 1), its byte
+ * count in lens[r]; `threads` host threads share the rows.  Status. */
+int mevi_format_ranked_rows(const int64_t *ids, const float *scores, int64_t rows, int64_t k, char *out, int64_t row_cap,
+                            int64_t *lens, int32_t threads);
 /* and back: one comma-separated field of such a file -> numbers (the consumers `eval()` every field,
  * evaluate.py:91-110, ensemble_marco.py:85-110).  Count, or a negative status when a token is not a plain number of
  * that kind (the caller falls back to Python's parser) or cap is short. */

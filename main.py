@@ -262,3 +262,7 @@ if __name__ == "__main__":
     if args.ignored_flags:
         print("accepted and ignored (training / ablation flags):", " ".join(f for f, _ in args.ignored_flags), file=sys.stderr)
     inference(args)
+    if len(args.n_gpu) == 1 and "RANK" not in os.environ:
+        from mevi_amd.phases import finish
+
+        finish()

@@ -56,39 +56,88 @@ class RankedArrays:
         return len(self.queries)
 
 
-def parse_ranked(path, template):
-    """`path` parsed in one native pass -> RankedArrays, or None when the file is not of the plain shape (then
-    io.parse_file gives it its Python meaning).  A duplicate query makes the dict path keep the LAST line at the FIRST
-    position; rare enough to leave to it."""
+PARSE_THREADS = 8       # the 172 MB dense TSV of MS MARCO dev: one native pass took 1.1 s of ensemble_marco.py's 2.0 s (tools/e2e_cli.py)
+
+
+def _parse_chunk(base, a, b, lines, n_commas, template):
+    """Bytes [a, b) of the file (whole lines) through the native parser: (span, seg_i, vals_i, seg_f, vals_f) or None."""
     from . import hip
 
-    if path.endswith(".pkl"):
-        return None
-    with open(path, "rb") as f:
-        buf = f.read()
-    lines = buf.count(b"\n") + (0 if buf.endswith(b"\n") or not buf else 1)
-    cap = buf.count(b",") + lines + 1
     ci, cf = template.get("pred"), template.get("score")
-    if ci is None or ci < 0 or template["query"] < 0 or (cf is not None and cf < 0):
-        return None
+    cap = n_commas + lines + 1
     span = np.empty((max(lines, 1), 2), np.int64)
     seg_i, vals_i = np.empty(lines + 1, np.int64), np.empty(cap, np.int64)
     seg_f, vals_f = (np.empty(lines + 1, np.int64), np.empty(cap, np.float64)) if cf is not None else (None, None)
-    n = hip.lib().mevi_parse_tsv_columns(buf, len(buf), template["query"], ci, -1 if cf is None else cf, span.ctypes.data,
+    n = hip.lib().mevi_parse_tsv_columns(base + a, b - a, template["query"], ci, -1 if cf is None else cf, span.ctypes.data,
                                          seg_i.ctypes.data, vals_i.ctypes.data, cap,
                                          None if cf is None else seg_f.ctypes.data, None if cf is None else vals_f.ctypes.data,
                                          cap, lines)
     if n != lines:
         return None
+    if cf is not None and not np.array_equal(seg_i, seg_f):      # a line whose ids and scores differ in number
+        return None
+    span[:, 0] += a                                              # spans relative to the whole file
+    return span[:lines], seg_i, vals_i[:seg_i[-1]], None if cf is None else vals_f[:seg_f[-1]]
+
+
+def parse_ranked(path, template):
+    """`path` parsed natively -> RankedArrays, or None when the file is not of the plain shape (then io.parse_file gives it
+    its Python meaning).  Large files are cut at line ends into PARSE_THREADS pieces parsed side by side (the parser is a C
+    function: ctypes drops the GIL) and stitched -- the same arrays as one pass.  A duplicate query makes the dict path keep the
+    LAST line at the FIRST position; rare enough to leave to it."""
+    import ctypes
+
+    if path.endswith(".pkl"):
+        return None
+    with open(path, "rb") as f:
+        buf = f.read()
+    ci, cf = template.get("pred"), template.get("score")
+    if ci is None or ci < 0 or template["query"] < 0 or (cf is not None and cf < 0):
+        return None
+    keep = ctypes.c_char_p(buf)                                  # points into `buf` (no copy); both stay alive to the end
+    base = ctypes.cast(keep, ctypes.c_void_p).value or 0
+    cuts = [0]
+    nthreads = PARSE_THREADS if len(buf) >= (8 << 20) else 1
+    for j in range(1, nthreads):
+        at = buf.find(b"\n", len(buf) * j // nthreads)
+        if at < 0:
+            break
+        if at + 1 > cuts[-1]:
+            cuts.append(at + 1)
+    cuts.append(len(buf))
+    cuts = sorted(set(cuts))
+
+    def work(j):
+        a, b = cuts[j], cuts[j + 1]
+        lines = buf.count(b"\n", a, b) + (0 if b == a or buf[b - 1:b] == b"\n" else 1)
+        return _parse_chunk(base, a, b, lines, buf.count(b",", a, b), template)
+
+    if len(cuts) > 2:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(len(cuts) - 1) as pool:
+            parts = list(pool.map(work, range(len(cuts) - 1)))
+    else:
+        parts = [work(0)] if buf else [_parse_chunk(base, 0, 0, 0, 0, template)]
+    if any(p is None for p in parts):
+        return None
+    span = np.concatenate([p[0] for p in parts])
+    seg = [np.zeros(1, np.int64)]
+    total = 0
+    for p in parts:
+        seg.append(p[1][1:] + total)
+        total += int(p[1][-1])
+    seg_i = np.concatenate(seg)
+    vals_i = np.concatenate([p[2] for p in parts])
+    vals_f = None if cf is None else np.concatenate([p[3] for p in parts])
     try:
-        queries = [buf[a:a + b].decode("utf-8") for a, b in span[:lines].tolist()]
+        queries = [buf[a:a + b].decode("utf-8") for a, b in span.tolist()]
     except UnicodeDecodeError:
         return None
     if len(set(queries)) != len(queries):
         return None
-    if cf is not None and not np.array_equal(seg_i, seg_f):      # a line whose ids and scores differ in number
-        return None
-    return RankedArrays(queries, seg_i, vals_i[:seg_i[-1]], None if cf is None else vals_f[:seg_f[-1]])
+    del keep
+    return RankedArrays(queries, seg_i, vals_i, vals_f)
 
 
 # ---- device primitives ------------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ import torch
 from . import dense as mdense
 from . import fine as mfine
 from . import hip
-from .io import RankLog, encode_batch, join_i64, upload_rows
+from .io import RankLog, encode_batch, join_i64, load_checkpoint, upload_rows
 from .phases import mark
 from .nci import MODEL_INFO, NCIModel, check_weights, config_from_weights, decode_token
 from .rq import ClusterIndex, ProductQuantization
@@ -35,7 +35,7 @@ BAD_WHOLE_KEYS = (   # dropped by try_load_ckpt's whole-model branch (MEVI/main.
 
 
 def _state_dict(path):
-    sd = torch.load(path, map_location="cpu")
+    sd = load_checkpoint(path)
     return sd["state_dict"] if "state_dict" in sd else sd
 
 
@@ -82,7 +82,7 @@ def load_hf_state_dict(model_dir):
     `model.safetensors` when a newer export of the same checkpoint ships only that."""
     path = os.path.join(model_dir, "pytorch_model.bin")
     if os.path.exists(path):
-        return torch.load(path, map_location="cpu")
+        return load_checkpoint(path)
     st = os.path.join(model_dir, "model.safetensors")
     if os.path.exists(st):
         from safetensors.torch import load_file
@@ -127,7 +127,7 @@ def load_bert_tower(model_path, device, batch_size=None):
         cfg_dir = os.path.join(os.path.split(model_path)[0],
                                "ernie-2.0-base-en" if model_path.endswith("ar2g_nq_finetune.pkl")
                                else "co-condenser-marco-retriever")
-        params = torch.load(model_path, map_location="cpu")["model_dict"]
+        params = load_checkpoint(model_path)["model_dict"]
         wq = strip({k[len("question_model."):]: v for k, v in params.items() if k.startswith("question_model.")})
         wp = strip({k[len("ctx_model."):]: v for k, v in params.items() if k.startswith("ctx_model.")})
     else:
@@ -205,6 +205,47 @@ class NqAnswers:
     def first_hit(self, qind, ranked_docs):
         hit = np.flatnonzero(np.isin(np.asarray(ranked_docs, dtype=np.int64), self.docs_answering(qind)))
         return int(hit[0]) if len(hit) else None
+
+
+def cluster_sidecar(pq_cluster_path):
+    return pq_cluster_path + ".index.npz"
+
+
+def write_cluster_sidecar(pq_cluster_path, index):
+    """The cluster dict of `rqclus*.pkl` as three arrays beside it (keys, offsets, document ids IN THE PICKLE'S ORDER) + the
+    pickle's fingerprint: unpickling the 1 M-key / 8.8 M-id dict and flattening it took main.py 1.35 s of every start
+    (tools/e2e_cli.py); the arrays load in ~50 ms.  Best effort (a read-only directory keeps the pickle path)."""
+    from .metrics import _pickle_fingerprint
+
+    try:
+        fp = _pickle_fingerprint(pq_cluster_path)
+        tmp = cluster_sidecar(pq_cluster_path) + ".tmp.npz"
+        np.savez(tmp, keys=index.keys, offsets=index.offsets, doc_ids=index.doc_ids,
+                 meta=np.array([index.M, index.K, fp["size"], fp["mtime_ns"]], np.int64))
+        os.replace(tmp, cluster_sidecar(pq_cluster_path))
+    except OSError:
+        pass
+
+
+def load_cluster_index(pq_cluster_path, M, K, write=True):
+    """ClusterIndex of `rqclus*.pkl` (MEVI/main_models.py:3200-3203): from the array sidecar when it was made for THIS pickle
+    (size and mtime_ns) and this (M, K), else from the pickle -- and the sidecar is (re)written for the next start."""
+    from .metrics import _pickle_fingerprint
+
+    side = cluster_sidecar(pq_cluster_path)
+    if os.path.exists(side) and os.environ.get("MEVI_CLUSTER_SIDECAR", "1") != "0":
+        try:
+            fp = _pickle_fingerprint(pq_cluster_path)
+            with np.load(side) as z:
+                if z["meta"].tolist() == [M, K, fp["size"], fp["mtime_ns"]]:
+                    return ClusterIndex(M, K, z["keys"], z["offsets"], z["doc_ids"])
+        except (OSError, ValueError, KeyError):
+            pass
+    with open(pq_cluster_path, "rb") as f:
+        index = ClusterIndex.from_dict(pickle.load(f), M, K)
+    if write:
+        write_cluster_sidecar(pq_cluster_path, index)
+    return index
 
 
 def rank_slice(n, rank, nrank):
@@ -295,8 +336,7 @@ class EvalRun:
         have_clusters = os.path.exists(a.pq_cluster_path) and os.path.exists(map_path)
         self.barrier()
         if have_clusters:
-            with open(a.pq_cluster_path, "rb") as f:
-                self.index = ClusterIndex.from_dict(pickle.load(f), self.M, self.K)
+            self.index = load_cluster_index(a.pq_cluster_path, self.M, self.K, write=(rank == 0))
             # rqmapping*.pkl is the inverse of the cluster dict (gen_pq_doc_cluster writes both from one encode); it is
             # rebuilt from the index as an array instead of unpickling 8.8 M tuples (9 s + 2 GB per rank on MS MARCO)
         else:
@@ -308,6 +348,7 @@ class EvalRun:
                 with open(map_path, "wb") as f:
                     pickle.dump(mapping, f)
                 del cluster, mapping
+                write_cluster_sidecar(a.pq_cluster_path, self.index)
                 from .metrics import write_mapping_sidecar
 
                 write_mapping_sidecar(map_path, self.index.doc_codes(n_docs))   # the same mapping as an array (ensemble scripts)

@@ -124,9 +124,10 @@ _SIGNATURES = {
                                c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "mevi_format_f32_list": (c_int64, [c_void_p, c_int64, c_void_p, c_int64]),
     "mevi_format_i64_list": (c_int64, [c_void_p, c_int64, c_void_p, c_int64]),
+    "mevi_format_ranked_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, ctypes.c_int32]),
     "mevi_parse_i64_list": (c_int64, [ctypes.c_char_p, c_int64, c_void_p, c_int64]),
     "mevi_parse_f64_list": (c_int64, [ctypes.c_char_p, c_int64, c_void_p, c_int64]),
-    "mevi_parse_tsv_columns": (c_int64, [ctypes.c_char_p, c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void_p,
+    "mevi_parse_tsv_columns": (c_int64, [c_void_p, c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void_p,
                                          c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "mevi_cluster_ranks_i32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                        ctypes.c_int32, c_void_p, c_void_p, c_void_p]),

@@ -189,6 +189,25 @@ def encode_batch(tokenizer, texts, max_length, **kw):
     return fn(list(texts), max_length=max_length, padding="max_length", truncation=True, return_tensors="pt", **kw)
 
 
+def load_checkpoint(path):
+    """`torch.load(path, map_location='cpu')` of a checkpoint the user trusts, as the reference loads its own (MEVI/main.py:
+    203-248, MEVI/generate.py:200-211) -- memory-mapped when the file is in torch's zip format (the tensors are then pages of
+    the file until they are uploaded: no 1-2 GB copy into anonymous memory first), and with the full unpickler when the file
+    holds more than tensors (a Lightning checkpoint carries its hyper-parameters as an argparse.Namespace, which
+    `weights_only=True`, the default of current torch releases, refuses)."""
+    import pickle as _pickle
+
+    import torch
+
+    for kw in ({"mmap": True, "weights_only": True}, {"weights_only": True}, {"mmap": True, "weights_only": False},
+               {"weights_only": False}):
+        try:
+            return torch.load(path, map_location="cpu", **kw)
+        except (RuntimeError, ValueError, _pickle.UnpicklingError, TypeError):
+            continue
+    return torch.load(path, map_location="cpu", weights_only=False)      # raises what torch raises
+
+
 class SpmT5Tokenizer:
     """The T5 SentencePiece tokenizer of a checkpoint directory WITHOUT importing `transformers` (whose import costs a CLI
     process about a second -- tools/e2e_cli.py: generate.py and main.py each paid it for 6980 short strings).
@@ -322,11 +341,34 @@ def to_file(query_path, output_path, dists, indices):
     """Dense ranked TSV, one line per line of `query_path` (query text = field 0)."""
     dists = np.asarray(dists)
     indices = np.asarray(indices)
-    text = _NativeText(dists.shape[1] if dists.ndim == 2 else 1)
-    with open(query_path, "r") as fr, open(output_path, "w") as fw:
-        for i, line in enumerate(fr):
-            query = line.split("\t")[0]
-            fw.write(f"{query}\t\t{text.i64(indices[i])}\t{text.f32(dists[i])}\n")
+    with open(query_path, "r") as fr:
+        queries = [line.split("\t")[0] for line in fr]
+    n = len(queries)
+    if dists.ndim != 2 or indices.shape != dists.shape or n > dists.shape[0] or n * dists.shape[1] < (1 << 16):
+        text = _NativeText(dists.shape[1] if dists.ndim == 2 else 1)         # small or ragged: row by row
+        with open(output_path, "w") as fw:
+            for i, query in enumerate(queries):
+                fw.write(f"{query}\t\t{text.i64(indices[i])}\t{text.f32(dists[i])}\n")
+        return
+    # MS MARCO dev is 6980 x 1000 -> 14 M renderings (0.32 s row by row): both list columns of every row in ONE native call
+    # whose host threads share the rows (mevi_format_ranked_rows); Python only joins query text and rows
+    from . import hip
+
+    k = dists.shape[1]
+    ids = np.ascontiguousarray(indices[:n], dtype=np.int64)
+    sc = np.ascontiguousarray(dists[:n], dtype=np.float32)
+    row_cap = 47 * k + 1
+    out = np.empty(n * row_cap, dtype=np.uint8)
+    lens = np.empty(n, dtype=np.int64)
+    hip.check(hip.lib().mevi_format_ranked_rows(ids.ctypes.data, sc.ctypes.data, n, k, out.ctypes.data, row_cap, lens.ctypes.data,
+                                                min(8, os.cpu_count() or 1)), "mevi_format_ranked_rows")
+    mv = memoryview(out)
+    with open(output_path, "w") as fw:
+        for i, query in enumerate(queries):
+            fw.write(query)
+            fw.write("\t\t")
+            fw.write(str(mv[i * row_cap:i * row_cap + int(lens[i])], "ascii"))
+            fw.write("\n")
 
 
 class RankLog:

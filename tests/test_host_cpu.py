@@ -471,3 +471,24 @@ def test_context_image_exponent_and_bounds():
     assert float((ln @ wv.T + bv).abs().max()) <= ops.norm_out_bound(ln_w, d, ln_b) * wmax * 1.001 + float(bv.abs().max())
     assert math.isclose(ops.norm_out_bound(ln_w, d), math.sqrt(d) * float(ln_w.abs().max()), rel_tol=1e-6)
     assert ops.ctx_bound(None, None) is None      # no bound, no image: the f32 form runs
+
+
+def test_to_file_whole_matrix_path_writes_pythons_bytes(tmp_path):
+    """faiss_search.to_file (MEVI/faiss_search.py:71-77) at a size that takes the one-call native renderer
+    (mevi_format_ranked_rows: both list columns of every row, host threads sharing the rows): the same bytes as
+    `','.join(str(x) for x in row.tolist())` per field -- incl. -1 padding ids, -FLT_MAX, signed zeros, subnormals, 1e16-style
+    reprs -- and as the row-by-row path (fewer query lines than rows: the extra rows are not written, as the reference's zip)."""
+    from mevi_amd import io as mio
+
+    rng = np.random.default_rng(4)
+    n, k = 90, 1000
+    d = rng.standard_normal((n, k)).astype(np.float32)
+    d[0, :8] = [0.0, -0.0, 1e-45, -3.4028235e38, 1e16, 123456.0, 1.5e-5, 16777216.0]
+    i = rng.integers(-1, 8_841_823, (n, k))
+    qp = tmp_path / "q.tsv"
+    qp.write_text("".join(f"what is w{j} é\t{j}\n" for j in range(n - 3)))
+    out = tmp_path / "dense.txt"
+    mio.to_file(str(qp), str(out), d, i)
+    want = "".join(f"what is w{j} é\t\t{','.join(str(x) for x in i[j].tolist())}\t{','.join(str(x) for x in d[j].tolist())}\n"
+                   for j in range(n - 3))
+    assert out.read_text() == want
