@@ -501,8 +501,9 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
         c, di2 = chain_c4.run(model, tower, docs, ids, mask, planted_ids(nq, n_docs), rn, M, K, R, TOPK, gen_batch, rng, repeats=1,
                               codebook="trained", plant=False)
         del di2
-        return {k_: c[k_] for k_ in ("codebook", "chain_ms", "queries_per_s", "ms", "fine_candidates_per_query", "fine_candidates_max",
-                                     "mrr10", "setup_untimed_ms", "planted_top1_ok")}
+        return {k_: c[k_] for k_ in ("codebook", "chain_ms", "queries_per_s", "fine_candidates_per_query", "fine_candidates_max",
+                                     "stage_ms_detail", "mrr10_detail", "setup_untimed_ms") if k_ in c} | {
+            "stage_ms_detail": c["ms"], "mrr10_detail": c["mrr10"], "planted_top1_ok": c["planted_top1_ok"]}
 
 
     if with_cpu:
@@ -603,11 +604,12 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
 
 # ---- the ONE line ---------------------------------------------------------------------------------------------------------
 LINE_BUDGET = 7600      # bytes: the driver keeps the last 8 KB of stdout beside `parsed`; the whole line must fit in it
-_DROP = ("note", "sample_detail", "per_size", "per_kind", "what", "slice", "per_rank", "per_batch", "layers", "checksums", "statistic", "stats",
-         "flop_split", "head_matrices_at", "adaptor_vectors_only_at", "one_shot_note", "setup_untimed_ms", "recall1000", "loadavg", "cgroup_cpu_max", "backend", "faiss",
+_DROP = ("note", "sample_detail", "per_size", "per_kind", "by_kind", "kinds", "level_ms", "bytes", "expected_queries", "ms_all", "chain_ms_all",
+         "chain_ms_min", "device_batch", "rows_per_s", "policy", "queries_per_pass", "real_tokens", "corpus_hours_on_one_gpu", "what", "slice", "per_rank", "per_batch", "layers", "checksums", "statistic", "stats",
+         "flop_split", "stage_ms_detail", "mrr10_detail", "head_matrices_at", "adaptor_vectors_only_at", "one_shot_note", "setup_untimed_ms", "recall1000", "loadavg", "cgroup_cpu_max", "backend", "faiss",
          "upload_sample", "seconds", "cpu_seconds", "oracle_seconds", "algorithmic_bytes", "flop_executed",
          "flop_per_query_survey_8d_padded", "flop_per_query_executed", "executed_f16_mfma_flop", "algorithmic_bytes_per_search")
-_DROP_ORDER = ("seq2seq_cpu_sample", "chain_c4_trained_codebook", "dense_small_batch", "gemm_roofline", "faiss_search_cli_inclusive", "dense_arm_with_tower", "seq2seq_batch_sweep",
+_DROP_ORDER = ("seq2seq_cpu_sample", "gemm_roofline", "dense_small_batch", "faiss_search_cli_inclusive", "dense_arm_with_tower", "chain_c4_trained_codebook", "seq2seq_batch_sweep",
                "seq2seq_arm_rq_3x256", "index_build", "multi_gpu")      # least important first, should the line still be long
 
 
@@ -677,6 +679,8 @@ def print_line(out):
     except OSError:
         pass
     line = _compact(out)
+    if "mrr10_match" in line and "mrr10_match" in line.get("config", {}):
+        line["mrr10_match"] = "see config.mrr10_match"            # the certificate's summary travels in `config`, its record in the detail file
     for leg in _DROP_ORDER:
         if len(json.dumps(line)) <= LINE_BUDGET:
             break

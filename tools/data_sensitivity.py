@@ -134,16 +134,22 @@ def sweep(device, n_docs, nq, kinds=synth.CORPUS_KINDS, with_rq=True, rq_kinds=(
     out = {
         "what": "DenseIndex.search (top-%d) and rq_encode with a trained codebook at %d rows x %d queries on four corpus "
                 "distributions (tools/synth.py); every result compared bit for bit with the exact path" % (k, n_docs, nq),
-        "dense_queries_per_s": qps, "dense_min": min(qps.values()), "dense_max": max(qps.values()),
+        "kinds": list(per), "dense_min": min(qps.values()), "dense_max": max(qps.values()),
         "dense_worst_vs_iid": round(min(qps.values()) / base, 4),
         "all_lists_identical": all(v["dense"].get("lists_identical_to_exact_f32_path", True) for v in per.values()),
-        "queries_to_second_pass": {k_: v["dense"]["second_pass_queries"] for k_, v in per.items()},
-        "queries_to_exact_fallback": {k_: v["dense"]["exact_fallback_queries"] for k_, v in per.items()},
-        "candidates_per_query": {k_: v["dense"]["filter_candidates_per_query"] for k_, v in per.items()},
+        "second_pass_queries_max": max(v["dense"]["second_pass_queries"] for v in per.values()),
+        "exact_fallback_queries_max": max(v["dense"]["exact_fallback_queries"] for v in per.values()),
+        "by_kind": {"dense_queries_per_s": qps,
+                    "queries_to_second_pass": {k_: v["dense"]["second_pass_queries"] for k_, v in per.items()},
+                    "queries_to_exact_fallback": {k_: v["dense"]["exact_fallback_queries"] for k_, v in per.items()},
+                    "candidates_per_query": {k_: v["dense"]["filter_candidates_per_query"] for k_, v in per.items()}},
         "per_kind": per}
     if with_rq:
         rqm = {k_: {s_: r["ms"] for s_, r in v["rq_trained_codebook"].items()} for k_, v in per.items() if "rq_trained_codebook" in v}
-        out["rq_ms_trained"] = rqm
+        out["by_kind"]["rq_ms_trained"] = rqm
+        for shape in sorted({s_ for v in rqm.values() for s_ in v}):
+            ms = [v[shape] for v in rqm.values() if shape in v]
+            out["rq_%s_trained_ms_min_max" % shape] = [min(ms), max(ms)]
         out["rq_all_codes_identical"] = all(r["codes_identical_to_exact_mode"] for v in per.values()
                                             for r in v.get("rq_trained_codebook", {}).values())
     return out
