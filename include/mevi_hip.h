@@ -196,8 +196,14 @@ int mevi_gemm_nt_split_f32(const void *a_img, const int8_t *a_exp, const void *w
  *     scale comes from the block sums, blocks added in index order (mevi_row_rscale_f32 states the formula; GEMMs on the
  *     latency kernels compute it themselves, the tile stream takes it from `rscale_ws`, filled by one small launch).
  * No pass over the rows exists any more just to normalise them (mevi_rmsnorm_split_f16 read and wrote 4 B per element).
- * Same value up to f32 rounding (the scale is applied after the product instead of before); a row's result has the same
- * bits in any batch and on either kernel family.  n of the stream: multiple of 16, <= 1024 (mevi_gemm_norm_fold_supported).
+ * The product is the same value up to f32 rounding (the scale is applied after the product instead of before) and a row's
+ * result has the same bits in any batch and on either kernel family -- but the IMAGE of the residual stream is coarser than
+ * the one mevi_rmsnorm_split_f16 writes: its exponent comes from the carried bound
+ *     out_bound = x_bound + ||a|| * w_norm_max (x 1.0001),
+ * which is never re-tightened and, after the 24-36 residual adds of a stack, sits tens to hundreds of times above the rows'
+ * real maximum, so the (hi, lo) pair keeps several bits fewer than its 22 in the deep layers.  The goldens hold at 5e-5 either
+ * way; an A/B against the default path compares unequal operand precision.  OFF by default (MEVI_FOLD_NORM=1 turns it on); it
+ * also measured slower at scale.  n of the stream: multiple of 16, <= 1024 (mevi_gemm_norm_fold_supported).
  * ---------------------------------------------------------------------- */
 int mevi_gemm_norm_fold_supported(int64_t n_stream);
 /* x f32 [m, k] -> image + exponents, bound[r] >= max |x_r| (the l2 norm, rounded up), ssq [m, k / 16] */
