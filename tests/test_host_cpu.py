@@ -492,3 +492,96 @@ def test_to_file_whole_matrix_path_writes_pythons_bytes(tmp_path):
     want = "".join(f"what is w{j} é\t\t{','.join(str(x) for x in i[j].tolist())}\t{','.join(str(x) for x in d[j].tolist())}\n"
                    for j in range(n - 3))
     assert out.read_text() == want
+
+
+def test_sentencepiece_t5_tokenizer_equals_the_hf_tokenizer(tmp_path):
+    """io.load_tokenizer serves a T5 SentencePiece directory with SpmT5Tokenizer (no `transformers` import in generate.py /
+    main.py): the ids and masks must be what `AutoTokenizer.from_pretrained(dir)(texts, max_length=L, padding='max_length',
+    truncation=True, return_tensors='pt')` returns -- the call of MEVI/generate.py:85-87, MEVI/main_models.py:445-455 -- on plain,
+    odd and over-long strings; a batch with a special-token spelling is handed to the HF object; MEVI_TOKENIZER=hf pins it."""
+    pytest.importorskip("sentencepiece")
+    from transformers import AutoTokenizer
+
+    from mevi_amd import io as mio
+    from spm_fixture import build_t5_tokenizer_dir
+
+    d = build_t5_tokenizer_dir(str(tmp_path / "t5-ance"))
+    hf = AutoTokenizer.from_pretrained(d)
+    fast = mio.load_tokenizer(d)
+    assert type(fast).__name__ == "SpmT5Tokenizer"
+    rng = np.random.default_rng(0)
+    texts = ["what is the capital of w5", "  leading and   multiple   spaces ", "", "w1", "UPPER case Words w7", "unicode é ü 中文 w3",
+             "tab\there", "q1 " * 60, "x" * 500, "w1?w2!w3,", "new\nline", "<not a special>", "a < b > c"]
+    texts += [" ".join(f"w{rng.integers(0, 300)}" for _ in range(rng.integers(1, 40))) for _ in range(200)]
+    for L in (32, 8, 128):
+        a = hf(texts, max_length=L, padding="max_length", truncation=True, return_tensors="pt")
+        b = mio.encode_batch(fast, texts, L)
+        assert torch.equal(a["input_ids"], b["input_ids"]) and torch.equal(a["attention_mask"], b["attention_mask"]), L
+    special = ["has </s> inside", "plain", "an <extra_id_3> sentinel", "<pad> <unk>"]
+    a = hf(special, max_length=16, padding="max_length", truncation=True, return_tensors="pt")
+    b = mio.encode_batch(fast, special, 16)
+    assert torch.equal(a["input_ids"], b["input_ids"]) and fast._hf is not None
+    os.environ["MEVI_TOKENIZER"] = "hf"
+    try:
+        assert type(mio.load_tokenizer(d)).__name__ != "SpmT5Tokenizer"
+    finally:
+        del os.environ["MEVI_TOKENIZER"]
+
+
+def test_cluster_index_sidecar_and_checkpoint_loader(tmp_path):
+    """evalrun.load_cluster_index: the arrays beside `rqclus*.pkl` reproduce the index built from the pickle (document order inside
+    a cluster included), are ignored when the pickle changed (size / mtime_ns fingerprint) or (M, K) differ, and are rewritten then;
+    io.load_checkpoint reads zip-format, legacy-format and Lightning-style checkpoints (a Namespace beside the tensors)."""
+    import argparse
+    import pickle
+
+    from mevi_amd import evalrun
+    from mevi_amd import io as mio
+
+    rng = np.random.default_rng(1)
+    M, K = 3, 8
+    cluster = {}
+    for doc in rng.permutation(500).tolist():                       # lists in a non-sorted order: the sidecar must keep it
+        cluster.setdefault(tuple(int(x) for x in rng.integers(0, K, M)), []).append(doc)
+    p = str(tmp_path / "rqclus3_3.pkl")
+    with open(p, "wb") as f:
+        pickle.dump(cluster, f)
+    a = evalrun.load_cluster_index(p, M, K)
+    assert os.path.exists(evalrun.cluster_sidecar(p))
+    b = evalrun.load_cluster_index(p, M, K)                         # from the arrays
+    for x, y in ((a.keys, b.keys), (a.offsets, b.offsets), (a.doc_ids, b.doc_ids)):
+        assert np.array_equal(x, y)
+    key = next(iter(cluster))
+    assert b.lookup(key).tolist() == cluster[key]
+    cluster[key] = cluster[key][::-1] + [999]
+    with open(p, "wb") as f:
+        pickle.dump(cluster, f)
+    os.utime(p, ns=(1, 1))                                          # even with an OLDER timestamp: a different fingerprint
+    c = evalrun.load_cluster_index(p, M, K)
+    assert c.lookup(key).tolist() == cluster[key]
+    assert np.array_equal(evalrun.load_cluster_index(p, M, K).doc_ids, c.doc_ids)
+    # checkpoints
+    ck = str(tmp_path / "c.ckpt")
+    w = {"a": torch.randn(7, 5)}
+    torch.save({"state_dict": w, "hyper_parameters": argparse.Namespace(lr=1e-4)}, ck)
+    sd = mio.load_checkpoint(ck)
+    assert torch.equal(sd["state_dict"]["a"], w["a"]) and sd["hyper_parameters"].lr == 1e-4
+    torch.save(w, ck, _use_new_zipfile_serialization=False)
+    assert torch.equal(mio.load_checkpoint(ck)["a"], w["a"])
+
+
+def test_phase_log_lines_and_fast_exit(tmp_path):
+    """mevi_amd.phases: with MEVI_PHASE_LOG every mark appends `script<TAB>phase<TAB>seconds<TAB>since start`; finish() leaves the
+    process at once with flushed streams (and is an ordinary return under MEVI_FAST_EXIT=0)."""
+    import subprocess
+    import sys
+
+    log = str(tmp_path / "phases.log")
+    code = ("import sys; sys.path.insert(0, %r); from mevi_amd import phases; phases.mark('imports'); print('out', flush=False); "
+            "phases.mark('work'); phases.finish(); print('never')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MEVI_PHASE_LOG=log))
+    assert r.returncode == 0 and r.stdout == "out\n", (r.stdout, r.stderr)
+    lines = [l.split("\t") for l in open(log).read().splitlines()]
+    assert [l[1] for l in lines] == ["imports", "work", "done"] and all(float(l[2]) >= 0 and float(l[3]) > 0 for l in lines)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MEVI_FAST_EXIT="0"))
+    assert r.returncode == 0 and r.stdout == "out\nnever\n"
