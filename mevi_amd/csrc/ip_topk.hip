@@ -682,6 +682,52 @@ __global__ __launch_bounds__(256) void compact_wave_kernel(unsigned long long *_
   }
 }
 
+// ---- sampled threshold (round 6) ------------------------------------------------------------------------------------------------
+// The chunk schedule raises tau to the k-th best score SEEN SO FAR after every launch, so a pass appends ~k (g - 1) keys per
+// query and launch -- 17 k over eight launches -- and the early launches are bound by those appends, not by their rows.  With
+// exchangeable row order (the premise of the schedule's growth already) the rows seen so far are a SAMPLE of the corpus: the
+// rank-r best score of `seen` rows estimates the rank r nd / seen score of all nd.  So once enough rows are in (r >= 96 ranks:
+// +-10 %), rank_tau_kernel sets tau to the score of rank r = c k seen / nd (c ~ 3) and ONE launch takes all remaining rows,
+// appending ~c k keys per query instead of ~k (g - 1) per launch of the rest of the schedule.  Exactness does not rest on the
+// estimate: the launch drops only rows with score <= tau_s, so the list is the exact top-k iff the k-th best score afterwards is
+// STRICTLY above tau_s (then at least k rows beat tau_s and every row that could belong was kept) -- sample_check_kernel flags
+// every other query (and compact_* flags overflow as always); flagged queries take the guaranteed path like any overflow.
+template <int KPL>
+__global__ __launch_bounds__(256) void rank_tau_kernel(const unsigned long long *__restrict__ buf, int nq, int S, int k, int rank,
+                                                      float *__restrict__ tau, float *__restrict__ tau_s) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (q >= nq) return;
+  const unsigned long long *row = buf + (size_t)q * S;
+  unsigned long long key[KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) key[j] = (64 * j + lane < k) ? row[64 * j + lane] : 0ull;
+  const int nj = (k + 63) >> 6;
+  unsigned long long T = 0ull;     // the largest T with at least `rank` keys >= T = the rank-th largest key
+  for (int b = 63; b >= 0; --b) {
+    const unsigned long long cand = T | (1ull << b);
+    int cnt = 0;
+#pragma unroll
+    for (int jb = 0; jb < KPL / 8; ++jb)
+      if (8 * jb < nj) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) cnt += __popcll(__ballot(key[8 * jb + jj] >= cand));
+      }
+    if (cnt >= rank) T = cand;
+  }
+  if (lane == 0) {
+    const float t = (T != 0ull) ? key_score(T) : -INFINITY;   // fewer than `rank` rows so far: no threshold, nothing is dropped
+    tau_s[q] = t;
+    tau[q] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void sample_check_kernel(const float *__restrict__ tau, const float *__restrict__ tau_s,
+                                                          unsigned int *__restrict__ failed, int nq) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q < nq && !(tau[q] > tau_s[q]) && tau_s[q] > -INFINITY) failed[q] = 1u;   // (tau_s = -inf: nothing was dropped)
+}
+
 // Sort every query's list (row[0, k)) descending: the last step of a pass whose lists are read as ranked output.
 __global__ __launch_bounds__(256) void sort_lists_kernel(unsigned long long *__restrict__ buf, int S, int k) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
@@ -1426,10 +1472,11 @@ struct SearchState {
   unsigned int *count;      // [nq]
   float *tau;               // [nq]
   unsigned int *failed;     // [nq]
+  float *tau_s;             // [nq]  the sampled threshold of the pass's last launch (run_pass), kept for its check
 };
 
 static size_t state_bytes(int64_t nq, const TopkGeom &g) {
-  return align_up((size_t)nq * g.S * 8, 256) + 3 * align_up((size_t)nq * 4, 256);
+  return align_up((size_t)nq * g.S * 8, 256) + 4 * align_up((size_t)nq * 4, 256);
 }
 
 static SearchState carve_state(char *&p, int64_t nq, const TopkGeom &g) {
@@ -1441,6 +1488,8 @@ static SearchState carve_state(char *&p, int64_t nq, const TopkGeom &g) {
   st.tau = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * 4, 256);
   st.failed = reinterpret_cast<unsigned int *>(p);
+  p += align_up((size_t)nq * 4, 256);
+  st.tau_s = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * 4, 256);
   return st;
 }
@@ -1562,6 +1611,28 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   // leaving the rest to whatever else is in flight (a second search's re-scoring on another stream)
   static const int cu_cap = [] { const char *e = getenv("MEVI_IP_FILTER_CUS"); return e ? atoi(e) : 0; }();
   if (cu_cap >= 8 && cu_cap < n_cu) n_cu = cu_cap / 8 * 8;
+  // sampled threshold for the pass's LAST launch (rank_tau_kernel above).  r ranks give the estimate +-1/sqrt(r); the launch is
+  // sized for c k expected keys per query with (1 - 1/c) sqrt(r) >= 4.5 deviations between that and the k it needs, and
+  // c k (1 + 8 / sqrt(r)) inside the candidate area.  MEVI_IP_SAMPLE_TAU=0: the geometric schedule to the end (A/B; same lists).
+  // Used for searches of up to 1024 queries (MEVI_IP_SAMPLE_TAU=1: any size): measured on one box (profiles/r06_sampled_threshold.txt)
+  // 64 / 128 / 255 queries at top-1000 3.54 / 3.56 / 4.46 -> 3.23 / 3.32 / 4.24 ms; at 6980 queries the launches it merges are
+  // matrix-bound already (-0.8 ms of 88) and on a corpus whose clusters sit in runs of adjacent rows the estimate's variance is
+  // that of ~r / 8 ranks: ~10 of 6980 queries are flagged, and their second pass (+2.3 ms) costs more than the merge returns.
+  static const int sample_mode = [] { const char *e = getenv("MEVI_IP_SAMPLE_TAU"); return e ? atoi(e) : -1; }();
+  const bool sample_on = sample_mode == 1 || (sample_mode != 0 && nq <= 1024);
+  double s_c = 0.0;
+  int64_t n_sample = 0;
+  bool sampled = false;
+  if (sample_on && !guaranteed && g.k <= 4096 && g.k >= 32) {
+    const double r = g.k / 2 < 16 ? 16.0 : (g.k / 2 > 96 ? 96.0 : (double)(g.k / 2));
+    double c = r >= 96.0 ? 3.0 : 8.0;
+    const double c_fit = (double)g.cap / ((double)g.k * (1.0 + 8.0 / sqrt(r)));
+    if (c_fit < c) c = c_fit;
+    if (c >= 1.5 && (1.0 - 1.0 / c) * sqrt(r) >= 4.5) {
+      s_c = c;
+      n_sample = (int64_t)ceil(r * (double)nd / (c * (double)g.k));
+    }
+  }
   int64_t seen = 0, launches = 0;
   while (seen < nd) {
     int64_t chunk = cap_docs;
@@ -1571,6 +1642,18 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       if (grown > chunk) chunk = grown;
     }
     if (chunk > nd - seen) chunk = nd - seen;
+    double expect_per_q = seen >= g.k ? (double)g.k * (double)chunk / (double)seen : (double)chunk;
+    if (s_c > 0.0 && !sampled && seen >= n_sample && seen >= g.k && chunk < nd - seen) {
+      // enough rows are in and the schedule would need more than one further launch: estimate, then everything that is left
+      const int64_t rank = (int64_t)ceil(s_c * (double)g.k * (double)seen / (double)nd);
+      if (rank >= 16 && rank <= g.k) {
+        hipLaunchKernelGGL(rank_tau_kernel<64>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, st.buf, (int)nq, g.S, g.k, (int)rank,
+                           st.tau, st.tau_s);
+        sampled = true;
+        chunk = nd - seen;
+        expect_per_q = s_c * (double)g.k;
+      }
+    }
     const int64_t n_dtiles = (chunk + 2 * BM - 1) / (2 * BM);  // doc-tile pairs (ping-pong kernel)
     const int64_t nwg = n_dtiles * n_qtiles;
     if (nwg > 0x7fffffffLL) {
@@ -1594,7 +1677,7 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       // wave tile; flush every T tiles with T r <= ~56 records (a stash holds 128)
       int flush_mask = H16_FLUSH_EVERY - 1;
       {
-        const double per_q = seen >= g.k ? (double)g.k * (double)chunk / (double)seen : (double)chunk;
+        const double per_q = expect_per_q;
         const double r = per_q / (double)chunk * 64.0 * 16.0 * (double)ni16;     // records per wave tile (64 rows x 16 NI queries)
         int T = H16_FLUSH_EVERY;
         while (T > 1 && T * r > 56.0) T >>= 1;
@@ -1628,6 +1711,8 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       hipLaunchKernelGGL(compact_kernel, dim3((unsigned)(nq < 8 * n_cu ? nq : 8 * n_cu)), dim3(256), compact_lds, stream,
                          st.buf, st.count, st.tau, st.failed, nq_i, g.S, g.k, g.cap);
     }
+    if (sampled && seen + chunk >= nd)   // the sampled launch was the last: did k rows beat its threshold?
+      hipLaunchKernelGGL(sample_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, st.tau, st.tau_s, st.failed, (int)nq);
     profile_mark(stream);
     g_stats.filter_flops += 2.0 * (double)nq * (double)chunk * (double)dim;
     if (g_profile) g_chunk_rows.push_back((long long)chunk);

@@ -552,3 +552,72 @@ def test_candidate_counters_of_profiling_level_two(cuda):
     kp = 100 + 48                                            # h1_kprime: every query keeps at least K' keys of the first launch
     assert st.n_filter_candidates >= 40 * kp and st.max_launch_candidates >= kp and st.n_list_overflows == 0, \
         (st.n_filter_candidates, st.max_launch_candidates, st.n_list_overflows)
+
+
+def _child_search(q, d, k, env, tmp):
+    """One indexed search in a child process (switches of the library are read once per process): ids, scores, filter launches."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys, ctypes, numpy as np, torch; sys.path.insert(0, %r); from mevi_amd import dense, hip; "
+            "q = np.load(sys.argv[1]); d = np.load(sys.argv[2]); dev = torch.device('cuda:0'); "
+            "s, i = dense.DenseIndex(torch.from_numpy(d).to(dev)).search(torch.from_numpy(q).to(dev), int(sys.argv[3])); torch.cuda.synchronize(); "
+            "st = hip.IpTopkStats(); hip.lib().mevi_ip_topk_get_stats(st); "
+            "np.save(sys.argv[4], i.cpu().numpy()); np.save(sys.argv[5], s.cpu().numpy()); print(int(st.n_chunks), int(st.n_failed_queries))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code, tmp + "/q.npy", tmp + "/d.npy", str(k), tmp + "/i.npy", tmp + "/s.npy"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    chunks, failed = (int(x) for x in r.stdout.split()[-2:])
+    return np.load(tmp + "/i.npy"), np.load(tmp + "/s.npy"), chunks, failed
+
+
+@pytest.mark.parametrize("nq,nd,dim,k", [(40, 2_000_000, 64, 1000), (130, 1_500_000, 64, 1000), (300, 3_000_000, 64, 100)])
+def test_sampled_threshold_for_the_last_launch(cuda, nq, nd, dim, k, tmp_path):
+    """Round 6: once enough rows are in, the pass estimates its threshold from the rank-r score of the rows seen (a sample under
+    exchangeable row order) and takes ALL remaining rows in one launch (csrc/ip_topk.hip: rank_tau_kernel, sample_check_kernel).
+    Fewer launches, the oracle's lists bit for bit, no query flagged on exchangeable data -- and the same lists as the geometric
+    schedule to the end (MEVI_IP_SAMPLE_TAU=0)."""
+    rng = np.random.default_rng(nq + nd + k)
+    q = rng.standard_normal((nq, dim), dtype=np.float32)
+    d = rng.standard_normal((nd, dim), dtype=np.float32)
+    es, ei = odense.ip_topk_exact(q, d, k)
+    tmp = str(tmp_path)
+    np.save(tmp + "/q.npy", q), np.save(tmp + "/d.npy", d)
+    i1, s1, chunks1, failed1 = _child_search(q, d, k, {}, tmp)
+    i0, s0, chunks0, failed0 = _child_search(q, d, k, {"MEVI_IP_SAMPLE_TAU": "0"}, tmp)
+    for i_, s_ in ((i1, s1), (i0, s0)):
+        np.testing.assert_array_equal(i_, ei)
+        np.testing.assert_array_equal(s_.view(np.uint32), es.view(np.uint32))
+    assert failed1 == 0 and failed0 == 0
+    assert chunks1 < chunks0, (chunks1, chunks0)
+    # and through the exact-f32 path (the same schedule on exact keys)
+    s, i = _run(q[:8], d, k, cuda)
+    np.testing.assert_array_equal(i, ei[:8])
+    np.testing.assert_array_equal(s.view(np.uint32), es[:8].view(np.uint32))
+
+
+@pytest.mark.parametrize("order", ["best rows first", "best rows last", "ties at the threshold"])
+def test_sampled_threshold_on_row_orders_that_break_its_premise(cuda, order):
+    """The estimate is only a guess; exactness rests on sample_check_kernel (k rows must beat the threshold) and on the overflow
+    flag.  Rows sorted so that the sample holds the BEST rows (threshold far too high: too few rows beat it -> flagged), the WORST
+    (too low: the last launch floods the candidate area -> flagged), and a corpus of a few distinct rows (scores tie AT the
+    threshold: rows equal to it are dropped, the check must notice): the oracle's lists every time, through the guaranteed path
+    where needed."""
+    rng = np.random.default_rng(17)
+    nq, nd, dim, k = 40, 1_500_000, 64, 1000                  # (33 .. 1024 queries: the searches that use the sampled threshold)
+    q = rng.standard_normal((nq, dim), dtype=np.float32)
+    d = rng.standard_normal((nd, dim), dtype=np.float32)
+    if order == "ties at the threshold":
+        d = d[:40][rng.integers(0, 40, nd)].copy()             # 40 distinct rows: every score value is shared by ~37 k rows
+    else:
+        sc = d @ q[0]
+        d = d[np.argsort(-sc if order == "best rows first" else sc, kind="stable")].copy()
+    es, ei = odense.ip_topk_exact(q, d, k)
+    for run in (_run_indexed, _run):
+        s, i = run(q, d, k, cuda)
+        st = _stats()
+        np.testing.assert_array_equal(i, ei)
+        np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
+        if order != "ties at the threshold" and run is _run_indexed:    # query 0 at least was flagged: second pass / guaranteed path
+            assert st.n_failed_queries + st.n_second_pass_queries >= 1, order    # (the exact path's 3096-slot area at k = 1000 is too
+                                                                                 # small for the sampled launch: geometric schedule)
