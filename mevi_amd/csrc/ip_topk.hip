@@ -63,6 +63,9 @@ static inline TopkGeom make_geom(int k, int64_t nq = (int64_t)1 << 40) {
   // first chunk (as many rows as slots, every row a candidate) and the compaction of large areas cost more than they save
   if (nq <= 32) {
     S = 2 * next_pow2(k) > 4096 ? 2 * next_pow2(k) : 4096;
+    // round 6: room for the sampled last launch (run_pass: ~3 k expected keys + 8 deviations need a candidate area of >= 2.8 k):
+    // one query at top-1000 2.87 -> 2.74 ms, 32 queries 3.13 -> 2.94 (profiles/r06_sampled_threshold.txt)
+    if ((double)(S - k) < 2.8 * (double)k) S *= 2;
     if (S > MAX_SORT) S = MAX_SORT;
     if (const char *e = getenv("MEVI_IP_TOPK_SMALL_SLOTS")) {  // tuning hook
       const int v = atoi(e);

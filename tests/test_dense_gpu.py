@@ -571,7 +571,8 @@ def _child_search(q, d, k, env, tmp):
     return np.load(tmp + "/i.npy"), np.load(tmp + "/s.npy"), chunks, failed
 
 
-@pytest.mark.parametrize("nq,nd,dim,k", [(40, 2_000_000, 64, 1000), (130, 1_500_000, 64, 1000), (300, 3_000_000, 64, 100)])
+@pytest.mark.parametrize("nq,nd,dim,k", [(40, 2_000_000, 64, 1000), (130, 1_500_000, 64, 1000), (300, 3_000_000, 64, 100),
+                                          (5, 2_000_000, 768, 1000)])       # (<= 32 queries: the streaming kernel, 8192 slots)
 def test_sampled_threshold_for_the_last_launch(cuda, nq, nd, dim, k, tmp_path):
     """Round 6: once enough rows are in, the pass estimates its threshold from the rank-r score of the rows seen (a sample under
     exchangeable row order) and takes ALL remaining rows in one launch (csrc/ip_topk.hip: rank_tau_kernel, sample_check_kernel).
