@@ -253,7 +253,8 @@ def dense_small_batch(device, index, query, n_docs):
                     "scripts ask, and top-100), mean of 10 calls, inputs and outputs on the device" % TOPK,
             "dtype": "f16 pre-filter (selection) + exact f32 chains (results)",
             "kernel": "ip_filter_h1_small_kernel for batch <= 32 (stationary query tile, every wave streaming its own corpus rows), "
-                      "ip_filter_h16_kernel<2> / <4> (query tiles of 64 / 128) up to 128 queries, the 256-query tile above",
+                      "ip_filter_h16_kernel<2> / <4> (query tiles of 64 / 128) up to 128 queries, the 256-query tile above; the last launch of "
+                      "a pass takes all remaining rows under a threshold estimated from the rows seen (rank_tau_kernel; exact by sample_check_kernel)",
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
                          "algorithmic_bytes_per_search": image_bytes,
                          "note": "bytes = the corpus' f16 image (N x 768 x 2), read once per search; the f32 rows of the re-scored "
