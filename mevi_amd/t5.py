@@ -197,8 +197,12 @@ def packed_offsets(attention_mask):
 # GEMMs of the reference; either way the tower stays within the goldens' 5e-5 (tests/test_t5_gpu.py)
 WOV_FUSE = os.environ.get("MEVI_TOWER_WOV", "1") != "0"
 
-# batches up to this many rows may run as one replayed HIP graph (graph=True); larger ones always run eagerly, packed
-GRAPH_MAX_ROWS = 8
+# batches up to this many rows may run as one replayed HIP graph (graph=True); larger ones always run eagerly, packed.
+# A graph needs fixed shapes, i.e. the PADDED layout (32 tokens per query instead of the real ~11): it trades the host's ~10 us per
+# launch for 3x the encoder rows.  tools/probe_graph_batches.py (profiles/r06_latency.txt), eager -> graph, ms per call:
+# tower 8 queries 2.73 -> 1.74, 16: 2.69 -> 2.33, 32: 3.03 -> 2.77, 64: 3.55 -> 4.12; NCI generate 8: 6.11 -> 3.80, 16: 6.18 -> 4.76,
+# 32: 6.50 -> 5.68, 64: 7.95 -> 8.58 -- same bits either way.  The crossover is between 32 and 64 queries.
+GRAPH_MAX_ROWS = 32
 
 
 class GraphCache:
