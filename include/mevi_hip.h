@@ -68,8 +68,13 @@ int mevi_ip_topk_f32(const float *q, int64_t nq, const float *docs, int64_t nd,
  * MEVI/faiss_search.py:19; mu = column mean of the shard); a search then selects k + margin candidates
  * per query with ONE f16 MFMA per product (16x the f32 MFMA rate), re-scores them with the exact f32
  * fmaf chain, and PROVES per query that no other row can enter the top-k:
- *   |approx + q.mu - exact| <= ||q|| * (c1 * max||d - mu|| + c2 * max||d||),
- *   c1 = 2^-10 + 2^-22 + 4 dim 2^-24 (f16 roundings + accumulation), c2 = dim 2^-24 (the exact chain);
+ *   |approx + q.mu - exact| <= ||dq|| max||d - mu|| + ||q16|| max||dd|| + c_acc ||q16|| (max||d - mu|| + max||dd||) + c2 ||q|| max||d||,
+ *   dq = q - its f16 image / S_q and dd = (d - mu) - the row's f16 image / S (both MEASURED while the images are written:
+ *   per query, and the maximum over the shard kept in the index), c_acc = 4 dim 2^-24 (f32 accumulation of the exact f16
+ *   products), c2 = dim 2^-24 (the exact chain) -- Cauchy-Schwarz on what the roundings did, about half the worst case
+ *   (2^-10 + 2^-22) ||q|| ||d - mu|| of rounds 1-5 (round 6; DESIGN 4.1b');
+ * survivors that provably cannot reach the top-k are not re-scored; searches of up to 1024 queries take the last launch of a
+ * pass under a threshold estimated from the rows already seen, checked exactly afterwards (DESIGN 4.1b');
  * unproven queries are retried once with twice as many survivors (when they are at most a quarter of the
  * batch), what is still unproven is re-run through the exact f32 path.  `docs` (f32) is still needed for the
  * exact re-scoring.
