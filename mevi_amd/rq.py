@@ -109,7 +109,11 @@ def _kmeans_pp(xs, K, gen):
     centers[0] = xs[first]
     d2 = ((xs - centers[0]) ** 2).sum(1)
     for c in range(1, K):
-        probs = (d2 / d2.sum().clamp_min(1e-30)).clamp_min(0)
+        # (every remaining point ON a chosen centre -- fewer distinct points than K, or a residual level that is already zero:
+        # d2 sums to 0 and torch.multinomial aborts the device on an all-zero distribution -- then any point will do: uniform)
+        tot = d2.sum()
+        probs = torch.where(tot > 0, (d2 / tot.clamp_min(1e-30)).clamp_min(0), torch.full_like(d2, 1.0 / m))
+        probs = torch.nan_to_num(probs, nan=1.0 / m, posinf=1.0 / m)
         cand = torch.multinomial(probs, trials, replacement=True, generator=gen)
         dc = torch.cdist(xs[cand], xs) ** 2                    # [trials, m]
         pot = torch.minimum(dc, d2[None]).sum(1)

@@ -272,3 +272,23 @@ def test_trained_codebook_on_realistic_corpora_equals_oracle(cuda, kind, M, K):
     assert st["path"] == "fast"
     assert np.array_equal(exact, want)
     assert np.array_equal(fast, want), (st, int((fast != want).any(1).sum()))
+
+
+def test_codebook_training_on_degenerate_residuals(cuda):
+    """Found by tools/stress_rq.py: with fewer distinct points than K x levels the residual of a later level is exactly zero,
+    the k-means++ seeding's distance distribution sums to 0 and `torch.multinomial` aborted the device.  Training must go through
+    (uniform seeding then), and the encode against such a codebook -- duplicated / zero centroids, every distance tying -- must
+    still return the oracle's codes (lowest index wins)."""
+    rng = np.random.default_rng(12)
+    base = rng.standard_normal((10, 96)).astype(np.float32)
+    x = torch.from_numpy(base[rng.integers(0, 10, 322)]).to(cuda)            # 10 distinct points, 322 rows
+    book, codes = rq.train_rq_codebook(x, 4, 16, seed=1, n_init=1, max_iter=5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(book).all()
+    fast, exact, st = _both(x.cpu().numpy(), book.cpu().numpy(), cuda)
+    want = orq.rq_encode(x.cpu().numpy(), book.cpu().numpy())
+    assert np.array_equal(exact, want) and np.array_equal(fast, want)
+    x2, _ = __import__("torch").randn((322, 96), device=cuda).sort(0)
+    book2, _ = rq.train_rq_codebook(x2.contiguous(), 8, 64, seed=1, n_init=1, max_iter=5)   # 8 x 64 centroids for 322 points: zero residuals
+    torch.cuda.synchronize()
+    assert torch.isfinite(book2).all()

@@ -185,7 +185,7 @@ def corpus(kind, dev, n_docs, dim=d, block=CORPUS_BLOCK, n_clusters=N_CLUSTERS):
         blk = corpus_block(spec, b, n_docs, block)
         out[b * block:b * block + blk.shape[0]] = blk
     info = {"kind": kind, "rows": n_docs, "dim": dim}
-    if kind == "duplicates":
+    if kind == "duplicates" and n_docs >= 8:
         g = torch.Generator(device=dev).manual_seed(4242)
         n_dup = max(1, n_docs // 100)
         perm = torch.randperm(n_docs, device=dev, generator=g)
