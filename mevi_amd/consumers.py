@@ -166,6 +166,8 @@ def cluster_ranks(codes_t, docs_t, seg_t, beam_t, n_clusters):
 
     nq, R, M = beam_t.shape
     out = torch.empty(docs_t.numel(), dtype=torch.int32, device=docs_t.device)
+    if docs_t.numel() == 0:                   # every dense list empty: nothing to rank (and no device pointers to hand over)
+        return out
     bad = torch.empty(1, dtype=torch.int64, device=docs_t.device)
     st = hip.lib().mevi_cluster_ranks_i32(hip.ptr(codes_t), codes_t.shape[0], M, hip.ptr(docs_t), hip.ptr(seg_t), nq,
                                           hip.ptr(beam_t), R, int(n_clusters), hip.ptr(out), hip.ptr(bad), hip.stream_ptr())
@@ -199,10 +201,14 @@ def ensemble_rank(seg_d, docs_d, sc_d, cr_d, fine, n_clusters, alpha, beta, gamm
     out_n = torch.empty(nq, dtype=torch.int32, device=seg_d.device)
     err = torch.empty(1, dtype=torch.int32, device=seg_d.device)
     fr, sf, df, scf = fine if fine is not None else (None, None, None, None)
+    # an EMPTY tensor has no device pointer, and the C ABI refuses null list pointers (it cannot see that every list is empty):
+    # hand it one unused element instead (found by tools/stress_consumers.py: a file whose dense -- or fine -- lists are all empty)
+    some = lambda x: x if x is None or x.numel() else torch.zeros(1, dtype=x.dtype, device=x.device)      # noqa: E731
+    docs_d, sc_d, cr_d, out_docs_arg, df, scf = some(docs_d), some(sc_d), some(cr_d), some(out_docs), some(df), some(scf)
     p = lambda x: None if x is None else hip.ptr(x)          # noqa: E731
     st = hip.lib().mevi_ensemble_rank_f64(hip.ptr(seg_d), hip.ptr(docs_d), hip.ptr(sc_d), hip.ptr(cr_d), p(fr), p(sf), p(df),
                                           p(scf), nq, int(max_entries), int(n_clusters), hip.ptr(term), float(punish),
-                                          hip.ptr(out_seg), hip.ptr(out_docs), hip.ptr(out_n), hip.ptr(err), hip.stream_ptr())
+                                          hip.ptr(out_seg), hip.ptr(out_docs_arg), hip.ptr(out_n), hip.ptr(err), hip.stream_ptr())
     hip.check(st, "mevi_ensemble_rank_f64")
     if int(err.item()) != 0:
         return None
@@ -219,6 +225,8 @@ def first_hits(lists_t, seg_t, list_n_t, pair_row, pair_doc):
     out = torch.empty(n, dtype=torch.int32, device=seg_t.device)
     if n:
         pr, pd = _t(np.asarray(pair_row, np.int64), torch.int64), _t(np.asarray(pair_doc, np.int64), torch.int64)
+        if lists_t.numel() == 0:              # every list empty: one unused element stands in for the (null) list pointer
+            lists_t = torch.zeros(1, dtype=lists_t.dtype, device=lists_t.device)
         st = hip.lib().mevi_first_hits_i64(hip.ptr(lists_t), hip.ptr(seg_t), None if list_n_t is None else hip.ptr(list_n_t),
                                            hip.ptr(pr), hip.ptr(pd), n, hip.ptr(out), hip.stream_ptr())
         hip.check(st, "mevi_first_hits_i64")

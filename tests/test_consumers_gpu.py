@@ -241,3 +241,24 @@ def test_inputs_the_device_path_declines_fall_back_to_the_dict_path(cuda, tmp_pa
     assert outs["host"][0] == 0 and outs["auto"][:2] == outs["host"][:2], outs["auto"][2]
     assert outs["device"][0] != 0 and "declined" in outs["device"][2]
 
+
+
+@pytest.mark.parametrize("with_fine", [True, False])
+def test_files_whose_lists_are_all_empty(cuda, with_fine):
+    """Found by tools/stress_consumers.py: when every dense (or fine) list of a file is empty the flat arrays have no device
+    pointer and the C ABI refused the call ("null pointer").  The ensemble of such a file is what the dict loop gives: the fine
+    list cut to the dense list's length, i.e. nothing."""
+    qs = ["q a", "q b"]
+    codes = np.zeros((10, 2), np.int32)
+    dense_p, dense_s = {q: [] for q in qs}, {q: [] for q in qs}
+    fine_p, fine_s = {q: [] for q in qs}, {q: [] for q in qs}
+    beams = {q: [[0, 0], [1, 1]] for q in qs}
+    cranks, n_clusters = metrics.cluster_ranks(dense_p, beams, metrics.ArrayMapping(codes))
+    inp = _inputs(codes, dense_p, dense_s, fine_p, fine_s, beams, with_fine)
+    cr = inp.ranks()
+    assert cr.numel() == 0
+    out_docs, out_n = inp.ensemble(cr, 0.6, 0.03, 0.02)
+    assert out_n.cpu().tolist() == [0, 0]
+    for q in qs:
+        assert _dict_loop(dense_p[q], dense_s[q], cranks[q], fine_p[q] if with_fine else None, fine_s[q] if with_fine else None,
+                          n_clusters, 0.6, 0.03, 0.02) == []
