@@ -207,6 +207,23 @@ class NqAnswers:
         return int(hit[0]) if len(hit) else None
 
 
+def _corpus_width_hint(a):
+    """Row width of `--embedding_path` when it can be known before the tower is loaded: the T5-ANCE directory's config.json
+    (`d_model`); None for the BERT-family towers and for anything unreadable."""
+    import json
+
+    mode = os.environ.get("MEVI_OVERLAP_UPLOAD", "1")          # "0": never, "always": also for small files (tests)
+    if (getattr(a, "document_encoder", None) or "ance") != "ance" or mode == "0":
+        return None
+    try:
+        with open(os.path.join(a.ckpt_dir, "t5-ance", "config.json")) as f:
+            d = int(json.load(f)["d_model"])
+        size = os.path.getsize(a.embedding_path)
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+    return d if d > 0 and (size >= (256 << 20) or mode == "always") and size % (4 * d) == 0 else None      # small files: nothing to overlap
+
+
 def cluster_sidecar(pq_cluster_path):
     return pq_cluster_path + ".index.npz"
 
@@ -266,6 +283,10 @@ class EvalRun:
         a = args
         self.M, self.K, self.R = a.subvector_num, 2 ** a.subvector_bits, a.num_return_sequences
         tower_override, ckpt_codebook = {}, None
+        # The 27 GB corpus upload (file reads + PCIe: ~0.8 s, 8 reader threads) and the checkpoint loads / model build below
+        # (one Python thread: ~0.8 s) need different resources: the upload starts NOW on a background thread and is joined
+        # where `self.emb` is first needed.  Only when the row width is known without loading the tower (T5-ANCE: config.json).
+        emb_job = self._start_corpus_upload(a)
         if getattr(a, "infer_ckpt", None):        # whole-model checkpoint (MEVI/main.py:203-230) takes precedence
             nci_w, tower_override, ckpt_codebook = split_whole_checkpoint(
                 _state_dict(a.infer_ckpt), bool(getattr(a, "not_load_document_encoder", 0)))
@@ -321,9 +342,18 @@ class EvalRun:
         # corpus embeddings resident in HBM (the reference keeps a CPU memmap and copies per cluster)
         d_model = self.tower.dim     # the corpus embeddings and the RQ codebook live in the tower's output space
         n_docs = os.path.getsize(a.embedding_path) // (4 * d_model)
-        emb = np.memmap(a.embedding_path, dtype=np.float32, mode="r", shape=(n_docs, d_model))
-        self.emb = upload_rows(emb, self.dev)
-        mark("corpus embeddings file -> HBM")
+        if emb_job is not None and emb_job[1] == d_model:
+            emb_job[0].join()
+            if "error" in emb_job[2]:
+                raise emb_job[2]["error"]
+            self.emb = emb_job[2]["emb"]
+        else:
+            if emb_job is not None:               # the tower's width is not what its config.json said: upload again, the right shape
+                emb_job[0].join()
+                emb_job[2].clear()
+            emb = np.memmap(a.embedding_path, dtype=np.float32, mode="r", shape=(n_docs, d_model))
+            self.emb = upload_rows(emb, self.dev)
+        mark("corpus embeddings file -> HBM (rest after the overlap with the model loads)" if emb_job is not None else "corpus embeddings file -> HBM")
         # RQ codebook + cluster index (pickles if present, else encode on the GPU and write them)
         self.pq = ProductQuantization("rq", self.M, a.subvector_bits, "l2", d_model, device=self.dev)
         if ckpt_codebook is not None:             # --infer_ckpt carries pq.codebook: pq.initialize is skipped (main_models.py:4252)
@@ -639,6 +669,31 @@ class EvalRun:
                 raise SystemExit(0)                     # the reference exit()s here, logs unmerged
             self.timing_step_for_infer += 1
         return results
+
+    def _start_corpus_upload(self, a):
+        """(thread, width, result dict) of a background `upload_rows` of the corpus file, or None (see __init__)."""
+        import threading
+
+        d = _corpus_width_hint(a)
+        if d is None:
+            return None
+        n_docs = os.path.getsize(a.embedding_path) // (4 * d)
+        res = {}
+        dev = self.dev
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                emb = np.memmap(a.embedding_path, dtype=np.float32, mode="r", shape=(n_docs, d))
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):       # its own stream: the model build's kernels do not queue behind 64 MiB copies
+                    res["emb"] = upload_rows(emb, dev)
+                    torch.cuda.current_stream().synchronize()
+            except BaseException as e:      # re-raised by the joining thread
+                res["error"] = e
+
+        th = threading.Thread(target=work, name="mevi-corpus-upload", daemon=True)
+        th.start()
+        return th, d, res
 
     def run(self, df):
         a = self.args

@@ -1037,3 +1037,24 @@ def test_faiss_search_py_under_torchrun_with_two_ranks(cuda, mini, tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-1500:]
     assert open(tmp_path / "one.txt", "rb").read() == open(tmp_path / "two.txt", "rb").read()
+
+
+def test_corpus_upload_overlapped_with_the_model_loads(cuda, mini, monkeypatch):
+    """Round 6: EvalRun starts the corpus upload on a background thread (its own stream) before it loads the checkpoints and
+    joins it where the embeddings are first needed (files >= 256 MB; MEVI_OVERLAP_UPLOAD=always forces it here).  The resident
+    matrix must be the file, and a run must log what the serial start-up logs."""
+    from mevi_amd.evalrun import EvalRun, _corpus_width_hint, load_queries
+
+    a = mini["args"]
+    monkeypatch.setenv("MEVI_OVERLAP_UPLOAD", "0")
+    assert _corpus_width_hint(a) is None
+    serial = EvalRun(a, tokenizer=FakeTokenizer(512), device=cuda)
+    want = serial.run(load_queries(a.data_dir))
+    monkeypatch.setenv("MEVI_OVERLAP_UPLOAD", "always")
+    assert _corpus_width_hint(a) == serial.tower.dim
+    over = EvalRun(a, tokenizer=FakeTokenizer(512), device=cuda)
+    assert torch.equal(over.emb, serial.emb)
+    emb_file = np.fromfile(a.embedding_path, dtype=np.float32).reshape(-1, serial.tower.dim)
+    assert np.array_equal(over.emb.cpu().numpy(), emb_file)
+    got = over.run(load_queries(a.data_dir))
+    assert got["recall"] == want["recall"] and got["ndoc"] == want["ndoc"]
