@@ -23,7 +23,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda", 0)
-t0, cases, swaps, beams_total, worst_sc, worst_tw = time.time(), 0, 0, 0, 0.0, 0.0
+t0, cases, swaps, beams_total, worst_sc, worst_tw, passages = time.time(), 0, 0, 0, 0.0, 0.0, 0
 while time.time() - t0 < budget:
     heads = int(rng.integers(1, 7))
     d = int(rng.choice([64, 128, 256, 384]))
@@ -77,9 +77,28 @@ while time.time() - t0 < budget:
     if tw > 2e-4:
         print("BAD tower", tag, tw)
         sys.exit(1)
+    if rng.random() < 0.4:      # the passage side of the tower: 128-token sequences (other attention kernels), ragged lengths 1..128
+        Bp, Sp = int(rng.integers(1, 9)), 128
+        pid = np.zeros((Bp, Sp), np.int64)
+        pm = np.zeros((Bp, Sp), np.int64)
+        for i in range(Bp):
+            L = int(rng.choice([1, 33, 128, int(np.clip(rng.normal(70, 30), 2, 128))]))
+            pid[i, :L - 1] = rng.integers(3, 1000, size=L - 1)
+            pid[i, L - 1] = 1
+            pm[i, :L] = 1
+        pid, pm = torch.from_numpy(pid), torch.from_numpy(pm)
+        with torch.no_grad():
+            opr = ot5.tower_encode(W, dict(cfg), pid, pm)
+        pr = tower.encode_passage({"input_ids": pid, "attention_mask": pm}).cpu()
+        tp = float((pr - opr).abs().max() / opr.abs().max())
+        worst_tw = max(worst_tw, tp)
+        passages += Bp
+        if tp > 2e-4:
+            print("BAD passage tower", tag, tp)
+            sys.exit(1)
     cases += 1
     if cases % 20 == 0:
         print(f"{cases} models ok ... last {tag}", flush=True)
     del model, tower
 print(f"{cases} random models, {beams_total} beams: all within tolerance; beams in a near-tie swap {swaps}; largest beam-score diff {worst_sc:.2e}, "
-      f"largest relative tower diff {worst_tw:.2e}")
+      f"largest relative tower diff {worst_tw:.2e} (incl. {passages} 128-token passages)")
