@@ -23,7 +23,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda", 0)
-t0, cases, swaps, beams_total, worst_sc, worst_tw, passages = time.time(), 0, 0, 0, 0.0, 0.0, 0
+t0, cases, swaps, beams_total, worst_sc, worst_tw, passages, trees = time.time(), 0, 0, 0, 0.0, 0.0, 0, 0
 while time.time() - t0 < budget:
     heads = int(rng.integers(1, 7))
     d = int(rng.choice([64, 128, 256, 384]))
@@ -77,6 +77,39 @@ while time.time() - t0 < budget:
     if tw > 2e-4:
         print("BAD tower", tag, tw)
         sys.exit(1)
+    if K ** M <= 1024 and rng.random() < 0.5:     # the two ablation searches: ALL code paths (_generate_all) and a generic prefix tree
+        with torch.no_grad():
+            oall, _ = ot5.nci_generate_all(W, cfg, ids, mask)
+        gall, _ = model.generate_all(ids, mask, max_rows=int(rng.choice([5, 64, 1 << 16])))
+        da = float((gall.cpu() - oall).abs().max())
+        worst_sc = max(worst_sc, da)
+        if da > 2e-4:
+            print("BAD generate_all", tag, da)
+            sys.exit(1)
+        allp = np.stack(np.meshgrid(*[np.arange(K)] * M, indexing="ij"), -1).reshape(-1, M)
+        paths = allp[rng.random(len(allp)) < rng.choice([0.1, 0.5, 1.0])]
+        if len(paths) == 0:
+            paths = allp[:1]
+        Rt = int(rng.choice([1, 2, 4]))
+        with torch.no_grad():
+            tdec, tsc, _ = ot5.nci_generate_tree(W, cfg, ids, mask, Rt, paths)
+        gd, gs, _, _ = model.generate(ids, mask, num_beams=Rt, decode_tree=nci.PrefixTree(paths, M, K, dev))
+        gs, tsn = np.asarray(gs), tsc.numpy()
+        real = tsn > -1e8                                    # (-1e9-seeded placeholder beams when the trie has fewer paths than beams)
+        if np.abs(gs[real] - tsn[real]).max(initial=0.0) > 2e-4 or not np.array_equal(gs > -1e8, real):
+            print("BAD tree scores", tag, len(paths), Rt)
+            sys.exit(1)
+        gtok, ttok, tq = gd.cpu().numpy().reshape(B, Rt, -1), tdec.numpy().reshape(B, Rt, -1), tsn.reshape(B, Rt)
+        for i in range(B):
+            for j in range(Rt):
+                if not real.reshape(B, Rt)[i, j] or (gtok[i, j] == ttok[i, j]).all():
+                    continue
+                twins = [jj for jj in range(Rt) if (gtok[i, j] == ttok[i, jj]).all()]
+                if not twins or abs(tq[i, twins[0]] - tq[i, j]) >= 4e-4:
+                    print("BAD tree beams", tag, i, j)
+                    sys.exit(1)
+                swaps += 1
+        trees += 1
     if rng.random() < 0.4:      # the passage side of the tower: 128-token sequences (other attention kernels), ragged lengths 1..128
         Bp, Sp = int(rng.integers(1, 9)), 128
         pid = np.zeros((Bp, Sp), np.int64)
@@ -101,4 +134,4 @@ while time.time() - t0 < budget:
         print(f"{cases} models ok ... last {tag}", flush=True)
     del model, tower
 print(f"{cases} random models, {beams_total} beams: all within tolerance; beams in a near-tie swap {swaps}; largest beam-score diff {worst_sc:.2e}, "
-      f"largest relative tower diff {worst_tw:.2e} (incl. {passages} 128-token passages)")
+      f"largest relative tower diff {worst_tw:.2e} (incl. {passages} 128-token passages); {trees} models also through generate_all and a random prefix tree")
