@@ -600,12 +600,39 @@ def extras(device, docs, nq, n_docs, search_ms, index_build_s, with_cpu, query=N
 
     if n_docs >= 1_000_000 or os.environ.get("MEVI_BENCH_SENSITIVITY") == "1":
         guarded("data_sensitivity", sensitivity)
+
+    def cli_chain():
+        """the four scripts as FRESH processes at MS MARCO size.  tools/e2e_cli.py writes a 27 GB corpus file and
+        takes ~40 s, so -- like the PMC traffic figure -- the bench line carries the RECORDED run (profiles/r06_e2e_cli.json),
+        not a live one; MEVI_BENCH_CLI_CHAIN=1 runs it live (scratch under $TMPDIR)."""
+        rec_path = os.path.join(ROOT, "profiles", "r06_e2e_cli.json")
+        live = os.environ.get("MEVI_BENCH_CLI_CHAIN") == "1"
+        if live:
+            import subprocess
+            import tempfile
+
+            scratch = tempfile.mkdtemp(prefix="mevi_e2e_cli_")
+            rec_path = os.path.join(scratch, "e2e_cli.json")
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_cli.py"), os.path.join(scratch, "data"), str(n_docs), rec_path],
+                           check=True, capture_output=True, timeout=1200)
+        with open(rec_path) as f:
+            rec = json.load(f)
+        return {"cli_chain_wall_s": rec["cli_chain_wall_s"], "cli_chain_wall_s_first_use": rec.get("cli_chain_wall_s_first_use"),
+                "queries_per_s_cli_chain": rec.get("queries_per_s_cli_chain"),
+                "live": live, "process_wall_s": {p["name"]: p["wall_s"] for p in rec["processes"]},
+                "measured": "live in this run" if live else "recorded run of `python tools/e2e_cli.py` (profiles/r06_e2e_cli.json; baseline of the "
+                                                            "round: profiles/r06_e2e_cli_baseline.json, 16.82 s)",
+                "note": "generate.py --gen_query + faiss_search.py --param Flat + main.py --mode eval (cluster pickles present) + "
+                        "ensemble_marco.py as fresh processes on a 27 GB docemb.bin, t5-base-shaped checkpoints, a real SentencePiece "
+                        "tokenizer, every flag of marco_eval_nci_rq.sh / marco_ensemble.sh; per-phase lines in profiles/r06_e2e_cli.txt"}
+
+    guarded("cli_chain", cli_chain)
     return out
 
 
 # ---- the ONE line ---------------------------------------------------------------------------------------------------------
 LINE_BUDGET = 7600      # bytes: the driver keeps the last 8 KB of stdout beside `parsed`; the whole line must fit in it
-_DROP = ("note", "sample_detail", "per_size", "per_kind", "by_kind", "kinds", "level_ms", "bytes", "expected_queries", "ms_all", "chain_ms_all",
+_DROP = ("note", "measured", "process_wall_s", "sample_detail", "per_size", "per_kind", "by_kind", "kinds", "level_ms", "bytes", "expected_queries", "ms_all", "chain_ms_all",
          "chain_ms_min", "device_batch", "rows_per_s", "policy", "queries_per_pass", "real_tokens", "corpus_hours_on_one_gpu", "what", "slice", "per_rank", "per_batch", "layers", "checksums", "statistic", "stats",
          "flop_split", "stage_ms_detail", "mrr10_detail", "head_matrices_at", "adaptor_vectors_only_at", "one_shot_note", "setup_untimed_ms", "recall1000", "loadavg", "cgroup_cpu_max", "backend", "faiss",
          "upload_sample", "seconds", "cpu_seconds", "oracle_seconds", "algorithmic_bytes", "flop_executed",
