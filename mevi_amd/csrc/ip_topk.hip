@@ -1596,6 +1596,21 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   }
   double growth = g_growth > 0.0 ? g_growth : (double)g.cap / (growth_div * g.k);
   if (growth < 1.0) growth = 1.0;
+  // Round 6: the growth the candidate area ALLOWS is not always the growth that is cheapest.  A launch whose chunk is g x the rows
+  // seen appends ~k g keys per query, and the pass needs ln(nd / first) / ln(1 + g) launches, so
+  //     cost(g) ~ (nq k t_key g + t_launch) / ln(1 + g),   t_key ~ 60 ns per appended key, t_launch ~ 0.2 ms (launch + compaction)
+  // (measured on the C2 search, profiles/r06_filter_launches.txt: growth 1.8 -> 1.0 = 8 -> 12 launches, 22.8 k -> 20.0 k keys per
+  // query, 88.6 -> 87.0 and 87.9 -> 87.0 ms on two boxes).  Large batches with long lists want g ~ 1, everything else the
+  // largest g its area allows (shards of a W-way search, small batches: launches dominate).  Not under the tuning hooks.
+  if (g_growth <= 0.0 && !getenv("MEVI_IP_TOPK_GROWTH_DIV") && !guaranteed) {
+    const double keys = (double)nq * (double)g.k * 60e-9 * 1e3, t_launch = 0.2;       // ms per unit g, ms per launch
+    double best = growth, best_cost = (keys * growth + t_launch) / log(1.0 + growth);
+    for (double cand = 1.0; cand < growth; cand += 0.25) {
+      const double c = (keys * cand + t_launch) / log(1.0 + cand);
+      if (c < best_cost * 0.99) best = cand, best_cost = c;                            // (ties go to fewer launches)
+    }
+    growth = best;
+  }
   const int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
   size_t pp_lds = h1 ? h1_lds_bytes() + 8 * STASH_BYTES_PER_WAVE : pp_lds_bytes<2>();
   const bool ktail = (dim % BK) != 0;
