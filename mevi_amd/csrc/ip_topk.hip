@@ -1611,7 +1611,11 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
     }
     growth = best;
   }
-  const int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
+  int64_t cap_docs = (g.cap / (2 * BM)) * (2 * BM);  // chunk that can never overflow, tile aligned
+  if (const char *e = getenv("MEVI_IP_TOPK_FIRST_CHUNK")) {  // tuning hook (rows of the first chunk, <= the candidate area), unset in production
+    const int64_t v = atoll(e) / (2 * BM) * (2 * BM);
+    if (v >= 2 * BM && v < cap_docs) cap_docs = v;
+  }
   size_t pp_lds = h1 ? h1_lds_bytes() + 8 * STASH_BYTES_PER_WAVE : pp_lds_bytes<2>();
   const bool ktail = (dim % BK) != 0;
   const void *fn = nullptr;
