@@ -1889,8 +1889,12 @@ inline IndexView view_index(const void *index, int64_t nd, int64_t dim) {
 // approximate score lies within the error bound of the k-th one; their number grows with the density of scores at rank
 // k, i.e. with k -- a fixed floor of 128 made the re-scoring of a sharded search's short first-round lists (k/W + slack)
 // the largest per-rank cost that does not shrink with the shard.  Unproven queries get the second pass (2 K').
+// Round 6 re-measured the margin with the tighter bound (MEVI_IP_KPRIME_DIV, 6980 queries x 8.84 M rows, k = 1000; profiles/
+// r06_filter_launches.txt): k / 8 (K' = 1152) is no faster on the i.i.d. corpus (86.7 vs 86.4 ms) and sends 1004 queries of the
+// CLUSTERED corpus to the second pass (98.3 ms); k / 16 sends ~3000 queries of three corpora to the exact fallback (700 ms).  k / 4 stays.
 inline int h1_kprime(int k) {
-  int extra = k / 4 < 48 ? 48 : k / 4;
+  static const int div = [] { const char *e = getenv("MEVI_IP_KPRIME_DIV"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 64 ? v : 4; }();  // tuning hook
+  int extra = k / div < 48 ? 48 : k / div;
   return (k + extra + 63) / 64 * 64;
 }
 }  // namespace
