@@ -27,9 +27,12 @@ while time.time() - t0 < budget:
     if dim == 768:
         nd = min(nd, 1_500_000)
     nq = int(rng.choice([1, 7, 32, 33, 64, 100, 128, 200, 300, 1500]))
+    if os.environ.get("STRESS_BIG"):          # large batches with long lists: the chunk schedule's cost model picks growth 1 (12+ launches)
+        nq, dim = int(rng.choice([3000, 5000, 7000])), 64
+        nd = int(rng.choice([300_000, 1_000_000]) * rng.uniform(0.6, 1.4))
     if nq > 300:
-        nd = min(nd, 400_000)
-    k = int(rng.choice([1, 10, 100, 257, 1000]))
+        nd = min(nd, 400_000) if not os.environ.get("STRESS_BIG") else nd
+    k = int(rng.choice([1, 10, 100, 257, 1000])) if not os.environ.get("STRESS_BIG") else int(rng.choice([257, 1000]))
     kind = str(rng.choice(["iid", "clustered", "duplicates", "ance_scale", "sorted_up", "sorted_down", "few_distinct"]))
     g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
     if kind in synth.CORPUS_KINDS:
