@@ -88,6 +88,30 @@ int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float *docs, cons
                              int64_t dim, int64_t k, int64_t id_offset, float *out_score, int64_t *out_id,
                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same search for FEW queries (nq <= 32: faiss_search.profile's batches, MEVI/faiss_search.py:32-68, and a resident
+ * service's single queries) through an optional 8-BIT image of the shard (round 6).  With one tile of query columns the
+ * filter is bound by reading the corpus image from HBM; an int8 image is half the f16 one.  The integer matrix cores
+ * accumulate exactly, so the approximate score's whole error is the two quantisations, both measured (per-column scales c
+ * folded into the query, per-row scales s_r; queries in two int8 digits):
+ *   exact <= t_q s_r (N + rho ||w|| / t_q) + q.mu + ||w - w^|| max||y^|| + 3 ulp + c2 ||q|| max||d||,
+ *   w = q * c, y = (d - mu) / c, y^ = s_r * int8 row, w^ = t_q * 15-bit integer query, N = the exact int32 sum,
+ *   rho = max over rows of ||y - y^|| / s_r (a row's quantisation error in units of its own step; measured at build):
+ * rows are ranked by that UPPER BOUND of their score (the row's own error term is inside the key), so a row outside the
+ * survivors is bounded by the last survivor's key plus the query-side terms only.
+ * The bound is ~100x the f16 one, so 3 k + 64 survivors are re-scored (exact f32 chains) instead of 1.25 k; lists are proven
+ * complete per query exactly as in the f16 search, and when any list of the batch stays open the call runs
+ * mevi_ip_topk_indexed_f32 for the batch (same results either way, bit for bit).  Shapes outside the 8-bit pass (nq > 32,
+ * padded dim < 256 or > 896, 3 k + 128 > 4096), index8 == NULL or MEVI_IP_I8=0: mevi_ip_topk_indexed_f32 directly.
+ *   index8 buffer: mevi_ip_index8_bytes(nd, dim) bytes (~ nd * dim + 8 nd), 256-byte aligned, built from the docs and the
+ *   f16 index of the same shard (its column mean).  Synchronising like mevi_ip_topk_f32. */
+size_t mevi_ip_index8_bytes(int64_t nd, int64_t dim);
+int mevi_ip_index8_build_f32(const float *docs, const void *index, int64_t nd, int64_t dim, void *index8, size_t index8_bytes,
+                             void *stream);
+size_t mevi_ip_topk_indexed8_workspace_bytes(int64_t nq, int64_t dim, int64_t k);
+int mevi_ip_topk_indexed8_f32(const float *q, int64_t nq, const float *docs, const void *index, const void *index8, int64_t nd,
+                              int64_t dim, int64_t k, int64_t id_offset, float *out_score, int64_t *out_id,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
 /* Merge `nlists` per-shard top-k lists into one (the step after the RCCL
  * all-gather of the row-sharded dense arm; new in this build).
  *   scores f32 [nlists, nq, k_in], ids i64 [nlists, nq, k_in] (id -1 = padding)
@@ -451,6 +475,10 @@ typedef struct mevi_ip_topk_stats {
   int64_t n_filter_candidates;
   int64_t max_launch_candidates;
   int64_t n_list_overflows;
+  /* mevi_ip_topk_indexed8_f32: queries that went through the 8-bit pass, and how many of them it left unproven (> 0: the batch
+   * was searched again through the f16 image; the other fields then describe both searches) */
+  int64_t n_i8_queries;
+  int64_t n_i8_unproven;
 } mevi_ip_topk_stats;
 void mevi_ip_topk_set_growth(double growth);
 void mevi_ip_topk_set_profiling(int enable); /* 1: record HIP events around every filter/compact launch; 2: also count candidates */

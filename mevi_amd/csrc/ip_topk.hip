@@ -1330,6 +1330,342 @@ __global__ __launch_bounds__(512, 2) void ip_filter_h1_small_kernel(
   stash_flush(stash, buf, count, S, k, cap);
 }
 
+// ---------------------------------------------------------------------------
+// Round 6 (late): an 8-BIT corpus image for searches of <= 32 queries.  The streaming kernel above is bound by reading the
+// f16 image once per launch set (13.6 GB at MS MARCO size: 2.5 ms at the 5.4 TB/s it reaches); an int8 image is half of
+// that.  What makes 8 bits usable for an EXACT search is that the integer matrix cores accumulate without rounding, so the
+// whole error of the approximate score is the two quantisations, and both are MEASURED:
+//   y_k = (d_k - mu_k) / c_k        c = per-column scale (the column's standard deviation: outlier dimensions of real encoders
+//                                   do not eat the 8 bits of the others); folded into the query: w_k = q_k c_k
+//   y^_k = s_r I_k                  I = int8 row, s_r = max_k |y_k| / 127 per ROW (rows of different length use all levels)
+//   w^_k = t_q Q_k                  Q = 15-bit integer in two int8 digits, Q = 128 hi + lo, lo in [-64, 63]: two MFMAs per
+//                                   product (the kernel is HBM-bound at 1/6 of the integer pipes)
+//   q.(d - mu) - t_q s_r (128 N_hi + N_lo) = w.(y - y^) + (w - w^).y^      N = exact int32 sums
+//   |.| <= ||w|| max_r ||y - y^|| + ||w - w^|| max_r ||y^||                 (Cauchy-Schwarz; both maxima measured at build,
+//                                                                            the query norms per search, in f64)
+// The first term is ~0.2 of the score deviation on Gaussian rows (f16: 0.002) and its MAXIMUM over rows half as much again
+// (a row with one 5.5-sigma coordinate has a coarser step) -- measured on the first build: with the shard's maximum in the
+// proof, 3 k survivors prove top-10 but not top-100 / top-1000 of 8.8 M rows.  So the term is carried PER ROW, inside the key:
+// ||y - y^||_r <= rho s_r with rho = max_r ||y - y^||_r / s_r (the quantisation noise of a row is uniform in its own step: 8.0
+// +- 0.7 at dim 768; measured at build), and the filter ranks rows by an UPPER BOUND of their centred score,
+//   key_r = fl((fl(128 N_hi + N_lo) + G_q) s_r),   G_q = rho ||w|| / t_q      (t_q key_r >= w.y_r - what is left below)
+// A row outside the K' survivors has key <= the K'-th key, so the proof needs only what is left: the query's quantisation
+// ||w - w^|| max ||y^|| and 3 ulp for the float form of the key (|N_hi|, |N_lo| < 2^24 for dimp <= 1024).  That is
+// h1_err_bound with (qdelta, qn16, dn, ddmax, c_acc) = (||w - w^||, ||w|| + ||w - w^||, ||y^||, 2^-20 rho max s_r, 2^-22): the
+// re-scoring, the proof and the observed / bound check (one-sided here: exact - key) are the SAME kernels as the f16
+// search's, with qinv = t_q; the exclusion of survivors is not used (its lower bound would need the two-sided error).
+// K' = 3 k + 64 (h8_kprime) instead of 1.25 k: re-scoring 3 k rows per query is nothing for <= 32 queries, and would be everything for 7 k.
+// A query the proof leaves open sends the whole (small) batch through the f16 search.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+constexpr int I8_QMAX = 127 * 128;
+
+// element (r, k) of the 8-bit image: blocks of 256 rows, inside a block the 64 k of unit u of all rows together
+// (the f16 image's layout with 64-k units: a unit is 16 KiB, a wave's 32 rows of it 2 KiB, a row of it 64 B)
+__device__ __forceinline__ size_t image8_at(long long r, int k, int dimp) {
+  return ((size_t)((r >> 8) * (dimp >> 6) + (k >> 6)) * 256 + (size_t)(r & 255)) * 64 + (k & 63);
+}
+
+// sum over rows of (d_k - mu_k)^2 per column, f64 (the column scale is its root mean; any positive scale is valid)
+__global__ __launch_bounds__(256) void colsq_kernel(const float *__restrict__ x, long long n, int dim, const float *__restrict__ mu,
+                                                   double *__restrict__ sum) {
+  const long long r0 = (long long)blockIdx.x * 512;
+  const long long r1 = r0 + 512 < n ? r0 + 512 : n;
+  for (int c = threadIdx.x; c < dim; c += 256) {
+    double a = 0.0;
+    const double m = (double)mu[c];
+    for (long long r = r0; r < r1; ++r) {
+      const double v = (double)x[(size_t)r * dim + c] - m;
+      a += v * v;
+    }
+    atomicAdd(&sum[c], a);
+  }
+}
+__global__ __launch_bounds__(256) void colscale_kernel(const double *__restrict__ sum, long long n, int dim, int dimp, float *__restrict__ cs) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= dimp) return;
+  float v = 1.f;
+  if (c < dim && n > 0) {
+    const float s = (float)sqrt(sum[c] / (double)n);
+    if (s > 1e-18f && s < 1e18f) v = s;   // (with the row limits below: keys (N + G) s_r stay far inside the float range)
+  }
+  cs[c] = v;
+}
+
+// docs -> int8 image + per-row scale + per-row ||y^|| (rounded up); bits[0] = max ||y^||, bits[2] = rho = max ||y - y^|| / s_r,
+// bits[4] = max ||y - y^|| (f64 per element, rounded up).  One wave per row; rows up to the end of the last block exist and are zero (scale 0).
+__global__ __launch_bounds__(256) void split_docs_i8_kernel(const float *__restrict__ x, long long n, int dim, int dimp,
+                                                           const float *__restrict__ mu, const float *__restrict__ cs,
+                                                           signed char *__restrict__ out, float *__restrict__ scale,
+                                                           float *__restrict__ ynorm, unsigned int *__restrict__ bits) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= ((n + 255) >> 8 << 8)) return;
+  const int lane = threadIdx.x & 63;
+  if (r >= n) {
+    for (int k = lane * 4; k < dimp; k += 256) *reinterpret_cast<unsigned int *>(out + image8_at(r, k, dimp)) = 0u;
+    if (lane == 0) scale[r] = 0.f, ynorm[r] = 0.f;
+    return;
+  }
+  const float *xr = x + (size_t)r * dim;
+  float m = 0.f;
+  bool bad = false;
+  for (int k = lane * 4; k < dim; k += 256) {
+    const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+    const float4 u = *reinterpret_cast<const float4 *>(mu + k);
+    const float4 c = *reinterpret_cast<const float4 *>(cs + k);
+    const float y0 = fabsf((v.x - u.x) / c.x), y1 = fabsf((v.y - u.y) / c.y), y2 = fabsf((v.z - u.z) / c.z), y3 = fabsf((v.w - u.w) / c.w);
+    bad = bad || !(y0 <= 1.0e25f) || !(y1 <= 1.0e25f) || !(y2 <= 1.0e25f) || !(y3 <= 1.0e25f);   // (inf, NaN, or out of the keys' range)
+    m = fmaxf(fmaxf(m, fmaxf(y0, y1)), fmaxf(y2, y3));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  bad = __any(bad || (m > 0.f && m < 1.0e-25f)) != 0;
+  const float s = bad ? 0.f : m / 127.f;
+  const float inv = (!bad && m > 0.f) ? 127.f / m : 0.f;
+  double ee = 0.0, yy = 0.0;
+  for (int k = lane * 4; k < dimp; k += 256) {
+    unsigned int word = 0u;
+    if (k < dim && !bad) {
+      const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+      const float4 u = *reinterpret_cast<const float4 *>(mu + k);
+      const float4 c = *reinterpret_cast<const float4 *>(cs + k);
+      const float vv[4] = {v.x, v.y, v.z, v.w}, uu[4] = {u.x, u.y, u.z, u.w}, cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int q = (int)rintf(((vv[j] - uu[j]) / cc[j]) * inv);
+        q = q > 127 ? 127 : (q < -127 ? -127 : q);
+        const double yh = (double)s * (double)q;
+        const double e = ((double)vv[j] - (double)uu[j]) / (double)cc[j] - yh;
+        ee += e * e;
+        yy += yh * yh;
+        word |= ((unsigned int)q & 0xFFu) << (8 * j);
+      }
+    }
+    *reinterpret_cast<unsigned int *>(out + image8_at(r, k, dimp)) = word;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ee += __shfl_xor(ee, off);
+    yy += __shfl_xor(yy, off);
+  }
+  if (lane == 0) {
+    float e = (float)sqrt(ee) * 1.0001f, y = (float)sqrt(yy) * 1.0001f;
+    if (bad || !(e >= 0.f) || e > 3.0e38f) e = 3.0e38f;   // inf / NaN rows: no bound -> every query takes the f16 search
+    if (!(y >= 0.f) || y > 3.0e38f) y = 3.0e38f;
+    scale[r] = s;
+    ynorm[r] = y;
+    float rho = s > 0.f ? (float)(sqrt(ee) / (double)s) * 1.0001f : (e > 0.f ? 3.0e38f : 0.f);
+    if (!(rho >= 0.f) || rho > 3.0e38f) rho = 3.0e38f;
+    const unsigned int eb = __float_as_uint(e), yb = __float_as_uint(y), rb = __float_as_uint(rho);
+    if (eb > __atomic_load_n(&bits[4], __ATOMIC_RELAXED)) atomicMax(&bits[4], eb);
+    if (yb > __atomic_load_n(&bits[0], __ATOMIC_RELAXED)) atomicMax(&bits[0], yb);
+    if (rb > __atomic_load_n(&bits[2], __ATOMIC_RELAXED)) atomicMax(&bits[2], rb);
+    const unsigned int sb = __float_as_uint(s);
+    if (sb > __atomic_load_n(&bits[5], __ATOMIC_RELAXED)) atomicMax(&bits[5], sb);
+  }
+}
+// bits[1] = max ||d|| of the f16 index (the f32 chain's own term of the bound); bits[3] = 2^-20 rho max s_r (what the proof's
+// formula still needs of the rows' quantisation: 3 ulp of the key's G_q s_r part, G_q s_r t_q = rho s_r ||w|| <= rho max s ||w||)
+__global__ void finish_bits8_kernel(const unsigned int *__restrict__ src, unsigned int *__restrict__ dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    dst[1] = src[1];
+    const double e = (double)__uint_as_float(dst[2]) * (double)__uint_as_float(dst[5]) * 1.0001 / 1048576.0;
+    dst[3] = __float_as_uint(e > 3.0e38 ? 3.0e38f : (float)e);
+  }
+}
+
+// queries (<= 32) -> two int8 digit images [digit][unit][32 rows][64 B] of round(q_k c_k / t_q); qnorm = ||q|| (up), qinv = t_q,
+// qshift = q.mu (f64), qdelta = ||w - w^|| (up), qn16 = ||w|| + ||w - w^|| (up), qub = G_q (the key's per-row error term in
+// raw units).  One wave per row, rows >= n zero.
+__global__ __launch_bounds__(256) void split_queries_i8_kernel(const float *__restrict__ x, int n, int dim, int dimp,
+                                                              const float *__restrict__ mu, const float *__restrict__ cs,
+                                                              signed char *__restrict__ out, float *__restrict__ qnorm,
+                                                              float *__restrict__ qinv, double *__restrict__ qshift,
+                                                              float *__restrict__ qdelta, float *__restrict__ qn16,
+                                                              const unsigned int *__restrict__ bits8, float *__restrict__ qub,
+                                                              unsigned int *__restrict__ qbad) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);   // 8 workgroups: rows 0..31
+  const int lane = threadIdx.x & 63;
+  const int U = dimp >> 6;
+  auto at = [&](int digit, int k) { return ((size_t)(digit * U + (k >> 6)) * 32 + r) * 64 + (k & 63); };
+  if (r >= n) {
+    for (int k = lane * 4; k < dimp; k += 256) {
+      *reinterpret_cast<unsigned int *>(out + at(0, k)) = 0u;
+      *reinterpret_cast<unsigned int *>(out + at(1, k)) = 0u;
+    }
+    if (lane == 0) qub[r] = 0.f, qbad[r] = 0u;
+    return;
+  }
+  const float *xr = x + (size_t)r * dim;
+  float ss = 0.f, mw = 0.f;
+  double sh = 0.0;
+  for (int k = lane * 4; k < dim; k += 256) {
+    const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+    const float4 m = *reinterpret_cast<const float4 *>(mu + k);
+    const float4 c = *reinterpret_cast<const float4 *>(cs + k);
+    ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
+    mw = fmaxf(fmaxf(mw, fmaxf(fabsf(v.x * c.x), fabsf(v.y * c.y))), fmaxf(fabsf(v.z * c.z), fabsf(v.w * c.w)));
+    sh += (double)v.x * m.x + (double)v.y * m.y + (double)v.z * m.z + (double)v.w * m.w;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ss += __shfl_xor(ss, off);
+    mw = fmaxf(mw, __shfl_xor(mw, off));
+    sh += __shfl_xor(sh, off);
+  }
+  float t = mw / (float)I8_QMAX;
+  if (!(t > 1e-37f) || !(t < 1e37f)) t = 1.f;
+  const double inv_t = 1.0 / (double)t;
+  double dq = 0.0, nw = 0.0;
+  for (int k = lane * 4; k < dimp; k += 256) {
+    unsigned int whi = 0u, wlo = 0u;
+    if (k < dim) {
+      const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+      const float4 c = *reinterpret_cast<const float4 *>(cs + k);
+      const float vv[4] = {v.x, v.y, v.z, v.w}, cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double w = (double)vv[j] * (double)cc[j];
+        double qd = rint(w * inv_t);
+        qd = qd > (double)I8_QMAX ? (double)I8_QMAX : (qd < -(double)I8_QMAX ? -(double)I8_QMAX : qd);
+        if (!(qd == qd)) qd = 0.0;
+        const int Q = (int)qd;
+        const int lo = ((Q + 64) & 127) - 64, hi = (Q - lo) >> 7;
+        const double e = w - (double)t * (double)Q;
+        dq += e * e;
+        nw += w * w;
+        whi |= ((unsigned int)hi & 0xFFu) << (8 * j);
+        wlo |= ((unsigned int)lo & 0xFFu) << (8 * j);
+      }
+    }
+    *reinterpret_cast<unsigned int *>(out + at(0, k)) = whi;
+    *reinterpret_cast<unsigned int *>(out + at(1, k)) = wlo;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    dq += __shfl_xor(dq, off);
+    nw += __shfl_xor(nw, off);
+  }
+  if (lane == 0) {
+    const float qn = sqrtf(ss) * 1.00001f, qd = (float)sqrt(dq) * 1.0001f, qw = (float)(sqrt(nw) + sqrt(dq)) * 1.0001f;
+    qnorm[r] = qn;
+    qinv[r] = t;
+    qshift[r] = sh;
+    qdelta[r] = qd;
+    qn16[r] = qw;
+    const float g = (float)((double)__uint_as_float(bits8[2]) * sqrt(nw) * inv_t * 1.0001);   // G_q = rho ||w|| / t_q, rounded up
+    qub[r] = g;
+    // a non-finite query, or rows the image could not hold (rho = 3e38): keys would be inf / NaN and NaN keys are silently
+    // dropped by the filter's comparisons -- the driver sends such a query's batch through the f16 search
+    const float chk = g + qd + qw + qn + (float)sh;
+    qbad[r] = (chk - chk == 0.f && g < 1e30f) ? 0u : 1u;
+  }
+}
+
+// ip_filter_h1_small_kernel on the 8-bit image: same ring, same DMA pieces, same LDS addresses (a unit row is 64 B in both:
+// 32 halves there, 64 bytes here), U = dimp / 64 units of four integer MFMAs (two k-steps x two query digits).  The int32
+// sums leave as the float keys (fl(128 N_hi + N_lo) + G_q) * s_row through the same epilogue (emit_tile).
+__global__ __launch_bounds__(512, 2) void ip_filter_i8_small_kernel(
+    const float *__restrict__ Qh, int nq, const float *__restrict__ Dh, long long doc_begin, long long doc_end, int dimp,
+    const float *__restrict__ tau, unsigned long long *__restrict__ buf, unsigned int *__restrict__ count, int S, int k,
+    int cap, unsigned int id_base, const float *__restrict__ row_scale, const float *__restrict__ qub) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lrow = lane & 31, half = lane >> 5;
+  const int U = dimp >> 6;
+  float *qst = lds;                                                    // [2 digits][U][32 rows][16 floats], piece-swizzled
+  float *ring = lds + (size_t)U * 1024 + (size_t)w8 * SM_NB * 512;     // this wave's units: [SM_NB][32 rows][16 floats]
+  const int voff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  {
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Qh), 0, (int)((size_t)U * 4096), 0x00020000);
+    for (int u = w8; u < 2 * U; u += 8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)(qst + u * 512 + i * 256), 16,
+                                                 voff + i * 1024, u * 2048, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const long long n_blocks = (doc_end - doc_begin + 255) >> 8;
+  long long blk = blockIdx.x;
+  if (blk >= n_blocks) return;
+  const size_t block_bytes = (size_t)256 * dimp;
+  auto src_of = [&](long long b) { return reinterpret_cast<const char *>(Dh) + (size_t)((doc_begin >> 8) + b) * block_bytes + (size_t)w8 * 2048; };
+  const char *cur = src_of(blk);
+  long long blk_n = blk + gridDim.x;
+  bool have_nxt = blk_n < n_blocks;
+  const char *nxt = have_nxt ? src_of(blk_n) : cur;
+  auto dma = [&](const char *base, bool live, int u, int slot) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, live ? (int)(block_bytes - (size_t)w8 * 2048) : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(ring + slot * 512 + i * 256), 16,
+                                               voff + i * 1024, u * 16384, 0, 0);
+  };
+  const int sw = (lrow >> 2) & 3;
+  const int off0 = lrow * 16 + (((0 + half) ^ sw) << 2), off1 = lrow * 16 + (((2 + half) ^ sw) << 2);  // k-steps j = 0, 1
+  float tq[1];
+  Stash stash;
+  {
+    char *sb = reinterpret_cast<char *>(lds) + sm_lds_bytes(dimp) + (size_t)w8 * STASH_BYTES_PER_WAVE;
+    stash.keys = reinterpret_cast<unsigned long long *>(sb);
+    stash.qs = reinterpret_cast<unsigned int *>(sb + (size_t)STASH_N * 8);
+    stash.n = 0;
+  }
+  load_tq<1>(tq, tau, 0, nq);
+  const float gq = qub[lrow];   // (32 entries, rows >= nq: 0)
+  int rs = 0;
+#pragma unroll
+  for (int u = 0; u < SM_NB - 1; ++u) dma(cur, true, u, u);   // U >= SM_NB - 1 is guaranteed by the host (dimp >= 256)
+  while (true) {
+    // the scales of the wave's 32 rows: a wave-uniform address, i.e. SCALAR loads (they count in lgkmcnt; a vector load here
+    // makes the compiler drain vmcnt -- the ring's look-ahead -- before the epilogue reads them)
+    const float *sp = row_scale + (doc_begin + blk * 256 + 32 * w8);
+    float sr[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) sr[j] = sp[j];
+    i32x16 nh, nl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nh[r] = 0, nl[r] = 0;
+    for (int u = 0; u < U; ++u) {
+      const int un = u + SM_NB - 1;
+      const bool spill = un >= U;
+      dma(spill ? nxt : cur, spill ? have_nxt : true, spill ? un - U : un, rs == 0 ? SM_NB - 1 : rs - 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      static_assert(SM_NB == 5, "vmcnt immediate above = 2 * (SM_NB - 1)");
+      const float *ub = ring + rs * 512;
+      const i32x4 a0 = *reinterpret_cast<const i32x4 *>(ub + off0), a1 = *reinterpret_cast<const i32x4 *>(ub + off1);
+      const float *qh = qst + u * 512, *ql = qst + (U + u) * 512;
+      const i32x4 h0 = *reinterpret_cast<const i32x4 *>(qh + off0), h1 = *reinterpret_cast<const i32x4 *>(qh + off1);
+      const i32x4 l0 = *reinterpret_cast<const i32x4 *>(ql + off0), l1 = *reinterpret_cast<const i32x4 *>(ql + off1);
+      nh = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, h0, nh, 0, 0, 0);
+      nl = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, l0, nl, 0, 0, 0);
+      nh = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, h1, nh, 0, 0, 0);
+      nl = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, l1, nl, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      rs = rs == SM_NB - 1 ? 0 : rs + 1;
+    }
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sc = half ? sr[8 * (r >> 2) + 4 + (r & 3)] : sr[8 * (r >> 2) + (r & 3)];   // row (r & 3) + 8 (r >> 2) + 4 half
+      acc[0][0][r] = (fmaf((float)nh[r], 128.f, (float)nl[r]) + gq) * sc;
+      acc[1][0][r] = -INFINITY;
+    }
+    emit_tile<1>(acc, tq, 0, doc_begin + blk * 256 + 32 * w8, doc_end, buf, count, S, k, cap, id_base, stash);
+    if (!have_nxt) break;
+    blk = blk_n;
+    cur = nxt;
+    blk_n += gridDim.x;
+    have_nxt = blk_n < n_blocks;
+    if (have_nxt) nxt = src_of(blk_n);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stash_flush(stash, buf, count, S, k, cap);
+}
+
 // Exact re-scoring of the kp approximate survivors of every query, exact top-k, and the proof that nothing
 // outside the survivors can belong to it.  With a = acc * qinv (the centred approximate score),
 //   chain(q, d) <= a + q.mu + eps_q,   eps_q = h1_err_bound(q; max||d - mu||, max||dd||) + c2 ||q|| max||d||
@@ -1354,7 +1690,7 @@ __global__ __launch_bounds__(256) void rescore_rows_kernel(const float *__restri
                                                           const float *__restrict__ dnorm_c,
                                                           unsigned int *__restrict__ err_ratio_bits,
                                                           const float *__restrict__ qdelta, const float *__restrict__ qn16,
-                                                          const float *__restrict__ acc_k) {
+                                                          const float *__restrict__ acc_k, int upper_keys = 0) {
   __shared__ __attribute__((aligned(16))) float tiles[4][64 * RS_LD];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1423,7 +1759,8 @@ __global__ __launch_bounds__(256) void rescore_rows_kernel(const float *__restri
       const double den = h1_err_bound(qdelta[q], qn16[q], (double)dnorm_c[my_id], (double)__uint_as_float(dmax_bits[3]), c1) +
                          (double)qnorm[q] * (double)c2 * __uint_as_float(dmax_bits[1]);
       const double est = (double)key_score(key) * (double)qinv[q] + qshift[q];
-      if (den > 0.0) ratio = (float)(fabs(est - (double)acc) / den);
+      // (upper_keys: the 8-bit search's keys are upper bounds -- only exact - key is held against the bound)
+      if (den > 0.0) ratio = (float)((upper_keys ? fmax((double)acc - est, 0.0) : fabs(est - (double)acc)) / den);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ratio = fmaxf(ratio, __shfl_xor(ratio, off));
@@ -1454,12 +1791,15 @@ __global__ __launch_bounds__(256) void rescore_finish_kernel(const unsigned long
   if (t == 0) {
     bool ok = true;
     const float a_last = tau[q];
+    const double eps = h1_err_bound(qdelta[q], qn16[q], (double)__uint_as_float(dmax_bits[0]), (double)__uint_as_float(dmax_bits[3]), c1) +
+                       (double)qnorm[q] * (double)c2 * __uint_as_float(dmax_bits[1]);
     if (a_last > -INFINITY) {  // the survivor list is full: there are documents outside it
       const unsigned long long kth = skeys[k - 1];
-      const double eps = h1_err_bound(qdelta[q], qn16[q], (double)__uint_as_float(dmax_bits[0]), (double)__uint_as_float(dmax_bits[3]), c1) +
-                         (double)qnorm[q] * (double)c2 * __uint_as_float(dmax_bits[1]);
       ok = (kth != 0ull) && ((double)a_last * (double)qinv[q] + qshift[q] + eps < (double)key_score(kth));
     }
+    // a bound that is not a finite number (inf / NaN rows or queries: the images then hold NaN accumulators, which every
+    // comparison of the filter drops) proves nothing, full list or not
+    if (!(eps < 1.0e38)) ok = false;
     if (!ok) failed[q] = 1u;  // keeps an overflow flag set by compact_kernel during the approximate pass
   }
 }
@@ -1547,7 +1887,9 @@ static void profile_collect() {
 // Walk docs [0, nd) in chunks; returns number of filter launches, <0 on error.
 static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, int dim,
                         const TopkGeom &g, uint32_t id_base, const SearchState &st, bool guaranteed,
-                        hipStream_t stream, bool h1 = false, unsigned long long *cand = nullptr) {
+                        hipStream_t stream, bool h1 = false, unsigned long long *cand = nullptr,
+                        const float *row_scale = nullptr /* non-null: Q, D = the 8-bit images (<= 32 queries), per-row scales */,
+                        const float *qub = nullptr /* ... and the queries' G_q */) {
   const long long total = nq * (long long)g.k;
   const long long init_n = total > nq ? total : nq;
   hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, stream,
@@ -1621,9 +1963,11 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
   const void *fn = nullptr;
 #define MEVI_PICK(NI_, T_) fn = reinterpret_cast<const void *>(ip_filter_kernel<NI_, T_>)
   // stationary-query streaming kernel: few queries, and the query tile + rings + stash fit the 160 KiB of LDS
-  const bool small = h1 && nq <= 32 && dim >= 160 && sm_lds_bytes(dim) + 8 * STASH_BYTES_PER_WAVE <= 160 * 1024 &&
-                     !getenv("MEVI_IP_TOPK_NO_SMALL");
-  if (small) fn = reinterpret_cast<const void *>(ip_filter_h1_small_kernel);
+  const bool small = row_scale != nullptr ||
+                     (h1 && nq <= 32 && dim >= 160 && sm_lds_bytes(dim) + 8 * STASH_BYTES_PER_WAVE <= 160 * 1024 &&
+                      !getenv("MEVI_IP_TOPK_NO_SMALL"));
+  if (row_scale) fn = reinterpret_cast<const void *>(ip_filter_i8_small_kernel);   // (the caller checked the shape: i8_eligible)
+  else if (small) fn = reinterpret_cast<const void *>(ip_filter_h1_small_kernel);
   else if (h1) {  // Q, D = f16 images, dim = padded dim.  MEVI_IP_FILTER_MFMA=32: the 32x32x16 form (A/B; same lists)
     fn = !k16shape ? reinterpret_cast<const void *>(ip_filter_h1_kernel)
          : ni16 == 8 ? reinterpret_cast<const void *>(ip_filter_h16_kernel<8>)
@@ -1725,7 +2069,7 @@ static int64_t run_pass(const float *Q, int64_t nq, const float *D, int64_t nd, 
       void *args16[] = {(void *)&Q, &nq_i, (void *)&D, &d0, &d1, &dim, (void *)&tau_c, (void *)&st.buf,
                         (void *)&st.count, (void *)&g.S, (void *)&g.k, (void *)&g.cap, &id_base, &n_qt, &n_dp, &flush_mask};
       void *args_small[] = {(void *)&Q, &nq_i, (void *)&D, &d0, &d1, &dim, (void *)&tau_c, (void *)&st.buf,
-                            (void *)&st.count, (void *)&g.S, (void *)&g.k, (void *)&g.cap, &id_base};
+                            (void *)&st.count, (void *)&g.S, (void *)&g.k, (void *)&g.cap, &id_base, (void *)&row_scale, (void *)&qub};
       if (small) {  // one workgroup per CU, each walking 256-row blocks of the chunk
         const int64_t nb = (chunk + 255) / 256;
         grid = (unsigned)(nb < n_cu ? nb : n_cu);
@@ -2156,6 +2500,205 @@ extern "C" int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float 
                        (long long)nq, out_score, reinterpret_cast<long long *>(out_id));
   MEVI_HIP_CHECK(hipGetLastError());
   return MEVI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The 8-bit image (searches of <= 32 queries; kernels and bound above ip_filter_i8_small_kernel).
+namespace {
+struct Index8View {
+  const float *image;        // int8 image, unit-major (64-k units), whole 256-row blocks
+  const float *scale;        // [image_rows(nd)] s_r
+  const float *ynorm;        // [image_rows(nd)] ||y^_r|| (rounded up)
+  const float *cscale;       // [dimp] c_k
+  const unsigned int *bits;  // [0] max ||y^||, [1] max ||d|| (from the f16 index), [2] rho, [3] 2^-20 rho max s_r, [4] max ||y - y^||, [5] max s_r  (float bits)
+  double *colsq;             // [dimp] build scratch
+};
+inline size_t index8_image_bytes(int64_t nd, int64_t dim) { return align_up((size_t)image_rows(nd) * pad_k(dim), 256); }
+inline Index8View view_index8(const void *index8, int64_t nd, int64_t dim) {
+  const char *p = reinterpret_cast<const char *>(index8);
+  Index8View v;
+  v.image = reinterpret_cast<const float *>(p);
+  p += index8_image_bytes(nd, dim);
+  v.scale = reinterpret_cast<const float *>(p);
+  p += align_up((size_t)image_rows(nd) * 4, 256);
+  v.ynorm = reinterpret_cast<const float *>(p);
+  p += align_up((size_t)image_rows(nd) * 4, 256);
+  v.cscale = reinterpret_cast<const float *>(p);
+  p += align_up((size_t)pad_k(dim) * 4, 256);
+  v.bits = reinterpret_cast<const unsigned int *>(p);
+  p += 256;
+  v.colsq = reinterpret_cast<double *>(const_cast<char *>(p));
+  return v;
+}
+// survivors of the 8-bit pass.  A row's error term is ~0.2 of the score deviation (Gaussian rows): the K'-th key has to lie that
+// far below the k-th exact score -- 2.3 k rows at k = 1000 of 8.8 M i.i.d. rows: K' = 3 k + 64.  Measured at MS MARCO size
+// (profiles/r06_i8_small.txt): every list proven on the i.i.d., ANCE-scale and duplicates corpora; on the CLUSTERED corpus a
+// third of the queries stay open in batches of 8 / 32 (the within-cluster spread of the scores is about the size of the term:
+// the list would have to hold the query's whole cluster).  A floor of 2048 survivors proves those too but costs more than it
+// returns: the chunk schedule grows with cap / K', 12 launches instead of 5-9 (one query top-10: 1.40 -> 1.88 ms, 32 queries
+// 1.53 -> 2.66 ms against 2.5-2.6 through the f16 image) -- so the list stays short and a corpus that keeps failing is
+// searched through the f16 image (DenseIndex keeps a running share of repeated searches).  MEVI_IP_I8_KPRIME_MUL / _MIN: hooks.
+inline int h8_kprime(int k) {
+  static const double mul = [] { const char *e = getenv("MEVI_IP_I8_KPRIME_MUL"); const double v = e ? atof(e) : 0.0; return v >= 1.25 && v <= 16.0 ? v : 3.0; }();
+  static const int kmin = [] { const char *e = getenv("MEVI_IP_I8_KPRIME_MIN"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 4096 ? v / 64 * 64 : 64; }();
+  int kp = ((int)(mul * (double)k) + 64 + 63) / 64 * 64;
+  if (kp < kmin) kp = kmin;
+  return kp;
+}
+// shapes the 8-bit pass takes: one query tile, four 64-k units at least (the ring's look-ahead), int32 digit sums below 2^24,
+// the stationary tile + rings + stash inside the LDS, a survivor list the proof kernel can sort and the exclusion can rank
+inline bool i8_eligible(int64_t nq, int64_t dim, int64_t k) {
+  const int64_t dimp = pad_k(dim);
+  return nq >= 1 && nq <= 32 && k >= 1 && k <= 4096 && dim % 4 == 0 && dimp >= 256 && dimp <= 1024 &&
+         sm_lds_bytes((int)dimp) + 8 * STASH_BYTES_PER_WAVE <= 160 * 1024 && h8_kprime((int)k) <= 4096;
+}
+inline size_t i8_own_workspace_bytes(int64_t nq, int64_t dim, int64_t k) {
+  const TopkGeom gp = make_geom(h8_kprime((int)k), nq);
+  return state_bytes(nq, gp) + align_up((size_t)nq * k * 8, 256) + align_up((size_t)pad_k(dim) * 64, 256) +
+         4 * align_up((size_t)(nq + 1) * 4, 256) + align_up((size_t)nq * 8, 256) + 512;
+}
+}  // namespace
+
+extern "C" size_t mevi_ip_index8_bytes(int64_t nd, int64_t dim) {
+  if (nd < 0 || dim <= 0) return 0;
+  return index8_image_bytes(nd, dim) + 2 * align_up((size_t)image_rows(nd) * 4, 256) + align_up((size_t)pad_k(dim) * 4, 256) + 256 +
+         align_up((size_t)pad_k(dim) * 8, 256);
+}
+
+extern "C" int mevi_ip_index8_build_f32(const float *docs, const void *index, int64_t nd, int64_t dim, void *index8,
+                                        size_t index8_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(nd >= 0 && dim > 0 && dim % 4 == 0, MEVI_ERR_INVALID_ARG, "ip_index8_build: bad shape");
+  MEVI_REQUIRE(index && index8 && index8_bytes >= mevi_ip_index8_bytes(nd, dim), MEVI_ERR_WORKSPACE, "ip_index8_build: index buffer too small");
+  MEVI_REQUIRE(((uintptr_t)index8 % 256) == 0 && ((uintptr_t)index % 256) == 0 && ((uintptr_t)docs % 16) == 0, MEVI_ERR_INVALID_ARG,
+               "ip_index8_build: indexes must be 256-byte, docs 16-byte aligned");
+  const IndexView iv = view_index(index, nd, dim);
+  Index8View v = view_index8(index8, nd, dim);
+  const int dimp = (int)pad_k(dim);
+  // scales, maxima and the scratch sums start from zero
+  MEVI_HIP_CHECK(hipMemsetAsync(const_cast<float *>(v.cscale), 0,
+                                align_up((size_t)dimp * 4, 256) + 256 + align_up((size_t)dimp * 8, 256), stream));
+  if (nd > 0) {
+    MEVI_REQUIRE(docs, MEVI_ERR_INVALID_ARG, "ip_index8_build: null docs");
+    hipLaunchKernelGGL(colsq_kernel, dim3((unsigned)((nd + 511) / 512)), dim3(256), 0, stream, docs, (long long)nd, (int)dim, iv.mu, v.colsq);
+  }
+  hipLaunchKernelGGL(colscale_kernel, dim3((unsigned)((dimp + 255) / 256)), dim3(256), 0, stream, v.colsq, (long long)nd, (int)dim, dimp,
+                     const_cast<float *>(v.cscale));
+  if (nd > 0)
+    hipLaunchKernelGGL(split_docs_i8_kernel, dim3((unsigned)(image_rows(nd) / 4)), dim3(256), 0, stream, docs, (long long)nd, (int)dim, dimp,
+                       iv.mu, v.cscale, reinterpret_cast<signed char *>(const_cast<float *>(v.image)), const_cast<float *>(v.scale),
+                       const_cast<float *>(v.ynorm), const_cast<unsigned int *>(v.bits));
+  hipLaunchKernelGGL(finish_bits8_kernel, dim3(1), dim3(64), 0, stream, iv.bits, const_cast<unsigned int *>(v.bits));
+  MEVI_HIP_CHECK(hipGetLastError());
+  return MEVI_OK;
+}
+
+extern "C" size_t mevi_ip_topk_indexed8_workspace_bytes(int64_t nq, int64_t dim, int64_t k) {
+  const size_t inner = mevi_ip_topk_indexed_workspace_bytes(nq, dim, k);
+  if (inner == 0) return 0;
+  return (i8_eligible(nq, dim, k) ? i8_own_workspace_bytes(nq, dim, k) : 0) + inner;
+}
+
+extern "C" int mevi_ip_topk_indexed8_f32(const float *q, int64_t nq, const float *docs, const void *index, const void *index8,
+                                         int64_t nd, int64_t dim, int64_t k, int64_t id_offset, float *out_score, int64_t *out_id,
+                                         void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  MEVI_REQUIRE(nq >= 0 && nd >= 0 && dim > 0 && k > 0, MEVI_ERR_INVALID_ARG, "ip_topk_indexed8: bad shape");
+  if (nq == 0) return MEVI_OK;
+  const size_t need = mevi_ip_topk_indexed8_workspace_bytes(nq, dim, k);
+  MEVI_REQUIRE(need != 0, MEVI_ERR_UNSUPPORTED, "ip_topk_indexed8: unsupported shape");
+  MEVI_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 256) == 0, MEVI_ERR_WORKSPACE,
+               "ip_topk_indexed8: workspace %zu bytes < required %zu (or misaligned)", workspace_bytes, need);
+  static const bool off = [] { const char *e = getenv("MEVI_IP_I8"); return e && atoi(e) == 0; }();
+  const bool use8 = !off && index8 != nullptr && i8_eligible(nq, dim, k) && nd > 0;
+  const size_t own = i8_eligible(nq, dim, k) ? i8_own_workspace_bytes(nq, dim, k) : 0;
+  char *inner_ws = reinterpret_cast<char *>(workspace) + own;
+  const size_t inner_bytes = workspace_bytes - own;
+  if (!use8)
+    return mevi_ip_topk_indexed_f32(q, nq, docs, index, nd, dim, k, id_offset, out_score, out_id, inner_ws, inner_bytes, stream_);
+
+  MEVI_REQUIRE(q && out_score && out_id && index && docs, MEVI_ERR_INVALID_ARG, "ip_topk_indexed8: null pointer");
+  MEVI_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)docs % 16) == 0 && ((uintptr_t)index % 256) == 0 && ((uintptr_t)index8 % 256) == 0,
+               MEVI_ERR_INVALID_ARG, "ip_topk_indexed8: misaligned pointer");
+  MEVI_REQUIRE(id_offset >= 0 && id_offset + nd < 0xFFFFFFFFLL, MEVI_ERR_UNSUPPORTED, "ip_topk_indexed8: ids out of range");
+  g_stats = {0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0};
+  for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
+  g_events.clear();
+  const int kp = h8_kprime((int)k);
+  const TopkGeom gp = make_geom(kp, nq);
+  const int64_t dimp = pad_k(dim);
+  const IndexView iv = view_index(index, nd, dim);
+  const Index8View v8 = view_index8(index8, nd, dim);
+  char *p = reinterpret_cast<char *>(workspace);
+  SearchState st = carve_state(p, nq, gp);
+  unsigned long long *top = reinterpret_cast<unsigned long long *>(p);
+  p += align_up((size_t)nq * k * 8, 256);
+  float *qimage = reinterpret_cast<float *>(p);  // two int8 digit images of the 32-row query tile
+  p += align_up((size_t)dimp * 64, 256);
+  float *qnorm = reinterpret_cast<float *>(p);
+  p += align_up((size_t)(nq + 1) * 4, 256);
+  float *qinv = reinterpret_cast<float *>(p);
+  p += align_up((size_t)(nq + 1) * 4, 256);
+  float *qdelta = reinterpret_cast<float *>(p);
+  p += align_up((size_t)(nq + 1) * 4, 256);
+  float *qn16 = reinterpret_cast<float *>(p);
+  p += align_up((size_t)(nq + 1) * 4, 256);
+  double *qshift = reinterpret_cast<double *>(p);
+  p += align_up((size_t)nq * 8, 256);
+  float *qub = reinterpret_cast<float *>(p);       // [32] G_q
+  p += 256;
+  unsigned int *qbad = reinterpret_cast<unsigned int *>(p);   // [32] queries the 8-bit pass must not answer
+  const float c1 = (float)(1.001 / 4194304.0), c2 = h1_c2(dim);   // c1: three roundings of the key's float form (< 2^-22)
+
+  hipLaunchKernelGGL(split_queries_i8_kernel, dim3(8), dim3(256), 0, stream, q, (int)nq, (int)dim, (int)dimp, iv.mu, v8.cscale,
+                     reinterpret_cast<signed char *>(qimage), qnorm, qinv, qshift, qdelta, qn16, v8.bits, qub, qbad);
+  const int64_t launches = run_pass(qimage, nq, v8.image, nd, (int)dimp, gp, (uint32_t)id_offset, st, false, stream, true, nullptr, v8.scale, qub);
+  if (launches < 0) return MEVI_ERR_HIP;
+  int P = 64;
+  while (P < kp) P <<= 1;
+  unsigned int *err_bits = reinterpret_cast<unsigned int *>(qnorm + nq);
+  MEVI_HIP_CHECK(hipMemsetAsync(err_bits, 0, 4, stream));
+  {
+    const long long waves = nq * (long long)((kp + 63) / 64);
+    // every survivor is re-scored (the keys are upper bounds: no lower bound to exclude against)
+    hipLaunchKernelGGL(rescore_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, q, docs, (int)dim, st.buf,
+                       gp.S, kp, (int)nq, (unsigned int)id_offset, qnorm, qinv, qshift, c1, c2, v8.bits, v8.ynorm, err_bits, qdelta, qn16,
+                       (const float *)nullptr, 1);
+    hipLaunchKernelGGL(rescore_finish_kernel, dim3((unsigned)nq), dim3(256), (size_t)P * 8, stream, st.buf, gp.S, (int)k, kp,
+                       st.tau, qnorm, qinv, qshift, c1, c2, v8.bits, st.failed, top, (int)k, qdelta, qn16);
+  }
+  const long long total = nq * (long long)k;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, top, (int)k, (int)k,
+                     (long long)nq, out_score, reinterpret_cast<long long *>(out_id));
+  unsigned int err_host = 0;
+  MEVI_HIP_CHECK(hipMemcpyAsync(&err_host, err_bits, 4, hipMemcpyDeviceToHost, stream));
+  MEVI_HIP_CHECK(hipGetLastError());
+  unsigned int failed[32], bad[32];
+  MEVI_HIP_CHECK(hipMemcpyAsync(failed, st.failed, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+  MEVI_HIP_CHECK(hipMemcpyAsync(bad, qbad, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+  MEVI_HIP_CHECK(hipStreamSynchronize(stream));
+  profile_collect();
+  float ratio;
+  memcpy(&ratio, &err_host, 4);
+  int64_t open = 0;
+  for (int64_t i = 0; i < nq; ++i) open += (failed[i] || bad[i]) ? 1 : 0;
+  if (!(ratio <= 1.0f)) open = nq;   // an observation above the bound: its premise is false (as the f16 search's safety net)
+  g_stats.n_chunks = launches;
+  g_stats.max_err_ratio = ratio;
+  g_stats.err_bound = 1.0;
+  g_stats.n_i8_queries = nq;
+  g_stats.n_i8_unproven = open;
+  if (open == 0) return MEVI_OK;
+  // some list is not proven: the whole (small) batch through the f16 search, which has its own second pass and fallback
+  const mevi_ip_topk_stats first = g_stats;
+  const int rc = mevi_ip_topk_indexed_f32(q, nq, docs, index, nd, dim, k, id_offset, out_score, out_id, inner_ws, inner_bytes, stream_);
+  g_stats.n_i8_queries = first.n_i8_queries;
+  g_stats.n_i8_unproven = first.n_i8_unproven;
+  g_stats.n_chunks += first.n_chunks;
+  g_stats.filter_ms += first.filter_ms;
+  g_stats.compact_ms += first.compact_ms;
+  g_stats.filter_flops += first.filter_flops;
+  return rc;
 }
 
 extern "C" size_t mevi_topk_merge_workspace_bytes(int64_t, int64_t, int64_t, int64_t) { return 0; }

@@ -71,6 +71,50 @@ class DenseIndex:
         with hip.device_guard(docs.device):
             st = L.mevi_ip_index_build_f32(hip.ptr(self.docs), nd, dim, hip.ptr(self.index), nbytes, hip.stream_ptr())
         hip.check(st, "mevi_ip_index_build_f32")
+        self.index8 = None          # the 8-bit image for searches of <= 32 queries: built by the first of them
+        self._i8_open = {}          # per k: running share of small searches the 8-bit pass left unproven (above I8_GIVE_UP: not used)
+
+    SMALL_QUERIES = 32              # searches up to this many queries go through the 8-bit image (csrc/ip_topk.hip: i8_eligible)
+    I8_GIVE_UP = 0.4                # ... while the running share of searches it had to repeat through the f16 image stays below this
+                                    # (a repeated search costs both passes: the 8-bit image pays as long as t8 + p t16 < t16, t8 ~ 0.55 t16)
+
+    def small_image_wanted(self, nq, k):
+        nd, dim = self.docs.shape
+        dimp = max(128, (dim + 63) // 64 * 64)
+        return (0 < nq <= self.SMALL_QUERIES and nd >= int(os.environ.get("MEVI_IP_I8_MIN_ROWS", "65536")) and 256 <= dimp <= 896 and 3 * k + 128 <= 4096
+                and os.environ.get("MEVI_IP_I8", "1") != "0" and self._i8_open.get(k, 0) < self.I8_GIVE_UP)
+
+    def prepare_small(self):
+        """Build the 8-bit image now (otherwise the first small search does): nd * dim bytes + 8 per row, one pass over the rows."""
+        if self.index8 is None:
+            nd, dim = self.docs.shape
+            L = hip.lib()
+            nbytes = L.mevi_ip_index8_bytes(nd, dim)
+            index8 = torch.empty(nbytes, dtype=torch.uint8, device=self.docs.device)
+            with hip.device_guard(self.docs.device):
+                st = L.mevi_ip_index8_build_f32(hip.ptr(self.docs), hip.ptr(self.index), nd, dim, hip.ptr(index8), nbytes, hip.stream_ptr())
+            hip.check(st, "mevi_ip_index8_build_f32")
+            self.index8 = index8
+        return self
+
+    def _search_small(self, query, k, id_offset, out_s, out_i):
+        nq, dim = query.shape
+        nd = self.docs.shape[0]
+        L = hip.lib()
+        self.prepare_small()
+        ws_bytes = L.mevi_ip_topk_indexed8_workspace_bytes(nq, dim, k)
+        if ws_bytes == 0:
+            raise hip.MeviHipError(f"ip_topk_indexed8: unsupported shape nq={nq} dim={dim} k={k}")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=query.device)
+        with hip.device_guard(query.device):
+            st = L.mevi_ip_topk_indexed8_f32(hip.ptr(query), nq, hip.ptr(self.docs), hip.ptr(self.index), hip.ptr(self.index8), nd, dim, k,
+                                             id_offset, hip.ptr(out_s), hip.ptr(out_i), hip.ptr(ws), ws_bytes, hip.stream_ptr())
+        hip.check(st, "mevi_ip_topk_indexed8_f32")
+        stats = hip.IpTopkStats()
+        L.mevi_ip_topk_get_stats(stats)
+        if stats.n_i8_queries:      # a corpus whose scores are too dense for the 8-bit bound pays both searches: stop trying
+            self._i8_open[k] = 0.75 * self._i8_open.get(k, 0.0) + (0.25 if stats.n_i8_unproven else 0.0)
+        return out_s, out_i
 
     def search(self, query, k, id_offset=0):
         assert query.is_cuda and query.dtype == torch.float32 and query.dim() == 2 and query.shape[1] == self.docs.shape[1]
@@ -82,6 +126,8 @@ class DenseIndex:
         out_i = torch.empty((nq, k), dtype=torch.int64, device=query.device)
         if nq == 0:
             return out_s, out_i
+        if self.small_image_wanted(nq, k):
+            return self._search_small(query, k, id_offset, out_s, out_i)
         ws_bytes = L.mevi_ip_topk_indexed_workspace_bytes(nq, dim, k)
         if ws_bytes == 0:
             raise hip.MeviHipError(f"ip_topk_indexed: unsupported shape nq={nq} dim={dim} k={k}")

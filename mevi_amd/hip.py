@@ -22,7 +22,8 @@ class IpTopkStats(ctypes.Structure):
     _fields_ = [("n_chunks", c_int64), ("n_failed_queries", c_int64), ("n_fallback_chunks", c_int64),
                 ("filter_ms", c_double), ("compact_ms", c_double), ("filter_flops", c_double),
                 ("max_err_ratio", c_double), ("err_bound", c_double), ("n_second_pass_queries", c_int64),
-                ("n_filter_candidates", c_int64), ("max_launch_candidates", c_int64), ("n_list_overflows", c_int64)]
+                ("n_filter_candidates", c_int64), ("max_launch_candidates", c_int64), ("n_list_overflows", c_int64),
+                ("n_i8_queries", c_int64), ("n_i8_unproven", c_int64)]
 
 
 _SIGNATURES = {
@@ -36,6 +37,11 @@ _SIGNATURES = {
     "mevi_ip_topk_indexed_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mevi_ip_topk_indexed_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mevi_ip_index8_bytes": (c_size_t, [c_int64, c_int64]),
+    "mevi_ip_index8_build_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "mevi_ip_topk_indexed8_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "mevi_ip_topk_indexed8_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mevi_topk_merge_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "mevi_topk_merge_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

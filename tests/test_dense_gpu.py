@@ -622,3 +622,120 @@ def test_sampled_threshold_on_row_orders_that_break_its_premise(cuda, order):
         if order != "ties at the threshold" and run is _run_indexed:    # query 0 at least was flagged: second pass / guaranteed path
             assert st.n_failed_queries + st.n_second_pass_queries >= 1, order    # (the exact path's 3096-slot area at k = 1000 is too
                                                                                  # small for the sampled launch: geometric schedule)
+
+
+# ---- round 6 (late): the 8-bit image of small searches --------------------------------------------------------------
+def _small_index(d, cuda, monkeypatch):
+    monkeypatch.setenv("MEVI_IP_I8_MIN_ROWS", "0")
+    return dense.DenseIndex(torch.from_numpy(d).to(cuda))
+
+
+@pytest.mark.parametrize("nq,nd,dim,k", [
+    (1, 70000, 768, 100), (2, 33333, 768, 1000), (8, 50001, 768, 10), (32, 20000, 768, 300), (7, 9000, 256, 50),
+    (3, 12345, 200, 64), (31, 257, 768, 100), (4, 300000, 768, 1000), (32, 4097, 320, 1), (5, 1000, 896, 1300),
+])
+def test_small_searches_through_the_8_bit_image_return_the_oracles_lists(cuda, monkeypatch, nq, nd, dim, k):
+    """<= 32 queries: int8 image + integer matrix cores + upper-bound keys + exact re-scoring + proof (mevi_ip_topk_indexed8_f32)
+    must return the oracle's lists bit for bit -- padded dims (200 -> 256), ragged last blocks, k = 1, k past the corpus, a
+    non-zero id offset; and the 8-bit pass must be what ran and proved them on Gaussian rows."""
+    rng = np.random.default_rng(nq * 131 + nd + dim)
+    q = rng.standard_normal((nq, dim), dtype=np.float32)
+    d = rng.standard_normal((nd, dim), dtype=np.float32)
+    d += 0.3                                                     # a common component (the image is centred)
+    idx = _small_index(d, cuda, monkeypatch)
+    for off in (0, 1_000_003):
+        s, i = idx.search(torch.from_numpy(q).to(cuda), k, id_offset=off)
+        st = _stats()
+        es, ei = odense.ip_topk_exact(q, d, k, off)
+        np.testing.assert_array_equal(i.cpu().numpy(), ei)
+        np.testing.assert_array_equal(s.cpu().numpy().view(np.uint32), es.view(np.uint32))
+        if 3 * k + 128 <= 4096:
+            assert st.n_i8_queries == nq and st.max_err_ratio <= 1.0, (st.n_i8_queries, st.max_err_ratio)
+            if k * 8 < nd:
+                assert st.n_i8_unproven == 0, st.n_i8_unproven
+        else:
+            assert st.n_i8_queries == 0                          # 3 k + 64 survivors would not fit the proof kernel's sort
+    assert idx.index8 is not None or 3 * k + 128 > 4096
+
+
+@pytest.mark.parametrize("case", ["massive ties", "outlier rows and columns", "zero rows and a zero query", "best rows last", "non-finite row"])
+def test_8_bit_image_on_inputs_that_break_its_premises(cuda, monkeypatch, case):
+    """What the 8-bit bound cannot prove goes through the f16 image (and what that cannot prove through the exact path): the
+    lists are the oracle's in every case, and the share of repeated searches switches the 8-bit pass off for that k."""
+    rng = np.random.default_rng(len(case))
+    nq, nd, dim, k = 9, 40000, 768, 20
+    q = rng.standard_normal((nq, dim), dtype=np.float32)
+    d = rng.standard_normal((nd, dim), dtype=np.float32)
+    if case == "massive ties":
+        d = d[:50][rng.integers(0, 50, nd)].copy()               # 50 distinct rows: every score 800 times
+    elif case == "outlier rows and columns":
+        d[:, 5] *= 300.0
+        d[:, 700] *= 1e-4
+        d[rng.integers(0, nd, 40)] *= 50.0                        # long rows (their step is coarse, their scores large)
+        d[rng.integers(0, nd, 40), rng.integers(0, dim, 40)] = 900.0   # single huge coordinates
+        q[2] *= 1e-8
+    elif case == "zero rows and a zero query":
+        d[::7] = 0.0
+        q[4] = 0.0
+    elif case == "best rows last":
+        d = d[np.argsort(d @ q[0])].copy()
+    elif case == "non-finite row":
+        d[123, 45] = np.inf
+    idx = _small_index(d, cuda, monkeypatch)
+    tq = torch.from_numpy(q).to(cuda)
+    unproven = 0
+    for rep in range(4):
+        s, i = idx.search(tq, k)
+        st = _stats()
+        unproven += int(st.n_i8_unproven > 0)
+        if case == "non-finite row":                              # (the oracle's chain and the kernel's agree on inf / nan placement
+            ref_s, ref_i = dense.ip_topk(tq, idx.docs, k)        #  only through the same exact path: compare with that)
+            assert torch.equal(i, ref_i) and torch.equal(s.view(torch.int32), ref_s.view(torch.int32))
+        else:
+            es, ei = odense.ip_topk_exact(q, d, k)
+            np.testing.assert_array_equal(i.cpu().numpy(), ei)
+            np.testing.assert_array_equal(s.cpu().numpy().view(np.uint32), es.view(np.uint32))
+        assert st.max_err_ratio <= 1.0
+    if case == "non-finite row":                                  # the same through the f16 image alone (33 queries)
+        q33 = torch.cat([tq] * 4)[:33].contiguous()
+        s33, i33 = idx.search(q33, k)
+        r33s, r33i = dense.ip_topk(q33, idx.docs, k)
+        assert torch.equal(i33, r33i) and torch.equal(s33.view(torch.int32), r33s.view(torch.int32))
+    if case in ("massive ties", "non-finite row"):
+        assert unproven == 2 and idx._i8_open[k] > idx.I8_GIVE_UP   # two repeated searches, then the f16 image directly
+        assert not idx.small_image_wanted(nq, k) and idx.small_image_wanted(nq, k + 1)
+    # (the other cases may or may not be proven by the short survivor list: a zero query ties every row, a row with one huge
+    #  coordinate doubles rho, best-rows-last breaks the sampled threshold's premise -- the lists above are what is asserted)
+
+
+def test_8_bit_image_through_the_c_abi_and_its_switches(cuda, monkeypatch):
+    """mevi_ip_topk_indexed8_f32 with index8 = NULL, with a shape outside the 8-bit pass (33 queries) and under MEVI_IP_I8=0 is
+    mevi_ip_topk_indexed_f32; realistic corpora (tools/synth.py) return the exact path's lists through the 8-bit image."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+
+    L = hip.lib()
+    for kind in synth.CORPUS_KINDS:
+        docs, info = synth.corpus(kind, cuda, 150_000, 768, block=16384, n_clusters=40)
+        q, _ = synth.corpus_queries(kind, docs, 33, info)
+        monkeypatch.setenv("MEVI_IP_I8_MIN_ROWS", "0")
+        idx = dense.DenseIndex(docs).prepare_small()
+        for nq, k in ((1, 10), (32, 100), (8, 1000), (33, 100)):
+            es, ei = dense.ip_topk(q[:nq].contiguous(), docs, k)
+            s, i = idx.search(q[:nq].contiguous(), k)
+            st = _stats()
+            assert torch.equal(i, ei) and torch.equal(s.view(torch.int32), es.view(torch.int32)), (kind, nq, k)
+            assert st.n_i8_queries == (nq if nq <= 32 else 0)
+            # the C entry point with no 8-bit image: the f16 search
+            ws = torch.empty(L.mevi_ip_topk_indexed8_workspace_bytes(nq, 768, k), dtype=torch.uint8, device=cuda)
+            s2, i2 = torch.empty_like(s), torch.empty_like(i)
+            rc = L.mevi_ip_topk_indexed8_f32(hip.ptr(q), nq, hip.ptr(docs), hip.ptr(idx.index), None, docs.shape[0], 768, k, 0,
+                                             hip.ptr(s2), hip.ptr(i2), hip.ptr(ws), ws.numel(), hip.stream_ptr())
+            assert rc == 0 and _stats().n_i8_queries == 0
+            assert torch.equal(i2, ei) and torch.equal(s2.view(torch.int32), es.view(torch.int32))
+        del idx, docs
+        torch.cuda.empty_cache()
+    monkeypatch.setenv("MEVI_IP_I8", "0")
+    assert not dense.DenseIndex(torch.randn(70000, 768, device=cuda)).small_image_wanted(4, 10)
