@@ -230,7 +230,8 @@ def dense_small_batch(device, index, query, n_docs):
     """The reference's own timing hook for the dense arm is small batches (faiss_search.profile, MEVI/faiss_search.py:32-68:
     search at batch 1 / 2 / 4 / 8 x 10 batches).  With few queries the filter is bound by streaming the corpus' f16 image
     ("at query micro-batch <= 64 it flips to HBM"): ms per search on resident tensors, HBM rate of the image."""
-    image_bytes = float(n_docs) * DIM * 2
+    from mevi_amd import hip
+
     per = []
     for bs in (1, 2, 4, 8, 32, 64, 128, 255):
         row = {"batch": bs}
@@ -240,25 +241,34 @@ def dense_small_batch(device, index, query, n_docs):
             torch.cuda.synchronize()
             reps = 10
             t = time.perf_counter()
+            unproven = 0
             for r in range(reps):
                 index.search(query[r * bs:(r + 1) * bs].contiguous(), kk)
+                st = hip.IpTopkStats()
+                hip.lib().mevi_ip_topk_get_stats(st)
+                unproven += int(st.n_i8_unproven > 0)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t) / reps * 1e3
-            row["top%d" % kk] = {"ms_per_search": round(ms, 3), "queries_per_s": round(bs / ms * 1e3, 1),
+            i8 = st.n_i8_queries > 0
+            image_bytes = float(n_docs) * (DIM + 4) if i8 else float(n_docs) * DIM * 2   # int8 rows + their scales | f16 rows
+            row["top%d" % kk] = {"ms_per_search": round(ms, 3), "queries_per_s": round(bs / ms * 1e3, 1), "image": "int8" if i8 else "f16",
                                  "image_gb_per_s": round(image_bytes / ms / 1e6, 1),
                                  "frac_of_hbm_peak": round(image_bytes / ms / 1e6 / 8000.0, 3)}
+            if i8:
+                row["top%d" % kk]["searches_repeated_through_f16"] = unproven
         per.append(row)
     best = per[0]["top%d" % TOPK]
     return {"what": "faiss_search.profile's regime: ONE index.search call of <batch> queries over the resident corpus (top-%d as the "
                     "scripts ask, and top-100), mean of 10 calls, inputs and outputs on the device" % TOPK,
-            "dtype": "f16 pre-filter (selection) + exact f32 chains (results)",
-            "kernel": "ip_filter_h1_small_kernel for batch <= 32 (stationary query tile, every wave streaming its own corpus rows), "
+            "dtype": "batch <= 32: int8 pre-filter (exact int32 sums, upper-bound keys); above: f16 pre-filter; results: exact f32 chains",
+            "kernel": "ip_filter_i8_small_kernel for batch <= 32 (8-bit image, stationary query tile in two int8 digits, every wave streaming "
+                      "its own corpus rows; MEVI_IP_I8=0: ip_filter_h1_small_kernel on the f16 image), "
                       "ip_filter_h16_kernel<2> / <4> (query tiles of 64 / 128) up to 128 queries, the 256-query tile above; the last launch of "
                       "a pass takes all remaining rows under a threshold estimated from the rows seen (rank_tau_kernel; exact by sample_check_kernel)",
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
-                         "algorithmic_bytes_per_search": image_bytes,
-                         "note": "bytes = the corpus' f16 image (N x 768 x 2), read once per search; the f32 rows of the re-scored "
-                                 "survivors (K' x 3 KB per query) are not counted; the guide's achievable copy rate is 6.3 TB/s",
+                         "algorithmic_bytes_per_search": float(n_docs) * (DIM + 4) if best["image"] == "int8" else float(n_docs) * DIM * 2,
+                         "note": "bytes = the image the search reads once (int8: N x (768 + 4); f16: N x 768 x 2 -- per row in per_batch); the f32 "
+                                 "rows of the re-scored survivors (K' x 3 KB per query) are not counted; the guide's achievable copy rate is 6.3 TB/s",
                          "achieved": best["image_gb_per_s"], "frac": best["frac_of_hbm_peak"]},
             "per_batch": per}
 

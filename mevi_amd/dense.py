@@ -430,6 +430,8 @@ def profile(query, doc, dim, topk, param, bs=[1, 2, 4, 8], device=None):
         all_time["train"] += time.time() - t
         t = time.time()
         index = ivf.IVFFlatIndex(d, nlist, centroids=cent) if use_ivf else (DenseIndex(d) if topk <= MAX_K else None)
+        if isinstance(index, DenseIndex) and any(index.small_image_wanted(b, topk) for b in bs):
+            index.prepare_small()                               # the 8-bit image of the small batches is part of index.add
         torch.cuda.synchronize()
         all_time["add"] += upload + time.time() - t
 

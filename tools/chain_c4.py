@@ -85,7 +85,7 @@ def latency_b1(model, tower, dindex, fs, ids, mask, M, K, R, topk, n=24):
     out["chain_in_sequence_ms"] = round(med(whole), 3)
     out["note"] = ("one query, resident model / corpus / index, tower and beam search as HIP-graph replays (same bits as the batched "
                    "path); the beam search's figure includes the 10 x M token read-back and decode_token, the fine stage its host-side "
-                   "cluster look-up; weight-streaming floors: tower 0.89 GB, NCI 1.25 GB, dense 13.6 GB of f16 image per query")
+                   "cluster look-up; weight-streaming floors: tower 0.89 GB, NCI 1.25 GB, dense 6.9 GB of int8 image per query (13.6 GB of f16 image with MEVI_IP_I8=0)")
     return out
 
 
