@@ -232,6 +232,10 @@ def dense_small_batch(device, index, query, n_docs):
     ("at query micro-batch <= 64 it flips to HBM"): ms per search on resident tensors, HBM rate of the image."""
     from mevi_amd import hip
 
+    t = time.perf_counter()
+    index.prepare_small()              # the 8-bit image of the <= 32-query searches (faiss_search.profile builds it inside `add`)
+    torch.cuda.synchronize()
+    index8_ms = (time.perf_counter() - t) * 1e3
     per = []
     for bs in (1, 2, 4, 8, 32, 64, 128, 255):
         row = {"batch": bs}
@@ -270,7 +274,7 @@ def dense_small_batch(device, index, query, n_docs):
                          "note": "bytes = the image the search reads once (int8: N x (768 + 4); f16: N x 768 x 2 -- per row in per_batch); the f32 "
                                  "rows of the re-scored survivors (K' x 3 KB per query) are not counted; the guide's achievable copy rate is 6.3 TB/s",
                          "achieved": best["image_gb_per_s"], "frac": best["frac_of_hbm_peak"]},
-            "per_batch": per}
+            "index8_build_ms": round(index8_ms, 1), "per_batch": per}
 
 
 def index_build_leg(device, docs, rn, n_docs):

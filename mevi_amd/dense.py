@@ -73,8 +73,12 @@ class DenseIndex:
         hip.check(st, "mevi_ip_index_build_f32")
         self.index8 = None          # the 8-bit image for searches of <= 32 queries: built by the first of them
         self._i8_open = {}          # per k: running share of small searches the 8-bit pass left unproven (above I8_GIVE_UP: not used)
+        self._small_calls = 0       # small searches seen so far (the image is built when they keep coming: SMALL_BUILD_AFTER)
 
     SMALL_QUERIES = 32              # searches up to this many queries go through the 8-bit image (csrc/ip_topk.hip: i8_eligible)
+    SMALL_BUILD_AFTER = 8           # ... once the index has seen this many of them: building the image is two passes over the rows
+                                    # (42 ms at 8.8 M x 768 = the saving of ~40 searches) -- an index made for one search never pays it;
+                                    # prepare_small() builds it at once (faiss_search.profile does, inside its `add` time)
     I8_GIVE_UP = 0.4                # ... while the running share of searches it had to repeat through the f16 image stays below this
                                     # (a repeated search costs both passes: the 8-bit image pays as long as t8 + p t16 < t16, t8 ~ 0.55 t16)
 
@@ -127,7 +131,9 @@ class DenseIndex:
         if nq == 0:
             return out_s, out_i
         if self.small_image_wanted(nq, k):
-            return self._search_small(query, k, id_offset, out_s, out_i)
+            self._small_calls += 1
+            if self.index8 is not None or self._small_calls > self.SMALL_BUILD_AFTER:
+                return self._search_small(query, k, id_offset, out_s, out_i)
         ws_bytes = L.mevi_ip_topk_indexed_workspace_bytes(nq, dim, k)
         if ws_bytes == 0:
             raise hip.MeviHipError(f"ip_topk_indexed: unsupported shape nq={nq} dim={dim} k={k}")

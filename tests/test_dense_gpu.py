@@ -627,7 +627,7 @@ def test_sampled_threshold_on_row_orders_that_break_its_premise(cuda, order):
 # ---- round 6 (late): the 8-bit image of small searches --------------------------------------------------------------
 def _small_index(d, cuda, monkeypatch):
     monkeypatch.setenv("MEVI_IP_I8_MIN_ROWS", "0")
-    return dense.DenseIndex(torch.from_numpy(d).to(cuda))
+    return dense.DenseIndex(torch.from_numpy(d).to(cuda)).prepare_small()
 
 
 @pytest.mark.parametrize("nq,nd,dim,k", [
@@ -737,5 +737,13 @@ def test_8_bit_image_through_the_c_abi_and_its_switches(cuda, monkeypatch):
             assert torch.equal(i2, ei) and torch.equal(s2.view(torch.int32), es.view(torch.int32))
         del idx, docs
         torch.cuda.empty_cache()
+    # an index that sees only a few small searches never builds the image; the ninth does
+    idx = dense.DenseIndex(torch.randn(70000, 768, device=cuda))
+    q4 = torch.randn(4, 768, device=cuda)
+    es, ei = dense.ip_topk(q4, idx.docs, 10)
+    for n in range(1, idx.SMALL_BUILD_AFTER + 2):
+        s, i = idx.search(q4, 10)
+        assert torch.equal(i, ei) and torch.equal(s.view(torch.int32), es.view(torch.int32))
+        assert (idx.index8 is not None) == (n > idx.SMALL_BUILD_AFTER) and (_stats().n_i8_queries == 4) == (n > idx.SMALL_BUILD_AFTER)
     monkeypatch.setenv("MEVI_IP_I8", "0")
     assert not dense.DenseIndex(torch.randn(70000, 768, device=cuda)).small_image_wanted(4, 10)

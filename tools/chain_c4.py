@@ -61,6 +61,7 @@ def latency_b1(model, tower, dindex, fs, ids, mask, M, K, R, topk, n=24):
 
     nq = ids.shape[0]
     one = lambda i: (ids[i % nq:i % nq + 1], mask[i % nq:i % nq + 1])       # noqa: E731
+    dindex.prepare_small()      # a resident service's index: the 8-bit image of its single-query searches is built up front
 
     def tower_q(i):
         a, m = one(i)

@@ -47,7 +47,10 @@ while time.time() - t0 < budget:
             sc = docs @ q[0]
             docs = docs[torch.argsort(sc, descending=(kind == "sorted_down"))].contiguous()
     es, ei = dense.ip_topk(q, docs, k)
-    s, i = dense.DenseIndex(docs).search(q, k)
+    index = dense.DenseIndex(docs)
+    if os.environ.get("MEVI_IP_I8_MIN_ROWS") == "0":    # drive the <= 32-query cases through the 8-bit image (built on demand otherwise)
+        index.prepare_small()
+    s, i = index.search(q, k)
     torch.cuda.synchronize()
     st = hip.IpTopkStats()
     L.mevi_ip_topk_get_stats(st)
@@ -61,6 +64,6 @@ while time.time() - t0 < budget:
         bad = (i != ei).any(1).nonzero().view(-1)[:5].tolist()
         print("   first differing queries:", bad)
         sys.exit(1)
-    del docs, q, s, i, es, ei
+    del docs, q, s, i, es, ei, index
     torch.cuda.empty_cache()
 print(f"{n_cases} cases, all identical to the exact-f32 path; searches with a second pass {fired['second_pass']}, with an exact fallback {fired['fallback']}")
