@@ -58,7 +58,8 @@ class DenseIndex:
     """A corpus shard prepared for searching -- the analogue of faiss `index.add(doc)`
     (MEVI/faiss_search.py:19): keeps the f32 rows and their centred, scaled f16 image (+ norms, mean, scales).
     `search` returns exactly what `ip_topk` returns (bit for bit), ~3x faster: candidates are
-    selected with f16 MFMAs, re-scored with the exact f32 chain and proven complete per query."""
+    selected with f16 MFMAs, re-scored with the exact f32 chain and proven complete per query.  Searches of up to 32 queries
+    select through an int8 image instead (half the bytes of the HBM-bound small search; DESIGN 4.1c'): same lists."""
 
     def __init__(self, docs):
         hip.require_gpu()
@@ -71,7 +72,7 @@ class DenseIndex:
         with hip.device_guard(docs.device):
             st = L.mevi_ip_index_build_f32(hip.ptr(self.docs), nd, dim, hip.ptr(self.index), nbytes, hip.stream_ptr())
         hip.check(st, "mevi_ip_index_build_f32")
-        self.index8 = None          # the 8-bit image for searches of <= 32 queries: built by the first of them
+        self.index8 = None          # the 8-bit image for searches of <= 32 queries (prepare_small, or once they keep coming)
         self._i8_open = {}          # per k: running share of small searches the 8-bit pass left unproven (above I8_GIVE_UP: not used)
         self._small_calls = 0       # small searches seen so far (the image is built when they keep coming: SMALL_BUILD_AFTER)
 
@@ -89,7 +90,8 @@ class DenseIndex:
                 and os.environ.get("MEVI_IP_I8", "1") != "0" and self._i8_open.get(k, 0) < self.I8_GIVE_UP)
 
     def prepare_small(self):
-        """Build the 8-bit image now (otherwise the first small search does): nd * dim bytes + 8 per row, one pass over the rows."""
+        """Build the 8-bit image now (otherwise the search after SMALL_BUILD_AFTER small ones does): nd * dim bytes + 8 per row,
+        two passes over the rows (column scales, then the image)."""
         if self.index8 is None:
             nd, dim = self.docs.shape
             L = hip.lib()
