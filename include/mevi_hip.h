@@ -93,11 +93,12 @@ int mevi_ip_topk_indexed_f32(const float *q, int64_t nq, const float *docs, cons
  * filter is bound by reading the corpus image from HBM; an int8 image is half the f16 one.  The integer matrix cores
  * accumulate exactly, so the approximate score's whole error is the two quantisations, both measured (per-column scales c
  * folded into the query, per-row scales s_r; queries in two int8 digits):
- *   exact <= t_q s_r (N + rho ||w|| / t_q) + q.mu + ||w - w^|| max||y^|| + 3 ulp + c2 ||q|| max||d||,
- *   w = q * c, y = (d - mu) / c, y^ = s_r * int8 row, w^ = t_q * 15-bit integer query, N = the exact int32 sum,
- *   rho = max over rows of ||y - y^|| / s_r (a row's quantisation error in units of its own step; measured at build):
- * rows are ranked by that UPPER BOUND of their score (the row's own error term is inside the key), so a row outside the
- * survivors is bounded by the last survivor's key plus the query-side terms only.
+ *   exact <= t_q s_r (N + (rho ||w|| + eta ||w - w^||) / t_q) + q.mu + 3 ulp + c2 ||q|| max||d||,
+ *   w = q * c, y = (d - mu) / c, y^ = s_r * int8 row I_r, w^ = t_q * 15-bit integer query, N = the exact int32 sum,
+ *   rho = max over rows of ||y - y^|| / s_r (a row's quantisation error in units of its own step), eta = max ||I_r|| (both
+ *   measured at build):
+ * rows are ranked by that UPPER BOUND of their score (both quantisation terms are inside the key, per row through s_r), so a
+ * row outside the survivors is bounded by the last survivor's key plus rounding only.
  * The bound is ~100x the f16 one, so 3 k + 64 survivors are re-scored (exact f32 chains) instead of 1.25 k; lists are proven
  * complete per query exactly as in the f16 search, and when any list of the batch stays open the call runs
  * mevi_ip_topk_indexed_f32 for the batch (same results either way, bit for bit).  Shapes outside the 8-bit pass (nq > 32,

@@ -1348,10 +1348,12 @@ __global__ __launch_bounds__(512, 2) void ip_filter_h1_small_kernel(
 // proof, 3 k survivors prove top-10 but not top-100 / top-1000 of 8.8 M rows.  So the term is carried PER ROW, inside the key:
 // ||y - y^||_r <= rho s_r with rho = max_r ||y - y^||_r / s_r (the quantisation noise of a row is uniform in its own step: 8.0
 // +- 0.7 at dim 768; measured at build), and the filter ranks rows by an UPPER BOUND of their centred score,
-//   key_r = fl((fl(128 N_hi + N_lo) + G_q) s_r),   G_q = rho ||w|| / t_q      (t_q key_r >= w.y_r - what is left below)
-// A row outside the K' survivors has key <= the K'-th key, so the proof needs only what is left: the query's quantisation
-// ||w - w^|| max ||y^|| and 3 ulp for the float form of the key (|N_hi|, |N_lo| < 2^24 for dimp <= 1024).  That is
-// h1_err_bound with (qdelta, qn16, dn, ddmax, c_acc) = (||w - w^||, ||w|| + ||w - w^||, ||y^||, 2^-20 rho max s_r, 2^-22): the
+//   key_r = fl((fl(128 N_hi + N_lo) + G_q) s_r),   G_q = (rho ||w|| + eta ||w - w^||) / t_q      (t_q key_r >= w.y_r - 3 ulp)
+// with eta = max_r ||I_r|| (the query's quantisation against row r is at most ||w - w^|| s_r ||I_r||: per row as well, +2.5 %
+// on G_q, and rows of extreme length no longer widen every other row's bound through max ||y^||).
+// A row outside the K' survivors has key <= the K'-th key, so the proof needs only what is left: 3 ulp for the float form of
+// the key (|N_hi|, |N_lo| < 2^24 for dimp <= 1024).  That is
+// h1_err_bound with (qdelta, qn16, dn, ddmax, c_acc) = (0, ||w|| + ||w - w^||, ||y^||, 2^-20 rho max s_r, 2^-22): the
 // re-scoring, the proof and the observed / bound check (one-sided here: exact - key) are the SAME kernels as the f16
 // search's, with qinv = t_q; the exclusion of survivors is not used (its lower bound would need the two-sided error).
 // K' = 3 k + 64 (h8_kprime) instead of 1.25 k: re-scoring 3 k rows per query is nothing for <= 32 queries, and would be everything for 7 k.
@@ -1462,6 +1464,9 @@ __global__ __launch_bounds__(256) void split_docs_i8_kernel(const float *__restr
     if (rb > __atomic_load_n(&bits[2], __ATOMIC_RELAXED)) atomicMax(&bits[2], rb);
     const unsigned int sb = __float_as_uint(s);
     if (sb > __atomic_load_n(&bits[5], __ATOMIC_RELAXED)) atomicMax(&bits[5], sb);
+    const float eta = s > 0.f ? (float)(sqrt(yy) / (double)s) * 1.0001f : 0.f;   // ||I_r||, the length of the int8 row (<= 127 sqrt(dim))
+    const unsigned int hb = __float_as_uint(eta <= 3.0e38f ? eta : 3.0e38f);
+    if (hb > __atomic_load_n(&bits[6], __ATOMIC_RELAXED)) atomicMax(&bits[6], hb);
   }
 }
 // bits[1] = max ||d|| of the f16 index (the f32 chain's own term of the bound); bits[3] = 2^-20 rho max s_r (what the proof's
@@ -1475,8 +1480,8 @@ __global__ void finish_bits8_kernel(const unsigned int *__restrict__ src, unsign
 }
 
 // queries (<= 32) -> two int8 digit images [digit][unit][32 rows][64 B] of round(q_k c_k / t_q); qnorm = ||q|| (up), qinv = t_q,
-// qshift = q.mu (f64), qdelta = ||w - w^|| (up), qn16 = ||w|| + ||w - w^|| (up), qub = G_q (the key's per-row error term in
-// raw units).  One wave per row, rows >= n zero.
+// qshift = q.mu (f64), qdelta = 0 (the query's quantisation is inside G_q), qn16 = ||w|| + ||w - w^|| (up), qub = G_q (the key's
+// per-row error terms in raw units).  One wave per row, rows >= n zero.
 __global__ __launch_bounds__(256) void split_queries_i8_kernel(const float *__restrict__ x, int n, int dim, int dimp,
                                                               const float *__restrict__ mu, const float *__restrict__ cs,
                                                               signed char *__restrict__ out, float *__restrict__ qnorm,
@@ -1551,9 +1556,11 @@ __global__ __launch_bounds__(256) void split_queries_i8_kernel(const float *__re
     qnorm[r] = qn;
     qinv[r] = t;
     qshift[r] = sh;
-    qdelta[r] = qd;
+    qdelta[r] = 0.f;     // the query's own quantisation is inside G_q too (below): nothing of it is left for the proof's formula
     qn16[r] = qw;
-    const float g = (float)((double)__uint_as_float(bits8[2]) * sqrt(nw) * inv_t * 1.0001);   // G_q = rho ||w|| / t_q, rounded up
+    // G_q = (rho ||w|| + eta ||w - w^||) / t_q, rounded up: |w.(y - y^)_r| <= ||w|| rho s_r and |(w - w^).y^_r| <= ||w - w^|| s_r ||I_r||
+    // <= ||w - w^|| s_r eta -- both per ROW through s_r, so a few rows of extreme length do not widen every other row's bound
+    const float g = (float)(((double)__uint_as_float(bits8[2]) * sqrt(nw) + (double)__uint_as_float(bits8[6]) * sqrt(dq)) * inv_t * 1.0001);
     qub[r] = g;
     // a non-finite query, or rows the image could not hold (rho = 3e38): keys would be inf / NaN and NaN keys are silently
     // dropped by the filter's comparisons -- the driver sends such a query's batch through the f16 search
@@ -2510,7 +2517,7 @@ struct Index8View {
   const float *scale;        // [image_rows(nd)] s_r
   const float *ynorm;        // [image_rows(nd)] ||y^_r|| (rounded up)
   const float *cscale;       // [dimp] c_k
-  const unsigned int *bits;  // [0] max ||y^||, [1] max ||d|| (from the f16 index), [2] rho, [3] 2^-20 rho max s_r, [4] max ||y - y^||, [5] max s_r  (float bits)
+  const unsigned int *bits;  // [0] max ||y^||, [1] max ||d|| (from the f16 index), [2] rho, [3] 2^-20 rho max s_r, [4] max ||y - y^||, [5] max s_r, [6] eta = max ||I_r||  (float bits)
   double *colsq;             // [dimp] build scratch
 };
 inline size_t index8_image_bytes(int64_t nd, int64_t dim) { return align_up((size_t)image_rows(nd) * pad_k(dim), 256); }
