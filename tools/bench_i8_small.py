@@ -38,6 +38,7 @@ for kind in kinds:
     docs, info = synth.corpus(kind, dev, n, dim)
     queries, _ = synth.corpus_queries(kind, docs, 64, info, seed=5)
     index = dense.DenseIndex(docs)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     index.prepare_small()
     torch.cuda.synchronize()
